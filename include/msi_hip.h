@@ -1,0 +1,169 @@
+/*
+ * msi_hip.h -- C ABI of libmsi_hip.so: the MI355X (gfx950) native kernels of the
+ * multi-sphere-image infer -> render hot path.
+ *
+ * The reference (brownvc/matryodshka) has no native code and no FFI: its only
+ * seam is the Python class matryodshka.msi.MSI called from test.py:127-159.
+ * Each entry point below therefore cites the reference *Python function* whose
+ * arithmetic it replaces (file:line inside the reference checkout); the Python
+ * class matryodshka_amd.msi.MSI keeps the reference's method signatures and is
+ * the only caller (INTEGRATION.md shows the ctypes binding).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross this boundary;
+ *   - the CALLER owns every buffer (device pointers unless the name ends in
+ *     `_host`); the library never allocates persistent device memory; scratch
+ *     is passed in, sized by the matching `*_workspace_bytes` query;
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream); no hidden synchronisation;
+ *   - return value: MSI_OK (0) or a negative MSI_E_* code; never a C++
+ *     exception; msi_last_error_string() gives the thread-local detail;
+ *   - re-entrant: no mutable global state besides the thread-local error text;
+ *   - all tensors are contiguous fp32 in the documented layout, dims int32.
+ *
+ * Layouts
+ *   image        [B,H,W,3]     preprocessed, range [-1,1]
+ *   psv          [B,H,W,C]     C = 6*D for the two-source ODS volume; channel
+ *                              = src*3D + d*3 + c (projector.py:164-169,
+ *                              msi.py:1124-1129)
+ *   pred         [B,H,W,2*D]   tanh output of the CNN (blend weights | alphas)
+ *   rgba_native  [B,D,H,W,4]   the layer stack, D-major (what msi.py:422
+ *                              transposes to before warping); float4 texels
+ *   out          [B,H,W,3]
+ *   trig         [2W+2H]       cosS[W] sinS[W] cosT[H] sinT[H] of the lat-long
+ *                              grid (spherical.py:42-44), host-built
+ */
+#ifndef MSI_HIP_H
+#define MSI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSI_OK 0
+#define MSI_E_BADARG (-1)
+#define MSI_E_LAUNCH (-2)
+#define MSI_E_UNSUPPORTED (-3)
+#define MSI_E_WORKSPACE (-4)
+
+typedef void *msi_stream_t; /* hipStream_t */
+
+const char *msi_version(void);
+const char *msi_last_error_string(void);
+
+/* ---- geometry tables (host) -------------------------------------------------
+ * spherical.lat_long_grid (spherical.py:42-44) is separable; the kernels take
+ * cos/sin of its two axes as a table.  tf.linspace fp32 semantics, then the
+ * correctly rounded fp32 cos/sin of each fp32 angle (DESIGN.md "trig tables"). */
+size_t msi_trig_table_floats(int32_t height, int32_t width);
+int msi_build_trig_tables_host(int32_t height, int32_t width, float *out_host);
+
+/* ---- pre / de-process -------------------------------------------------------
+ * MSI.preprocess_image (msi.py:1163-1171): uint8 -> x*(1/255), then x*2-1. */
+int msi_preprocess_u8_f32(const uint8_t *in, float *out, size_t n, msi_stream_t stream);
+int msi_preprocess_f32(const float *in, float *out, size_t n, msi_stream_t stream);
+/* MSI.deprocess_image (msi.py:1173-1181): trunc(((x+1)/2)*255.5) -> uint8;
+ * is_depth != 0: MSI.deprocess_depth_image (msi.py:1186-1194): trunc(x*255.5).
+ * Values are clamped to [0,255] before the cast. */
+int msi_deprocess_f32_u8(const float *in, uint8_t *out, size_t n, int32_t is_depth,
+                         msi_stream_t stream);
+
+/* ---- K1: ODS sphere sweep -----------------------------------------------------
+ * pj.ods_sphere_sweep -> sweep_one (projector.py:209-211, 129-170) with
+ * backproject_spherical (spherical.py:116-129), apply_pose (projector.py:275-291),
+ * project_ods (spherical.py:170-233) and the wrap-around bilinear gather
+ * sampling.resample (sampling.py:135-197), fused; nothing is materialised but
+ * the output.  Writes channels [channel_offset, channel_offset+3*D) of psv.
+ *   pose [B,4,4] (curr_pose = src_pose @ ref_pose_inv, msi.py:1125),
+ *   intrinsics [B,3,3] (ODS baseline in [b,0,0], data_loader.py:160),
+ *   depths [D], order = +1 (ref) / -1 (src) (msi.py:1127). */
+int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float *intrinsics,
+                             const float *depths, const float *trig, int32_t batch,
+                             int32_t height, int32_t width, int32_t num_depths, int32_t order,
+                             float *psv, int32_t psv_channels, int32_t channel_offset,
+                             msi_stream_t stream);
+
+/* ---- K3: RGBA layer assembly ----------------------------------------------------
+ * infer_msi "layer_prediction", which_color_pred = blend_psv (msi.py:130-147):
+ * w=(pred[..,d]+1)/2, a=(pred[..,D+d]+1)/2, rgb = w*psv_ref_d + (1-w)*psv_src_d.
+ * Writes rgba_native [B,D,H,W,4]; blend_weights / alphas ([B,H,W,D]) may be NULL
+ * (the optional extra outputs of msi.py:281-287). */
+int msi_assemble_rgba_f32(const float *psv, const float *pred, float *rgba_native,
+                          float *blend_weights, float *alphas, int32_t batch, int32_t height,
+                          int32_t width, int32_t num_planes, msi_stream_t stream);
+
+/* ---- K4: target-view reprojection + over-composite -------------------------------
+ * MSI.msi_render_equirect_view / _depth (msi.py:407-429, 384-405):
+ * pj.projective_forward_sphere (projector.py:34-62) = spherical.intersect_sphere
+ * (spherical.py:268-326) -> project_spherical (:235-246) -> theta_phi_to_pixels
+ * (:54-68) -> sampling.resample per layer, then pj.over_composite
+ * (projector.py:246-265) and/or pj.over_composite_depth (:225-244), fused in one
+ * pass: neither the pixel coordinates nor the warped layers are materialised,
+ * and RGB + depth share the warp.  out_rgb / out_depth may be NULL (not both).
+ *   tgt_pose_rt [B,4,4], tgt_pos [B,3], depths [D] (far -> near). */
+int msi_render_equirect_f32(const float *rgba_native, const float *tgt_pose_rt,
+                            const float *tgt_pos, const float *depths, const float *trig,
+                            int32_t batch, int32_t height, int32_t width, int32_t num_planes,
+                            float *out_rgb, float *out_depth, msi_stream_t stream);
+/* MSI.msi_render_equirect_view_single (msi.py:431-452): the warped, un-composited
+ * layers, out_layers [D,B,H,W,4]. */
+int msi_project_layers_f32(const float *rgba_native, const float *tgt_pose_rt,
+                           const float *tgt_pos, const float *depths, const float *trig,
+                           int32_t batch, int32_t height, int32_t width, int32_t num_planes,
+                           float *out_layers, msi_stream_t stream);
+
+/* ---- K2: encoder-decoder CNN -------------------------------------------------------
+ * nets.msi_coord_train_net (nets.py:471-515; coord_net=1) and nets.msi_train_net
+ * (nets.py:387-450; coord_net=0): 14x conv3x3 (+|sin(lat)| coordinate channel,
+ * nets.py:260-270), 3x conv-transpose 4x4 s2, LayerNorm over (H,W,C) + ReLU after
+ * each, 1x1 tanh head with bias.  Implicit-GEMM on fp32 MFMA; LayerNorm statistics
+ * are produced by the conv epilogue and applied (with the ReLU) in the consumer's
+ * operand loader. */
+typedef struct msi_net_desc {
+  int32_t batch, height, width; /* height, width multiples of 8 */
+  int32_t in_channels;          /* 6*D */
+  int32_t num_outputs;          /* 2*D for blend_psv */
+  int32_t ngf;                  /* 64 in the reference */
+  int32_t coord_net;            /* 1: msi_coord_train_net, 0: msi_train_net */
+} msi_net_desc;
+
+#define MSI_NET_NUM_LAYERS 18
+
+typedef struct msi_layer_info {
+  char name[16];          /* TF scope name: conv1_1 ... conv8_2, color_pred */
+  int32_t kind;           /* 0 conv3x3, 1 convT4x4s2, 2 head 1x1 */
+  int32_t cin, cout;      /* cin without the coordinate channel */
+  int32_t has_coord;
+  int32_t stride, rate;
+  int32_t in_h, in_w, out_h, out_w;
+  uint64_t param_offset;  /* float offset of `weights` in the parameter blob   */
+  uint64_t param_floats;  /* weights + gamma + beta (or + biases)              */
+  uint64_t raw_offset;    /* BYTE offset of the raw (pre-LayerNorm) output in  */
+                          /* the workspace; (uint64)-1 for the head             */
+  uint64_t affine_offset; /* BYTE offset of scale[cout] shift[cout] in the ws  */
+} msi_layer_info;
+
+/* Parameter blob ("reference layout"), fp32, layers in graph order; per layer
+ *   conv3x3 : weights [3,3,cin+has_coord,cout], gamma [cout], beta [cout]
+ *   convT   : weights [4,4,cout,cin],           gamma [cout], beta [cout]
+ *   head    : weights [1,1,cin,cout],           biases [cout]
+ * i.e. the TF variables net/<name>/weights, .../LayerNorm/gamma, .../LayerNorm/beta,
+ * net/color_pred/{weights,biases} (test.py:191-202 restores exactly these). */
+int msi_net_layer_info(const msi_net_desc *desc, int32_t layer, msi_layer_info *out);
+size_t msi_net_param_floats(const msi_net_desc *desc);
+size_t msi_net_packed_floats(const msi_net_desc *desc);
+int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params_host,
+                              float *packed_host);
+size_t msi_net_workspace_bytes(const msi_net_desc *desc);
+/* net_input [B,H,W,in_channels] -> pred [B,H,W,num_outputs]. */
+int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const float *net_input,
+                        float *pred, void *workspace, size_t workspace_bytes,
+                        msi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSI_HIP_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libmsi_hip.so (the C ABI declared in include/msi_hip.h).
+
+There is NO fallback: if the shared library is missing or does not export every
+symbol of the header, importing this module raises.  The CPU oracle under
+`oracle/` is test infrastructure and is never used from here.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char, c_char_p, c_float, c_int32, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsi_hip.so")
+
+MSI_OK = 0
+MSI_NET_NUM_LAYERS = 18
+
+
+class MsiError(RuntimeError):
+    pass
+
+
+class NetDesc(Structure):
+    _fields_ = [("batch", c_int32), ("height", c_int32), ("width", c_int32),
+                ("in_channels", c_int32), ("num_outputs", c_int32), ("ngf", c_int32),
+                ("coord_net", c_int32)]
+
+
+class LayerInfo(Structure):
+    _fields_ = [("name", c_char * 16), ("kind", c_int32), ("cin", c_int32), ("cout", c_int32),
+                ("has_coord", c_int32), ("stride", c_int32), ("rate", c_int32),
+                ("in_h", c_int32), ("in_w", c_int32), ("out_h", c_int32), ("out_w", c_int32),
+                ("param_offset", c_uint64), ("param_floats", c_uint64),
+                ("raw_offset", c_uint64), ("affine_offset", c_uint64)]
+
+
+_P = c_void_p
+_I = c_int32
+
+# name -> (restype, argtypes); must list every function declared in include/msi_hip.h
+SIGNATURES = {
+    "msi_version": (c_char_p, []),
+    "msi_last_error_string": (c_char_p, []),
+    "msi_trig_table_floats": (c_size_t, [_I, _I]),
+    "msi_build_trig_tables_host": (_I, [_I, _I, _P]),
+    "msi_preprocess_u8_f32": (_I, [_P, _P, c_size_t, _P]),
+    "msi_preprocess_f32": (_I, [_P, _P, c_size_t, _P]),
+    "msi_deprocess_f32_u8": (_I, [_P, _P, c_size_t, _I, _P]),
+    "msi_ods_sphere_sweep_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "msi_assemble_rgba_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msi_render_equirect_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "msi_project_layers_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "msi_net_layer_info": (_I, [POINTER(NetDesc), _I, POINTER(LayerInfo)]),
+    "msi_net_param_floats": (c_size_t, [POINTER(NetDesc)]),
+    "msi_net_packed_floats": (c_size_t, [POINTER(NetDesc)]),
+    "msi_net_pack_weights_host": (_I, [POINTER(NetDesc), _P, _P]),
+    "msi_net_workspace_bytes": (c_size_t, [POINTER(NetDesc)]),
+    "msi_net_forward_f32": (_I, [POINTER(NetDesc), _P, _P, _P, _P, c_size_t, _P]),
+}
+
+
+def _load():
+    # torch bundles its own libamdhip64.so.7; load it FIRST so that libmsi_hip.so's
+    # NEEDED libamdhip64.so.7 binds to the same runtime instance (two HIP runtimes in
+    # one process do not share devices, streams or allocations).
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "matryodshka_amd: %s is missing -- build it with `python -m matryodshka_amd.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ImportError("matryodshka_amd: %s does not export %s" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.msi_last_error_string().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != MSI_OK:
+        raise MsiError("%s failed (code %d): %s" % (what, rc, last_error()))

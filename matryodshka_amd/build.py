@@ -1,0 +1,65 @@
+"""Builds matryodshka_amd/libmsi_hip.so for gfx950 with hipcc (cross-compiles
+without a GPU).  `python -m matryodshka_amd.build [--force]`."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB = os.path.join(HERE, "libmsi_hip.so")
+OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
+
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
+          "-Wall", "-Wno-unused-function"]
+# (source, extra flags).  geometry.hip must not contract a*b+c into fma: see its header.
+SOURCES = [
+    ("common.cpp", ["-x", "hip"]),
+    ("geometry.hip", ["-ffp-contract=off"]),
+    ("cnn.hip", []),
+]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(INCLUDE, "msi_hip.h"), os.path.join(CSRC, "msi_common.h"), __file__]
+    objs = []
+    rebuilt = False
+    for src, extra in SOURCES:
+        spath = os.path.join(CSRC, src)
+        opath = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+        objs.append(opath)
+        if force or _newer(opath, [spath] + headers):
+            cmd = [hipcc] + COMMON + extra + ["-c", spath, "-o", opath]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or force or _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,543 @@
+// Geometry-side kernels of the MSI infer->render path for gfx950 (HBM-bound):
+//   K5 pre/deprocess, K1 ODS sphere sweep, K3 RGBA assembly,
+//   K4 fused reprojection + wrap-around bilinear gather + over-composite.
+//
+// This file is compiled with -ffp-contract=off: the reference evaluates every
+// elementwise TF op separately in fp32 (no FMA contraction), and project_ods'
+// discriminant is ill-conditioned enough that a contracted
+// multiply-add flips the `disc >= 0` branch on ~1% of far-plane pixels.  With the
+// reference's operation order, IEEE sqrt/div (hipcc default) and the host-built
+// trig tables, every branch below is bit-reproducible against the CPU oracle.
+#include <cmath>
+#include <cstdint>
+
+#include "msi_common.h"
+
+namespace {
+
+// fp32 constants the reference folds from Python doubles (spherical.py:54-68,
+// :222-223), rounded once on the host.
+struct PixConsts {
+  float pi, pi_over_w, u_den, wm1;          // u = ((theta + pi) - pi/W) / (2pi - 2pi/W) * (W-1)
+  float half_pi, half_pi_over_h, v_den, hm1;  // v = ((phi + pi/2) - (pi/2)/H) / (pi - pi/H) * (H-1)
+};
+
+PixConsts make_consts(int height, int width) {
+  const double PI = 3.14159265358979323846;
+  PixConsts k;
+  k.pi = (float)PI;
+  k.pi_over_w = (float)(PI / width);
+  k.u_den = (float)(2 * PI - 2 * PI / width);
+  k.wm1 = (float)(width - 1);
+  k.half_pi = (float)(0.5 * PI);
+  k.half_pi_over_h = (float)(0.5 * PI / height);
+  k.v_den = (float)(PI - PI / height);
+  k.hm1 = (float)(height - 1);
+  return k;
+}
+
+__device__ __forceinline__ int floor_mod(int a, int n) {
+  int m = a % n;
+  return m < 0 ? m + n : m;
+}
+
+// Corner indices and area weights of sampling.resample (sampling.py:150-165,
+// 187-190): weights from the UNWRAPPED corners, indices wrapped in both axes.
+struct Taps {
+  int x0, x1, y0, y1;
+  float wa, wb, wc, wd;
+};
+
+__device__ __forceinline__ Taps make_taps(float x, float y, int width, int height) {
+  Taps t;
+  const float fx0 = floorf(x), fy0 = floorf(y);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const int x1 = x0 + 1, y1 = y0 + 1;
+  const float dx0 = x - (float)x0, dy0 = y - (float)y0;
+  const float dx1 = (float)x1 - x, dy1 = (float)y1 - y;
+  t.x0 = floor_mod(x0 + width, width);
+  t.y0 = floor_mod(y0 + height, height);
+  t.x1 = floor_mod(x1 + width, width);
+  t.y1 = floor_mod(y1 + height, height);
+  t.wa = dy1 * dx1;
+  t.wb = dy1 * dx0;
+  t.wc = dy0 * dx1;
+  t.wd = dy0 * dx0;
+  return t;
+}
+
+__device__ __forceinline__ float blend4(const Taps &t, float a, float b, float c, float d) {
+  // tf.add_n([area_a*A, area_b*B, area_c*C, area_d*D]) summed in list order.
+  return ((t.wa * a + t.wb * b) + t.wc * c) + t.wd * d;
+}
+
+// ------------------------------------------------------------------------ K5
+__global__ void preprocess_u8_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
+                                     size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float x = (float)in[i] * (1.0f / 255.0f);
+    out[i] = x * 2.0f - 1.0f;
+  }
+}
+
+__global__ void preprocess_f32_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                      size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = in[i] * 2.0f - 1.0f;
+}
+
+__global__ void deprocess_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, size_t n,
+                                 int is_depth) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float x = in[i];
+    if (!is_depth) x = (x + 1.0f) / 2.0f;
+    float y = truncf(x * 255.5f);
+    y = fminf(fmaxf(y, 0.0f), 255.0f);
+    out[i] = (uint8_t)y;
+  }
+}
+
+// ------------------------------------------------------------------------ K1
+// One work item = (pixel, depth); depth is the fastest index so a wavefront's 64
+// lanes write 64 consecutive 12-byte texels of the NHWC volume (768 contiguous
+// bytes at D=32 per source).  The source image (2.4 MB) stays L2-resident.
+__global__ void __launch_bounds__(256)
+ods_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose,
+                 const float *__restrict__ intrinsics, const float *__restrict__ depths,
+                 const float *__restrict__ trig, int batch, int height, int width, int nd,
+                 float order, float *__restrict__ psv, int channels, int coff, PixConsts K) {
+  const long total = (long)batch * height * width * nd;
+  const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= total) return;
+  const int d = (int)(item % nd);
+  const long p = item / nd;
+  const int j = (int)(p % width);
+  const int i = (int)((p / width) % height);
+  const int b = (int)(p / ((long)width * height));
+
+  const float cs = trig[j], ss = trig[width + j];
+  const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
+  const float depth = depths[d];
+
+  // backproject_spherical (spherical.py:125-128)
+  float x = depth * (cs * ct);
+  float y = depth * st;
+  float z = depth * (ss * ct);
+
+  // apply_pose (projector.py:275-291): pose @ [x,y,z,1], terms summed left to right
+  const float *P = pose + (size_t)b * 16;
+  const float px_ = ((P[0] * x + P[1] * y) + P[2] * z) + P[3] * 1.0f;
+  const float py_ = ((P[4] * x + P[5] * y) + P[6] * z) + P[7] * 1.0f;
+  const float pz_ = ((P[8] * x + P[9] * y) + P[10] * z) + P[11] * 1.0f;
+  x = px_;
+  y = py_;
+  z = pz_;
+
+  // project_ods (spherical.py:181-229)
+  const float r = intrinsics[(size_t)b * 9];
+  const float f = r * r - (x * x + z * z);
+  const bool zlx = fabsf(z) > fabsf(x);
+  const float px = zlx ? x : z;
+  const float pz = zlx ? z : x;
+  const float pz2 = pz * pz;
+  const float a = 1.0f + (px * px) / pz2;
+  const float bq = ((-2.0f * f) * px) / pz2;
+  const float c = f + (f * f) / pz2;
+  const float disc = bq * bq - (4.0f * a) * c;
+  const float sgn = (pz > 0.0f) ? 1.0f : ((pz < 0.0f) ? -1.0f : pz);
+  float s = ((-order) * sgn) * sqrtf(disc);
+  s = zlx ? s : -s;
+  float dx = (-bq + s) / (2.0f * a);
+  float dz = (f - px * dx) / pz;
+  const float dxf = zlx ? -dx : -dz;
+  const float dzf = zlx ? -dz : -dx;
+  dx = dxf;
+  dz = dzf;
+  const float theta = -atan2f(dz, dx);
+  float phi = atan2f(y, sqrtf(dx * dx + dz * dz));
+  if (phi != phi) phi = 1.0f;
+  phi = (phi <= K.half_pi) ? phi : K.half_pi;
+  phi = (phi >= -K.half_pi) ? phi : -K.half_pi;
+  float u = (((theta + K.pi) - K.pi_over_w) / K.u_den) * K.wm1;
+  float v = (((phi + K.half_pi) - K.half_pi_over_h) / K.v_den) * K.hm1;
+  if (!(disc >= 0.0f)) {
+    u = 1.0f;
+    v = 1.0f;
+  }
+
+  // resample (sampling.py:135-197)
+  const Taps t = make_taps(u, v, width, height);
+  const float *img = image + (size_t)b * height * width * 3;
+  const float *pa = img + ((size_t)t.y0 * width + t.x0) * 3;
+  const float *pb = img + ((size_t)t.y0 * width + t.x1) * 3;
+  const float *pc = img + ((size_t)t.y1 * width + t.x0) * 3;
+  const float *pd = img + ((size_t)t.y1 * width + t.x1) * 3;
+  float *o = psv + (size_t)p * channels + coff + d * 3;
+  o[0] = blend4(t, pa[0], pb[0], pc[0], pd[0]);
+  o[1] = blend4(t, pa[1], pb[1], pc[1], pd[1]);
+  o[2] = blend4(t, pa[2], pb[2], pc[2], pd[2]);
+}
+
+// ------------------------------------------------------------------------ K3
+// A block owns TP=32 consecutive pixels.  Phase 1 streams the contiguous PSV
+// (32 x 6D floats) and pred (32 x 2D floats) tiles into LDS with 16-byte loads;
+// phase 2 re-reads them transposed (row stride padded to an odd dword count, so
+// the 32 lanes of a half-wave hit 32 different banks) and writes float4 texels
+// of the D-major stack: 512 contiguous bytes per (half-wave, layer).
+constexpr int K3_TP = 32;
+
+__global__ void __launch_bounds__(256)
+assemble_kernel(const float *__restrict__ psv, const float *__restrict__ pred,
+                float4 *__restrict__ rgba, float *__restrict__ bw_out,
+                float *__restrict__ al_out, long npix_total, int hw, int nd) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int c_psv = 6 * nd, c_pred = 2 * nd;
+  const int s_psv = c_psv + 1, s_pred = c_pred + 1;  // odd row strides
+  float *l_psv = smem;
+  float *l_pred = smem + K3_TP * s_psv;
+
+  const long p0 = (long)blockIdx.x * K3_TP;
+  const int npx = (int)((npix_total - p0) < K3_TP ? (npix_total - p0) : K3_TP);
+  const int tid = threadIdx.x;
+
+  {
+    const float4 *g = reinterpret_cast<const float4 *>(psv + p0 * c_psv);
+    const int nv = npx * c_psv / 4;
+    for (int v = tid; v < nv; v += 256) {
+      const float4 q = g[v];
+      const int e = v * 4;
+      const int row = e / c_psv, col = e - row * c_psv;  // c_psv % 4 == 0: no row straddle
+      float *dst = l_psv + row * s_psv + col;
+      dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
+    }
+  }
+  {
+    const float4 *g = reinterpret_cast<const float4 *>(pred + p0 * c_pred);
+    const int nv = npx * c_pred / 4;
+    for (int v = tid; v < nv; v += 256) {
+      float4 q = g[v];
+      // (x + 1) / 2 (msi.py:132-133)
+      q.x = (q.x + 1.0f) / 2.0f; q.y = (q.y + 1.0f) / 2.0f;
+      q.z = (q.z + 1.0f) / 2.0f; q.w = (q.w + 1.0f) / 2.0f;
+      const int e = v * 4;
+      const int row = e / c_pred, col = e - row * c_pred;
+      float *dst = l_pred + row * s_pred + col;
+      dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
+      // optional extra outputs, [B,H,W,D] each (msi.py:281-287)
+      if (col < nd) {
+        if (bw_out) *reinterpret_cast<float4 *>(bw_out + (p0 + row) * nd + col) = q;
+      } else {
+        if (al_out) *reinterpret_cast<float4 *>(al_out + (p0 + row) * nd + (col - nd)) = q;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int px = tid & (K3_TP - 1);
+  if (px >= npx) return;
+  const long p = p0 + px;
+  const long b = p / hw;
+  const long off = p - b * hw;
+  const float *rp = l_psv + px * s_psv;
+  const float *rq = l_pred + px * s_pred;
+  for (int d = tid / K3_TP; d < nd; d += 256 / K3_TP) {
+    const float w = rq[d];
+    const float al = rq[nd + d];
+    const float omw = 1.0f - w;
+    const float *fg = rp + d * 3;
+    const float *bg = rp + (nd + d) * 3;
+    float4 o;
+    o.x = w * fg[0] + omw * bg[0];
+    o.y = w * fg[1] + omw * bg[1];
+    o.z = w * fg[2] + omw * bg[2];
+    o.w = al;
+    rgba[(b * nd + d) * hw + off] = o;
+  }
+}
+
+// ------------------------------------------------------------------------ K4
+// One thread per target pixel, 64x4-pixel tiles (a wavefront = 64 consecutive
+// columns, so each tap row is a ~1 KiB coalesced float4 segment and vertically
+// adjacent waves share tap rows in L1).  The ray/sphere quadratic's a and b do
+// not depend on the layer, so per layer only sqrt, one divide and the two atan2
+// remain; the running composite lives in registers and every texel of the
+// D x H x W x 4 stack is fetched from HBM once.
+enum RenderMode { RENDER_RGB = 1, RENDER_DEPTH = 2, RENDER_LAYERS = 4 };
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt,
+              const float *__restrict__ tgt_pos, const float *__restrict__ depths,
+              const float *__restrict__ trig, int batch, int height, int width, int nd,
+              float *__restrict__ out_rgb, float *__restrict__ out_depth,
+              float4 *__restrict__ out_layers, PixConsts K) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  const int b = blockIdx.z;
+  if (j >= width || i >= height) return;
+
+  const float cs = trig[j], ss = trig[width + j];
+  const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
+  // ray direction (spherical.py:280-284)
+  float rx = cs * ct, ry = st, rz = ss * ct;
+  const float *P = pose_rt + (size_t)b * 16;
+  {
+    const float x = (P[0] * rx + P[1] * ry) + P[2] * rz;
+    const float y = (P[4] * rx + P[5] * ry) + P[6] * rz;
+    const float z = (P[8] * rx + P[9] * ry) + P[10] * rz;
+    rx = x; ry = y; rz = z;
+  }
+  // ray origin: the x<->z swap of spherical.py:286-288, then the full 4x4
+  const float *tp = tgt_pos + (size_t)b * 3;
+  float cx = tp[2], cy = tp[1], cz = tp[0];
+  {
+    const float x = ((P[0] * cx + P[1] * cy) + P[2] * cz) + P[3] * 1.0f;
+    const float y = ((P[4] * cx + P[5] * cy) + P[6] * cz) + P[7] * 1.0f;
+    const float z = ((P[8] * cx + P[9] * cy) + P[10] * cz) + P[11] * 1.0f;
+    cx = x; cy = y; cz = z;
+  }
+  const float qa = (rx * rx + ry * ry) + rz * rz;
+  const float qb = 2.0f * ((rx * cx + ry * cy) + rz * cz);
+  const float cc = (cx * cx + cy * cy) + cz * cz;
+  const float qb2 = qb * qb;
+  const float fa = 4.0f * qa, ta = 2.0f * qa;
+
+  const size_t hw = (size_t)height * width;
+  const size_t pix = (size_t)i * width + j;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, od = 0.f;
+
+#pragma unroll 4
+  for (int d = 0; d < nd; ++d) {
+    const float radius = depths[d];
+    const float qc = cc - radius * radius;
+    const float disc = qb2 - fa * qc;
+    const float t = (-qb + sqrtf(disc)) / ta;
+    const float x = cx + t * rx;
+    const float y = cy + t * ry;
+    const float z = cz + t * rz;
+    // project_spherical (spherical.py:243-246) + theta_phi_to_pixels (:54-68)
+    const float theta = -atan2f(z, x);
+    const float phi = atan2f(y, sqrtf(x * x + z * z));
+    const float u = (((theta + K.pi) - K.pi_over_w) / K.u_den) * K.wm1;
+    const float v = (((phi + K.half_pi) - K.half_pi_over_h) / K.v_den) * K.hm1;
+
+    const Taps tp4 = make_taps(u, v, width, height);
+    const float4 *L = rgba + ((size_t)b * nd + d) * hw;
+    const float4 A = L[(size_t)tp4.y0 * width + tp4.x0];
+    const float4 Bv = L[(size_t)tp4.y0 * width + tp4.x1];
+    const float4 C = L[(size_t)tp4.y1 * width + tp4.x0];
+    const float4 Dv = L[(size_t)tp4.y1 * width + tp4.x1];
+    const float al = blend4(tp4, A.w, Bv.w, C.w, Dv.w);
+    if (MODE & RENDER_LAYERS) {
+      float4 o;
+      o.x = blend4(tp4, A.x, Bv.x, C.x, Dv.x);
+      o.y = blend4(tp4, A.y, Bv.y, C.y, Dv.y);
+      o.z = blend4(tp4, A.z, Bv.z, C.z, Dv.z);
+      o.w = al;
+      out_layers[((size_t)d * batch + b) * hw + pix] = o;
+    }
+    if (MODE & RENDER_RGB) {
+      const float r = blend4(tp4, A.x, Bv.x, C.x, Dv.x);
+      const float g = blend4(tp4, A.y, Bv.y, C.y, Dv.y);
+      const float bl = blend4(tp4, A.z, Bv.z, C.z, Dv.z);
+      if (d == 0) {  // projector.py:259-260: the farthest layer's alpha is ignored
+        o0 = r; o1 = g; o2 = bl;
+      } else {       // projector.py:262-263
+        const float om = 1.0f - al;
+        o0 = r * al + o0 * om;
+        o1 = g * al + o1 * om;
+        o2 = bl * al + o2 * om;
+      }
+    }
+    if (MODE & RENDER_DEPTH) {
+      if (d == 0) {
+        od = 0.0f;   // projector.py:239-240
+      } else {       // projector.py:242: (i / len) * alpha + output * (1 - alpha)
+        const float frac = (float)((double)d / (double)nd);
+        od = frac * al + od * (1.0f - al);
+      }
+    }
+  }
+  if (MODE & RENDER_RGB) {
+    float *o = out_rgb + ((size_t)b * hw + pix) * 3;
+    o[0] = o0; o[1] = o1; o[2] = o2;
+  }
+  if (MODE & RENDER_DEPTH) {
+    float *o = out_depth + ((size_t)b * hw + pix) * 3;
+    o[0] = od; o[1] = od; o[2] = od;
+  }
+}
+
+int grid_1d(size_t n) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
+  if (blocks == 0) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace
+
+// ============================================================================
+// C ABI
+// ============================================================================
+extern "C" {
+
+size_t msi_trig_table_floats(int32_t height, int32_t width) {
+  if (height <= 0 || width <= 0) return 0;
+  return (size_t)2 * width + (size_t)2 * height;
+}
+
+static void linspace_f32(double start_d, double stop_d, int n, float *out) {
+  // tf.linspace, TF 1.14: step = (stop - start) / (num - 1); v[i] = start + step * i (fp32)
+  const float start = (float)start_d, stop = (float)stop_d;
+  if (n == 1) { out[0] = start; return; }
+  volatile float step = (stop - start) / (float)(n - 1);
+  for (int i = 0; i < n; ++i) {
+    volatile float prod = step * (float)i;  // volatile: one rounding per op on the host too
+    out[i] = start + prod;
+  }
+}
+
+int msi_build_trig_tables_host(int32_t height, int32_t width, float *out_host) {
+  MSI_REQUIRE(height > 0 && width > 0 && out_host, "build_trig_tables: bad arguments");
+  const double PI = 3.14159265358979323846;
+  float *cs = out_host, *ss = out_host + width;
+  float *ct = out_host + 2 * width, *st = ct + height;
+  linspace_f32(-PI + PI / width, PI - PI / width, width, cs);
+  linspace_f32(-PI / 2.0 + PI / (2 * height), PI / 2.0 - PI / (2 * height), height, ct);
+  for (int j = 0; j < width; ++j) {
+    const double a = (double)cs[j];
+    ss[j] = (float)sin(a);
+    cs[j] = (float)cos(a);
+  }
+  for (int i = 0; i < height; ++i) {
+    const double a = (double)ct[i];
+    st[i] = (float)sin(a);
+    ct[i] = (float)cos(a);
+  }
+  return MSI_OK;
+}
+
+int msi_preprocess_u8_f32(const uint8_t *in, float *out, size_t n, msi_stream_t stream) {
+  MSI_REQUIRE(in && out, "preprocess_u8: null pointer");
+  if (n == 0) return MSI_OK;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_1d(n)), dim3(256), 0, msi::as_stream(stream),
+                     in, out, n);
+  return msi::check_launch("preprocess_u8");
+}
+
+int msi_preprocess_f32(const float *in, float *out, size_t n, msi_stream_t stream) {
+  MSI_REQUIRE(in && out, "preprocess_f32: null pointer");
+  if (n == 0) return MSI_OK;
+  hipLaunchKernelGGL(preprocess_f32_kernel, dim3(grid_1d(n)), dim3(256), 0, msi::as_stream(stream),
+                     in, out, n);
+  return msi::check_launch("preprocess_f32");
+}
+
+int msi_deprocess_f32_u8(const float *in, uint8_t *out, size_t n, int32_t is_depth,
+                         msi_stream_t stream) {
+  MSI_REQUIRE(in && out, "deprocess: null pointer");
+  if (n == 0) return MSI_OK;
+  hipLaunchKernelGGL(deprocess_kernel, dim3(grid_1d(n)), dim3(256), 0, msi::as_stream(stream), in,
+                     out, n, (int)is_depth);
+  return msi::check_launch("deprocess");
+}
+
+int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float *intrinsics,
+                             const float *depths, const float *trig, int32_t batch,
+                             int32_t height, int32_t width, int32_t num_depths, int32_t order,
+                             float *psv, int32_t psv_channels, int32_t channel_offset,
+                             msi_stream_t stream) {
+  MSI_REQUIRE(image && pose && intrinsics && depths && trig && psv, "ods_sphere_sweep: null pointer");
+  MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_depths > 0, "ods_sphere_sweep: bad dims");
+  MSI_REQUIRE(order == 1 || order == -1, "ods_sphere_sweep: order must be +1 or -1");
+  MSI_REQUIRE(channel_offset >= 0 && channel_offset + 3 * num_depths <= psv_channels,
+              "ods_sphere_sweep: channel window [%d,%d) outside %d channels", channel_offset,
+              channel_offset + 3 * num_depths, psv_channels);
+  const long total = (long)batch * height * width * num_depths;
+  if (total == 0) return MSI_OK;
+  const long blocks = (total + 255) / 256;
+  MSI_REQUIRE(blocks < 2147483647L, "ods_sphere_sweep: problem too large");
+  hipLaunchKernelGGL(ods_sweep_kernel, dim3((unsigned)blocks), dim3(256), 0, msi::as_stream(stream),
+                     image, pose, intrinsics, depths, trig, batch, height, width, num_depths,
+                     (float)order, psv, psv_channels, channel_offset, make_consts(height, width));
+  return msi::check_launch("ods_sphere_sweep");
+}
+
+int msi_assemble_rgba_f32(const float *psv, const float *pred, float *rgba_native,
+                          float *blend_weights, float *alphas, int32_t batch, int32_t height,
+                          int32_t width, int32_t num_planes, msi_stream_t stream) {
+  MSI_REQUIRE(psv && pred && rgba_native, "assemble_rgba: null pointer");
+  MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_planes > 0, "assemble_rgba: bad dims");
+  if (num_planes % 4 != 0)
+    return msi::fail(MSI_E_UNSUPPORTED, "assemble_rgba: num_planes=%d must be a multiple of 4",
+                     num_planes);
+  const size_t lds = (size_t)K3_TP * (8 * num_planes + 2) * sizeof(float);
+  if (lds > 160 * 1024)
+    return msi::fail(MSI_E_UNSUPPORTED, "assemble_rgba: num_planes=%d needs %zu B of LDS", num_planes,
+                     lds);
+  const long npix = (long)batch * height * width;
+  if (npix == 0) return MSI_OK;
+  const long blocks = (npix + K3_TP - 1) / K3_TP;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(assemble_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "assemble_rgba: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), lds, msi::as_stream(stream),
+                     psv, pred, reinterpret_cast<float4 *>(rgba_native), blend_weights, alphas, npix,
+                     height * width, num_planes);
+  return msi::check_launch("assemble_rgba");
+}
+
+static int render_common(int mode, const float *rgba_native, const float *tgt_pose_rt,
+                         const float *tgt_pos, const float *depths, const float *trig, int32_t batch,
+                         int32_t height, int32_t width, int32_t num_planes, float *out_rgb,
+                         float *out_depth, float *out_layers, msi_stream_t stream) {
+  MSI_REQUIRE(rgba_native && tgt_pose_rt && tgt_pos && depths && trig, "render: null pointer");
+  MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_planes > 0, "render: bad dims");
+  if (batch == 0) return MSI_OK;
+  const dim3 grid((width + 63) / 64, (height + 3) / 4, batch), block(64, 4);
+  const PixConsts K = make_consts(height, width);
+  const float4 *src = reinterpret_cast<const float4 *>(rgba_native);
+  float4 *lay = reinterpret_cast<float4 *>(out_layers);
+  hipStream_t s = msi::as_stream(stream);
+#define MSI_LAUNCH_RENDER(M)                                                                     \
+  hipLaunchKernelGGL(render_kernel<M>, grid, block, 0, s, src, tgt_pose_rt, tgt_pos, depths, trig, \
+                     batch, height, width, num_planes, out_rgb, out_depth, lay, K)
+  switch (mode) {
+    case RENDER_RGB: MSI_LAUNCH_RENDER(RENDER_RGB); break;
+    case RENDER_DEPTH: MSI_LAUNCH_RENDER(RENDER_DEPTH); break;
+    case RENDER_RGB | RENDER_DEPTH: MSI_LAUNCH_RENDER(RENDER_RGB | RENDER_DEPTH); break;
+    case RENDER_LAYERS: MSI_LAUNCH_RENDER(RENDER_LAYERS); break;
+    default: return msi::fail(MSI_E_BADARG, "render: bad mode %d", mode);
+  }
+#undef MSI_LAUNCH_RENDER
+  return msi::check_launch("render");
+}
+
+int msi_render_equirect_f32(const float *rgba_native, const float *tgt_pose_rt,
+                            const float *tgt_pos, const float *depths, const float *trig,
+                            int32_t batch, int32_t height, int32_t width, int32_t num_planes,
+                            float *out_rgb, float *out_depth, msi_stream_t stream) {
+  MSI_REQUIRE(out_rgb || out_depth, "render_equirect: both outputs are NULL");
+  const int mode = (out_rgb ? RENDER_RGB : 0) | (out_depth ? RENDER_DEPTH : 0);
+  return render_common(mode, rgba_native, tgt_pose_rt, tgt_pos, depths, trig, batch, height, width,
+                       num_planes, out_rgb, out_depth, nullptr, stream);
+}
+
+int msi_project_layers_f32(const float *rgba_native, const float *tgt_pose_rt,
+                           const float *tgt_pos, const float *depths, const float *trig,
+                           int32_t batch, int32_t height, int32_t width, int32_t num_planes,
+                           float *out_layers, msi_stream_t stream) {
+  MSI_REQUIRE(out_layers, "project_layers: output is NULL");
+  return render_common(RENDER_LAYERS, rgba_native, tgt_pose_rt, tgt_pos, depths, trig, batch, height,
+                       width, num_planes, nullptr, nullptr, out_layers, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+"""MI355X-native counterpart of the reference's `matryodshka.msi.MSI` class for the
+infer -> render hot path, with the reference's method names and argument order
+(so it drops into a test.py-style harness, test.py:127-159).
+
+All arithmetic runs in libmsi_hip.so (hand-written HIP for gfx950) through the C
+ABI of include/msi_hip.h; torch is used for device memory, streams and tiny 4x4
+pose algebra only.  There is no CPU path: tensors must live on a HIP device.
+
+Differences from the reference that are forced by leaving TF graph mode:
+  * hidden graph inputs (`ref_pose_inv:0`, msi.py:1115) are keyword arguments with
+    the test.py defaults (ref_pose_inv = inverse(ref_pose), no jitter);
+  * global FLAGS become constructor arguments (coord_net);
+  * batch semantics: the reference only works for B=1 (test.py:89, msi.py:1109);
+    here B frames are B independent B=1 evaluations;
+  * `rgba_layers` keeps the public [B,H,W,D,4] shape but is a permuted VIEW of the
+    D-major [B,D,H,W,4] stack the kernels use (the layout msi.py:422 transposes to).
+"""
+import numpy as np
+import torch
+
+from . import _native as N
+from . import nets
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class MSI(object):
+    """Class definition for the MSI inference module (reference: msi.py:33-38)."""
+
+    def __init__(self, weights=None, coord_net=True, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("matryodshka_amd.MSI needs a HIP device (no CPU fallback)")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.coord_net = bool(coord_net)
+        self._weights = None
+        self._blob_cache = {}     # (in_channels, num_outputs, ngf) -> np blob
+        self._packed_cache = {}   # desc key -> device tensor
+        self._ws_cache = {}       # desc key -> device workspace
+        self._trig_cache = {}     # (H, W) -> device tensor
+        self._planes_cache = {}   # tuple(planes) -> device tensor
+        if weights is not None:
+            self.load_weights(weights)
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _f32(self, x):
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x, dtype=np.float32))
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _trig(self, height, width):
+        key = (height, width)
+        t = self._trig_cache.get(key)
+        if t is None:
+            host = np.empty(N.lib.msi_trig_table_floats(height, width), dtype=np.float32)
+            N.check(N.lib.msi_build_trig_tables_host(height, width, host.ctypes.data), "msi_build_trig_tables_host")
+            t = torch.from_numpy(host).to(self.device)
+            self._trig_cache[key] = t
+        return t
+
+    def _planes(self, planes):
+        if torch.is_tensor(planes):
+            return planes.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+        key = tuple(float(p) for p in planes)
+        t = self._planes_cache.get(key)
+        if t is None:
+            t = torch.tensor(key, dtype=torch.float32).to(self.device)
+            self._planes_cache[key] = t
+        return t
+
+    def load_weights(self, weights):
+        """weights: dict TF-variable-name -> array (see nets.variable_shapes)."""
+        self._weights = weights
+        self._blob_cache.clear()
+        self._packed_cache.clear()
+
+    def _net(self, batch, height, width, in_channels, num_outputs, ngf):
+        if self._weights is None:
+            raise RuntimeError("MSI: no network weights loaded (load_weights / weights=...)")
+        key = (batch, height, width, in_channels, num_outputs, ngf, self.coord_net)
+        desc = nets.make_desc(batch, height, width, in_channels, num_outputs, ngf, self.coord_net)
+        pkey = key[1:]  # packing does not depend on the batch size
+        packed = self._packed_cache.get(pkey)
+        if packed is None:
+            bkey = (in_channels, num_outputs, ngf)
+            blob = self._blob_cache.get(bkey)
+            if blob is None:
+                blob = nets.flatten_params(self._weights, in_channels, num_outputs, ngf, self.coord_net)
+                self._blob_cache[bkey] = blob
+            packed = torch.from_numpy(nets.pack_params(desc, blob)).to(self.device)
+            self._packed_cache[pkey] = packed
+        ws = self._ws_cache.get(key)
+        if ws is None:
+            nbytes = N.lib.msi_net_workspace_bytes(desc)
+            if nbytes == 0:
+                raise N.MsiError("unsupported network configuration: " + N.last_error())
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_cache[key] = ws
+        return desc, packed, ws
+
+    # ------------------------------------------------------------------ msi.py:1196-1217
+    def inv_depths(self, start_depth, end_depth, num_depths):
+        """Sample reversed, sorted inverse depths between a near and far plane."""
+        inv_start_depth = 1.0 / start_depth
+        inv_end_depth = 1.0 / end_depth
+        depths = [start_depth, end_depth]
+        for i in range(1, num_depths - 1):
+            fraction = float(i) / float(num_depths - 1)
+            inv_depth = inv_start_depth + (inv_end_depth - inv_start_depth) * fraction
+            depths.append(1.0 / inv_depth)
+        depths = sorted(depths)
+        return depths[::-1]
+
+    # ------------------------------------------------------------------ msi.py:1163-1194
+    def preprocess_image(self, image):
+        """uint8 [0,255] or float [0,1] -> float [-1,1] (msi.py:1163-1171)."""
+        if not torch.is_tensor(image):
+            image = torch.as_tensor(np.asarray(image))
+        image = image.to(self.device).contiguous()
+        out = torch.empty(image.shape, dtype=torch.float32, device=self.device)
+        if image.dtype == torch.uint8:
+            N.check(N.lib.msi_preprocess_u8_f32(image.data_ptr(), out.data_ptr(), image.numel(), self._stream()),
+                    "msi_preprocess_u8_f32")
+        else:
+            image = image.to(torch.float32)
+            N.check(N.lib.msi_preprocess_f32(image.data_ptr(), out.data_ptr(), image.numel(), self._stream()),
+                    "msi_preprocess_f32")
+        return out
+
+    def _deprocess(self, image, is_depth):
+        image = self._f32(image)
+        out = torch.empty(image.shape, dtype=torch.uint8, device=self.device)
+        N.check(N.lib.msi_deprocess_f32_u8(image.data_ptr(), out.data_ptr(), image.numel(), is_depth, self._stream()),
+                "msi_deprocess_f32_u8")
+        return out
+
+    def deprocess_image(self, image):
+        """float [-1,1] -> uint8 (msi.py:1173-1181)."""
+        return self._deprocess(image, 0)
+
+    def deprocess_depth_image(self, image):
+        """float [0,1] -> uint8 without the (x+1)/2 (msi.py:1186-1194)."""
+        return self._deprocess(image, 1)
+
+    # ------------------------------------------------------------------ msi.py:1094-1130
+    def format_network_input(self, ref_image, src_image, ref_pose, src_pose, planes, intrinsics,
+                             ref_pose_inv=None):
+        """Format the network input into the double sphere-sweep volume.
+        Returns net_input [B,H,W,2*3*len(planes)]."""
+        ref_image = self._f32(ref_image)
+        src_image = self._f32(src_image)
+        b, h, w, c = ref_image.shape
+        if c != 3 or src_image.shape != ref_image.shape:
+            raise ValueError("format_network_input: images must be [B,H,W,3] and agree")
+        ref_pose = torch.as_tensor(ref_pose, dtype=torch.float32)
+        src_pose = torch.as_tensor(src_pose, dtype=torch.float32)
+        if ref_pose_inv is None:
+            ref_pose_inv = torch.linalg.inv(ref_pose.cpu().double()).float()
+        ref_pose_inv = torch.as_tensor(ref_pose_inv, dtype=torch.float32).cpu()
+        depths = self._planes(planes)
+        nd = depths.numel()
+        intr = self._f32(intrinsics)
+        trig = self._trig(h, w)
+        psv = torch.empty((b, h, w, 6 * nd), dtype=torch.float32, device=self.device)
+        # order = +1 for the reference image (i = 0), -1 for the source (i = 1), msi.py:1127
+        for i, (img, pose) in enumerate(((ref_image, ref_pose), (src_image, src_pose))):
+            curr_pose = self._f32(torch.matmul(pose.cpu(), ref_pose_inv))      # msi.py:1125
+            order = 1 if (i % 2) == 0 else -1
+            N.check(N.lib.msi_ods_sphere_sweep_f32(
+                img.data_ptr(), curr_pose.data_ptr(), intr.data_ptr(), depths.data_ptr(), trig.data_ptr(),
+                b, h, w, nd, order, psv.data_ptr(), 6 * nd, i * 3 * nd, self._stream()),
+                "msi_ods_sphere_sweep_f32")
+        return psv
+
+    # ------------------------------------------------------------------ msi.py:40-289
+    def infer_msi(self, raw_src_image, raw_ref_image, raw_hres_src_image, raw_hres_ref_image,
+                  ref_pose, src_pose, intrinsics, which_color_pred, num_msi_planes, psv_planes,
+                  extra_outputs='', ngf=64, ref_pose_inv=None):
+        """Construct and run the MSI inference path.  Returns (pred dict, net_input).
+        Note the reference's argument order: src before ref (msi.py:40-46)."""
+        if which_color_pred != 'blend_psv':
+            raise NotImplementedError("which_color_pred=%r (only blend_psv, the reference default)" % which_color_pred)
+        if len(psv_planes) != num_msi_planes:
+            # msi.py:138 indexes the src PSV with num_msi_planes
+            raise ValueError("infer_msi assumes len(psv_planes) == num_msi_planes (msi.py:138)")
+        src_image = self.preprocess_image(raw_src_image)
+        ref_image = self.preprocess_image(raw_ref_image)
+        net_input = self.format_network_input(ref_image, src_image, ref_pose, src_pose, psv_planes,
+                                              intrinsics, ref_pose_inv=ref_pose_inv)
+        msi_pred = self.run_net(net_input, num_msi_planes * 2, ngf)
+        pred = self.assemble_layers(net_input, msi_pred, num_msi_planes, extra_outputs)
+        return pred, net_input
+
+    def run_net(self, net_input, num_outputs, ngf=64):
+        """msi_net(net_input, num_outputs) (msi.py:95-125): [B,H,W,Cin] -> [B,H,W,num_outputs]."""
+        b, h, w, cin = net_input.shape
+        desc, packed, ws = self._net(b, h, w, cin, num_outputs, ngf)
+        pred = torch.empty((b, h, w, num_outputs), dtype=torch.float32, device=self.device)
+        N.check(N.lib.msi_net_forward_f32(desc, packed.data_ptr(), net_input.data_ptr(), pred.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), self._stream()), "msi_net_forward_f32")
+        return pred
+
+    def assemble_layers(self, net_input, msi_pred, num_msi_planes, extra_outputs=''):
+        """layer_prediction of infer_msi (msi.py:130-147, 276-289)."""
+        b, h, w, _ = net_input.shape
+        d = num_msi_planes
+        rgba = torch.empty((b, d, h, w, 4), dtype=torch.float32, device=self.device)
+        bw = torch.empty((b, h, w, d), dtype=torch.float32, device=self.device) if 'blend_weights' in extra_outputs else None
+        al = torch.empty((b, h, w, d), dtype=torch.float32, device=self.device) if 'alpha' in extra_outputs else None
+        N.check(N.lib.msi_assemble_rgba_f32(net_input.data_ptr(), msi_pred.data_ptr(), rgba.data_ptr(),
+                                            _ptr(bw), _ptr(al), b, h, w, d, self._stream()),
+                "msi_assemble_rgba_f32")
+        pred = {'rgba_layers': rgba.permute(0, 2, 3, 1, 4)}
+        if bw is not None:
+            pred['blend_weights'] = bw
+        if al is not None:
+            pred['alphas'] = al
+        if 'psv' in extra_outputs:
+            pred['psv'] = net_input
+        return pred
+
+    # ------------------------------------------------------------------ msi.py:384-452
+    def _native_layers(self, rgba_layers):
+        rgba_layers = rgba_layers.to(device=self.device, dtype=torch.float32) if torch.is_tensor(rgba_layers) \
+            else self._f32(rgba_layers)
+        if rgba_layers.dim() != 5 or rgba_layers.shape[-1] != 4:
+            raise ValueError("rgba_layers must be [B,H,W,D,4]")
+        native = rgba_layers.permute(0, 3, 1, 2, 4)   # [B,D,H,W,4]
+        return native if native.is_contiguous() else native.contiguous()
+
+    def _render_args(self, rgba_layers, tgt_pose_rt, tgt_pos, planes):
+        native = self._native_layers(rgba_layers)
+        b, d, h, w, _ = native.shape
+        if not torch.is_tensor(tgt_pos) or not tgt_pos.is_cuda:
+            # domain guard (host side only, never a device sync): a target centre outside
+            # the innermost sphere makes spherical.py:316-318 take sqrt of a negative number
+            tp = np.asarray(torch.as_tensor(tgt_pos).cpu(), dtype=np.float64).reshape(-1, 3)
+            pl = np.asarray(planes.cpu() if torch.is_tensor(planes) else planes, dtype=np.float64)
+            if np.any(np.linalg.norm(tp, axis=1) >= pl.min()):
+                raise ValueError("tgt_pos must lie inside the innermost sphere (radius %g)" % pl.min())
+        pose = self._f32(tgt_pose_rt).reshape(-1, 4, 4)
+        # batch size is taken from tgt_pose_rt in the reference (msi.py:419); broadcast a single pose
+        if pose.shape[0] == 1 and b > 1:
+            pose = pose.expand(b, 4, 4).contiguous()
+        pos = self._f32(tgt_pos).reshape(-1, 3)
+        if pose.shape[0] != b or pos.shape[0] != b:
+            raise ValueError("tgt_pose_rt / tgt_pos batch must match rgba_layers")
+        depths = self._planes(planes)
+        if depths.numel() != d:
+            raise ValueError("len(planes) != number of layers")
+        return native, pose, pos, depths, self._trig(h, w), (b, d, h, w)
+
+    def msi_render_equirect_view(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics):
+        """Render a target view from an MSI representation -> [B,H,W,3] (msi.py:407-429)."""
+        out, _ = self.msi_render_equirect_view_and_depth(rgba_layers, tgt_pose_rt, tgt_pos, planes,
+                                                         intrinsics, want_rgb=True, want_depth=False)
+        return out
+
+    def msi_render_equirect_depth(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics):
+        """Composite the normalised layer index instead of colour (msi.py:384-405)."""
+        _, out = self.msi_render_equirect_view_and_depth(rgba_layers, tgt_pose_rt, tgt_pos, planes,
+                                                         intrinsics, want_rgb=False, want_depth=True)
+        return out
+
+    def msi_render_equirect_view_and_depth(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics,
+                                           want_rgb=True, want_depth=True):
+        """Both outputs of test.py:149-159 from ONE warp (the reference recomputes it)."""
+        native, pose, pos, depths, trig, (b, d, h, w) = self._render_args(rgba_layers, tgt_pose_rt, tgt_pos, planes)
+        rgb = torch.empty((b, h, w, 3), dtype=torch.float32, device=self.device) if want_rgb else None
+        dep = torch.empty((b, h, w, 3), dtype=torch.float32, device=self.device) if want_depth else None
+        N.check(N.lib.msi_render_equirect_f32(native.data_ptr(), pose.data_ptr(), pos.data_ptr(),
+                                              depths.data_ptr(), trig.data_ptr(), b, h, w, d,
+                                              _ptr(rgb), _ptr(dep), self._stream()), "msi_render_equirect_f32")
+        return rgb, dep
+
+    def msi_render_equirect_view_single(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics):
+        """Warped, un-composited layers [D,B,H,W,4] (msi.py:431-452)."""
+        native, pose, pos, depths, trig, (b, d, h, w) = self._render_args(rgba_layers, tgt_pose_rt, tgt_pos, planes)
+        out = torch.empty((d, b, h, w, 4), dtype=torch.float32, device=self.device)
+        N.check(N.lib.msi_project_layers_f32(native.data_ptr(), pose.data_ptr(), pos.data_ptr(),
+                                             depths.data_ptr(), trig.data_ptr(), b, h, w, d,
+                                             out.data_ptr(), self._stream()), "msi_project_layers_f32")
+        return out

@@ -1,0 +1,138 @@
+"""Oracle (TEST INFRASTRUCTURE ONLY, parity unpinned -- see oracle/__init__.py):
+CPU restatement of matryodshka/msi.py's infer -> render path with the
+reference's method names and argument order, on numpy arrays.
+
+Reference followed: matryodshka/msi.py
+  :40-52, 68-88, 119-147, 276-289   infer_msi (blend_psv)
+  :384-429                          msi_render_equirect_depth / _view
+  :431-452                          msi_render_equirect_view_single
+  :1094-1130, 1157-1161             format_network_input / sweep_src
+  :1163-1194                        preprocess / deprocess
+  :1196-1217                        inv_depths
+Hidden graph inputs of the reference (`ref_pose_inv:0`, global FLAGS) are
+explicit keyword arguments here; defaults reproduce test.py's ODS path
+(test.py:106-159).
+"""
+import numpy as np
+
+from . import geometry as G
+from . import nets
+
+F = np.float32
+
+
+class MSI(object):
+    def __init__(self, weights=None, coord_net=True):
+        self.weights = weights
+        self.coord_net = coord_net
+
+    # -- msi.py:1196-1217 ---------------------------------------------------
+    def inv_depths(self, start_depth, end_depth, num_depths):
+        inv_start_depth = 1.0 / start_depth
+        inv_end_depth = 1.0 / end_depth
+        depths = [start_depth, end_depth]
+        for i in range(1, num_depths - 1):
+            fraction = float(i) / float(num_depths - 1)
+            inv_depth = inv_start_depth + (inv_end_depth - inv_start_depth) * fraction
+            depths.append(1.0 / inv_depth)
+        depths = sorted(depths)
+        return depths[::-1]
+
+    # -- msi.py:1163-1194; tf.image.convert_image_dtype [TF-knowledge] --------
+    def preprocess_image(self, image):
+        image = np.asarray(image)
+        if image.dtype == np.uint8:
+            image = image.astype(F) * F(1.0 / 255.0)
+        else:
+            image = image.astype(F)
+        return image * F(2) - F(1)
+
+    @staticmethod
+    def _to_uint8(x):
+        # convert_image_dtype(float -> uint8, saturate=False): cast(x * 255.5)
+        # (truncation); out-of-range float->uint8 casts are undefined in TF, the
+        # oracle clamps so comparisons are well defined (inputs are in range
+        # whenever alpha, rgb are -- they are convex combinations).
+        y = x.astype(F) * F(255.5)
+        return np.clip(np.trunc(y), 0, 255).astype(np.uint8)
+
+    def deprocess_image(self, image):
+        image = (np.asarray(image, dtype=F) + F(1.0)) / F(2.0)
+        return self._to_uint8(image)
+
+    def deprocess_depth_image(self, image):
+        return self._to_uint8(np.asarray(image, dtype=F))
+
+    # -- msi.py:1094-1130 -----------------------------------------------------
+    def format_network_input(self, ref_image, src_image, ref_pose, src_pose, planes,
+                             intrinsics, ref_pose_inv=None):
+        ref_image = np.asarray(ref_image, dtype=F)
+        src_image = np.asarray(src_image, dtype=F)
+        ref_pose = np.asarray(ref_pose, dtype=F)
+        src_pose = np.asarray(src_pose, dtype=F)
+        if ref_pose_inv is None:
+            ref_pose_inv = np.linalg.inv(ref_pose.astype(np.float64)).astype(F)
+        net_input = []
+        # The reference concatenates [ref_pose, src_pose] on the batch axis and
+        # so only works for B=1 (msi.py:1109-1110); here batch element b uses
+        # (ref_pose[b], src_pose[b]) -- "B independent B=1 evaluations".
+        for i, (img, pose) in enumerate(((ref_image, ref_pose), (src_image, src_pose))):
+            curr_pose = np.matmul(pose.astype(F), ref_pose_inv.astype(F)).astype(F)
+            order = 1 if (i % 2) == 0 else -1
+            net_input.append(G.ods_sphere_sweep(img, order, planes, curr_pose, intrinsics))
+        return np.concatenate(net_input, axis=3)
+
+    # -- msi.py:40-289 (blend_psv) -------------------------------------------
+    def infer_msi(self, raw_src_image, raw_ref_image, raw_hres_src_image, raw_hres_ref_image,
+                  ref_pose, src_pose, intrinsics, which_color_pred, num_msi_planes, psv_planes,
+                  extra_outputs='', ngf=64, ref_pose_inv=None):
+        assert which_color_pred == 'blend_psv'
+        src_image = self.preprocess_image(raw_src_image)
+        ref_image = self.preprocess_image(raw_ref_image)
+        net_input = self.format_network_input(ref_image, src_image, ref_pose, src_pose,
+                                              psv_planes, intrinsics, ref_pose_inv=ref_pose_inv)
+        msi_pred = nets.forward(self.weights, net_input, coord_net=self.coord_net)
+        pred = self.assemble(net_input, msi_pred, num_msi_planes, extra_outputs)
+        return pred, net_input
+
+    def assemble(self, net_input, msi_pred, num_msi_planes, extra_outputs=''):
+        """layer_prediction, msi.py:130-147."""
+        d = num_msi_planes
+        b, h, w, _ = net_input.shape
+        blend_weights = (msi_pred[..., :d] + F(1.)) / F(2.)
+        alphas = (msi_pred[..., d:2 * d] + F(1.)) / F(2.)
+        rgba = np.empty((b, h, w, d, 4), dtype=F)
+        for i in range(d):
+            fg_rgb = net_input[..., i * 3:(1 + i) * 3]
+            bg_rgb = net_input[..., (d + i) * 3:(d + 1 + i) * 3]
+            wgt = blend_weights[..., i:i + 1]
+            rgba[..., i, :3] = wgt * fg_rgb + (F(1) - wgt) * bg_rgb
+            rgba[..., i, 3] = alphas[..., i]
+        pred = {'rgba_layers': rgba}
+        if 'blend_weights' in extra_outputs:
+            pred['blend_weights'] = blend_weights
+        if 'alpha' in extra_outputs:
+            pred['alphas'] = alphas
+        if 'psv' in extra_outputs:
+            pred['psv'] = net_input
+        return pred
+
+    # -- msi.py:384-452 ---------------------------------------------------------
+    def _project(self, rgba_layers, tgt_pose_rt, tgt_pos, planes):
+        rgba_layers = np.asarray(rgba_layers, dtype=F)
+        tgt_pose_rt = np.asarray(tgt_pose_rt, dtype=F)
+        batch_size = tgt_pose_rt.shape[0]
+        depths = np.tile(np.asarray(planes, dtype=F).reshape(-1, 1), (1, batch_size))
+        layers = np.transpose(rgba_layers, (3, 0, 1, 2, 4))
+        return G.projective_forward_sphere(layers, tgt_pose_rt, tgt_pos, depths)
+
+    def msi_render_equirect_view(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics):
+        proj = self._project(rgba_layers, tgt_pose_rt, tgt_pos, planes)
+        return G.over_composite([proj[i] for i in range(len(planes))])
+
+    def msi_render_equirect_depth(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics):
+        proj = self._project(rgba_layers, tgt_pose_rt, tgt_pos, planes)
+        return G.over_composite_depth([proj[i] for i in range(len(planes))])
+
+    def msi_render_equirect_view_single(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics):
+        return self._project(rgba_layers, tgt_pose_rt, tgt_pos, planes)

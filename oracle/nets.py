@@ -1,0 +1,192 @@
+"""Oracle (TEST INFRASTRUCTURE ONLY, parity unpinned -- see oracle/__init__.py):
+torch-CPU fp32 restatement of the reference's encoder-decoder CNN.
+
+Reference followed: matryodshka/nets.py
+  :260-270  add_sph_coords / coord_conv2d       (CoordNet, `--coord_net`)
+  :288-295  wrap_pad
+  :387-450  msi_train_net        (horizontal wrap + vertical zero pad, VALID)
+  :471-515  msi_coord_train_net  (SAME zero pad + |sin(lat)| coordinate channel)
+
+tf.contrib.slim semantics restated here are [TF-knowledge]:
+  * slim.conv2d: NHWC, weights [kh,kw,Cin,Cout], cross-correlation, SAME pad =
+    total max((ceil(in/s)-1)*s + k_eff - in, 0), floor(total/2) before, the
+    rest after; no bias when a normalizer is set; conv -> LayerNorm -> ReLU.
+  * slim.conv2d_transpose k4 s2: weights [kh,kw,Cout,Cin]; SAME: out = 2*in,
+    y[2i+k-1] += x[i]*w[k]  (== torch conv_transpose2d(stride=2,padding=1));
+    VALID: out = 2*in+2, y[2i+k] += x[i]*w[k].
+  * slim.layer_norm: per sample over (H,W,C); gamma/beta per channel;
+    eps = 1e-12; two-pass variance.
+  * head `color_pred`: 1x1 conv with bias, tanh, no normalizer.
+Variable names mirror the TF checkpoint scope `net/` (nets.py:483).
+"""
+import math
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+F32 = np.float32
+LN_EPS = 1e-12
+
+# (name, kind, cout_mult, stride, rate) ; kind: 'c' conv3x3, 't' convT4x4s2
+_ENCODER = [
+    ("conv1_1", 1, 1, 1), ("conv1_2", 2, 2, 1), ("conv2_1", 2, 1, 1), ("conv2_2", 4, 2, 1),
+    ("conv3_1", 4, 1, 1), ("conv3_2", 4, 1, 1), ("conv3_3", 8, 2, 1),
+    ("conv4_1", 8, 1, 2), ("conv4_2", 8, 1, 2), ("conv4_3", 8, 1, 2),
+]
+
+
+def layer_table(in_channels, num_outputs, ngf=64, coord_net=True):
+    """[(name, kind, cin (without coord channel), cout)] in graph order."""
+    ex = 1 if coord_net else 0
+    t = []
+    cin = in_channels
+    for name, mult, _s, _r in _ENCODER:
+        t.append((name, "c", cin, ngf * mult, ex))
+        cin = ngf * mult
+    t.append(("conv6_1", "t", ngf * 16, ngf * 4, 0))
+    t.append(("conv6_2", "c", ngf * 4, ngf * 4, ex))
+    t.append(("conv6_3", "c", ngf * 4, ngf * 4, ex))
+    t.append(("conv7_1", "t", ngf * 8, ngf * 2, 0))
+    t.append(("conv7_2", "c", ngf * 2, ngf * 2, ex))
+    t.append(("conv8_1", "t", ngf * 4, ngf, 0))
+    t.append(("conv8_2", "c", ngf, ngf, ex))
+    t.append(("color_pred", "h", ngf, num_outputs, 0))
+    return t
+
+
+def init_weights(in_channels, num_outputs, ngf=64, coord_net=True, seed=8964,
+                 randomize_affine=False):
+    """Xavier-uniform weights (slim default [TF-knowledge]), LN gamma=1 beta=0,
+    head bias 0.  `randomize_affine` perturbs gamma/beta/bias so tests exercise
+    them.  Returns dict name -> np.float32 array in TF variable layout."""
+    rng = np.random.RandomState(seed)
+    w = {}
+    for name, kind, cin, cout, ex in layer_table(in_channels, num_outputs, ngf, coord_net):
+        if kind == "c":
+            shape = (3, 3, cin + ex, cout)
+            fan_in, fan_out = 9 * (cin + ex), 9 * cout
+        elif kind == "t":
+            shape = (4, 4, cout, cin)
+            # slim: fan_in/out from shape[-2]/shape[-1] times the receptive field
+            fan_in, fan_out = 16 * cout, 16 * cin
+        else:
+            shape = (1, 1, cin, cout)
+            fan_in, fan_out = cin, cout
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        w[name + "/weights"] = rng.uniform(-lim, lim, size=shape).astype(F32)
+        if kind == "h":
+            b = rng.uniform(-0.1, 0.1, size=(cout,)) if randomize_affine else np.zeros(cout)
+            w[name + "/biases"] = b.astype(F32)
+        else:
+            if randomize_affine:
+                g = rng.uniform(0.5, 1.5, size=(cout,))
+                be = rng.uniform(-0.2, 0.2, size=(cout,))
+            else:
+                g, be = np.ones(cout), np.zeros(cout)
+            w[name + "/LayerNorm/gamma"] = g.astype(F32)
+            w[name + "/LayerNorm/beta"] = be.astype(F32)
+    return w
+
+
+def _same_pad(size, k_eff, stride):
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k_eff - size, 0)
+    return total // 2, total - total // 2
+
+
+def add_sph_coords(x):
+    """nets.add_sph_coords (nets.py:260-265). x: torch [B,C,H,W]. The
+    `input/float_info.max` term is exactly +0 in fp32."""
+    b, _, h, w = x.shape
+    coord = np.abs(np.sin(np.linspace(-np.pi / 2.0, np.pi / 2.0, h))).astype(F32)
+    c = torch.from_numpy(coord).view(1, 1, h, 1).expand(b, 1, h, w)
+    return torch.cat([x, c], dim=1)
+
+
+def layer_norm_relu(x, gamma, beta):
+    """slim.layer_norm over (H,W,C) per sample + ReLU (nets.py:401,485 arg_scope).
+    Statistics in fp64 (the ideal two-pass value), normalisation in fp32."""
+    xd = x.double()
+    mean = xd.mean(dim=(1, 2, 3), keepdim=True)
+    var = ((xd - mean) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+    inv = torch.rsqrt(var + LN_EPS)
+    g = torch.from_numpy(gamma).view(1, -1, 1, 1).double()
+    be = torch.from_numpy(beta).view(1, -1, 1, 1).double()
+    scale = (inv * g).float()
+    shift = (be - mean * inv * g).float()
+    return torch.relu(x * scale + shift)
+
+
+def _conv_w(w):   # [kh,kw,Cin,Cout] -> [Cout,Cin,kh,kw]
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(w, (3, 2, 0, 1))))
+
+
+def _convT_w(w):  # [kh,kw,Cout,Cin] -> [Cin,Cout,kh,kw]
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(w, (3, 2, 0, 1))))
+
+
+def wrap_pad(x, lp, rp):
+    """nets.wrap_pad (nets.py:288-295) on NCHW: wrap along W, zeros along H."""
+    x = torch.cat([x[..., -lp:], x, x[..., :rp]], dim=-1)
+    return TF.pad(x, (0, 0, lp, rp))
+
+
+def forward(weights, net_input, coord_net=True, return_activations=False):
+    """msi_coord_train_net (nets.py:471-515) / msi_train_net (:387-450).
+    net_input: np [B,H,W,Cin] fp32.  Returns np [B,H,W,num_outputs] fp32."""
+    x = torch.from_numpy(np.ascontiguousarray(np.transpose(net_input, (0, 3, 1, 2)))).float()
+    acts = {}
+
+    def conv(name, x, stride=1, rate=1):
+        w = _conv_w(weights[name + "/weights"])
+        if coord_net:
+            x = add_sph_coords(x)
+            _, _, h, wd = x.shape
+            pt, pb = _same_pad(h, 2 * rate + 1, stride)
+            pl, pr = _same_pad(wd, 2 * rate + 1, stride)
+            x = TF.pad(x, (pl, pr, pt, pb))
+        else:
+            x = wrap_pad(x, rate, rate)
+        y = TF.conv2d(x, w, stride=stride, dilation=rate)
+        acts[name + "/raw"] = y
+        y = layer_norm_relu(y, weights[name + "/LayerNorm/gamma"], weights[name + "/LayerNorm/beta"])
+        acts[name] = y
+        return y
+
+    def convT(name, x):
+        w = _convT_w(weights[name + "/weights"])
+        if coord_net:
+            y = TF.conv_transpose2d(x, w, stride=2, padding=1)
+        else:
+            y = TF.conv_transpose2d(wrap_pad(x, 2, 2), w, stride=2, padding=0)
+            y = y[:, :, 5:-5, 5:-5]
+        acts[name + "/raw"] = y
+        y = layer_norm_relu(y, weights[name + "/LayerNorm/gamma"], weights[name + "/LayerNorm/beta"])
+        acts[name] = y
+        return y
+
+    with torch.no_grad():
+        c11 = conv("conv1_1", x)
+        c12 = conv("conv1_2", c11, stride=2)
+        c21 = conv("conv2_1", c12)
+        c22 = conv("conv2_2", c21, stride=2)
+        c31 = conv("conv3_1", c22)
+        c32 = conv("conv3_2", c31)
+        c33 = conv("conv3_3", c32, stride=2)
+        c41 = conv("conv4_1", c33, rate=2)
+        c42 = conv("conv4_2", c41, rate=2)
+        c43 = conv("conv4_3", c42, rate=2)
+        c61 = convT("conv6_1", torch.cat([c43, c33], dim=1))
+        c62 = conv("conv6_2", c61)
+        c63 = conv("conv6_3", c62)
+        c71 = convT("conv7_1", torch.cat([c63, c22], dim=1))
+        c72 = conv("conv7_2", c71)
+        c81 = convT("conv8_1", torch.cat([c72, c12], dim=1))
+        c82 = conv("conv8_2", c81)
+        w = _conv_w(weights["color_pred/weights"])
+        b = torch.from_numpy(weights["color_pred/biases"])
+        pred = torch.tanh(TF.conv2d(c82, w, bias=b))
+    out = np.ascontiguousarray(pred.permute(0, 2, 3, 1).numpy())
+    if return_activations:
+        return out, {k: np.ascontiguousarray(v.permute(0, 2, 3, 1).numpy()) for k, v in acts.items()}
+    return out

@@ -1,0 +1,76 @@
+"""GPU parity of K2 (implicit-GEMM fp32-MFMA CNN) against the torch-CPU oracle,
+layer by layer (raw pre-LayerNorm activations read back from the workspace) and
+end to end.  Tolerance 1e-3 max-abs on the tanh output (north_star); raw
+activations are compared relative to their own scale (fp32 summation-order
+differences only)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from matryodshka_amd import MSI, nets, _native
+    from oracle import nets as onets
+    return torch, MSI, nets, _native, onets
+
+
+def _run(env, b, h, w, cin, nout, ngf, coord, seed=0):
+    torch, MSI, nets, N, onets = env
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=seed, randomize_affine=True)
+    rng = np.random.RandomState(seed + 1)
+    x = rng.uniform(-1, 1, size=(b, h, w, cin)).astype(np.float32)
+    m = MSI(weights=weights, coord_net=coord)
+    pred = m.run_net(torch.from_numpy(x).cuda(), nout, ngf)
+    torch.cuda.synchronize()
+    ref, acts = onets.forward(weights, x, coord_net=coord, return_activations=True)
+    desc, _, ws = m._net(b, h, w, cin, nout, ngf)
+    raws = {}
+    for info in nets.layer_infos(desc):
+        if info.kind == nets.KIND_HEAD:
+            continue
+        n = b * info.out_h * info.out_w * info.cout
+        raw = ws[info.raw_offset:info.raw_offset + 4 * n].view(torch.float32).reshape(b, info.out_h, info.out_w, info.cout)
+        raws[info.name.decode()] = raw.cpu().numpy()
+    return pred.cpu().numpy(), ref, raws, acts
+
+
+@pytest.mark.parametrize("coord", [True, False])
+@pytest.mark.parametrize("b,h,w,cin,nout,ngf", [(1, 32, 64, 96, 32, 16), (2, 16, 40, 24, 8, 16)])
+def test_net_matches_oracle(env, coord, b, h, w, cin, nout, ngf):
+    pred, ref, raws, acts = _run(env, b, h, w, cin, nout, ngf, coord)
+    for name, raw in raws.items():
+        o = acts[name + "/raw"]
+        assert raw.shape == o.shape, name
+        scale = np.abs(o).max() + 1e-12
+        err = np.abs(raw - o).max() / scale
+        assert err < 2e-4, "%s: relative max err %g" % (name, err)
+    assert pred.shape == ref.shape
+    assert np.abs(pred - ref).max() <= 1e-3, np.abs(pred - ref).max()
+
+
+def test_net_reference_width_channels(env):
+    """ngf=64 (the reference's width) on a small image: exercises the 128-wide N tiles,
+    the two-source skip concat at 1024/512/256 channels and Cout=512 layers."""
+    pred, ref, raws, acts = _run(env, 1, 16, 32, 48, 16, 64, True, seed=5)
+    for name, raw in raws.items():
+        o = acts[name + "/raw"]
+        err = np.abs(raw - o).max() / (np.abs(o).max() + 1e-12)
+        assert err < 2e-4, "%s: relative max err %g" % (name, err)
+    assert np.abs(pred - ref).max() <= 1e-3
+
+
+def test_workspace_too_small_is_an_error(env):
+    torch, MSI, nets, N, onets = env
+    desc = nets.make_desc(1, 16, 32, 24, 8, 16, True)
+    packed = torch.zeros(N.lib.msi_net_packed_floats(desc), device="cuda")
+    x = torch.zeros((1, 16, 32, 24), device="cuda")
+    y = torch.zeros((1, 16, 32, 8), device="cuda")
+    ws = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    rc = N.lib.msi_net_forward_f32(desc, packed.data_ptr(), x.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == -4 and b"workspace" in N.lib.msi_last_error_string()

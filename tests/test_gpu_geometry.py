@@ -1,0 +1,182 @@
+"""GPU parity of the geometry kernels (K1 sweep, K3 assemble, K4 render, K5
+pre/deprocess) against the CPU oracle, through the C ABI (via the MSI class).
+
+Tolerances: the sweep's branch masks are checked bit-exactly through the
+invalid-pixel rule; float outputs within 1e-3 max-abs (north_star), observed
+~1e-5; uint8 outputs equal up to +-1 LSB on <0.1% of pixels.
+"""
+import numpy as np
+import pytest
+
+from tests.util import make_inputs, random_rgba
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from matryodshka_amd import MSI
+    from oracle.msi import MSI as OracleMSI
+    return torch, MSI(), OracleMSI()
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("b,h,w,d", [(1, 32, 64, 4), (2, 40, 80, 8), (1, 64, 128, 32)])
+def test_preprocess_and_sweep_matches_oracle(gpu, b, h, w, d):
+    torch, m, o = gpu
+    inp = make_inputs(1 + h, b, h, w)
+    planes = m.inv_depths(1.0, 100.0, d)
+    assert planes == o.inv_depths(1.0, 100.0, d)
+    ref = m.preprocess_image(torch.from_numpy(inp["ref_image"]))
+    src = m.preprocess_image(torch.from_numpy(inp["src_image"]))
+    ref_o = o.preprocess_image(inp["ref_image"])
+    src_o = o.preprocess_image(inp["src_image"])
+    assert np.array_equal(_np(ref), ref_o)  # K5 is exact
+    psv = m.format_network_input(ref, src, inp["ref_pose"], inp["src_pose"], planes, inp["intrinsics"])
+    psv_o = o.format_network_input(ref_o, src_o, inp["ref_pose"], inp["src_pose"], planes, inp["intrinsics"])
+    assert psv.shape == psv_o.shape == (b, h, w, 6 * d)
+    err = np.abs(_np(psv) - psv_o)
+    assert err.max() <= TOL, "max-abs %g" % err.max()
+    # every branch (z_larger_x, disc>=0) agreed: a flipped branch samples pixel (1,1) or a
+    # far-away texel and shows up as O(1) error, so a tight percentile bound pins it
+    assert np.percentile(err, 99.99) < 1e-4
+
+
+def test_sweep_float_input_and_nonidentity_pose(gpu):
+    torch, m, o = gpu
+    b, h, w, d = 1, 32, 64, 8
+    inp = make_inputs(7, b, h, w, as_uint8=False)
+    planes = m.inv_depths(1.0, 100.0, d)
+    th = 0.05
+    pose = np.array([[np.cos(th), 0, np.sin(th), 0.01], [0, 1, 0, -0.02], [-np.sin(th), 0, np.cos(th), 0.015],
+                     [0, 0, 0, 1]], dtype=np.float32)[None]
+    ref = m.preprocess_image(torch.from_numpy(inp["ref_image"]))
+    src = m.preprocess_image(torch.from_numpy(inp["src_image"]))
+    psv = m.format_network_input(ref, src, inp["ref_pose"], pose, planes, inp["intrinsics"])
+    psv_o = o.format_network_input(o.preprocess_image(inp["ref_image"]), o.preprocess_image(inp["src_image"]),
+                                   inp["ref_pose"], pose, planes, inp["intrinsics"])
+    err = np.abs(_np(psv) - psv_o)
+    # a rotated pose is not exact in either implementation; allow isolated branch flips
+    assert np.percentile(err, 99.9) < 1e-3
+
+
+@pytest.mark.parametrize("b,h,w,d", [(1, 32, 64, 4), (2, 24, 96, 8), (1, 20, 50, 12)])
+def test_assemble_matches_oracle(gpu, b, h, w, d):
+    torch, m, o = gpu
+    rng = np.random.RandomState(3)
+    psv = rng.uniform(-1, 1, size=(b, h, w, 6 * d)).astype(np.float32)
+    pred = np.tanh(rng.normal(size=(b, h, w, 2 * d))).astype(np.float32)
+    out = m.assemble_layers(torch.from_numpy(psv).cuda(), torch.from_numpy(pred).cuda(), d,
+                            extra_outputs="blend_weights_alphas_psv")
+    ref = o.assemble(psv, pred, d, "blend_weights_alphas_psv")
+    assert tuple(out["rgba_layers"].shape) == (b, h, w, d, 4)
+    assert np.array_equal(_np(out["rgba_layers"]), ref["rgba_layers"])   # same op order: exact
+    assert np.array_equal(_np(out["blend_weights"]), ref["blend_weights"])
+    assert np.array_equal(_np(out["alphas"]), ref["alphas"])
+
+
+@pytest.mark.parametrize("b,h,w,d", [(1, 32, 64, 4), (2, 40, 80, 8), (1, 30, 70, 5)])
+def test_render_matches_oracle(gpu, b, h, w, d):
+    torch, m, o = gpu
+    rgba = random_rgba(11, b, h, w, d)
+    inp = make_inputs(5, b, h, w)
+    planes = m.inv_depths(1.0, 100.0, d)
+    t_rgba = torch.from_numpy(rgba).cuda()
+    rgb = m.msi_render_equirect_view(t_rgba, inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    dep = m.msi_render_equirect_depth(t_rgba, inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    lay = m.msi_render_equirect_view_single(t_rgba, inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    rgb_o = o.msi_render_equirect_view(rgba, inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    dep_o = o.msi_render_equirect_depth(rgba, inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    lay_o = o.msi_render_equirect_view_single(rgba, inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    assert np.abs(_np(rgb) - rgb_o).max() <= TOL
+    assert np.abs(_np(dep) - dep_o).max() <= TOL
+    assert np.abs(_np(lay) - lay_o).max() <= TOL
+    both_rgb, both_dep = m.msi_render_equirect_view_and_depth(t_rgba, inp["tgt_pose_rt"], inp["tgt_pos"], planes,
+                                                              inp["intrinsics"])
+    assert torch.equal(both_rgb, rgb) and torch.equal(both_dep, dep)
+    # uint8 outputs of test.py:149-159
+    u8 = _np(m.deprocess_image(rgb)).astype(int)
+    u8_o = o.deprocess_image(rgb_o).astype(int)
+    diff = np.abs(u8 - u8_o)
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    d8 = _np(m.deprocess_depth_image(dep)).astype(int)
+    d8_o = o.deprocess_depth_image(dep_o).astype(int)
+    assert np.abs(d8 - d8_o).max() <= 1
+
+
+def test_render_identity_is_mirrored_composite(gpu):
+    """KAT 3: tgt_pos = 0, pose = I  =>  u = W-1-j, v = i, so the render is the
+    over-composite of the horizontally mirrored layers (to bilinear round-off 6e-5 px)."""
+    torch, m, o = gpu
+    b, h, w, d = 1, 32, 64, 6
+    rgba = random_rgba(2, b, h, w, d)
+    planes = m.inv_depths(1.0, 100.0, d)
+    zero = np.zeros((1, 3), np.float32)
+    rgb = _np(m.msi_render_equirect_view(torch.from_numpy(rgba).cuda(), np.eye(4, dtype=np.float32)[None], zero,
+                                         planes, None))
+    mirrored = rgba[:, :, ::-1]
+    out = mirrored[..., 0, :3]
+    for i in range(1, d):
+        a = mirrored[..., i, 3:]
+        out = mirrored[..., i, :3] * a + out * (1 - a)
+    assert np.abs(rgb - out).max() < 5e-4
+
+
+def test_render_opaque_layer_kat(gpu):
+    """KAT 7: alpha_k = 1 and alpha_{>k} = 0 => out = rgb_k (warped), depth = k/D;
+    the farthest layer's alpha is ignored."""
+    torch, m, o = gpu
+    b, h, w, d, k = 1, 16, 32, 8, 3
+    rgba = random_rgba(4, b, h, w, d)
+    rgba[..., :, 3] = 0.0
+    rgba[..., k, 3] = 1.0
+    rgba[..., 0, 3] = 0.37  # ignored
+    for i in range(d):
+        rgba[..., i, :3] = (i + 1) / 10.0   # constant colour per layer: warp-invariant
+    planes = m.inv_depths(1.0, 100.0, d)
+    pos = np.array([[0.05, -0.02, 0.03]], np.float32)
+    t = torch.from_numpy(rgba).cuda()
+    rgb, dep = m.msi_render_equirect_view_and_depth(t, np.eye(4, dtype=np.float32)[None], pos, planes, None)
+    assert np.abs(_np(rgb) - (k + 1) / 10.0).max() < 1e-5
+    assert np.abs(_np(dep) - k / d).max() < 1e-5
+
+
+def test_domain_guard(gpu):
+    torch, m, o = gpu
+    rgba = torch.zeros((1, 8, 16, 2, 4), device="cuda")
+    with pytest.raises(ValueError):
+        m.msi_render_equirect_view(rgba, np.eye(4, dtype=np.float32)[None], np.array([[1.5, 0, 0]], np.float32),
+                                   [100.0, 1.0], None)
+
+
+def test_full_size_render_properties(gpu):
+    """BASELINE size (640x320x32): size-independent properties instead of the oracle --
+    (a) constant-colour layers composite to the closed form, (b) linearity in rgb."""
+    torch, m, o = gpu
+    b, h, w, d = 1, 320, 640, 32
+    g = torch.Generator(device="cpu").manual_seed(0)
+    alpha = torch.rand((b, d, h, w, 1), generator=g)
+    col = torch.linspace(-1, 1, d).view(1, d, 1, 1, 1).expand(b, d, h, w, 3)
+    rgba = torch.cat([col, alpha.mul(0).add(0.25)], dim=-1).cuda().permute(0, 2, 3, 1, 4)
+    planes = m.inv_depths(1.0, 100.0, d)
+    pos = np.array([[0.03, 0.05, -0.08]], np.float32)
+    eye = np.eye(4, dtype=np.float32)[None]
+    rgb = m.msi_render_equirect_view(rgba, eye, pos, planes, None)
+    exp = float(col[0, 0, 0, 0, 0])
+    for i in range(1, d):
+        exp = float(col[0, i, 0, 0, 0]) * 0.25 + exp * 0.75
+    assert torch.abs(rgb - exp).max().item() < 1e-5
+    # linearity: render(2*rgb_layers) == 2*render(rgb_layers) for the colour channels
+    rnd = torch.rand((b, h, w, d, 4), generator=g).cuda()
+    r1 = m.msi_render_equirect_view(rnd, eye, pos, planes, None)
+    rnd2 = rnd.clone()
+    rnd2[..., :3] *= 2
+    r2 = m.msi_render_equirect_view(rnd2, eye, pos, planes, None)
+    assert torch.allclose(r2, 2 * r1, atol=1e-5)
