@@ -26,6 +26,8 @@
 // k-step s+1 issued before the MFMAs of step s, one barrier per k-step.
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -34,6 +36,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 struct copies lower to memcpy through scratch)
 
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = 36;
@@ -44,7 +47,9 @@ enum { MODE_CONV = 0, MODE_CONVT = 1, MODE_HEAD = 2 };
 
 struct ConvParams {
   const float *x0, *x1;      // NHWC sources (x1 = second half of a skip concat or null)
-  const float *aff0, *aff1;  // per sample [2][C]: scale | shift of the producer's LayerNorm, or null
+  const float *aff0, *aff1;  // [2][C]: scale | shift of the producer's LayerNorm (identity table for raw inputs)
+  int aff_bs0, aff_bs1;      // per-sample stride of aff0/aff1 in floats (2*C, or 0 for the identity table)
+  float floor0, floor1;      // 0 (ReLU after LayerNorm) or -inf (raw input)
   const float *wpk;          // packed weights [nclass][ksteps][npad][32]
   const float *coord;        // |sin(lat)| per input row [Hin], or null
   const float *bias;         // head only
@@ -56,15 +61,16 @@ struct ConvParams {
   int ntaps, cpt, ksteps;    // taps, 32-channel chunks per tap, total k-steps (incl. coord step)
   int stride, rate, pad_t, pad_l;
   int mode, wrap, nclass;
+  int ablate;                // debug only (MSI_CONV_ABLATE): 1 = skip global loads, 2 = skip MFMAs
 };
 
-__device__ __forceinline__ void tap_offset(const ConvParams &p, int tap, int ph, int pw, int &dh,
-                                           int &dw) {
-  if (p.mode == MODE_CONV) {
+template <int MODE>
+__device__ __forceinline__ void tap_offset(int rate, int tap, int ph, int pw, int &dh, int &dw) {
+  if (MODE == MODE_CONV) {
     const int kh = tap / 3, kw = tap - kh * 3;
-    dh = kh * p.rate;
-    dw = kw * p.rate;
-  } else if (p.mode == MODE_CONVT) {
+    dh = kh * rate;
+    dw = kw * rate;
+  } else if (MODE == MODE_CONVT) {
     // y[2i + k - 1] += x[i] w[k]: even outputs use k=1 (i = o/2) and k=3 (i = o/2 - 1),
     // odd outputs k=2 (i = (o-1)/2) and k=0 (i = (o+1)/2).
     const int th = tap >> 1, tw = tap & 1;
@@ -76,11 +82,11 @@ __device__ __forceinline__ void tap_offset(const ConvParams &p, int tap, int ph,
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int MODE>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(const ConvParams p) {
   constexpr int MT = BM / 64, NT = BN / 64;  // 32x32 tiles per wave (2x2 waves)
-  constexpr int AR = BM / 32, BR = BN / 32;  // float4 rows per thread per k-step
+  constexpr int AR = BM / 32, BR = BN / 32;  // v4f rows per thread per k-step
   constexpr int STAGE = (BM + BN) * LDS_STRIDE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -104,98 +110,145 @@ conv_igemm_kernel(const ConvParams p) {
     if (m < mtot) r_ok |= 1u << rr;
   }
   const size_t in_pix = (size_t)p.Hin * p.Win;
-  const float *wbase = p.wpk + ((size_t)cls * p.ksteps * p.npad + (size_t)tile_n * BN) * BK;
+  const int wrap_w = p.wrap ? p.Win : 0;
+  const float *wbase = p.wpk + ((size_t)cls * p.ksteps * p.npad + (size_t)tile_n * BN) * BK + tid * 4;
 
-  float4 ra[AR], rb[BR];
-  float4 sc4, sh4;
-  unsigned okm = 0;
-  bool has_aff = false;
+  // register staging of one k-step (A rows, B rows, the producer's LayerNorm affine, masks);
+  // two instances: the loads of steps s+1 and s+2 are both in flight while step s computes
+  struct Stage {
+    v4f ra[AR], rb[BR];
+    v4f sc4, sh4;
+    float floor_v;
+    unsigned okm;
+  };
+  Stage stA, stB;
 
-  auto load_step = [&](int s) {
-    const bool coord_step = (p.coord != nullptr) && (s == p.ksteps - 1);
-    okm = 0;
-    has_aff = false;
-    if (!coord_step) {
-      const int tap = s / p.cpt;
-      const int c0 = (s - tap * p.cpt) * BK;
-      int dh, dw;
-      tap_offset(p, tap, ph, pw, dh, dw);
-      const float *src, *aff;
-      int C, c;
-      if (c0 < p.C0) {
-        C = p.C0; c = c0 + cq * 4;
-        src = p.x0 + (size_t)b * in_pix * C;
-        aff = p.aff0 ? p.aff0 + (size_t)b * 2 * C : nullptr;
-      } else {
-        C = p.C1; c = c0 - p.C0 + cq * 4;
-        src = p.x1 + (size_t)b * in_pix * C;
-        aff = p.aff1 ? p.aff1 + (size_t)b * 2 * C : nullptr;
-      }
-      const bool cvalid = c < C;
-      if (aff && cvalid) {
-        has_aff = true;
-        sc4 = *reinterpret_cast<const float4 *>(aff + c);
-        sh4 = *reinterpret_cast<const float4 *>(aff + C + c);
-      }
+  // Input coordinates of GEMM row rr for tap offset (dh, dw); loads are UNCONDITIONAL from a
+  // clamped address (no control flow around the global loads, so the whole k-step is one basic
+  // block and the loads stay in flight across the MFMAs); the validity bit masks the value when
+  // it is written to LDS.
+  auto tap_coords = [&](int rr, int dh, int dw, int &ihc, int &iwc) __attribute__((always_inline)) -> bool {
+    const int ih = r_ih[rr] + dh;
+    int iw = r_iw[rr] + dw;
+    iw = iw < 0 ? iw + wrap_w : (iw >= p.Win ? iw - wrap_w : iw);  // wrap_w = 0: plain zero padding
+    const bool ok = ((r_ok >> rr) & 1u) & (ih >= 0) & (ih < p.Hin) & (iw >= 0) & (iw < p.Win);
+    ihc = min(max(ih, 0), p.Hin - 1);
+    iwc = min(max(iw, 0), p.Win - 1);
+    return ok;
+  };
+
+  // Regular k-step = 32 channels [c0, c0+32) of tap `tap`.  The expensive part of the address
+  // arithmetic (tap offset, wrap, bounds, clamping) depends only on the tap, so it is done once
+  // per tap (new_tap) and a k-step itself costs one multiply-add per row (gen_addr).
+  int t_pix[AR];             // clamped input pixel index of each row for the current tap
+  unsigned t_okm = 0;        // validity of each row for the current tap
+  int a_off[AR];             // element offsets of the A rows inside the selected source
+  unsigned a_okm = 0;
+  const float *a_src = p.x0, *a_aff = p.aff0, *a_wb = wbase;
+  int a_C = p.C0;
+  int a_cc = 0;
+  float a_floor = -INFINITY;
+  // per-source bases hoisted into SGPRs (selecting p.x0/p.x1 directly makes the compiler index
+  // the kernarg segment with a dependent s_load every k-step)
+  const int kC0 = p.C0, kC1 = p.C1;
+  const float *src0 = p.x0 + (size_t)b * in_pix * kC0;
+  const float *src1 = p.x1 + (size_t)b * in_pix * kC1;
+  const float *affp0 = p.aff0 + (size_t)b * p.aff_bs0;
+  const float *affp1 = p.aff1 + (size_t)b * p.aff_bs1;
+  const float kfloor0 = p.floor0, kfloor1 = p.floor1;
+  // source selection as a byte delta from source 0 (a select between two POINTERS is lowered to a
+  // lookup in a private array + flat loads; an integer select stays in SGPRs and keeps the
+  // global address space)
+  const long d_src = (const char *)src1 - (const char *)src0;
+  const long d_aff = (const char *)affp1 - (const char *)affp0;
+
+  auto new_tap = [&](int tap) __attribute__((always_inline)) {
+    int dh, dw;
+    tap_offset<MODE>(p.rate, tap, ph, pw, dh, dw);
+    t_okm = 0;
 #pragma unroll
-      for (int rr = 0; rr < AR; ++rr) {
-        const int ih = r_ih[rr] + dh;
-        int iw = r_iw[rr] + dw;
-        if (p.wrap) iw = iw < 0 ? iw + p.Win : (iw >= p.Win ? iw - p.Win : iw);
-        const bool ok = ((r_ok >> rr) & 1u) && cvalid && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-          v = *reinterpret_cast<const float4 *>(src + ((size_t)ih * p.Win + iw) * C + c);
-          okm |= 1u << rr;
-        }
-        ra[rr] = v;
-      }
-    } else {
-      // CoordNet channel: "channel" kk of this k-step is tap kk of the coordinate plane.
+    for (int rr = 0; rr < AR; ++rr) {
+      int ihc, iwc;
+      const bool ok = tap_coords(rr, dh, dw, ihc, iwc);
+      t_pix[rr] = ihc * p.Win + iwc;
+      t_okm |= (ok ? 1u : 0u) << rr;
+    }
+  };
+
+  auto gen_addr = [&](int s, int c0) __attribute__((always_inline)) {
+    const bool first = c0 < kC0;  // wave-uniform: scalar selects, no branch
+    const int C = first ? kC0 : kC1;
+    const int c = (first ? c0 : c0 - kC0) + cq * 4;
+    a_src = reinterpret_cast<const float *>((const char *)src0 + (first ? 0L : d_src));
+    a_aff = reinterpret_cast<const float *>((const char *)affp0 + (first ? 0L : d_aff));
+    a_floor = first ? kfloor0 : kfloor1;
+    a_C = C;
+    const bool cvalid = c < C;
+    a_cc = cvalid ? c : 0;
+    a_okm = cvalid ? t_okm : 0u;
 #pragma unroll
-      for (int rr = 0; rr < AR; ++rr) {
-        float vv[4];
+    for (int rr = 0; rr < AR; ++rr) a_off[rr] = t_pix[rr] * C + a_cc;
+    a_wb = wbase + (size_t)s * p.npad * BK;
+  };
+
+  auto issue_load = [&](Stage &st) __attribute__((always_inline)) {
+    st.sc4 = *reinterpret_cast<const v4f *>(a_aff + a_cc);
+    st.sh4 = *reinterpret_cast<const v4f *>(a_aff + a_C + a_cc);
+    st.floor_v = a_floor;
+    st.okm = a_okm;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int tap = cq * 4 + e;
-          float val = 0.f;
-          if (tap < p.ntaps) {
-            int dh, dw;
-            tap_offset(p, tap, ph, pw, dh, dw);
-            const int ih = r_ih[rr] + dh;
-            int iw = r_iw[rr] + dw;
-            if (p.wrap) iw = iw < 0 ? iw + p.Win : (iw >= p.Win ? iw - p.Win : iw);
-            const bool ok = ((r_ok >> rr) & 1u) && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
-            if (ok) val = p.coord[ih];
-          }
-          vv[e] = val;
-        }
-        ra[rr] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    for (int rr = 0; rr < AR; ++rr) st.ra[rr] = *reinterpret_cast<const v4f *>(a_src + a_off[rr]);
+#pragma unroll
+    for (int rr = 0; rr < BR; ++rr) st.rb[rr] = *reinterpret_cast<const v4f *>(a_wb + rr * 1024);
+  };
+
+  // CoordNet k-step (the last one): "channel" kk is tap kk of the |sin(lat)| plane
+  auto load_coord_step = [&](int s, Stage &st) __attribute__((always_inline)) {
+    st.sc4 = v4f{1.f, 1.f, 1.f, 1.f};
+    st.sh4 = v4f{0.f, 0.f, 0.f, 0.f};
+    st.floor_v = -INFINITY;
+    st.okm = r_ok;
+#pragma unroll
+    for (int rr = 0; rr < AR; ++rr) {
+      float vv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int tap = cq * 4 + e;
+        int dh, dw, ihc, iwc;
+        tap_offset<MODE>(p.rate, tap < p.ntaps ? tap : 0, ph, pw, dh, dw);
+        const bool ok = tap_coords(rr, dh, dw, ihc, iwc) & (tap < p.ntaps);
+        const float cv = p.coord[ihc];
+        vv[e] = ok ? cv : 0.f;
       }
+      st.ra[rr] = v4f{vv[0], vv[1], vv[2], vv[3]};
     }
     const float *wb = wbase + (size_t)s * p.npad * BK;
 #pragma unroll
-    for (int rr = 0; rr < BR; ++rr) rb[rr] = *reinterpret_cast<const float4 *>(wb + tid * 4 + rr * 1024);
+    for (int rr = 0; rr < BR; ++rr) st.rb[rr] = *reinterpret_cast<const v4f *>(wb + rr * 1024);
   };
 
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, const Stage &st) __attribute__((always_inline)) {
     float *As = smem + buf * STAGE;
     float *Bs = As + BM * LDS_STRIDE;
 #pragma unroll
     for (int rr = 0; rr < AR; ++rr) {
-      float4 v = ra[rr];
-      if (has_aff && ((okm >> rr) & 1u)) {
-        // slim.layer_norm + ReLU of the producer: y = x*inv*gamma + (beta - mean*inv*gamma)
-        v.x = fmaxf(v.x * sc4.x + sh4.x, 0.f);
-        v.y = fmaxf(v.y * sc4.y + sh4.y, 0.f);
-        v.z = fmaxf(v.z * sc4.z + sh4.z, 0.f);
-        v.w = fmaxf(v.w * sc4.w + sh4.w, 0.f);
-      }
-      *reinterpret_cast<float4 *>(As + (lr + 32 * rr) * LDS_STRIDE + cq * 4) = v;
+      v4f v = st.ra[rr];
+      // slim.layer_norm + ReLU of the producer: y = max(x*inv*gamma + (beta - mean*inv*gamma), 0);
+      // raw sources (the network input) use scale 1, shift 0, floor -inf: the identity.
+      v.x = fmaxf(v.x * st.sc4.x + st.sh4.x, st.floor_v);
+      v.y = fmaxf(v.y * st.sc4.y + st.sh4.y, st.floor_v);
+      v.z = fmaxf(v.z * st.sc4.z + st.sh4.z, st.floor_v);
+      v.w = fmaxf(v.w * st.sc4.w + st.sh4.w, st.floor_v);
+      const bool ok = (st.okm >> rr) & 1u;  // zero padding / tile tails (applied AFTER the LayerNorm)
+      v.x = ok ? v.x : 0.f;
+      v.y = ok ? v.y : 0.f;
+      v.z = ok ? v.z : 0.f;
+      v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<v4f *>(As + (lr + 32 * rr) * LDS_STRIDE + cq * 4) = v;
     }
 #pragma unroll
     for (int rr = 0; rr < BR; ++rr)
-      *reinterpret_cast<float4 *>(Bs + (lr + 32 * rr) * LDS_STRIDE + cq * 4) = rb[rr];
+      *reinterpret_cast<v4f *>(Bs + (lr + 32 * rr) * LDS_STRIDE + cq * 4) = st.rb[rr];
   };
 
   f32x16 acc[MT][NT];
@@ -206,28 +259,22 @@ conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_step(0);
-  store_step(0);
-  __syncthreads();
-
   const int arow = wm * (MT * 32) + (lane & 31);
   const int brow = wn * (NT * 32) + (lane & 31);
   const int kh0 = (lane >> 5) * 16;
 
-  for (int s = 0; s < p.ksteps; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < p.ksteps) load_step(s + 1);
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const float *As = smem + buf * STAGE;
     const float *Bs = As + BM * LDS_STRIDE;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float4 a[MT], bb[NT];
+      v4f a[MT], bb[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
-        a[i] = *reinterpret_cast<const float4 *>(As + (arow + i * 32) * LDS_STRIDE + kh0 + q * 4);
+        a[i] = *reinterpret_cast<const v4f *>(As + (arow + i * 32) * LDS_STRIDE + kh0 + q * 4);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        bb[j] = *reinterpret_cast<const float4 *>(Bs + (brow + j * 32) * LDS_STRIDE + kh0 + q * 4);
+        bb[j] = *reinterpret_cast<const v4f *>(Bs + (brow + j * 32) * LDS_STRIDE + kh0 + q * 4);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -238,7 +285,58 @@ conv_igemm_kernel(const ConvParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, bb[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (s + 1 < p.ksteps) store_step(buf ^ 1);
+  };
+
+  // ---- main loop ---------------------------------------------------------------------------
+  // Two k-steps of global loads are in flight (register stages stA/stB) while a third computes:
+  //   top    : addresses (one mad per row) + global loads of step s+2
+  //   middle : 16*MT*NT MFMAs of step s from LDS buffer s&1
+  //   bottom : wait for step s+1's loads (issued one iteration ago), LayerNorm/ReLU/mask,
+  //            ds_write to the other LDS buffer, barrier
+  // The loop is unrolled by two so the stages are addressed statically; past the last step the
+  // address generator re-issues the last step instead of branching around the loads.
+  const int nreg = p.ntaps * p.cpt;  // regular k-steps; + 1 coord step when p.coord
+  int tap = 0, chunk = 0, gstep = 0;
+  auto next_addr = [&]() __attribute__((always_inline)) {
+    if (gstep + 1 < nreg) {              // wave-uniform
+      ++gstep;
+      if (++chunk == p.cpt) {            // once per tap
+        chunk = 0;
+        new_tap(++tap);
+      }
+    }
+    gen_addr(gstep, chunk * BK);
+  };
+  new_tap(0);
+  gen_addr(0, 0);
+  issue_load(stA);
+  store_step(0, stA);
+  next_addr();
+  issue_load(stA);                       // step 1 in flight
+  __syncthreads();
+  for (int s = 0; s < nreg; s += 2) {
+    next_addr();
+    if (!(p.ablate & 1)) issue_load(stB);  // step s+2
+    __builtin_amdgcn_sched_barrier(0);     // keep the loads above the MFMAs
+    if (!(p.ablate & 2)) compute(0);       // step s
+    __builtin_amdgcn_sched_barrier(0);     // the tail must not pull its vmcnt wait up
+    store_step(1, stA);                    // step s+1
+    __syncthreads();
+    if (s + 1 >= nreg) break;
+    next_addr();
+    if (!(p.ablate & 1)) issue_load(stA);  // step s+3
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(p.ablate & 2)) compute(1);       // step s+1
+    __builtin_amdgcn_sched_barrier(0);
+    store_step(0, stB);                    // step s+2
+    __syncthreads();
+  }
+  if (p.coord != nullptr) {
+    const int buf = nreg & 1;
+    load_coord_step(nreg, stA);
+    store_step(buf, stA);
+    __syncthreads();
+    compute(buf);
     __syncthreads();
   }
 
@@ -254,7 +352,7 @@ conv_igemm_kernel(const ConvParams p) {
       const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
       if (m >= mtot) continue;
       size_t opix;
-      if (p.mode == MODE_CONVT) {
+      if (MODE == MODE_CONVT) {
         const int mh = m / p.Mw, mw = m - mh * p.Mw;
         opix = ((size_t)b * p.Hout + (2 * mh + ph)) * p.Wout + (2 * mw + pw);
       } else {
@@ -265,19 +363,19 @@ conv_igemm_kernel(const ConvParams p) {
         const int n = tile_n * BN + wn * (NT * 32) + j * 32 + col;
         if (n >= p.Cout) continue;
         float v = acc[i][j][r];
-        if (p.mode == MODE_HEAD) v = tanhf(v + p.bias[n]);
+        if (MODE == MODE_HEAD) v = tanhf(v + p.bias[n]);
         p.y[opix * p.Cout + n] = v;
         lsum += v;
         cnt += 1.f;
       }
     }
   }
-  if (p.stats == nullptr) return;
+  if (MODE == MODE_HEAD || p.stats == nullptr) return;
 
   // block mean, then M2 about the block mean (two-pass inside the block: the values
   // are still in registers), reduced in a fixed order.
   float *red = smem;  // all LDS reads of the main loop are behind the last barrier
-  auto block_sum = [&](float v) -> float {
+  auto block_sum = [&](float v) __attribute__((always_inline)) -> float {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     __syncthreads();
@@ -383,6 +481,7 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Net {
   std::vector<Layer> layers;
   size_t param_floats = 0, packed_floats = 0, ws_bytes = 0, stats_off = 0, stats_bytes = 0;
+  size_t ident_off = 0;  // floats inside the packed blob: ones[in_channels] zeros[in_channels]
 };
 
 int build_net(const msi_net_desc *d, Net &net) {
@@ -451,6 +550,8 @@ int build_net(const msi_net_desc *d, Net &net) {
     if (L.c1 > 0 && L.c0 % BK)
       return msi::fail(MSI_E_UNSUPPORTED, "net: first skip operand of %s has %d channels (need a multiple of %d)",
                        s.name, L.c0, BK);
+    if ((size_t)sh * sw * (size_t)(L.c0 > L.c1 ? L.c0 : L.c1) >= ((size_t)1 << 31))
+      return msi::fail(MSI_E_UNSUPPORTED, "net: %s input exceeds 2^31 elements per sample", s.name);
     L.cpt = (int)((L.cin + BK - 1) / BK);
     L.ksteps = L.ntaps * L.cpt + (L.has_coord ? 1 : 0);
     L.npad = (int)round_up(L.cout, NPAD_ALIGN);
@@ -485,6 +586,8 @@ int build_net(const msi_net_desc *d, Net &net) {
     if (parts > max_parts) max_parts = parts;
   }
   net.param_floats = poff;
+  net.ident_off = koff;
+  koff = round_up(koff + (size_t)2 * d->in_channels, 64);
   net.packed_floats = koff;
   net.stats_off = woff;
   net.stats_bytes = round_up((size_t)d->batch * max_parts * 4 * sizeof(float), 256);
@@ -492,23 +595,32 @@ int build_net(const msi_net_desc *d, Net &net) {
   return MSI_OK;
 }
 
-template <int BM, int BN>
-int launch_conv(const ConvParams &p, int batch, hipStream_t stream, int *nparts) {
+template <int BM, int BN, int MODE>
+int launch_conv_mode(const ConvParams &p, int batch, hipStream_t stream, int *nparts) {
   const int mtot = p.Mh * p.Mw;
   const dim3 grid((mtot + BM - 1) / BM, (p.Cout + BN - 1) / BN, batch * p.nclass);
   const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
   if (lds > 64 * 1024) {
     static thread_local bool done = false;
     if (!done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, MODE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "conv: %s", hipGetErrorString(e));
       done = true;
     }
   }
   *nparts = grid.x * grid.y * p.nclass;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE>), grid, dim3(256), lds, stream, p);
   return msi::check_launch("conv_igemm");
+}
+
+template <int BM, int BN>
+int launch_conv(const ConvParams &p, int batch, hipStream_t stream, int *nparts) {
+  switch (p.mode) {
+    case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV>(p, batch, stream, nparts);
+    case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT>(p, batch, stream, nparts);
+    default: return launch_conv_mode<BM, BN, MODE_HEAD>(p, batch, stream, nparts);
+  }
 }
 
 // Tile choice: the largest tile that still gives every CU about two workgroups.
@@ -566,6 +678,7 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
   if (rc) return rc;
   MSI_REQUIRE(params && packed, "net_pack_weights: null pointer");
   memset(packed, 0, net.packed_floats * sizeof(float));
+  for (int c = 0; c < desc->in_channels; ++c) packed[net.ident_off + c] = 1.0f;  // identity affine of the raw input
   for (const Layer &L : net.layers) {
     const float *w = params + L.param_off;
     float *o = packed + L.packed_off;
@@ -640,15 +753,25 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
     auto src_ptr = [&](int s) -> const float * {
       return s < 0 ? net_input : reinterpret_cast<const float *>(ws + net.layers[s].raw_off);
     };
-    auto aff_ptr = [&](int s) -> const float * {
-      return s < 0 ? nullptr : reinterpret_cast<const float *>(ws + net.layers[s].aff_off);
+    auto set_src = [&](int s, const float *&x, const float *&aff, int &bs, float &floor_v, int C) {
+      if (s < 0) {  // the network input: no LayerNorm/ReLU in front of it
+        x = net_input;
+        aff = packed + net.ident_off;
+        bs = 0;
+        floor_v = -INFINITY;
+      } else {
+        x = reinterpret_cast<const float *>(ws + net.layers[s].raw_off);
+        aff = reinterpret_cast<const float *>(ws + net.layers[s].aff_off);
+        bs = 2 * C;
+        floor_v = 0.0f;
+      }
     };
-    p.x0 = src_ptr(L.src0);
-    p.aff0 = aff_ptr(L.src0);
+    set_src(L.src0, p.x0, p.aff0, p.aff_bs0, p.floor0, L.c0);
     p.C0 = L.c0;
+    // unused second source: alias the first (never selected since c0 < C0 always holds)
+    p.x1 = p.x0; p.aff1 = p.aff0; p.aff_bs1 = p.aff_bs0; p.floor1 = p.floor0; p.C1 = 0;
     if (L.src1 >= 0) {
-      p.x1 = src_ptr(L.src1);
-      p.aff1 = aff_ptr(L.src1);
+      set_src(L.src1, p.x1, p.aff1, p.aff_bs1, p.floor1, L.c1);
       p.C1 = L.c1;
     }
     p.wpk = packed + L.packed_off;
@@ -681,6 +804,12 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
     }
     int bm, bn, nparts = 0;
     choose_tile(p.Mh * p.Mw, L.cout, desc->batch * L.nclass, bm, bn);
+    {  // debug knobs, read once
+      static const char *abl = getenv("MSI_CONV_ABLATE");
+      static const char *til = getenv("MSI_CONV_TILE");
+      p.ablate = abl ? atoi(abl) : 0;
+      if (til) { int a = 0, c = 0; if (sscanf(til, "%dx%d", &a, &c) == 2 && (c <= 64 || L.cout > 64)) { bm = a; bn = c; } }
+    }
     if (bm == 128 && bn == 128) rc = launch_conv<128, 128>(p, desc->batch, stream, &nparts);
     else if (bm == 128 && bn == 64) rc = launch_conv<128, 64>(p, desc->batch, stream, &nparts);
     else rc = launch_conv<64, 64>(p, desc->batch, stream, &nparts);

@@ -156,11 +156,14 @@ class MSI(object):
         b, h, w, c = ref_image.shape
         if c != 3 or src_image.shape != ref_image.shape:
             raise ValueError("format_network_input: images must be [B,H,W,3] and agree")
+        # 4x4 pose composition stays on whatever device the poses live on; only a missing
+        # ref_pose_inv is computed on the host (pass it explicitly to avoid the round trip)
         ref_pose = torch.as_tensor(ref_pose, dtype=torch.float32)
-        src_pose = torch.as_tensor(src_pose, dtype=torch.float32)
+        pdev = ref_pose.device
+        src_pose = torch.as_tensor(src_pose, dtype=torch.float32).to(pdev)
         if ref_pose_inv is None:
-            ref_pose_inv = torch.linalg.inv(ref_pose.cpu().double()).float()
-        ref_pose_inv = torch.as_tensor(ref_pose_inv, dtype=torch.float32).cpu()
+            ref_pose_inv = torch.linalg.inv(ref_pose.cpu().double()).float()   # test.py:111
+        ref_pose_inv = torch.as_tensor(ref_pose_inv, dtype=torch.float32).to(pdev)
         depths = self._planes(planes)
         nd = depths.numel()
         intr = self._f32(intrinsics)
@@ -168,7 +171,7 @@ class MSI(object):
         psv = torch.empty((b, h, w, 6 * nd), dtype=torch.float32, device=self.device)
         # order = +1 for the reference image (i = 0), -1 for the source (i = 1), msi.py:1127
         for i, (img, pose) in enumerate(((ref_image, ref_pose), (src_image, src_pose))):
-            curr_pose = self._f32(torch.matmul(pose.cpu(), ref_pose_inv))      # msi.py:1125
+            curr_pose = self._f32(torch.matmul(pose, ref_pose_inv))            # msi.py:1125
             order = 1 if (i % 2) == 0 else -1
             N.check(N.lib.msi_ods_sphere_sweep_f32(
                 img.data_ptr(), curr_pose.data_ptr(), intr.data_ptr(), depths.data_ptr(), trig.data_ptr(),

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Turns a rocprofv3 rocpd database (`rocprofv3 --kernel-trace --stats -d DIR -o NAME`, which
+writes DIR/NAME_results.db on ROCm 7.2) into the text summary kept under profiles/:
+per-kernel totals (the --stats table) and, for the conv kernel, one line per layer of the
+last frame with its achieved TFLOP/s.
+
+    python tools/rocprof_summary.py gpurun_out/prof/x_results.db [--frames N] > profiles/rNN_kernel_stats.txt
+"""
+import argparse
+import sqlite3
+import sys
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("db")
+    ap.add_argument("--frames", type=int, default=0, help="frames in the profiled run (warmup + steps), for per-frame totals")
+    args = ap.parse_args()
+    c = sqlite3.connect(args.db)
+    rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                     "from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    print("# rocprofv3 --kernel-trace --stats summary of %s" % args.db)
+    print("%-100s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
+    for r in rows[:24]:
+        print("%-100s %7d %12.1f %10.2f %10.2f %10.2f %6.2f" % (r[0][:100], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot))
+    if args.frames:
+        print("\n# per frame (%d frames): " % args.frames + ", ".join(
+            "%s %.1f us" % (r[0].split("(")[0].split("::")[-1][:40], r[2] / 1e3 / args.frames) for r in rows[:8]))
+    conv = c.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, lds_size, vgpr_count, accum_vgpr_count "
+                     "from kernels where name like '%conv_igemm%' order by start").fetchall()
+    if len(conv) >= 18:
+        print("\n# conv_igemm launches of the last frame (18 layers, graph order)")
+        names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2",
+                 "conv4_3", "conv6_1", "conv6_2", "conv6_3", "conv7_1", "conv7_2", "conv8_1", "conv8_2", "color_pred"]
+        for nm, r in zip(names, conv[-18:]):
+            tmpl = r[0].split("<")[1].split(">")[0] if "<" in r[0] else "?"
+            print("%-10s tile<%s> blocks=(%d,%d,%d) lds=%d vgpr=%d agpr=%d  %9.1f us" % (
+                nm, tmpl, r[3] // r[6], r[4], r[5], r[7], r[8], r[9], (r[2] - r[1]) / 1e3))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
