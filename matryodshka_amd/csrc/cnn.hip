@@ -2,28 +2,40 @@
 // (reference nets.py:471-515 / 387-450) as implicit-GEMM convolutions on the
 // gfx950 fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32, a k-ordered fma chain).
 //
+// Design rule (measured, tools/ubench/mfma_valu_overlap.hip): on gfx950 the fp32-input MFMA
+// runs on the SIMD's fp32 ALUs -- MFMA and VALU work do NOT overlap, neither inside one wave
+// (8 MFMA + 128 fma = 6.3 ms vs 4.4 + 2.6 alone) nor between two waves of one SIMD.  Every
+// VALU instruction in the k-loop is therefore paid for in matrix throughput, so the k-loop of
+// this kernel contains no VALU at all:
+//   * both GEMM operands go HBM/L2 -> LDS by buffer DMA (`buffer_load_dwordx4 ... lds`):
+//     no VGPR staging, no ds_write; the per-lane offsets are constant over a (tap, source)
+//     segment and the channel walk is a scalar soffset;
+//   * zero padding, M-tile tails and channel tails are lanes whose offset is out of range of the
+//     buffer descriptor: the hardware zero-fills those LDS slots (probed: tools/ubench/dma_oob.hip);
+//   * the LDS image is linear per row (128 B = 32 channels) with the 16-byte slot XOR-swizzled by
+//     (row>>1)&7 -- applied to the per-lane SOURCE offset for A and baked into the packed
+//     weights for B -- which makes the ds_read_b128 operand fetch bank-conflict free;
+//   * ds_read addresses are precomputed per (stage, quarter) so the loop needs no address VALU;
+//   * a 3-stage LDS ring with counted vmcnt keeps two k-steps of DMA in flight across the
+//     single barrier per k-step.
+// Consequence: the producer's LayerNorm + ReLU can no longer be applied in the operand loader;
+// it is applied once, in place, by ln_apply_kernel (HBM-bound, ~1 read + 1 write per activation)
+// instead of 9 x Cout/BN times in VALU.
+//
 // One kernel template serves every layer:
 //   * conv3x3 (stride 1/2, rate 1/2, SAME-zero or wrap padding), the 1x1 head,
 //     and conv-transpose 4x4 s2 as four output-parity sub-convolutions of 2x2
 //     taps each (blockIdx.z selects the parity class);
 //   * GEMM view: M = pixels of one sample, N = Cout, K = taps x Cin, walked in
-//     k-steps of 32 channels of one tap; A is gathered on the fly from the NHWC
-//     producer(s) (two sources = skip concat by pointer pair, no concat copy);
-//   * the producer's LayerNorm (+ReLU) is applied in the A-operand loader as a
-//     per-channel scale/shift (zero padding stays zero: padding is applied to
-//     the normalised activation in the reference), so normalised activations
-//     are never written to HBM;
+//     k-steps of 32 channels of one tap; two sources = skip concat by descriptor pair;
 //   * CoordNet's |sin(lat)| channel (nets.py:260-265) is constant along W: it is
-//     one extra k-step whose 32 "channels" are the <=9 taps of that channel,
-//     keeping K a multiple of 32;
+//     one extra k-step whose 32 "channels" are the <=9 taps of that channel, read from a small
+//     host-built table indexed by (output row, column border class);
 //   * the epilogue writes the raw conv output and one (count, mean, M2) partial
-//     per workgroup; a small finish kernel merges the partials in fp64 in a fixed
-//     order (Chan) into the per-channel scale/shift the consumer loads.
+//     per workgroup; ln_finish_kernel merges the partials in fp64 in a fixed
+//     order (Chan) into the per-channel scale/shift; ln_apply_kernel normalises in place.
 //
-// Tiling: 256 threads = 4 wavefronts (2x2), wave tile (BM/2)x(BN/2) of 32x32
-// MFMA tiles, BK=32, double-buffered LDS (row stride 36 floats: ds_read_b128 of
-// 16 distinct rows is bank-conflict free), register-staged global prefetch of
-// k-step s+1 issued before the MFMAs of step s, one barrier per k-step.
+// Tiling: 256 threads = 4 wavefronts (2x2), wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, BK=32.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -36,32 +48,33 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 struct copies lower to memcpy through scratch)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int BK = 32;
-constexpr int LDS_STRIDE = 36;
+constexpr int ROW_BYTES = BK * 4;   // one LDS row = 32 channels of one GEMM row
+constexpr int NSTAGE = 3;
 constexpr int NPAD_ALIGN = 128;
+constexpr int COORD_CLASSES = 5;    // column border classes of the CoordNet table: 0,1 | interior | W-2,W-1
+constexpr unsigned OOB = 0x80000000u;  // per-lane offset that is out of range of every descriptor
 constexpr double LN_EPS = 1e-12;  // slim.layer_norm variance epsilon [TF-knowledge]
 
 enum { MODE_CONV = 0, MODE_CONVT = 1, MODE_HEAD = 2 };
 
 struct ConvParams {
-  const float *x0, *x1;      // NHWC sources (x1 = second half of a skip concat or null)
-  const float *aff0, *aff1;  // [2][C]: scale | shift of the producer's LayerNorm (identity table for raw inputs)
-  int aff_bs0, aff_bs1;      // per-sample stride of aff0/aff1 in floats (2*C, or 0 for the identity table)
-  float floor0, floor1;      // 0 (ReLU after LayerNorm) or -inf (raw input)
-  const float *wpk;          // packed weights [nclass][ksteps][npad][32]
-  const float *coord;        // |sin(lat)| per input row [Hin], or null
+  const float *x0, *x1;      // NHWC sources, already normalised (x1 = second half of a skip concat)
+  const float *wpk;          // packed weights [nclass][ksteps][npad][32], slots pre-swizzled
+  const float *coord_tab;    // CoordNet table [Mh][COORD_CLASSES][32] or null
   const float *bias;         // head only
   float *y;                  // raw output NHWC [B,Hout,Wout,Cout]
   float *stats;              // [B][nparts][4] (count, mean, M2, -) or null
   int C0, C1;
   int Hin, Win, Hout, Wout, Cout, npad;
   int Mh, Mw;                // GEMM row grid per sample (output grid; input grid for convT)
-  int ntaps, cpt, ksteps;    // taps, 32-channel chunks per tap, total k-steps (incl. coord step)
+  int ntaps, cpt0, cpt1, ksteps;  // taps, 32-channel chunks per tap of each source, total k-steps
   int stride, rate, pad_t, pad_l;
   int mode, wrap, nclass;
-  int ablate;                // debug only (MSI_CONV_ABLATE): 1 = skip global loads, 2 = skip MFMAs
+  int ablate;                // debug only (MSI_CONV_ABLATE): 1 = skip DMA, 2 = skip MFMAs
 };
 
 template <int MODE>
@@ -82,174 +95,155 @@ __device__ __forceinline__ void tap_offset(int rate, int tap, int ph, int pw, in
   }
 }
 
+__device__ __forceinline__ int coord_class(int mw, int Mw) {
+  return mw < 2 ? mw : (mw >= Mw - 2 ? 3 + (mw - (Mw - 2)) : 2);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int BM, int BN, int MODE>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(const ConvParams p) {
-  constexpr int MT = BM / 64, NT = BN / 64;  // 32x32 tiles per wave (2x2 waves)
-  constexpr int AR = BM / 32, BR = BN / 32;  // v4f rows per thread per k-step
-  constexpr int STAGE = (BM + BN) * LDS_STRIDE;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (the body uses device-only types)
+  constexpr int MT = BM / 64, NT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
+  constexpr int AI = BM / 32, BI = BN / 32;  // DMA wave-instructions (8 rows x 128 B each) per wave per k-step
+  constexpr int ND = AI + BI;
+  constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tile_m = blockIdx.x, tile_n = blockIdx.y;
   const int cls = blockIdx.z % p.nclass, b = blockIdx.z / p.nclass;
   const int ph = cls >> 1, pw = cls & 1;
   const int mtot = p.Mh * p.Mw;
-
-  // ---- loader-side row bookkeeping ---------------------------------------------------------
-  const int cq = tid & 7, lr = tid >> 3;
-  int r_ih[AR], r_iw[AR];
-  unsigned r_ok = 0;
-#pragma unroll
-  for (int rr = 0; rr < AR; ++rr) {
-    const int m = tile_m * BM + lr + 32 * rr;
-    const int mh = m / p.Mw, mw = m - mh * p.Mw;
-    r_ih[rr] = mh * p.stride - p.pad_t;
-    r_iw[rr] = mw * p.stride - p.pad_l;
-    if (m < mtot) r_ok |= 1u << rr;
-  }
-  const size_t in_pix = (size_t)p.Hin * p.Win;
   const int wrap_w = p.wrap ? p.Win : 0;
-  const float *wbase = p.wpk + ((size_t)cls * p.ksteps * p.npad + (size_t)tile_n * BN) * BK + tid * 4;
 
-  // register staging of one k-step (A rows, B rows, the producer's LayerNorm affine, masks);
-  // two instances: the loads of steps s+1 and s+2 are both in flight while step s computes
-  struct Stage {
-    v4f ra[AR], rb[BR];
-    v4f sc4, sh4;
-    float floor_v;
-    unsigned okm;
-  };
-  Stage stA, stB;
+  // ---- DMA lane mapping: instruction i of this wave fills LDS rows [wave*BM/4 + 8i, +8);
+  // lane -> (row = lane>>3, 16-byte slot = lane&7); the slot holds data chunk slot ^ ((row>>1)&7).
+  const int drow = lane >> 3, dslot = lane & 7;
+  int r_ih[AI], r_iw[AI], r_mh[AI], r_cls[AI];
+  unsigned r_ok = 0;
+  int a_chunk[AI];   // data chunk (0..7) this lane fetches for A row i
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int r = wave * (BM / 4) + i * 8 + drow;
+    const int m = tile_m * BM + r;
+    const int mh = m / p.Mw, mw = m - mh * p.Mw;
+    r_ih[i] = mh * p.stride - p.pad_t;
+    r_iw[i] = mw * p.stride - p.pad_l;
+    r_mh[i] = mh;
+    r_cls[i] = coord_class(mw, p.Mw);
+    if (m < mtot) r_ok |= 1u << i;
+    a_chunk[i] = dslot ^ ((r >> 1) & 7);
+  }
+  // B: rows [wave*BN/4 + 8i, +8) of the weight tile; the packed blob is already swizzled
+  unsigned b_voff[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i)
+    b_voff[i] = (unsigned)(((tile_n * BN + wave * (BN / 4) + i * 8 + drow) * BK + dslot * 4) * 4);
 
-  // Input coordinates of GEMM row rr for tap offset (dh, dw); loads are UNCONDITIONAL from a
-  // clamped address (no control flow around the global loads, so the whole k-step is one basic
-  // block and the loads stay in flight across the MFMAs); the validity bit masks the value when
-  // it is written to LDS.
-  auto tap_coords = [&](int rr, int dh, int dw, int &ihc, int &iwc) __attribute__((always_inline)) -> bool {
-    const int ih = r_ih[rr] + dh;
-    int iw = r_iw[rr] + dw;
-    iw = iw < 0 ? iw + wrap_w : (iw >= p.Win ? iw - wrap_w : iw);  // wrap_w = 0: plain zero padding
-    const bool ok = ((r_ok >> rr) & 1u) & (ih >= 0) & (ih < p.Hin) & (iw >= 0) & (iw < p.Win);
-    ihc = min(max(ih, 0), p.Hin - 1);
-    iwc = min(max(iw, 0), p.Win - 1);
-    return ok;
-  };
+  const size_t in_pix = (size_t)p.Hin * p.Win;
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(p.wpk + (size_t)cls * p.ksteps * p.npad * BK), 0, (int)((size_t)p.ksteps * p.npad * ROW_BYTES), 0x00020000);
+  const char *src0 = (const char *)(p.x0 + (size_t)b * in_pix * p.C0);
+  const long d_src = (const char *)(p.x1 + (size_t)b * in_pix * p.C1) - src0;  // integer select, see gen below
+  const int bytes0 = (int)(in_pix * p.C0 * 4), bytes1 = (int)(in_pix * p.C1 * 4);
 
-  // Regular k-step = 32 channels [c0, c0+32) of tap `tap`.  The expensive part of the address
-  // arithmetic (tap offset, wrap, bounds, clamping) depends only on the tap, so it is done once
-  // per tap (new_tap) and a k-step itself costs one multiply-add per row (gen_addr).
-  int t_pix[AR];             // clamped input pixel index of each row for the current tap
-  unsigned t_okm = 0;        // validity of each row for the current tap
-  int a_off[AR];             // element offsets of the A rows inside the selected source
-  unsigned a_okm = 0;
-  const float *a_src = p.x0, *a_aff = p.aff0, *a_wb = wbase;
-  int a_C = p.C0;
-  int a_cc = 0;
-  float a_floor = -INFINITY;
-  // per-source bases hoisted into SGPRs (selecting p.x0/p.x1 directly makes the compiler index
-  // the kernarg segment with a dependent s_load every k-step)
-  const int kC0 = p.C0, kC1 = p.C1;
-  const float *src0 = p.x0 + (size_t)b * in_pix * kC0;
-  const float *src1 = p.x1 + (size_t)b * in_pix * kC1;
-  const float *affp0 = p.aff0 + (size_t)b * p.aff_bs0;
-  const float *affp1 = p.aff1 + (size_t)b * p.aff_bs1;
-  const float kfloor0 = p.floor0, kfloor1 = p.floor1;
-  // source selection as a byte delta from source 0 (a select between two POINTERS is lowered to a
-  // lookup in a private array + flat loads; an integer select stays in SGPRs and keeps the
-  // global address space)
-  const long d_src = (const char *)src1 - (const char *)src0;
-  const long d_aff = (const char *)affp1 - (const char *)affp0;
+  // ---- k-step generator: (tap, source, chunk) segments ------------------------------------------
+  // Per segment the per-lane A offsets are fixed; the channel walk is the scalar soffset.
+  unsigned a_voff[AI];       // byte offset of (pixel, data chunk) inside the source, or OOB
+  unsigned a_voff_tail[AI];  // same with lanes beyond the source's channel count disabled (last chunk)
+  __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, bytes0, 0x00020000);
+  int g_step = 0, g_tap = 0, g_src = 0, g_chunk = 0, g_C = p.C0;
+  const int nreg = p.ntaps * (p.cpt0 + p.cpt1);  // regular k-steps; + 1 coord step when p.coord_tab
 
-  auto new_tap = [&](int tap) __attribute__((always_inline)) {
+  auto new_segment = [&]() __attribute__((always_inline)) {
     int dh, dw;
-    tap_offset<MODE>(p.rate, tap, ph, pw, dh, dw);
-    t_okm = 0;
+    tap_offset<MODE>(p.rate, g_tap, ph, pw, dh, dw);
+    g_C = g_src ? p.C1 : p.C0;
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(src0 + (g_src ? d_src : 0L)), 0, g_src ? bytes1 : bytes0,
+                                               0x00020000);
+    const int ctail = g_C & (BK - 1);  // channels in the last (partial) chunk, 0 = full
 #pragma unroll
-    for (int rr = 0; rr < AR; ++rr) {
-      int ihc, iwc;
-      const bool ok = tap_coords(rr, dh, dw, ihc, iwc);
-      t_pix[rr] = ihc * p.Win + iwc;
-      t_okm |= (ok ? 1u : 0u) << rr;
+    for (int i = 0; i < AI; ++i) {
+      const int ih = r_ih[i] + dh;
+      int iw = r_iw[i] + dw;
+      iw = iw < 0 ? iw + wrap_w : (iw >= p.Win ? iw - wrap_w : iw);  // wrap_w = 0: plain zero padding
+      const bool ok = ((r_ok >> i) & 1u) & (ih >= 0) & (ih < p.Hin) & (iw >= 0) & (iw < p.Win);
+      const unsigned off = (unsigned)(((ih * p.Win + iw) * g_C + a_chunk[i] * 4) * 4);
+      a_voff[i] = ok ? off : OOB;
+      a_voff_tail[i] = (ok && (ctail == 0 || a_chunk[i] * 4 < ctail)) ? off : OOB;
     }
   };
 
-  auto gen_addr = [&](int s, int c0) __attribute__((always_inline)) {
-    const bool first = c0 < kC0;  // wave-uniform: scalar selects, no branch
-    const int C = first ? kC0 : kC1;
-    const int c = (first ? c0 : c0 - kC0) + cq * 4;
-    a_src = reinterpret_cast<const float *>((const char *)src0 + (first ? 0L : d_src));
-    a_aff = reinterpret_cast<const float *>((const char *)affp0 + (first ? 0L : d_aff));
-    a_floor = first ? kfloor0 : kfloor1;
-    a_C = C;
-    const bool cvalid = c < C;
-    a_cc = cvalid ? c : 0;
-    a_okm = cvalid ? t_okm : 0u;
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+    // A and B tiles of k-step g_step -> LDS stage; then advance the generator by one k-step.
+    char *sA = smem + stage * STAGE_BYTES + wave * (BM / 4) * ROW_BYTES;
+    char *sB = smem + stage * STAGE_BYTES + BM * ROW_BYTES + wave * (BN / 4) * ROW_BYTES;
+    const int soff_b = g_step * p.npad * ROW_BYTES;
+    if (g_step < nreg) {
+      const int soff_a = g_chunk * ROW_BYTES;
+      const bool tail = (g_chunk + 1) * BK > g_C;  // wave-uniform; only when C % 32 != 0
+      if (!tail) {
 #pragma unroll
-    for (int rr = 0; rr < AR; ++rr) a_off[rr] = t_pix[rr] * C + a_cc;
-    a_wb = wbase + (size_t)s * p.npad * BK;
-  };
-
-  auto issue_load = [&](Stage &st) __attribute__((always_inline)) {
-    st.sc4 = *reinterpret_cast<const v4f *>(a_aff + a_cc);
-    st.sh4 = *reinterpret_cast<const v4f *>(a_aff + a_C + a_cc);
-    st.floor_v = a_floor;
-    st.okm = a_okm;
+        for (int i = 0; i < AI; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void *)(sA + i * 8 * ROW_BYTES), 16, a_voff[i], soff_a, 0, 0);
+      } else {
 #pragma unroll
-    for (int rr = 0; rr < AR; ++rr) st.ra[rr] = *reinterpret_cast<const v4f *>(a_src + a_off[rr]);
-#pragma unroll
-    for (int rr = 0; rr < BR; ++rr) st.rb[rr] = *reinterpret_cast<const v4f *>(a_wb + rr * 1024);
-  };
-
-  // CoordNet k-step (the last one): "channel" kk is tap kk of the |sin(lat)| plane
-  auto load_coord_step = [&](int s, Stage &st) __attribute__((always_inline)) {
-    st.sc4 = v4f{1.f, 1.f, 1.f, 1.f};
-    st.sh4 = v4f{0.f, 0.f, 0.f, 0.f};
-    st.floor_v = -INFINITY;
-    st.okm = r_ok;
-#pragma unroll
-    for (int rr = 0; rr < AR; ++rr) {
-      float vv[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int tap = cq * 4 + e;
-        int dh, dw, ihc, iwc;
-        tap_offset<MODE>(p.rate, tap < p.ntaps ? tap : 0, ph, pw, dh, dw);
-        const bool ok = tap_coords(rr, dh, dw, ihc, iwc) & (tap < p.ntaps);
-        const float cv = p.coord[ihc];
-        vv[e] = ok ? cv : 0.f;
+        for (int i = 0; i < AI; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void *)(sA + i * 8 * ROW_BYTES), 16, a_voff_tail[i], soff_a, 0, 0);
       }
-      st.ra[rr] = v4f{vv[0], vv[1], vv[2], vv[3]};
-    }
-    const float *wb = wbase + (size_t)s * p.npad * BK;
+    } else {
+      // CoordNet k-step: row m reads table[mh][column class][32]
+      const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)p.coord_tab, 0, p.Mh * COORD_CLASSES * ROW_BYTES, 0x00020000);
 #pragma unroll
-    for (int rr = 0; rr < BR; ++rr) st.rb[rr] = *reinterpret_cast<const v4f *>(wb + rr * 1024);
+      for (int i = 0; i < AI; ++i) {
+        const unsigned off = (unsigned)(((r_mh[i] * COORD_CLASSES + r_cls[i]) * BK + a_chunk[i] * 4) * 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_void *)(sA + i * 8 * ROW_BYTES), 16,
+                                                 ((r_ok >> i) & 1u) ? off : OOB, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB + i * 8 * ROW_BYTES), 16, b_voff[i], soff_b, 0, 0);
+    // advance (wave-uniform scalar state)
+    ++g_step;
+    if (g_step < nreg) {
+      ++g_chunk;
+      const int cpt = g_src ? p.cpt1 : p.cpt0;
+      if (g_chunk == cpt) {
+        g_chunk = 0;
+        if (g_src == 0 && p.cpt1 > 0) {
+          g_src = 1;
+        } else {
+          g_src = 0;
+          ++g_tap;
+        }
+        new_segment();
+      }
+    }
   };
 
-  auto store_step = [&](int buf, const Stage &st) __attribute__((always_inline)) {
-    float *As = smem + buf * STAGE;
-    float *Bs = As + BM * LDS_STRIDE;
+  // ---- MFMA side: precomputed ds_read addresses (no VALU in the loop) --------------------------
+  // lane reads row (lane&31) of its wave tile, k-quarter q of half h = lane>>5: data chunk h*4+q
+  // lives in slot (h*4+q) ^ ((row>>1)&7).
+  const int frow = lane & 31, fh = lane >> 5;
+  const int fswz = (frow >> 1) & 7;
+  unsigned a_rd[NSTAGE][4], b_rd[NSTAGE][4];
 #pragma unroll
-    for (int rr = 0; rr < AR; ++rr) {
-      v4f v = st.ra[rr];
-      // slim.layer_norm + ReLU of the producer: y = max(x*inv*gamma + (beta - mean*inv*gamma), 0);
-      // raw sources (the network input) use scale 1, shift 0, floor -inf: the identity.
-      v.x = fmaxf(v.x * st.sc4.x + st.sh4.x, st.floor_v);
-      v.y = fmaxf(v.y * st.sc4.y + st.sh4.y, st.floor_v);
-      v.z = fmaxf(v.z * st.sc4.z + st.sh4.z, st.floor_v);
-      v.w = fmaxf(v.w * st.sc4.w + st.sh4.w, st.floor_v);
-      const bool ok = (st.okm >> rr) & 1u;  // zero padding / tile tails (applied AFTER the LayerNorm)
-      v.x = ok ? v.x : 0.f;
-      v.y = ok ? v.y : 0.f;
-      v.z = ok ? v.z : 0.f;
-      v.w = ok ? v.w : 0.f;
-      *reinterpret_cast<v4f *>(As + (lr + 32 * rr) * LDS_STRIDE + cq * 4) = v;
+  for (int st = 0; st < NSTAGE; ++st)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int slot = ((fh * 4 + q) ^ fswz) * 16;
+      a_rd[st][q] = st * STAGE_BYTES + (wm * (MT * 32) + frow) * ROW_BYTES + slot;
+      b_rd[st][q] = st * STAGE_BYTES + BM * ROW_BYTES + (wn * (NT * 32) + frow) * ROW_BYTES + slot;
     }
-#pragma unroll
-    for (int rr = 0; rr < BR; ++rr)
-      *reinterpret_cast<v4f *>(Bs + (lr + 32 * rr) * LDS_STRIDE + cq * 4) = st.rb[rr];
-  };
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -259,22 +253,14 @@ conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int arow = wm * (MT * 32) + (lane & 31);
-  const int brow = wn * (NT * 32) + (lane & 31);
-  const int kh0 = (lane >> 5) * 16;
-
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const float *As = smem + buf * STAGE;
-    const float *Bs = As + BM * LDS_STRIDE;
+  auto compute = [&](const unsigned (&ard)[4], const unsigned (&brd)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       v4f a[MT], bb[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        a[i] = *reinterpret_cast<const v4f *>(As + (arow + i * 32) * LDS_STRIDE + kh0 + q * 4);
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const v4f *>(smem + ard[q] + i * 32 * ROW_BYTES);
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        bb[j] = *reinterpret_cast<const v4f *>(Bs + (brow + j * 32) * LDS_STRIDE + kh0 + q * 4);
+      for (int j = 0; j < NT; ++j) bb[j] = *reinterpret_cast<const v4f *>(smem + brd[q] + j * 32 * ROW_BYTES);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -287,58 +273,32 @@ conv_igemm_kernel(const ConvParams p) {
     }
   };
 
-  // ---- main loop ---------------------------------------------------------------------------
-  // Two k-steps of global loads are in flight (register stages stA/stB) while a third computes:
-  //   top    : addresses (one mad per row) + global loads of step s+2
-  //   middle : 16*MT*NT MFMAs of step s from LDS buffer s&1
-  //   bottom : wait for step s+1's loads (issued one iteration ago), LayerNorm/ReLU/mask,
-  //            ds_write to the other LDS buffer, barrier
-  // The loop is unrolled by two so the stages are addressed statically; past the last step the
-  // address generator re-issues the last step instead of branching around the loads.
-  const int nreg = p.ntaps * p.cpt;  // regular k-steps; + 1 coord step when p.coord
-  int tap = 0, chunk = 0, gstep = 0;
-  auto next_addr = [&]() __attribute__((always_inline)) {
-    if (gstep + 1 < nreg) {              // wave-uniform
-      ++gstep;
-      if (++chunk == p.cpt) {            // once per tap
-        chunk = 0;
-        new_tap(++tap);
-      }
-    }
-    gen_addr(gstep, chunk * BK);
-  };
-  new_tap(0);
-  gen_addr(0, 0);
-  issue_load(stA);
-  store_step(0, stA);
-  next_addr();
-  issue_load(stA);                       // step 1 in flight
-  __syncthreads();
-  for (int s = 0; s < nreg; s += 2) {
-    next_addr();
-    if (!(p.ablate & 1)) issue_load(stB);  // step s+2
-    __builtin_amdgcn_sched_barrier(0);     // keep the loads above the MFMAs
-    if (!(p.ablate & 2)) compute(0);       // step s
-    __builtin_amdgcn_sched_barrier(0);     // the tail must not pull its vmcnt wait up
-    store_step(1, stA);                    // step s+1
-    __syncthreads();
-    if (s + 1 >= nreg) break;
-    next_addr();
-    if (!(p.ablate & 1)) issue_load(stA);  // step s+3
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(p.ablate & 2)) compute(1);       // step s+1
-    __builtin_amdgcn_sched_barrier(0);
-    store_step(0, stB);                    // step s+2
-    __syncthreads();
+  // ---- main loop: 3-stage LDS ring, two k-steps of DMA in flight ---------------------------------
+  //   iteration s: issue DMA(s+2) -> stage (s+2)%3 | MFMAs of step s from stage s%3 |
+  //                s_waitcnt vmcnt(ND): step s+1 has landed (only step s+2 may be pending) | barrier
+  const int nsteps = p.ksteps;
+  new_segment();
+  issue(0);
+  if (nsteps > 1) issue(1);
+  if (nsteps > 1) wait_vmcnt<ND>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+#define MSI_KSTEP(ST, S)                                                      \
+  {                                                                           \
+    const bool more = (S) + 2 < nsteps;                                       \
+    if (more && !(p.ablate & 1)) issue(((ST) + 2) % NSTAGE);                  \
+    if (!(p.ablate & 2)) compute(a_rd[ST], b_rd[ST]);                         \
+    if (more) wait_vmcnt<ND>(); else wait_vmcnt<0>();                         \
+    __builtin_amdgcn_s_barrier();                                             \
   }
-  if (p.coord != nullptr) {
-    const int buf = nreg & 1;
-    load_coord_step(nreg, stA);
-    store_step(buf, stA);
-    __syncthreads();
-    compute(buf);
-    __syncthreads();
+  for (int s = 0; s < nsteps; s += 3) {
+    MSI_KSTEP(0, s);
+    if (s + 1 >= nsteps) break;
+    MSI_KSTEP(1, s + 1);
+    if (s + 2 >= nsteps) break;
+    MSI_KSTEP(2, s + 2);
   }
+#undef MSI_KSTEP
 
   // ---- epilogue: store + LayerNorm partial ------------------------------------------------
   // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -374,7 +334,7 @@ conv_igemm_kernel(const ConvParams p) {
 
   // block mean, then M2 about the block mean (two-pass inside the block: the values
   // are still in registers), reduced in a fixed order.
-  float *red = smem;  // all LDS reads of the main loop are behind the last barrier
+  float *red = reinterpret_cast<float *>(smem);  // all LDS reads of the main loop are behind the last barrier
   auto block_sum = [&](float v) __attribute__((always_inline)) -> float {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -412,6 +372,7 @@ conv_igemm_kernel(const ConvParams p) {
     o[2] = bm2;
     o[3] = 0.f;
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 // Merge the per-workgroup (count, mean, M2) partials of one sample in fp64 (Chan's
@@ -458,6 +419,29 @@ ln_finish_kernel(const float *__restrict__ stats, int nparts, const float *__res
   }
 }
 
+// slim.layer_norm + ReLU applied in place: x = max(x*scale[c] + shift[c], 0) (nets.py:401,485
+// arg_scope: normalizer then the default ReLU).  HBM-bound streaming pass, 16 B per lane.
+__global__ void __launch_bounds__(256)
+ln_apply_kernel(float *__restrict__ x, const float *__restrict__ aff, size_t per_sample, int C) {
+  const int b = blockIdx.y;
+  v4f *xv = reinterpret_cast<v4f *>(x + (size_t)b * per_sample);
+  const float *sc = aff + (size_t)b * 2 * C;
+  const float *sh = sc + C;
+  const size_t nvec = per_sample / 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int c = (int)((i * 4) % C);
+    const v4f s4 = *reinterpret_cast<const v4f *>(sc + c);
+    const v4f t4 = *reinterpret_cast<const v4f *>(sh + c);
+    v4f v = xv[i];
+    v.x = fmaxf(v.x * s4.x + t4.x, 0.f);
+    v.y = fmaxf(v.y * s4.y + t4.y, 0.f);
+    v.z = fmaxf(v.z * s4.z + t4.z, 0.f);
+    v.w = fmaxf(v.w * s4.w + t4.w, 0.f);
+    xv[i] = v;
+  }
+}
+
 // ============================================================================================
 // host: layer table, parameter packing, forward
 // ============================================================================================
@@ -468,7 +452,7 @@ struct Layer {
   int in_h, in_w, out_h, out_w;
   int src0, src1;  // producer layer indices (-1 = net_input; src1 = -1: none)
   int c0, c1;
-  int ntaps, cpt, ksteps, nclass, npad;
+  int ntaps, cpt0, cpt1, ksteps, nclass, npad;
   size_t param_off, param_floats;  // floats
   size_t packed_off;               // floats: weights, then gamma, beta (or bias), then coord table
   size_t packed_w_floats;
@@ -481,7 +465,6 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Net {
   std::vector<Layer> layers;
   size_t param_floats = 0, packed_floats = 0, ws_bytes = 0, stats_off = 0, stats_bytes = 0;
-  size_t ident_off = 0;  // floats inside the packed blob: ones[in_channels] zeros[in_channels]
 };
 
 int build_net(const msi_net_desc *d, Net &net) {
@@ -547,13 +530,11 @@ int build_net(const msi_net_desc *d, Net &net) {
       L.ntaps = 1;
       L.nclass = 1;
     }
-    if (L.c1 > 0 && L.c0 % BK)
-      return msi::fail(MSI_E_UNSUPPORTED, "net: first skip operand of %s has %d channels (need a multiple of %d)",
-                       s.name, L.c0, BK);
-    if ((size_t)sh * sw * (size_t)(L.c0 > L.c1 ? L.c0 : L.c1) >= ((size_t)1 << 31))
-      return msi::fail(MSI_E_UNSUPPORTED, "net: %s input exceeds 2^31 elements per sample", s.name);
-    L.cpt = (int)((L.cin + BK - 1) / BK);
-    L.ksteps = L.ntaps * L.cpt + (L.has_coord ? 1 : 0);
+    if ((size_t)sh * sw * (size_t)(L.c0 > L.c1 ? L.c0 : L.c1) * 4 >= ((size_t)1 << 31))
+      return msi::fail(MSI_E_UNSUPPORTED, "net: %s input exceeds 2 GiB per sample", s.name);
+    L.cpt0 = (L.c0 + BK - 1) / BK;
+    L.cpt1 = (L.c1 + BK - 1) / BK;
+    L.ksteps = L.ntaps * (L.cpt0 + L.cpt1) + (L.has_coord ? 1 : 0);
     L.npad = (int)round_up(L.cout, NPAD_ALIGN);
     // parameter blob (reference layout)
     const size_t wf = (s.kind == MODE_CONV)    ? (size_t)9 * (L.cin + L.has_coord) * L.cout
@@ -568,7 +549,7 @@ int build_net(const msi_net_desc *d, Net &net) {
     L.gamma_off = L.packed_off + L.packed_w_floats;
     L.beta_off = L.gamma_off + round_up(L.cout, 4);
     L.coord_off = L.beta_off + round_up(L.cout, 4);
-    koff = L.coord_off + (L.has_coord ? round_up(L.in_h, 4) : 0);
+    koff = L.coord_off + (L.has_coord ? (size_t)L.out_h * COORD_CLASSES * BK : 0);
     koff = round_up(koff, 64);
     // workspace
     if (s.kind != MODE_HEAD) {
@@ -586,8 +567,6 @@ int build_net(const msi_net_desc *d, Net &net) {
     if (parts > max_parts) max_parts = parts;
   }
   net.param_floats = poff;
-  net.ident_off = koff;
-  koff = round_up(koff + (size_t)2 * d->in_channels, 64);
   net.packed_floats = koff;
   net.stats_off = woff;
   net.stats_bytes = round_up((size_t)d->batch * max_parts * 4 * sizeof(float), 256);
@@ -599,7 +578,7 @@ template <int BM, int BN, int MODE>
 int launch_conv_mode(const ConvParams &p, int batch, hipStream_t stream, int *nparts) {
   const int mtot = p.Mh * p.Mw;
   const dim3 grid((mtot + BM - 1) / BM, (p.Cout + BN - 1) / BN, batch * p.nclass);
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
+  const size_t lds = (size_t)NSTAGE * (BM + BN) * ROW_BYTES;
   if (lds > 64 * 1024) {
     static thread_local bool done = false;
     if (!done) {
@@ -678,21 +657,28 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
   if (rc) return rc;
   MSI_REQUIRE(params && packed, "net_pack_weights: null pointer");
   memset(packed, 0, net.packed_floats * sizeof(float));
-  for (int c = 0; c < desc->in_channels; ++c) packed[net.ident_off + c] = 1.0f;  // identity affine of the raw input
   for (const Layer &L : net.layers) {
     const float *w = params + L.param_off;
     float *o = packed + L.packed_off;
     const int cin_w = L.cin + L.has_coord;  // channel extent of the TF weight tensor
+    const int cpt = L.cpt0 + L.cpt1;
     for (int cls = 0; cls < L.nclass; ++cls) {
       const int ph = cls >> 1, pw = cls & 1;
       for (int s = 0; s < L.ksteps; ++s) {
         const bool coord_step = L.has_coord && s == L.ksteps - 1;
+        // k-step order of the kernel's generator: tap-major, then source 0 chunks, then source 1 chunks
+        const int tap_s = coord_step ? 0 : s / cpt;
+        const int within = coord_step ? 0 : s % cpt;
+        const int src = within < L.cpt0 ? 0 : 1;
+        const int chunk = src ? within - L.cpt0 : within;
+        const int csrc = src ? L.c1 : L.c0, cbase = src ? L.c0 : 0;
         for (int n = 0; n < L.cout; ++n) {
           float *row = o + (((size_t)cls * L.ksteps + s) * L.npad + n) * BK;
+          const int swz = (n >> 1) & 7;  // LDS slot j of row n holds data chunk j ^ swz (see the kernel)
           for (int kk = 0; kk < BK; ++kk) {
             int tap, c;
             if (coord_step) { tap = kk; c = L.cin; if (tap >= L.ntaps) continue; }
-            else { tap = s / L.cpt; c = (s % L.cpt) * BK + kk; if (c >= L.cin) continue; }
+            else { tap = tap_s; if (chunk * BK + kk >= csrc) continue; c = cbase + chunk * BK + kk; }
             float v;
             if (L.kind == MODE_CONV) {            // [3,3,cin_w,cout]
               v = w[((size_t)tap * cin_w + c) * L.cout + n];
@@ -704,7 +690,7 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
             } else {                              // [1,1,cin,cout]
               v = w[(size_t)c * L.cout + n];
             }
-            row[kk] = v;
+            row[(((kk >> 2) ^ swz) << 2) + (kk & 3)] = v;
           }
         }
       }
@@ -717,16 +703,35 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
       memcpy(packed + L.beta_off, w + wf + L.cout, L.cout * sizeof(float));
     }
     if (L.has_coord) {
-      // nets.add_sph_coords (nets.py:260-265): abs(sin(np.linspace(-pi/2, pi/2, H))) in fp64 -> fp32
+      // nets.add_sph_coords (nets.py:260-265): abs(sin(np.linspace(-pi/2, pi/2, H))) in fp64 -> fp32,
+      // tabulated as the A rows of the CoordNet k-step: table[out_row][column class][tap] =
+      // coord[ih] where tap (kh,kw) lands inside the image, else 0 (zero padding).
       const double PI = 3.14159265358979323846;
       const double start = -PI / 2.0, stop = PI / 2.0;
       const int h = L.in_h;
       const double step = h > 1 ? (stop - start) / (h - 1) : 0.0;
+      std::vector<float> coord(h);
       for (int i = 0; i < h; ++i) {
         double a = (double)i * step + start;
         if (i == h - 1 && h > 1) a = stop;
-        packed[L.coord_off + i] = (float)fabs(sin(a));
+        coord[i] = (float)fabs(sin(a));
       }
+      const int keff = 2 * L.rate + 1;
+      const int th = (L.out_h - 1) * L.stride + keff - L.in_h, tw = (L.out_w - 1) * L.stride + keff - L.in_w;
+      const int pad_t = (th > 0 ? th : 0) / 2, pad_l = (tw > 0 ? tw : 0) / 2;  // TF SAME (CoordNet only)
+      const int reps[COORD_CLASSES] = {0, 1, 2, L.out_w - 2, L.out_w - 1};
+      float *tab = packed + L.coord_off;
+      for (int mh = 0; mh < L.out_h; ++mh)
+        for (int cc = 0; cc < COORD_CLASSES; ++cc) {
+          const int mw = reps[cc];
+          if (mw < 0 || mw >= L.out_w) continue;
+          for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            const int ih = mh * L.stride - pad_t + kh * L.rate, iw = mw * L.stride - pad_l + kw * L.rate;
+            const bool ok = ih >= 0 && ih < L.in_h && iw >= 0 && iw < L.in_w;
+            tab[((size_t)mh * COORD_CLASSES + cc) * BK + tap] = ok ? coord[ih] : 0.0f;
+          }
+        }
     }
   }
   return MSI_OK;
@@ -750,38 +755,26 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
     const Layer &L = net.layers[li];
     ConvParams p;
     memset(&p, 0, sizeof(p));
+    // sources are the in-place normalised outputs of their producers (or the raw network input)
     auto src_ptr = [&](int s) -> const float * {
       return s < 0 ? net_input : reinterpret_cast<const float *>(ws + net.layers[s].raw_off);
     };
-    auto set_src = [&](int s, const float *&x, const float *&aff, int &bs, float &floor_v, int C) {
-      if (s < 0) {  // the network input: no LayerNorm/ReLU in front of it
-        x = net_input;
-        aff = packed + net.ident_off;
-        bs = 0;
-        floor_v = -INFINITY;
-      } else {
-        x = reinterpret_cast<const float *>(ws + net.layers[s].raw_off);
-        aff = reinterpret_cast<const float *>(ws + net.layers[s].aff_off);
-        bs = 2 * C;
-        floor_v = 0.0f;
-      }
-    };
-    set_src(L.src0, p.x0, p.aff0, p.aff_bs0, p.floor0, L.c0);
+    p.x0 = src_ptr(L.src0);
     p.C0 = L.c0;
-    // unused second source: alias the first (never selected since c0 < C0 always holds)
-    p.x1 = p.x0; p.aff1 = p.aff0; p.aff_bs1 = p.aff_bs0; p.floor1 = p.floor0; p.C1 = 0;
+    p.x1 = p.x0;  // unused second source: alias the first (cpt1 = 0 keeps it unselected)
+    p.C1 = 0;
     if (L.src1 >= 0) {
-      set_src(L.src1, p.x1, p.aff1, p.aff_bs1, p.floor1, L.c1);
+      p.x1 = src_ptr(L.src1);
       p.C1 = L.c1;
     }
     p.wpk = packed + L.packed_off;
-    p.coord = L.has_coord ? packed + L.coord_off : nullptr;
+    p.coord_tab = L.has_coord ? packed + L.coord_off : nullptr;
     p.bias = L.kind == MODE_HEAD ? packed + L.gamma_off : nullptr;
     p.y = L.kind == MODE_HEAD ? pred : reinterpret_cast<float *>(ws + L.raw_off);
     p.stats = L.kind == MODE_HEAD ? nullptr : stats;
     p.Hin = L.in_h; p.Win = L.in_w; p.Hout = L.out_h; p.Wout = L.out_w;
     p.Cout = L.cout; p.npad = L.npad;
-    p.ntaps = L.ntaps; p.cpt = L.cpt; p.ksteps = L.ksteps;
+    p.ntaps = L.ntaps; p.cpt0 = L.cpt0; p.cpt1 = L.cpt1; p.ksteps = L.ksteps;
     p.mode = L.kind; p.nclass = L.nclass;
     p.wrap = desc->coord_net ? 0 : 1;
     p.rate = L.rate;
@@ -819,6 +812,14 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
                          packed + L.gamma_off, packed + L.beta_off, L.cout,
                          reinterpret_cast<float *>(ws + L.aff_off));
       rc = msi::check_launch("ln_finish");
+      if (rc) return rc;
+      const size_t per_sample = (size_t)L.out_h * L.out_w * L.cout;
+      size_t blocks = (per_sample / 4 + 255) / 256;
+      if (blocks > 256 * 8) blocks = 256 * 8;
+      hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)blocks, desc->batch), dim3(256), 0, stream,
+                         reinterpret_cast<float *>(ws + L.raw_off), reinterpret_cast<const float *>(ws + L.aff_off),
+                         per_sample, L.cout);
+      rc = msi::check_launch("ln_apply");
       if (rc) return rc;
     }
   }

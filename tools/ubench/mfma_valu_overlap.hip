@@ -8,12 +8,12 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int MODE, int NV>
-__global__ void __launch_bounds__(256) k(float *out, int iters, float a, float b) {
+__global__ void __launch_bounds__(512) k(float *out, int iters, float a, float b) {
   f32x16 acc0 = {0}, acc1 = {0};
   float v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 0.001f + i;
-  const int wave = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 8;  // waves 0-3 (one per SIMD) vs waves 4-7 (their SIMD partners)
   const bool do_m = MODE == 0 || MODE == 2 || (MODE == 3 && (wave & 1) == 0);
   const bool do_v = MODE == 1 || MODE == 2 || (MODE == 3 && (wave & 1) == 1);
   for (int it = 0; it < iters; ++it) {
