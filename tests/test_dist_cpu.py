@@ -1,0 +1,63 @@
+"""The N>1 path on CPU: world_size-2 gloo processes exercise frame sharding, the flat weight
+broadcast and the max-over-ranks timing reduction of matryodshka_amd/dist.py (on the GPU box the
+same code runs with backend nccl == RCCL over xGMI)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from matryodshka_amd import dist as mdist, nets
+    mdist.init_process_group(backend="gloo")
+    cin, nout, ngf = 24, 8, 8
+    w = nets.init_weights(cin, nout, ngf, True, seed=100 + rank)      # ranks start out different
+    w = mdist.broadcast_weights(w if rank == 0 else None, cin, nout, ngf, True, torch.device("cpu"), src=0)
+    blob = nets.flatten_params(w, cin, nout, ngf, True)
+    lo, hi = mdist.shard_frames(7, rank, world)
+    t = mdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    mdist.barrier()
+    q.put((rank, float(blob.sum()), blob.size, (lo, hi), t))
+    dist.destroy_process_group()
+
+
+def test_shard_frames_partitions_exactly():
+    from matryodshka_amd.dist import shard_frames
+    for n in (0, 1, 7, 8, 32, 65):
+        for world in (1, 2, 3, 8):
+            parts = [shard_frames(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts[:-1], parts[1:]))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_broadcast_and_reduce(native_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from matryodshka_amd import nets
+    ref = nets.flatten_params(nets.init_weights(24, 8, 8, True, seed=100), 24, 8, 8, True)
+    assert res[0][1] == res[1][1] == float(ref.sum()) and res[0][2] == ref.size   # both hold rank 0's weights
+    assert res[0][3] == (0, 4) and res[1][3] == (4, 7)
+    assert res[0][4] == res[1][4] == 2.0

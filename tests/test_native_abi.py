@@ -1,0 +1,148 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/msi_hip.h
+declares, its host-side entry points (trig tables, layer table, weight packing) agree with the
+oracle / with an index-level restatement, and argument errors come back as codes, not crashes.
+No kernel is launched here (there is no GPU in the build container)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import geometry as G
+from oracle import nets as onets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_header_symbol_is_exported(native_lib):
+    header = open(os.path.join(ROOT, "include", "msi_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(msi_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 17
+    assert declared == set(native_lib.SIGNATURES), declared ^ set(native_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(native_lib.lib, name), name
+    assert native_lib.lib.msi_version().startswith(b"msi_hip")
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under matryodshka_amd/ or include/ may mention it."""
+    for base in ("matryodshka_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".cpp", ".h")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), os.path.join(dirpath, f)
+
+
+@pytest.mark.parametrize("h,w", [(320, 640), (32, 64), (640, 1280), (20, 50)])
+def test_trig_tables_bit_equal_oracle(native_lib, h, w):
+    n = native_lib.lib.msi_trig_table_floats(h, w)
+    assert n == 2 * w + 2 * h
+    tab = np.empty(n, np.float32)
+    assert native_lib.lib.msi_build_trig_tables_host(h, w, tab.ctypes.data) == 0
+    cs, ss, ct, st = G.trig_tables(h, w)
+    assert np.array_equal(tab[:w], cs) and np.array_equal(tab[w:2 * w], ss)
+    assert np.array_equal(tab[2 * w:2 * w + h], ct) and np.array_equal(tab[2 * w + h:], st)
+
+
+def test_bad_arguments_return_codes(native_lib):
+    lib = native_lib.lib
+    assert lib.msi_build_trig_tables_host(0, 8, None) == -1
+    assert b"bad arguments" in lib.msi_last_error_string()
+    assert lib.msi_ods_sphere_sweep_f32(None, None, None, None, None, 1, 8, 8, 4, 1, None, 24, 0, None) == -1
+    assert lib.msi_render_equirect_f32(None, None, None, None, None, 1, 8, 8, 4, None, None, None) == -1
+    assert lib.msi_assemble_rgba_f32(None, None, None, None, None, 1, 8, 8, 4, None) == -1
+    from matryodshka_amd import nets
+    bad = nets.make_desc(1, 30, 64, 24, 8, 16, True)        # height not a multiple of 8
+    assert lib.msi_net_workspace_bytes(bad) == 0 and b"multiples of 8" in lib.msi_last_error_string()
+
+
+def test_variable_table_matches_oracle_and_reference_count(native_lib):
+    from matryodshka_amd import nets
+    for coord in (True, False):
+        shapes = dict(nets.variable_shapes(192, 64, 64, coord))
+        ow = onets.init_weights(192, 64, 64, coord)
+        assert {k: tuple(v.shape) for k, v in ow.items()} == {k: tuple(v) for k, v in shapes.items()}
+    desc = nets.make_desc(1, 320, 640, 192, 64, 64, True)
+    assert native_lib.lib.msi_net_param_floats(desc) == 16980160
+    infos = nets.layer_infos(desc)
+    assert [i.name.decode() for i in infos] == nets.LAYER_NAMES
+    assert (infos[0].out_h, infos[0].out_w, infos[9].out_h, infos[9].out_w) == (320, 640, 40, 80)
+    assert (infos[10].kind, infos[10].cin, infos[10].cout, infos[10].out_h) == (1, 1024, 256, 80)
+    blob = nets.flatten_params(ow if coord else ow, 192, 64, 64, False)
+    back = nets.unflatten_params(blob, 192, 64, 64, False)
+    assert all(np.array_equal(back[k], ow[k]) for k in ow)
+
+
+def _unswizzle_row(row, n):
+    """Packed rows store data chunk j^((n>>1)&7) in 16-byte slot j (bank-conflict-free LDS image)."""
+    swz = (n >> 1) & 7
+    out = np.empty_like(row)
+    for j in range(8):
+        out[(j ^ swz) * 4:(j ^ swz) * 4 + 4] = row[j * 4:j * 4 + 4]
+    return out
+
+
+@pytest.mark.parametrize("coord", [True, False])
+def test_weight_packing_index_level(native_lib, coord):
+    """msi_net_pack_weights_host against an index-level restatement of the documented layout
+    [class][k-step][npad][32]: k-steps are tap-major, then source-0 chunks, then source-1 chunks,
+    then (CoordNet) one step holding the 9 taps of the coordinate channel."""
+    from matryodshka_amd import nets
+    cin, nout, ngf = 24, 8, 16
+    w = onets.init_weights(cin, nout, ngf, coord, seed=3, randomize_affine=True)
+    desc = nets.make_desc(1, 16, 32, cin, nout, ngf, coord)
+    packed = nets.pack_params(desc, nets.flatten_params(w, cin, nout, ngf, coord))
+    infos = nets.layer_infos(desc)
+    off = 0
+    skips = {"conv6_1": (ngf * 8, ngf * 8), "conv7_1": (ngf * 4, ngf * 4), "conv8_1": (ngf * 2, ngf * 2)}
+    for info in infos:
+        name = info.name.decode()
+        wt = w[name + "/weights"]
+        c0, c1 = skips.get(name, (info.cin, 0))
+        cpt0, cpt1 = -(-c0 // 32), -(-c1 // 32)
+        ntaps = {0: 9, 1: 4, 2: 1}[info.kind]
+        ncls = 4 if info.kind == 1 else 1
+        ksteps = ntaps * (cpt0 + cpt1) + (1 if info.has_coord else 0)
+        npad = -(-info.cout // 128) * 128
+        wp = packed[off:off + ncls * ksteps * npad * 32].reshape(ncls, ksteps, npad, 32)
+        rng = np.random.RandomState(hash(name) % 1000)
+        for _ in range(40):
+            cls, s, n = rng.randint(ncls), rng.randint(ksteps), rng.randint(info.cout)
+            row = _unswizzle_row(wp[cls, s, n], n)
+            exp = np.zeros(32, np.float32)
+            if info.has_coord and s == ksteps - 1:
+                for tap in range(9):
+                    exp[tap] = wt[tap // 3, tap % 3, info.cin, n]
+            else:
+                tap, within = divmod(s, cpt0 + cpt1)
+                src, chunk = (0, within) if within < cpt0 else (1, within - cpt0)
+                base, csrc = (0, c0) if src == 0 else (c0, c1)
+                for kk in range(32):
+                    if chunk * 32 + kk >= csrc:
+                        continue
+                    c = base + chunk * 32 + kk
+                    if info.kind == 0:
+                        exp[kk] = wt[tap // 3, tap % 3, c, n]
+                    elif info.kind == 1:
+                        ph, pw = cls >> 1, cls & 1
+                        th, tw = tap >> 1, tap & 1
+                        kh = 1 + 2 * th if ph == 0 else 2 - 2 * th
+                        kw = 1 + 2 * tw if pw == 0 else 2 - 2 * tw
+                        exp[kk] = wt[kh, kw, n, c]
+                    else:
+                        exp[kk] = wt[0, 0, c, n]
+            assert np.array_equal(row, exp), (name, cls, s, n)
+        assert not wp[:, :, info.cout:, :].any()          # N padding is zero
+        off_next = off + wp.size
+        # gamma/beta (or bias) follow the weights
+        if info.kind == 2:
+            assert np.array_equal(packed[off_next:off_next + info.cout], w[name + "/biases"])
+        else:
+            assert np.array_equal(packed[off_next:off_next + info.cout], w[name + "/LayerNorm/gamma"])
+        # next layer's packed offset: walk by the library's own rule (64-float alignment)
+        r4 = -(-info.cout // 4) * 4
+        off = off_next + 2 * r4 + (info.out_h * 5 * 32 if info.has_coord else 0)
+        off = -(-off // 64) * 64
+    assert off == packed.size
