@@ -18,7 +18,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE
 SOURCES = [
     ("common.cpp", ["-x", "hip"]),
     ("geometry.hip", ["-ffp-contract=off"]),
-    ("cnn.hip", []),
+    ("cnn.hip", os.environ.get("MSI_CNN_DEFINES", "").split()),   # e.g. MSI_CNN_DEFINES="-DMSI_NSTAGE=2" (tuning)
 ]
 
 

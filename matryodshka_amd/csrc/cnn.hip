@@ -53,7 +53,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int BK = 32;
 constexpr int ROW_BYTES = BK * 4;   // one LDS row = 32 channels of one GEMM row
-constexpr int NSTAGE = 3;
+#ifndef MSI_NSTAGE
+#define MSI_NSTAGE 2
+#endif
+constexpr int NSTAGE = MSI_NSTAGE;  // LDS ring depth: NSTAGE-1 k-steps of DMA in flight.  Measured (r01): 2 beats 3 and 4
+                                     // (3.29 / 3.41 / 3.80 ms per frame): LDS-limited occupancy matters more than prefetch depth
 constexpr int NPAD_ALIGN = 128;
 constexpr int COORD_CLASSES = 5;    // column border classes of the CoordNet table: 0,1 | interior | W-2,W-1
 constexpr unsigned OOB = 0x80000000u;  // per-lane offset that is out of range of every descriptor
@@ -273,32 +277,47 @@ conv_igemm_kernel(const ConvParams p) {
     }
   };
 
-  // ---- main loop: 3-stage LDS ring, two k-steps of DMA in flight ---------------------------------
-  //   iteration s: issue DMA(s+2) -> stage (s+2)%3 | MFMAs of step s from stage s%3 |
-  //                s_waitcnt vmcnt(ND): step s+1 has landed (only step s+2 may be pending) | barrier
+  // ---- main loop: NSTAGE-deep LDS ring, NSTAGE-1 k-steps of DMA in flight ---------------------
+  //   iteration s: issue DMA(s+NSTAGE-1) -> stage (s-1)%NSTAGE | MFMAs of step s from stage s%NSTAGE |
+  //                s_waitcnt vmcnt((NSTAGE-2)*ND): step s+1 has landed | barrier
+  // (unrolled by NSTAGE so that every stage index is static)
   const int nsteps = p.ksteps;
   new_segment();
   issue(0);
-  if (nsteps > 1) issue(1);
-  if (nsteps > 1) wait_vmcnt<ND>(); else wait_vmcnt<0>();
+  if constexpr (NSTAGE > 2) { if (nsteps > 1) issue(1); }
+  if constexpr (NSTAGE > 3) { if (nsteps > 2) issue(2); }
+  if (nsteps >= NSTAGE - 1) wait_vmcnt<(NSTAGE - 2) * ND>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-#define MSI_KSTEP(ST, S)                                                      \
-  {                                                                           \
-    const bool more = (S) + 2 < nsteps;                                       \
-    if (more && !(p.ablate & 1)) issue(((ST) + 2) % NSTAGE);                  \
-    if (!(p.ablate & 2)) compute(a_rd[ST], b_rd[ST]);                         \
-    if (more) wait_vmcnt<ND>(); else wait_vmcnt<0>();                         \
-    __builtin_amdgcn_s_barrier();                                             \
+  // (explicitly unrolled with literal stage indices: an index that is not a compile-time constant
+  //  sends the precomputed ds_read address arrays to scratch)
+#define MSI_KSTEP(U, S)                                                                   \
+  {                                                                                       \
+    const bool more = (S) + NSTAGE - 1 < nsteps;                                          \
+    if (more && !(p.ablate & 1)) issue(((U) + NSTAGE - 1) % NSTAGE);                      \
+    if (!(p.ablate & 2)) compute(a_rd[U], b_rd[U]);                                       \
+    /* all but the newest NSTAGE-2 pending k-steps must have landed; near the end fewer   \
+       are pending and a full drain is both correct and free */                          \
+    if (more) wait_vmcnt<(NSTAGE - 2) * ND>(); else wait_vmcnt<0>();                      \
+    __builtin_amdgcn_s_barrier();                                                         \
   }
-  for (int s = 0; s < nsteps; s += 3) {
+  for (int s = 0; s < nsteps; s += NSTAGE) {
     MSI_KSTEP(0, s);
-    if (s + 1 >= nsteps) break;
-    MSI_KSTEP(1, s + 1);
-    if (s + 2 >= nsteps) break;
-    MSI_KSTEP(2, s + 2);
+    if constexpr (NSTAGE > 1) {
+      if (s + 1 >= nsteps) break;
+      MSI_KSTEP(1, s + 1);
+    }
+    if constexpr (NSTAGE > 2) {
+      if (s + 2 >= nsteps) break;
+      MSI_KSTEP(2, s + 2);
+    }
+    if constexpr (NSTAGE > 3) {
+      if (s + 3 >= nsteps) break;
+      MSI_KSTEP(3, s + 3);
+    }
   }
 #undef MSI_KSTEP
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "LDS ring depth");
 
   // ---- epilogue: store + LayerNorm partial ------------------------------------------------
   // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -602,18 +621,14 @@ int launch_conv(const ConvParams &p, int batch, hipStream_t stream, int *nparts)
   }
 }
 
-// Tile choice: the largest tile that still gives every CU about two workgroups.
+// Tile choice.  Measured on the BASELINE network (profiles/r01_*): with the DMA-fed loop the 64x64
+// tile wins on every layer (3.17 ms vs 3.29 ms mixed vs 3.85 ms all-128x128): its 32 KB of LDS lets
+// five workgroups share a CU, and occupancy hides the per-k-step barrier better than a larger
+// tile's higher arithmetic intensity helps.  The larger tiles stay available (MSI_CONV_TILE).
 void choose_tile(int mtot, int cout, int zdim, int &bm, int &bn) {
-  const int cands[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-  const long target = 2 * 256;
-  long best_blocks = -1;
-  bm = 64; bn = 64;
-  for (auto &c : cands) {
-    if (c[1] > 64 && cout <= 64) continue;  // do not pad N to 128 for 64-channel layers
-    const long blocks = (long)((mtot + c[0] - 1) / c[0]) * ((cout + c[1] - 1) / c[1]) * zdim;
-    if (blocks >= target) { bm = c[0]; bn = c[1]; return; }
-    if (blocks > best_blocks) { best_blocks = blocks; bm = c[0]; bn = c[1]; }
-  }
+  (void)mtot; (void)cout; (void)zdim;
+  bm = 64;
+  bn = 64;
 }
 
 }  // namespace
