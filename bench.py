@@ -57,6 +57,19 @@ def cnn_flops(h, w, cin, nout, ngf, coord):
     return total
 
 
+def cnn_traffic():
+    """HBM bytes per frame of the conv kernels (18 launches) from the committed PMC passes
+    (profiles/r01_c_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH
+    doubled per the gfx950 note of MI355X_MICROARCH.md); None if the profile is not present."""
+    path = os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]["conv_igemm_kernel"]
+        return {"hbm_bytes_per_frame": k["hbm_bytes"], "source": "profiles/r01_c_hbm_traffic.json (separate --pmc passes)"}
+    except Exception:
+        return None
+
+
 def geometry_bytes(h, w, d):
     """Algorithmic HBM bytes per frame of the HBM-bound stages."""
     img = h * w * 3 * 4
@@ -192,7 +205,7 @@ def main():
                    "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world},
         "roofline": {"kernel": "conv_igemm_kernel (18 launches/frame, fp32 MFMA implicit GEMM; + 17 ln_finish)",
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": cnn_traffic(),
                      "algorithmic_flops_per_frame": flops, "ms_per_frame": round(stage_ms["cnn"], 4)},
         "stages": stages,
     }

@@ -32,8 +32,8 @@
 //     one extra k-step whose 32 "channels" are the <=9 taps of that channel, read from a small
 //     host-built table indexed by (output row, column border class);
 //   * the epilogue writes the raw conv output and one (count, mean, M2) partial
-//     per workgroup; ln_finish_kernel merges the partials in fp64 in a fixed
-//     order (Chan) into the per-channel scale/shift; ln_apply_kernel normalises in place.
+//     per workgroup; ln_apply_kernel merges the partials in fp64 in a fixed order (Chan)
+//     into the per-channel scale/shift and normalises in place.
 //
 // Tiling: 256 threads = 4 wavefronts (2x2), wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, BK=32.
 #include <cmath>
@@ -108,7 +108,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int KPB>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (the body uses device-only types)
@@ -239,9 +239,9 @@ conv_igemm_kernel(const ConvParams p) {
   // lives in slot (h*4+q) ^ ((row>>1)&7).
   const int frow = lane & 31, fh = lane >> 5;
   const int fswz = (frow >> 1) & 7;
-  unsigned a_rd[NSTAGE][4], b_rd[NSTAGE][4];
+  unsigned a_rd[NSTAGE * KPB][4], b_rd[NSTAGE * KPB][4];
 #pragma unroll
-  for (int st = 0; st < NSTAGE; ++st)
+  for (int st = 0; st < NSTAGE * KPB; ++st)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int slot = ((fh * 4 + q) ^ fswz) * 16;
@@ -277,53 +277,49 @@ conv_igemm_kernel(const ConvParams p) {
     }
   };
 
-  // ---- main loop: NSTAGE-deep LDS ring, NSTAGE-1 k-steps of DMA in flight ---------------------
-  //   iteration s: issue DMA(s+NSTAGE-1) -> stage (s-1)%NSTAGE | MFMAs of step s from stage s%NSTAGE |
-  //                s_waitcnt vmcnt((NSTAGE-2)*ND): step s+1 has landed | barrier
-  // (unrolled by NSTAGE so that every stage index is static)
+  // ---- main loop: double-buffered LDS, KPB k-steps per barrier -----------------------------------
+  //   super-step S: issue the DMA of super-step S+1 into the other buffer | MFMAs of the KPB k-steps
+  //   of super-step S | s_waitcnt vmcnt(0) | barrier.
+  // KPB = 2 doubles the MFMA work per barrier (and the LDS per workgroup): used for the layers
+  // whose grid is too small to hide the barrier with occupancy.  Unrolled by two with literal
+  // buffer indices (a run-time index would send the ds_read address arrays to scratch).
+  static_assert(NSTAGE == 2, "the main loop is written for a double buffer");
   const int nsteps = p.ksteps;
+  const int nsuper = (nsteps + KPB - 1) / KPB;
   new_segment();
-  issue(0);
-  if constexpr (NSTAGE > 2) { if (nsteps > 1) issue(1); }
-  if constexpr (NSTAGE > 3) { if (nsteps > 2) issue(2); }
-  if (nsteps >= NSTAGE - 1) wait_vmcnt<(NSTAGE - 2) * ND>(); else wait_vmcnt<0>();
+  auto issue_super = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < KPB; ++kk)
+      if (g_step < nsteps) issue(buf * KPB + kk);
+  };
+  issue_super(0);
+  wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-  // (explicitly unrolled with literal stage indices: an index that is not a compile-time constant
-  //  sends the precomputed ds_read address arrays to scratch)
-#define MSI_KSTEP(U, S)                                                                   \
+#define MSI_SUPERSTEP(U, S)                                                               \
   {                                                                                       \
-    const bool more = (S) + NSTAGE - 1 < nsteps;                                          \
-    if (more && !(p.ablate & 1)) issue(((U) + NSTAGE - 1) % NSTAGE);                      \
-    if (!(p.ablate & 2)) compute(a_rd[U], b_rd[U]);                                       \
-    /* all but the newest NSTAGE-2 pending k-steps must have landed; near the end fewer   \
-       are pending and a full drain is both correct and free */                          \
-    if (more) wait_vmcnt<(NSTAGE - 2) * ND>(); else wait_vmcnt<0>();                      \
+    if ((S) + 1 < nsuper && !(p.ablate & 1)) issue_super((U) ^ 1);                        \
+    if (!(p.ablate & 2)) {                                                                \
+      compute(a_rd[(U) * KPB], b_rd[(U) * KPB]);                                          \
+      if constexpr (KPB > 1) {                                                            \
+        if ((S) * KPB + 1 < nsteps) compute(a_rd[(U) * KPB + 1], b_rd[(U) * KPB + 1]);    \
+      }                                                                                   \
+    }                                                                                     \
+    wait_vmcnt<0>();                                                                      \
     __builtin_amdgcn_s_barrier();                                                         \
   }
-  for (int s = 0; s < nsteps; s += NSTAGE) {
-    MSI_KSTEP(0, s);
-    if constexpr (NSTAGE > 1) {
-      if (s + 1 >= nsteps) break;
-      MSI_KSTEP(1, s + 1);
-    }
-    if constexpr (NSTAGE > 2) {
-      if (s + 2 >= nsteps) break;
-      MSI_KSTEP(2, s + 2);
-    }
-    if constexpr (NSTAGE > 3) {
-      if (s + 3 >= nsteps) break;
-      MSI_KSTEP(3, s + 3);
-    }
+  static_assert(KPB == 1 || KPB == 2, "k-steps per barrier");
+  for (int S = 0; S < nsuper; S += 2) {
+    MSI_SUPERSTEP(0, S);
+    if (S + 1 >= nsuper) break;
+    MSI_SUPERSTEP(1, S + 1);
   }
-#undef MSI_KSTEP
-  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "LDS ring depth");
+#undef MSI_SUPERSTEP
 
   // ---- epilogue: store + LayerNorm partial ------------------------------------------------
   // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   const int col = lane & 31, rowq = 4 * (lane >> 5);
   float lsum = 0.f;
-  float cnt = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -345,7 +341,6 @@ conv_igemm_kernel(const ConvParams p) {
         if (MODE == MODE_HEAD) v = tanhf(v + p.bias[n]);
         p.y[opix * p.Cout + n] = v;
         lsum += v;
-        cnt += 1.f;
       }
     }
   }
@@ -363,7 +358,8 @@ conv_igemm_kernel(const ConvParams p) {
     return (red[0] + red[1]) + (red[2] + red[3]);
   };
   const float bsum = block_sum(lsum);
-  const float bcnt = block_sum(cnt);
+  // the count of valid outputs of this tile is known analytically (one reduction less)
+  const float bcnt = (float)(min(BM, mtot - tile_m * BM) * min(BN, p.Cout - tile_n * BN));
   const float bmean = bcnt > 0.f ? bsum / bcnt : 0.f;
   float lm2 = 0.f;
 #pragma unroll
@@ -394,18 +390,26 @@ conv_igemm_kernel(const ConvParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-// Merge the per-workgroup (count, mean, M2) partials of one sample in fp64 (Chan's
-// pairwise update, fixed order => deterministic) and emit the LayerNorm affine of
-// slim.layer_norm: scale = gamma * rsqrt(var + eps), shift = beta - mean * scale.
+// LayerNorm finish + apply in ONE launch.  Every workgroup first merges the per-workgroup (count,
+// mean, M2) partials of its sample in fp64 (Chan's pairwise update in a fixed order => identical
+// in every workgroup and deterministic) into the affine of slim.layer_norm,
+//   scale = gamma * rsqrt(var + eps), shift = beta - mean * scale,
+// keeps it in LDS, and then applies x = max(x*scale[c] + shift[c], 0) IN PLACE to its grid-stride
+// slice (nets.py:401,485 arg_scope: normalizer, then the default ReLU).  Merging redundantly
+// (<= 3200 partials = 51 KB from L2 per workgroup) is cheaper than a separate single-block launch
+// plus a kernel boundary per layer.  Workgroup 0 also publishes the affine (debug / tests).
 __global__ void __launch_bounds__(256)
-ln_finish_kernel(const float *__restrict__ stats, int nparts, const float *__restrict__ gamma,
-                 const float *__restrict__ beta, int C, float *__restrict__ aff) {
+ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int nparts,
+                const float *__restrict__ gamma, const float *__restrict__ beta, size_t per_sample, int C,
+                float *__restrict__ aff) {
+  extern __shared__ __attribute__((aligned(16))) float s_aff[];  // scale[C] shift[C]
   __shared__ double s_n[256], s_mean[256], s_m2[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.y, tid = threadIdx.x;
   const float *st = stats + (size_t)b * nparts * 4;
   double n = 0.0, mean = 0.0, m2 = 0.0;
   for (int i = tid; i < nparts; i += 256) {
-    const double nb = st[i * 4 + 0], mb = st[i * 4 + 1], m2b = st[i * 4 + 2];
+    const v4f pr = *reinterpret_cast<const v4f *>(st + (size_t)i * 4);
+    const double nb = pr.x, mb = pr.y, m2b = pr.z;
     if (nb > 0.0) {
       const double nt = n + nb, dl = mb - mean;
       mean += dl * (nb / nt);
@@ -430,28 +434,25 @@ ln_finish_kernel(const float *__restrict__ stats, int nparts, const float *__res
   const double var = s_m2[0] / s_n[0];
   const double inv = 1.0 / sqrt(var + LN_EPS);
   const double mu = s_mean[0];
-  float *o = aff + (size_t)b * 2 * C;
   for (int c = tid; c < C; c += 256) {
     const double sc = inv * (double)gamma[c];
-    o[c] = (float)sc;
-    o[C + c] = (float)((double)beta[c] - mu * sc);
+    const float fs = (float)sc, ft = (float)((double)beta[c] - mu * sc);
+    s_aff[c] = fs;
+    s_aff[C + c] = ft;
+    if (blockIdx.x == 0) {
+      aff[(size_t)b * 2 * C + c] = fs;
+      aff[(size_t)b * 2 * C + C + c] = ft;
+    }
   }
-}
+  __syncthreads();
 
-// slim.layer_norm + ReLU applied in place: x = max(x*scale[c] + shift[c], 0) (nets.py:401,485
-// arg_scope: normalizer then the default ReLU).  HBM-bound streaming pass, 16 B per lane.
-__global__ void __launch_bounds__(256)
-ln_apply_kernel(float *__restrict__ x, const float *__restrict__ aff, size_t per_sample, int C) {
-  const int b = blockIdx.y;
   v4f *xv = reinterpret_cast<v4f *>(x + (size_t)b * per_sample);
-  const float *sc = aff + (size_t)b * 2 * C;
-  const float *sh = sc + C;
   const size_t nvec = per_sample / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < nvec; i += stride) {
     const int c = (int)((i * 4) % C);
-    const v4f s4 = *reinterpret_cast<const v4f *>(sc + c);
-    const v4f t4 = *reinterpret_cast<const v4f *>(sh + c);
+    const v4f s4 = *reinterpret_cast<const v4f *>(s_aff + c);
+    const v4f t4 = *reinterpret_cast<const v4f *>(s_aff + C + c);
     v4f v = xv[i];
     v.x = fmaxf(v.x * s4.x + t4.x, 0.f);
     v.y = fmaxf(v.y * s4.y + t4.y, 0.f);
@@ -593,31 +594,31 @@ int build_net(const msi_net_desc *d, Net &net) {
   return MSI_OK;
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int KPB>
 int launch_conv_mode(const ConvParams &p, int batch, hipStream_t stream, int *nparts) {
   const int mtot = p.Mh * p.Mw;
   const dim3 grid((mtot + BM - 1) / BM, (p.Cout + BN - 1) / BN, batch * p.nclass);
-  const size_t lds = (size_t)NSTAGE * (BM + BN) * ROW_BYTES;
+  const size_t lds = (size_t)NSTAGE * KPB * (BM + BN) * ROW_BYTES;
   if (lds > 64 * 1024) {
     static thread_local bool done = false;
     if (!done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, MODE>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, MODE, KPB>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "conv: %s", hipGetErrorString(e));
       done = true;
     }
   }
   *nparts = grid.x * grid.y * p.nclass;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE>), grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, KPB>), grid, dim3(256), lds, stream, p);
   return msi::check_launch("conv_igemm");
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int KPB>
 int launch_conv(const ConvParams &p, int batch, hipStream_t stream, int *nparts) {
   switch (p.mode) {
-    case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV>(p, batch, stream, nparts);
-    case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT>(p, batch, stream, nparts);
-    default: return launch_conv_mode<BM, BN, MODE_HEAD>(p, batch, stream, nparts);
+    case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, KPB>(p, batch, stream, nparts);
+    case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, KPB>(p, batch, stream, nparts);
+    default: return launch_conv_mode<BM, BN, MODE_HEAD, KPB>(p, batch, stream, nparts);
   }
 }
 
@@ -625,10 +626,13 @@ int launch_conv(const ConvParams &p, int batch, hipStream_t stream, int *nparts)
 // tile wins on every layer (3.17 ms vs 3.29 ms mixed vs 3.85 ms all-128x128): its 32 KB of LDS lets
 // five workgroups share a CU, and occupancy hides the per-k-step barrier better than a larger
 // tile's higher arithmetic intensity helps.  The larger tiles stay available (MSI_CONV_TILE).
-void choose_tile(int mtot, int cout, int zdim, int &bm, int &bn) {
-  (void)mtot; (void)cout; (void)zdim;
+// k-steps per barrier: 2 when the grid cannot put ~4 workgroups on every CU (the barrier is then
+// hidden by more MFMA work per wave instead of by occupancy), else 1.
+void choose_tile(int mtot, int cout, int zdim, int &bm, int &bn, int &kpb) {
   bm = 64;
   bn = 64;
+  const long blocks = (long)((mtot + bm - 1) / bm) * ((cout + bn - 1) / bn) * zdim;
+  kpb = blocks < 4 * 256 ? 2 : 1;
 }
 
 }  // namespace
@@ -810,30 +814,29 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
     } else {
       p.Mh = L.out_h; p.Mw = L.out_w; p.stride = 1;
     }
-    int bm, bn, nparts = 0;
-    choose_tile(p.Mh * p.Mw, L.cout, desc->batch * L.nclass, bm, bn);
+    int bm, bn, kpb, nparts = 0;
+    choose_tile(p.Mh * p.Mw, L.cout, desc->batch * L.nclass, bm, bn, kpb);
     {  // debug knobs, read once
       static const char *abl = getenv("MSI_CONV_ABLATE");
       static const char *til = getenv("MSI_CONV_TILE");
+      static const char *kp = getenv("MSI_CONV_KPB");
       p.ablate = abl ? atoi(abl) : 0;
-      if (til) { int a = 0, c = 0; if (sscanf(til, "%dx%d", &a, &c) == 2 && (c <= 64 || L.cout > 64)) { bm = a; bn = c; } }
+      if (til) { int a = 0, c = 0; if (sscanf(til, "%dx%d", &a, &c) == 2) { bm = a; bn = c; } }
+      if (kp) kpb = atoi(kp);
     }
-    if (bm == 128 && bn == 128) rc = launch_conv<128, 128>(p, desc->batch, stream, &nparts);
-    else if (bm == 128 && bn == 64) rc = launch_conv<128, 64>(p, desc->batch, stream, &nparts);
-    else rc = launch_conv<64, 64>(p, desc->batch, stream, &nparts);
+    if (bm == 128 && kpb == 2) rc = launch_conv<128, 64, 2>(p, desc->batch, stream, &nparts);
+    else if (bm == 128) rc = launch_conv<128, 64, 1>(p, desc->batch, stream, &nparts);
+    else if (kpb == 2) rc = launch_conv<64, 64, 2>(p, desc->batch, stream, &nparts);
+    else rc = launch_conv<64, 64, 1>(p, desc->batch, stream, &nparts);
     if (rc) return rc;
     if (L.kind != MODE_HEAD) {
-      hipLaunchKernelGGL(ln_finish_kernel, dim3(desc->batch), dim3(256), 0, stream, stats, nparts,
-                         packed + L.gamma_off, packed + L.beta_off, L.cout,
-                         reinterpret_cast<float *>(ws + L.aff_off));
-      rc = msi::check_launch("ln_finish");
-      if (rc) return rc;
       const size_t per_sample = (size_t)L.out_h * L.out_w * L.cout;
       size_t blocks = (per_sample / 4 + 255) / 256;
-      if (blocks > 256 * 8) blocks = 256 * 8;
-      hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)blocks, desc->batch), dim3(256), 0, stream,
-                         reinterpret_cast<float *>(ws + L.raw_off), reinterpret_cast<const float *>(ws + L.aff_off),
-                         per_sample, L.cout);
+      if (blocks > 512) blocks = 512;  // grid-stride: keeps the redundant partial merge cheap
+      hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)blocks, desc->batch), dim3(256),
+                         (size_t)2 * L.cout * sizeof(float), stream, reinterpret_cast<float *>(ws + L.raw_off), stats,
+                         nparts, packed + L.gamma_off, packed + L.beta_off, per_sample, L.cout,
+                         reinterpret_cast<float *>(ws + L.aff_off));
       rc = msi::check_launch("ln_apply");
       if (rc) return rc;
     }
