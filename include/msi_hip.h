@@ -115,6 +115,23 @@ int msi_project_layers_f32(const float *rgba_native, const float *tgt_pose_rt,
                            int32_t batch, int32_t height, int32_t width, int32_t num_planes,
                            float *out_layers, msi_stream_t stream);
 
+/* MSI.msi_render_ods_view (msi.py:502-525): pj.projective_forward_ods (projector.py:100-127) =
+ * spherical.intersect_ods (spherical.py:328-365; eye rays tangent to the viewing circle of radius
+ * intrinsics[b,0,0], order +1 left / -1 right, transformed by pose [B,4,4]) -> resample ->
+ * over_composite.  out_rgb [B,H,W,3]. */
+int msi_render_ods_f32(const float *rgba_native, const float *pose, const float *intrinsics,
+                       const float *depths, const float *trig, int32_t batch, int32_t height,
+                       int32_t width, int32_t num_planes, int32_t order, float *out_rgb,
+                       msi_stream_t stream);
+/* MSI.msi_render_perspective_view (msi.py:475-500): pj.projective_forward_sphere_to_perspective
+ * (projector.py:64-98) = spherical.intersect_perspective (spherical.py:367-401; hard-coded
+ * 0.1/0.05 intrinsics) -> resample -> over_composite.  `pose` [B,4,4] is the crop rotation the
+ * caller builds from viewing_window (projector.py:78-86); out_rgb [B,tgt_height,tgt_width,3]. */
+int msi_render_perspective_f32(const float *rgba_native, const float *pose, const float *tgt_pos,
+                               const float *depths, int32_t batch, int32_t height, int32_t width,
+                               int32_t num_planes, int32_t tgt_height, int32_t tgt_width, float *out_rgb,
+                               msi_stream_t stream);
+
 /* ---- K2: encoder-decoder CNN -------------------------------------------------------
  * nets.msi_coord_train_net (nets.py:471-515; coord_net=1) and nets.msi_train_net
  * (nets.py:387-450; coord_net=0): 14x conv3x3 (+|sin(lat)| coordinate channel,

@@ -268,23 +268,50 @@ assemble_kernel(const float *__restrict__ psv, const float *__restrict__ pred,
 // remain; the running composite lives in registers and every texel of the
 // D x H x W x 4 stack is fetched from HBM once.
 enum RenderMode { RENDER_RGB = 1, RENDER_DEPTH = 2, RENDER_LAYERS = 4 };
+// ray model of the TARGET view: equirect (spherical.intersect_sphere, spherical.py:268-326),
+// ODS eye (intersect_ods, :328-365) or the hard-coded perspective crop (intersect_perspective, :367-401)
+enum RayModel { RAY_EQUIRECT = 0, RAY_ODS = 1, RAY_PERSPECTIVE = 2 };
 
-template <int MODE>
+struct RayParams {
+  int out_h, out_w;        // target image size (== layer size except for RAY_PERSPECTIVE)
+  float order;             // RAY_ODS: +1 left eye / -1 right eye
+  float s0, sstep, t0, tstep;  // RAY_PERSPECTIVE: uv_grid = tf.linspace(-1+1/n, 1-1/n, n) (spherical.py:46-48)
+};
+
+template <int MODE, int RAY>
 __global__ void __launch_bounds__(256)
 render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt,
-              const float *__restrict__ tgt_pos, const float *__restrict__ depths,
-              const float *__restrict__ trig, int batch, int height, int width, int nd,
-              float *__restrict__ out_rgb, float *__restrict__ out_depth,
-              float4 *__restrict__ out_layers, PixConsts K) {
+              const float *__restrict__ tgt_pos, const float *__restrict__ intrinsics,
+              const float *__restrict__ depths, const float *__restrict__ trig, int batch, int height,
+              int width, int nd, float *__restrict__ out_rgb, float *__restrict__ out_depth,
+              float4 *__restrict__ out_layers, PixConsts K, RayParams R) {
   const int j = blockIdx.x * 64 + threadIdx.x;
   const int i = blockIdx.y * 4 + threadIdx.y;
   const int b = blockIdx.z;
-  if (j >= width || i >= height) return;
+  if (j >= R.out_w || i >= R.out_h) return;
 
-  const float cs = trig[j], ss = trig[width + j];
-  const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
-  // ray direction (spherical.py:280-284)
-  float rx = cs * ct, ry = st, rz = ss * ct;
+  float rx, ry, rz, cx, cy, cz;
+  if (RAY == RAY_PERSPECTIVE) {
+    // spherical.py:381-392: rx = S*0.1, ry = T*0.05, rz = -0.05; centre (c0, c1, -c2)
+    const float S = R.s0 + R.sstep * (float)j, T = R.t0 + R.tstep * (float)i;
+    rx = S * 0.1f; ry = T * 0.05f; rz = -1.0f * 0.05f;
+    const float *tp = tgt_pos + (size_t)b * 3;
+    cx = tp[0]; cy = tp[1]; cz = -tp[2];
+  } else {
+    const float cs = trig[j], ss = trig[width + j];
+    const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
+    if (RAY == RAY_ODS) {
+      // spherical.py:349-358: ray (cosS cosT, sinT, -sinS cosT) from the viewing circle
+      const float bl = intrinsics[(size_t)b * 9];
+      rx = cs * ct; ry = st; rz = (-ss) * ct;
+      cx = ((-ss) * bl) * R.order; cy = 0.0f; cz = ((-cs) * bl) * R.order;
+    } else {
+      // spherical.py:280-288: ray (cosS cosT, sinT, sinS cosT); origin = tgt_pos with x<->z swapped
+      rx = cs * ct; ry = st; rz = ss * ct;
+      const float *tp = tgt_pos + (size_t)b * 3;
+      cx = tp[2]; cy = tp[1]; cz = tp[0];
+    }
+  }
   const float *P = pose_rt + (size_t)b * 16;
   {
     const float x = (P[0] * rx + P[1] * ry) + P[2] * rz;
@@ -292,9 +319,7 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
     const float z = (P[8] * rx + P[9] * ry) + P[10] * rz;
     rx = x; ry = y; rz = z;
   }
-  // ray origin: the x<->z swap of spherical.py:286-288, then the full 4x4
-  const float *tp = tgt_pos + (size_t)b * 3;
-  float cx = tp[2], cy = tp[1], cz = tp[0];
+  // ray origin through the full 4x4 (spherical.py:303-310 / transform_ray :70-94)
   {
     const float x = ((P[0] * cx + P[1] * cy) + P[2] * cz) + P[3] * 1.0f;
     const float y = ((P[4] * cx + P[5] * cy) + P[6] * cz) + P[7] * 1.0f;
@@ -307,8 +332,9 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
   const float qb2 = qb * qb;
   const float fa = 4.0f * qa, ta = 2.0f * qa;
 
-  const size_t hw = (size_t)height * width;
-  const size_t pix = (size_t)i * width + j;
+  const size_t hw = (size_t)height * width;             // source layer size
+  const size_t ohw = (size_t)R.out_h * R.out_w;          // target size
+  const size_t pix = (size_t)i * R.out_w + j;
   float o0 = 0.f, o1 = 0.f, o2 = 0.f, od = 0.f;
 
 #pragma unroll 4
@@ -339,7 +365,7 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
       o.y = blend4(tp4, A.y, Bv.y, C.y, Dv.y);
       o.z = blend4(tp4, A.z, Bv.z, C.z, Dv.z);
       o.w = al;
-      out_layers[((size_t)d * batch + b) * hw + pix] = o;
+      out_layers[((size_t)d * batch + b) * ohw + pix] = o;
     }
     if (MODE & RENDER_RGB) {
       const float r = blend4(tp4, A.x, Bv.x, C.x, Dv.x);
@@ -364,11 +390,11 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
     }
   }
   if (MODE & RENDER_RGB) {
-    float *o = out_rgb + ((size_t)b * hw + pix) * 3;
+    float *o = out_rgb + ((size_t)b * ohw + pix) * 3;
     o[0] = o0; o[1] = o1; o[2] = o2;
   }
   if (MODE & RENDER_DEPTH) {
-    float *o = out_depth + ((size_t)b * hw + pix) * 3;
+    float *o = out_depth + ((size_t)b * ohw + pix) * 3;
     o[0] = od; o[1] = od; o[2] = od;
   }
 }
@@ -495,30 +521,44 @@ int msi_assemble_rgba_f32(const float *psv, const float *pred, float *rgba_nativ
   return msi::check_launch("assemble_rgba");
 }
 
-static int render_common(int mode, const float *rgba_native, const float *tgt_pose_rt,
-                         const float *tgt_pos, const float *depths, const float *trig, int32_t batch,
-                         int32_t height, int32_t width, int32_t num_planes, float *out_rgb,
+static int render_common(int mode, int ray, const float *rgba_native, const float *pose, const float *tgt_pos,
+                         const float *intrinsics, const float *depths, const float *trig, int32_t batch,
+                         int32_t height, int32_t width, int32_t num_planes, RayParams R, float *out_rgb,
                          float *out_depth, float *out_layers, msi_stream_t stream) {
-  MSI_REQUIRE(rgba_native && tgt_pose_rt && tgt_pos && depths && trig, "render: null pointer");
-  MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_planes > 0, "render: bad dims");
+  MSI_REQUIRE(rgba_native && pose && depths, "render: null pointer");
+  MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_planes > 0 && R.out_h > 0 && R.out_w > 0,
+              "render: bad dims");
   if (batch == 0) return MSI_OK;
-  const dim3 grid((width + 63) / 64, (height + 3) / 4, batch), block(64, 4);
+  const dim3 grid((R.out_w + 63) / 64, (R.out_h + 3) / 4, batch), block(64, 4);
   const PixConsts K = make_consts(height, width);
   const float4 *src = reinterpret_cast<const float4 *>(rgba_native);
   float4 *lay = reinterpret_cast<float4 *>(out_layers);
   hipStream_t s = msi::as_stream(stream);
-#define MSI_LAUNCH_RENDER(M)                                                                     \
-  hipLaunchKernelGGL(render_kernel<M>, grid, block, 0, s, src, tgt_pose_rt, tgt_pos, depths, trig, \
-                     batch, height, width, num_planes, out_rgb, out_depth, lay, K)
-  switch (mode) {
-    case RENDER_RGB: MSI_LAUNCH_RENDER(RENDER_RGB); break;
-    case RENDER_DEPTH: MSI_LAUNCH_RENDER(RENDER_DEPTH); break;
-    case RENDER_RGB | RENDER_DEPTH: MSI_LAUNCH_RENDER(RENDER_RGB | RENDER_DEPTH); break;
-    case RENDER_LAYERS: MSI_LAUNCH_RENDER(RENDER_LAYERS); break;
-    default: return msi::fail(MSI_E_BADARG, "render: bad mode %d", mode);
+#define MSI_LAUNCH_RENDER(M, RY)                                                                       \
+  hipLaunchKernelGGL((render_kernel<M, RY>), grid, block, 0, s, src, pose, tgt_pos, intrinsics, depths, \
+                     trig, batch, height, width, num_planes, out_rgb, out_depth, lay, K, R)
+  if (ray == RAY_EQUIRECT) {
+    switch (mode) {
+      case RENDER_RGB: MSI_LAUNCH_RENDER(RENDER_RGB, RAY_EQUIRECT); break;
+      case RENDER_DEPTH: MSI_LAUNCH_RENDER(RENDER_DEPTH, RAY_EQUIRECT); break;
+      case RENDER_RGB | RENDER_DEPTH: MSI_LAUNCH_RENDER(RENDER_RGB | RENDER_DEPTH, RAY_EQUIRECT); break;
+      case RENDER_LAYERS: MSI_LAUNCH_RENDER(RENDER_LAYERS, RAY_EQUIRECT); break;
+      default: return msi::fail(MSI_E_BADARG, "render: bad mode %d", mode);
+    }
+  } else if (ray == RAY_ODS) {
+    MSI_LAUNCH_RENDER(RENDER_RGB, RAY_ODS);
+  } else {
+    MSI_LAUNCH_RENDER(RENDER_RGB, RAY_PERSPECTIVE);
   }
 #undef MSI_LAUNCH_RENDER
   return msi::check_launch("render");
+}
+
+static RayParams same_size(int32_t height, int32_t width) {
+  RayParams R;
+  R.out_h = height; R.out_w = width; R.order = 1.0f;
+  R.s0 = R.sstep = R.t0 = R.tstep = 0.0f;
+  return R;
 }
 
 int msi_render_equirect_f32(const float *rgba_native, const float *tgt_pose_rt,
@@ -526,18 +566,47 @@ int msi_render_equirect_f32(const float *rgba_native, const float *tgt_pose_rt,
                             int32_t batch, int32_t height, int32_t width, int32_t num_planes,
                             float *out_rgb, float *out_depth, msi_stream_t stream) {
   MSI_REQUIRE(out_rgb || out_depth, "render_equirect: both outputs are NULL");
+  MSI_REQUIRE(tgt_pos && trig, "render_equirect: null pointer");
   const int mode = (out_rgb ? RENDER_RGB : 0) | (out_depth ? RENDER_DEPTH : 0);
-  return render_common(mode, rgba_native, tgt_pose_rt, tgt_pos, depths, trig, batch, height, width,
-                       num_planes, out_rgb, out_depth, nullptr, stream);
+  return render_common(mode, RAY_EQUIRECT, rgba_native, tgt_pose_rt, tgt_pos, nullptr, depths, trig, batch, height,
+                       width, num_planes, same_size(height, width), out_rgb, out_depth, nullptr, stream);
 }
 
 int msi_project_layers_f32(const float *rgba_native, const float *tgt_pose_rt,
                            const float *tgt_pos, const float *depths, const float *trig,
                            int32_t batch, int32_t height, int32_t width, int32_t num_planes,
                            float *out_layers, msi_stream_t stream) {
-  MSI_REQUIRE(out_layers, "project_layers: output is NULL");
-  return render_common(RENDER_LAYERS, rgba_native, tgt_pose_rt, tgt_pos, depths, trig, batch, height,
-                       width, num_planes, nullptr, nullptr, out_layers, stream);
+  MSI_REQUIRE(out_layers && tgt_pos && trig, "project_layers: null pointer");
+  return render_common(RENDER_LAYERS, RAY_EQUIRECT, rgba_native, tgt_pose_rt, tgt_pos, nullptr, depths, trig, batch,
+                       height, width, num_planes, same_size(height, width), nullptr, nullptr, out_layers, stream);
+}
+
+int msi_render_ods_f32(const float *rgba_native, const float *pose, const float *intrinsics,
+                       const float *depths, const float *trig, int32_t batch, int32_t height,
+                       int32_t width, int32_t num_planes, int32_t order, float *out_rgb,
+                       msi_stream_t stream) {
+  MSI_REQUIRE(out_rgb && intrinsics && trig, "render_ods: null pointer");
+  MSI_REQUIRE(order == 1 || order == -1, "render_ods: order must be +1 or -1");
+  RayParams R = same_size(height, width);
+  R.order = (float)order;
+  return render_common(RENDER_RGB, RAY_ODS, rgba_native, pose, nullptr, intrinsics, depths, trig, batch, height,
+                       width, num_planes, R, out_rgb, nullptr, nullptr, stream);
+}
+
+int msi_render_perspective_f32(const float *rgba_native, const float *pose, const float *tgt_pos,
+                               const float *depths, int32_t batch, int32_t height, int32_t width,
+                               int32_t num_planes, int32_t tgt_height, int32_t tgt_width, float *out_rgb,
+                               msi_stream_t stream) {
+  MSI_REQUIRE(out_rgb && tgt_pos, "render_perspective: null pointer");
+  MSI_REQUIRE(tgt_height > 1 && tgt_width > 1, "render_perspective: bad target size");
+  RayParams R = same_size(tgt_height, tgt_width);
+  // spherical.uv_grid (spherical.py:46-48) with tf.linspace fp32 semantics
+  const float s0 = (float)(-1.0 + 1.0 / tgt_width), s1 = (float)(1.0 - 1.0 / tgt_width);
+  const float t0 = (float)(-1.0 + 1.0 / tgt_height), t1 = (float)(1.0 - 1.0 / tgt_height);
+  R.s0 = s0; R.sstep = (s1 - s0) / (float)(tgt_width - 1);
+  R.t0 = t0; R.tstep = (t1 - t0) / (float)(tgt_height - 1);
+  return render_common(RENDER_RGB, RAY_PERSPECTIVE, rgba_native, pose, tgt_pos, nullptr, depths, nullptr, batch,
+                       height, width, num_planes, R, out_rgb, nullptr, nullptr, stream);
 }
 
 }  // extern "C"

@@ -288,3 +288,55 @@ class MSI(object):
                                              depths.data_ptr(), trig.data_ptr(), b, h, w, d,
                                              out.data_ptr(), self._stream()), "msi_project_layers_f32")
         return out
+
+    # ------------------------------------------------------------------ msi.py:502-525
+    def msi_render_ods_view(self, rgba_layers, order, jitter_pose, tgt_pos, planes, intrinsics):
+        """Render the left (order=+1) / right (order=-1) ODS eye from an MSI -> [B,H,W,3].
+        `tgt_pos` is accepted and unused, as in the reference (spherical.intersect_ods ignores it)."""
+        native = self._native_layers(rgba_layers)
+        b, d, h, w, _ = native.shape
+        pose = self._f32(jitter_pose).reshape(-1, 4, 4)
+        if pose.shape[0] == 1 and b > 1:
+            pose = pose.expand(b, 4, 4).contiguous()
+        intr = self._f32(intrinsics).reshape(-1, 3, 3)
+        if pose.shape[0] != b or intr.shape[0] != b:
+            raise ValueError("jitter_pose / intrinsics batch must match rgba_layers")
+        depths = self._planes(planes)
+        if depths.numel() != d:
+            raise ValueError("len(planes) != number of layers")
+        out = torch.empty((b, h, w, 3), dtype=torch.float32, device=self.device)
+        N.check(N.lib.msi_render_ods_f32(native.data_ptr(), pose.data_ptr(), intr.data_ptr(), depths.data_ptr(),
+                                         self._trig(h, w).data_ptr(), b, h, w, d, int(order), out.data_ptr(),
+                                         self._stream()), "msi_render_ods_f32")
+        return out
+
+    # ------------------------------------------------------------------ msi.py:475-500
+    @staticmethod
+    def _crop_pose(viewing_window):
+        """projector.py:78-86: from_euler([0, vw*pi/2, 0]) = Ry, zero translation; fp32 entries are
+        the correctly rounded cos/sin of the fp32 angle."""
+        ang = float(np.float32(viewing_window * np.pi / 2.0))
+        c, s = np.float32(np.cos(ang)), np.float32(np.sin(ang))
+        m = np.eye(4, dtype=np.float32)
+        m[0, 0] = c; m[0, 2] = s; m[2, 0] = -s; m[2, 2] = c
+        return m
+
+    def msi_render_perspective_view(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics,
+                                    viewing_window=3, psp_height=270, psp_width=480):
+        """Perspective crop of the MSI -> [B,psp_height,psp_width,3].  As in the reference, the
+        passed tgt_pose_rt only supplies the batch size: the crop rotation replaces it
+        (projector.py:78-86)."""
+        native = self._native_layers(rgba_layers)
+        b, d, h, w, _ = native.shape
+        pose = self._f32(np.tile(self._crop_pose(viewing_window)[None], (b, 1, 1)))
+        pos = self._f32(tgt_pos).reshape(-1, 3)
+        if pos.shape[0] != b:
+            raise ValueError("tgt_pos batch must match rgba_layers")
+        depths = self._planes(planes)
+        if depths.numel() != d:
+            raise ValueError("len(planes) != number of layers")
+        out = torch.empty((b, psp_height, psp_width, 3), dtype=torch.float32, device=self.device)
+        N.check(N.lib.msi_render_perspective_f32(native.data_ptr(), pose.data_ptr(), pos.data_ptr(), depths.data_ptr(),
+                                                 b, h, w, d, psp_height, psp_width, out.data_ptr(), self._stream()),
+                "msi_render_perspective_f32")
+        return out

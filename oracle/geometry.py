@@ -282,6 +282,118 @@ def intersect_sphere(pos, center, radius, width, height):
     return theta_phi_to_pixels(theta.astype(F), phi.astype(F), width, height)
 
 
+def _transform_ray(r, c, pos):
+    """spherical.transform_ray (spherical.py:70-94): rotate the direction by pos[:3,:3], move the
+    origin by the full 4x4; dot products summed left to right in fp32."""
+    rx, ry, rz = r
+    cx, cy, cz = c
+    pos = _f(pos)
+    rot = pos[:3, :3]
+    nr = [((rot[k, 0] * rx + rot[k, 1] * ry) + rot[k, 2] * rz).astype(F) for k in range(3)]
+    one = F(1)
+    nc = [(((pos[k, 0] * cx + pos[k, 1] * cy) + pos[k, 2] * cz) + pos[k, 3] * one).astype(F) for k in range(3)]
+    return nr, nc
+
+
+def _sphere_hit_pixels(r, c, radius, width, height):
+    """spherical.get_sphere_intersections (:96-111) + project_spherical (:235-246)."""
+    rx, ry, rz = r
+    cx, cy, cz = c
+    with np.errstate(all="ignore"):
+        a = (rx * rx + ry * ry) + rz * rz
+        b = F(2) * ((rx * cx + ry * cy) + rz * cz)
+        cc = ((cx * cx + cy * cy) + cz * cz) - radius * radius
+        disc = b * b - (F(4) * a) * cc
+        t = (-b + np.sqrt(disc)) / (F(2) * a)
+        x = cx + t * rx
+        y = cy + t * ry
+        z = cz + t * rz
+        theta = -np.arctan2(z, x)
+        phi = np.arctan2(y, np.sqrt(x * x + z * z))
+    return theta_phi_to_pixels(theta.astype(F), phi.astype(F), width, height)
+
+
+def intersect_ods(pose, order, baseline, radius, width, height):
+    """spherical.intersect_ods (spherical.py:328-365): rays of the left (order=+1) / right (-1)
+    ODS eye, tangent to the viewing circle of radius `baseline` (= intrinsics[0][0][0], :346)."""
+    radius = _f(radius).reshape(-1, 1, 1)
+    S, T = lat_long_grid((height, width))
+    cosT = cos_f32(T)
+    bl = F(baseline)
+    od = F(order)
+    rx = (cos_f32(S) * cosT)[None]
+    ry = sin_f32(T)[None]
+    rz = ((-sin_f32(S)) * cosT)[None]
+    cx = (((-sin_f32(S)) * bl) * od)[None]
+    cy = np.zeros_like(cx)
+    cz = (((-cos_f32(S)) * bl) * od)[None]
+    r, c = _transform_ray((rx, ry, rz), (cx, cy, cz), pose)
+    return _sphere_hit_pixels(r, c, radius, width, height)
+
+
+def uv_axes(height, width):
+    """spherical.uv_grid (spherical.py:46-48)."""
+    return (linspace_f32(-1. + 1. / width, 1. - 1. / width, width),
+            linspace_f32(-1. + 1. / height, 1. - 1. / height, height))
+
+
+def intersect_perspective(pos, center, radius, width, height, tgt_width, tgt_height):
+    """spherical.intersect_perspective (spherical.py:367-401): hard-coded intrinsics
+    (rx = S*0.1, ry = T*0.05, rz = -0.05), centre (c0, c1, -c2)."""
+    radius = _f(radius).reshape(-1, 1, 1)
+    center = _f(center).reshape(-1)
+    s, t = uv_axes(tgt_height, tgt_width)
+    S, T = np.meshgrid(s, t)
+    rx = (S.astype(F) * F(0.1))[None]
+    ry = (T.astype(F) * F(0.05))[None]
+    rz = (-np.ones_like(S, dtype=F) * F(0.05))[None]
+    cx, cy, cz = center[0], center[1], -center[2]
+    r, c = _transform_ray((rx, ry, rz), (cx, cy, cz), pos)
+    return _sphere_hit_pixels(r, c, radius, width, height)
+
+
+def euler_y_pose(viewing_window):
+    """The crop rotation of projector.py:78-86: tfgt.rotation_matrix_3d.from_euler([0, vw*pi/2, 0])
+    = Ry(theta) [tensorflow-graphics 1.0.0, TF-knowledge], zero translation.  cos/sin are the
+    correctly rounded fp32 values of the fp32 angle (as for the trig tables)."""
+    ang = F(viewing_window * np.pi / 2.)
+    c, s = cos_f32(ang), sin_f32(ang)
+    m = np.eye(4, dtype=F)
+    m[0, 0] = c; m[0, 2] = s; m[2, 0] = -s; m[2, 2] = c
+    return m
+
+
+def _warp_layers(src_images, coords_per_batch):
+    coords = np.transpose(np.stack(coords_per_batch, axis=0), (1, 0, 2, 3, 4))   # [D,B,Ht,Wt,2]
+    return np.stack([resample(src_images[i], coords[i]) for i in range(src_images.shape[0])], axis=0)
+
+
+def projective_forward_ods(src_images, order, intrinsics, jitter_pose, depths):
+    """projector.projective_forward_ods (projector.py:100-127).  Batch element i uses pose
+    jitter_pose[i] and its own baseline (the reference reads intrinsics[0][0][0] for every
+    element, spherical.py:346 -- identical for the B=1 it supports)."""
+    src_images = _f(src_images)
+    n_layers, n_batch, height, width, _ = src_images.shape
+    depths = _f(depths)
+    coords = [intersect_ods(jitter_pose[i], order, _f(intrinsics)[i, 0, 0], depths[:, i], width, height)
+              for i in range(n_batch)]
+    return _warp_layers(src_images, coords)
+
+
+def projective_forward_sphere_to_perspective(src_images, tgt_pos, depths, viewing_window=3,
+                                             tgt_height=320, tgt_width=640):
+    """projector.projective_forward_sphere_to_perspective (projector.py:64-98); the caller's
+    tgt_pose_rt is overwritten by the crop rotation there (:78-86)."""
+    src_images = _f(src_images)
+    n_layers, n_batch, height, width, _ = src_images.shape
+    depths = _f(depths)
+    tgt_pos = _f(tgt_pos).reshape(n_batch, 3)
+    pose = euler_y_pose(viewing_window)
+    coords = [intersect_perspective(pose, tgt_pos[i], depths[:, i], width, height, tgt_width, tgt_height)
+              for i in range(n_batch)]
+    return _warp_layers(src_images, coords)
+
+
 def projective_forward_sphere(src_images, tgt_pose_rt, tgt_pos, depths):
     """projector.projective_forward_sphere (projector.py:34-62).
     src_images [D,B,H,W,C]; tgt_pose_rt [B,4,4]; tgt_pos [B,3]; depths [D,B].

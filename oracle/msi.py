@@ -136,3 +136,24 @@ class MSI(object):
 
     def msi_render_equirect_view_single(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics):
         return self._project(rgba_layers, tgt_pose_rt, tgt_pos, planes)
+
+    # -- msi.py:502-525 -------------------------------------------------------------
+    def msi_render_ods_view(self, rgba_layers, order, jitter_pose, tgt_pos, planes, intrinsics):
+        rgba_layers = np.asarray(rgba_layers, dtype=F)
+        intrinsics = np.asarray(intrinsics, dtype=F)
+        batch_size = intrinsics.shape[0]
+        depths = np.tile(np.asarray(planes, dtype=F).reshape(-1, 1), (1, batch_size))
+        layers = np.transpose(rgba_layers, (3, 0, 1, 2, 4))
+        jitter_pose = np.broadcast_to(np.asarray(jitter_pose, dtype=F).reshape(-1, 4, 4), (batch_size, 4, 4))
+        proj = G.projective_forward_ods(layers, order, intrinsics, jitter_pose, depths)
+        return G.over_composite([proj[i] for i in range(len(planes))])
+
+    # -- msi.py:475-500 -------------------------------------------------------------
+    def msi_render_perspective_view(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics,
+                                    viewing_window=3, psp_height=270, psp_width=480):
+        rgba_layers = np.asarray(rgba_layers, dtype=F)
+        batch_size = np.asarray(tgt_pose_rt).reshape(-1, 4, 4).shape[0]
+        depths = np.tile(np.asarray(planes, dtype=F).reshape(-1, 1), (1, batch_size))
+        layers = np.transpose(rgba_layers, (3, 0, 1, 2, 4))
+        proj = G.projective_forward_sphere_to_perspective(layers, tgt_pos, depths, viewing_window, psp_height, psp_width)
+        return G.over_composite([proj[i] for i in range(len(planes))])

@@ -180,3 +180,34 @@ def test_full_size_render_properties(gpu):
     rnd2[..., :3] *= 2
     r2 = m.msi_render_equirect_view(rnd2, eye, pos, planes, None)
     assert torch.allclose(r2, 2 * r1, atol=1e-5)
+
+
+@pytest.mark.parametrize("order", [1, -1])
+def test_render_ods_view_matches_oracle(gpu, order):
+    """msi_render_ods_view (msi.py:502-525; test.py:176-188 renders both eyes)."""
+    torch, m, o = gpu
+    b, h, w, d = 2, 32, 64, 6
+    rgba = random_rgba(21, b, h, w, d)
+    inp = make_inputs(9, b, h, w)
+    planes = m.inv_depths(1.0, 100.0, d)
+    eye = np.eye(4, dtype=np.float32)[None]
+    got = m.msi_render_ods_view(torch.from_numpy(rgba).cuda(), order, eye, inp["tgt_pos"], planes, inp["intrinsics"])
+    ref = o.msi_render_ods_view(rgba, order, eye, inp["tgt_pos"], planes, inp["intrinsics"])
+    assert tuple(got.shape) == ref.shape == (b, h, w, 3)
+    assert np.abs(_np(got) - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("vw", [0, 1, 3])
+def test_render_perspective_view_matches_oracle(gpu, vw):
+    """msi_render_perspective_view (msi.py:475-500; test.py:160-175 renders four crops)."""
+    torch, m, o = gpu
+    b, h, w, d = 1, 32, 64, 5
+    rgba = random_rgba(22, b, h, w, d)
+    inp = make_inputs(10, b, h, w)
+    planes = m.inv_depths(1.0, 100.0, d)
+    got = m.msi_render_perspective_view(torch.from_numpy(rgba).cuda(), inp["tgt_pose_rt"], inp["tgt_pos"], planes,
+                                        inp["intrinsics"], viewing_window=vw, psp_height=27, psp_width=48)
+    ref = o.msi_render_perspective_view(rgba, inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"],
+                                        viewing_window=vw, psp_height=27, psp_width=48)
+    assert tuple(got.shape) == ref.shape == (b, 27, 48, 3)
+    assert np.abs(_np(got) - ref).max() <= TOL
