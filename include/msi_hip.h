@@ -95,6 +95,18 @@ int msi_assemble_rgba_f32(const float *psv, const float *pred, float *rgba_nativ
                           float *blend_weights, float *alphas, int32_t batch, int32_t height,
                           int32_t width, int32_t num_planes, msi_stream_t stream);
 
+/* High-res re-render (test.py:283-394): the per-plane loop there is (a) the high-res sphere
+ * sweep (msi_ods_sphere_sweep_f32 at the high resolution), (b) tf.image.resize(BILINEAR,
+ * align_corners=True) of the low-res blend weights / alphas (test.py:319-325), (c) the blend of
+ * test.py:327-334 and (d) the warp + over-composite of test.py:337-382.  (b) and (c) are: */
+int msi_resize_bilinear_f32(const float *in, float *out, int32_t batch, int32_t in_h, int32_t in_w,
+                            int32_t channels, int32_t out_h, int32_t out_w, msi_stream_t stream);
+/* as msi_assemble_rgba_f32, but `weights_alphas` [B,H,W,2*D] already holds blend weights | alphas
+ * in (0,1) (i.e. after the (x+1)/2 of msi.py:132-133). */
+int msi_assemble_rgba_scaled_f32(const float *psv, const float *weights_alphas, float *rgba_native,
+                                 int32_t batch, int32_t height, int32_t width, int32_t num_planes,
+                                 msi_stream_t stream);
+
 /* ---- K4: target-view reprojection + over-composite -------------------------------
  * MSI.msi_render_equirect_view / _depth (msi.py:407-429, 384-405):
  * pj.projective_forward_sphere (projector.py:34-62) = spherical.intersect_sphere

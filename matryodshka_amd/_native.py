@@ -47,6 +47,8 @@ SIGNATURES = {
     "msi_deprocess_f32_u8": (_I, [_P, _P, c_size_t, _I, _P]),
     "msi_ods_sphere_sweep_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "msi_assemble_rgba_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msi_resize_bilinear_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msi_assemble_rgba_scaled_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "msi_render_equirect_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "msi_project_layers_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "msi_render_ods_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -194,7 +194,7 @@ constexpr int K3_TP = 32;
 __global__ void __launch_bounds__(256)
 assemble_kernel(const float *__restrict__ psv, const float *__restrict__ pred,
                 float4 *__restrict__ rgba, float *__restrict__ bw_out,
-                float *__restrict__ al_out, long npix_total, int hw, int nd) {
+                float *__restrict__ al_out, long npix_total, int hw, int nd, int pred_scaled) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int c_psv = 6 * nd, c_pred = 2 * nd;
   const int s_psv = c_psv + 1, s_pred = c_pred + 1;  // odd row strides
@@ -221,9 +221,10 @@ assemble_kernel(const float *__restrict__ psv, const float *__restrict__ pred,
     const int nv = npx * c_pred / 4;
     for (int v = tid; v < nv; v += 256) {
       float4 q = g[v];
-      // (x + 1) / 2 (msi.py:132-133)
-      q.x = (q.x + 1.0f) / 2.0f; q.y = (q.y + 1.0f) / 2.0f;
-      q.z = (q.z + 1.0f) / 2.0f; q.w = (q.w + 1.0f) / 2.0f;
+      if (!pred_scaled) {  // (x + 1) / 2 (msi.py:132-133); already applied on the high-res path
+        q.x = (q.x + 1.0f) / 2.0f; q.y = (q.y + 1.0f) / 2.0f;
+        q.z = (q.z + 1.0f) / 2.0f; q.w = (q.w + 1.0f) / 2.0f;
+      }
       const int e = v * 4;
       const int row = e / c_pred, col = e - row * c_pred;
       float *dst = l_pred + row * s_pred + col;
@@ -399,6 +400,41 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
   }
 }
 
+// tf.image.resize(..., BILINEAR, align_corners=True) [TF-knowledge: resize_bilinear_op]:
+// src = dst * (in-1)/(out-1); lower = floor(src), upper = min(ceil(src), in-1), lerp = src - lower;
+// top = tl + (tr - tl)*xl; bottom = bl + (br - bl)*xl; out = top + (bottom - top)*yl.
+// Used by the high-res re-render to upsample blend weights / alphas (test.py:319-325).
+__global__ void resize_bilinear_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n,
+                                       int in_h, int in_w, int c4, int out_h, int out_w, float sy, float sx) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; idx < n; idx += stride) {
+    const int c = (int)(idx % c4);
+    size_t r = idx / c4;
+    const int x = (int)(r % out_w);
+    r /= out_w;
+    const int y = (int)(r % out_h);
+    const size_t b = r / out_h;
+    const float fy = (float)y * sy, fx = (float)x * sx;
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = min((int)ceilf(fy), in_h - 1), x1 = min((int)ceilf(fx), in_w - 1);
+    const float yl = fy - (float)y0, xl = fx - (float)x0;
+    const float4 *base = in + b * (size_t)in_h * in_w * c4;
+    const float4 tl = base[((size_t)y0 * in_w + x0) * c4 + c], tr = base[((size_t)y0 * in_w + x1) * c4 + c];
+    const float4 bl = base[((size_t)y1 * in_w + x0) * c4 + c], br = base[((size_t)y1 * in_w + x1) * c4 + c];
+    float4 o;
+#define MSI_LERP2(f)                                                        \
+    {                                                                       \
+      const float top = tl.f + (tr.f - tl.f) * xl;                          \
+      const float bot = bl.f + (br.f - bl.f) * xl;                          \
+      o.f = top + (bot - top) * yl;                                         \
+    }
+    MSI_LERP2(x) MSI_LERP2(y) MSI_LERP2(z) MSI_LERP2(w)
+#undef MSI_LERP2
+    out[idx] = o;
+  }
+}
+
 int grid_1d(size_t n) {
   size_t blocks = (n + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
@@ -495,9 +531,9 @@ int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float 
   return msi::check_launch("ods_sphere_sweep");
 }
 
-int msi_assemble_rgba_f32(const float *psv, const float *pred, float *rgba_native,
-                          float *blend_weights, float *alphas, int32_t batch, int32_t height,
-                          int32_t width, int32_t num_planes, msi_stream_t stream) {
+static int assemble_common(const float *psv, const float *pred, float *rgba_native,
+                           float *blend_weights, float *alphas, int32_t batch, int32_t height,
+                           int32_t width, int32_t num_planes, int pred_scaled, msi_stream_t stream) {
   MSI_REQUIRE(psv && pred && rgba_native, "assemble_rgba: null pointer");
   MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_planes > 0, "assemble_rgba: bad dims");
   if (num_planes % 4 != 0)
@@ -517,8 +553,37 @@ int msi_assemble_rgba_f32(const float *psv, const float *pred, float *rgba_nativ
   }
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), lds, msi::as_stream(stream),
                      psv, pred, reinterpret_cast<float4 *>(rgba_native), blend_weights, alphas, npix,
-                     height * width, num_planes);
+                     height * width, num_planes, pred_scaled);
   return msi::check_launch("assemble_rgba");
+}
+
+int msi_assemble_rgba_f32(const float *psv, const float *pred, float *rgba_native,
+                          float *blend_weights, float *alphas, int32_t batch, int32_t height,
+                          int32_t width, int32_t num_planes, msi_stream_t stream) {
+  return assemble_common(psv, pred, rgba_native, blend_weights, alphas, batch, height, width, num_planes, 0, stream);
+}
+
+int msi_assemble_rgba_scaled_f32(const float *psv, const float *weights_alphas, float *rgba_native,
+                                 int32_t batch, int32_t height, int32_t width, int32_t num_planes,
+                                 msi_stream_t stream) {
+  return assemble_common(psv, weights_alphas, rgba_native, nullptr, nullptr, batch, height, width, num_planes, 1,
+                         stream);
+}
+
+int msi_resize_bilinear_f32(const float *in, float *out, int32_t batch, int32_t in_h, int32_t in_w,
+                            int32_t channels, int32_t out_h, int32_t out_w, msi_stream_t stream) {
+  MSI_REQUIRE(in && out, "resize_bilinear: null pointer");
+  MSI_REQUIRE(batch >= 0 && in_h > 0 && in_w > 0 && channels > 0 && out_h > 0 && out_w > 0, "resize_bilinear: bad dims");
+  if (channels % 4 != 0)
+    return msi::fail(MSI_E_UNSUPPORTED, "resize_bilinear: channels=%d must be a multiple of 4", channels);
+  const size_t n = (size_t)batch * out_h * out_w * (channels / 4);
+  if (n == 0) return MSI_OK;
+  const float sy = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.0f;
+  const float sx = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.0f;
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_1d(n)), dim3(256), 0, msi::as_stream(stream),
+                     reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), n, in_h, in_w,
+                     channels / 4, out_h, out_w, sy, sx);
+  return msi::check_launch("resize_bilinear");
 }
 
 static int render_common(int mode, int ray, const float *rgba_native, const float *pose, const float *tgt_pos,

@@ -340,3 +340,31 @@ class MSI(object):
                                                  b, h, w, d, psp_height, psp_width, out.data_ptr(), self._stream()),
                 "msi_render_perspective_f32")
         return out
+
+    # ------------------------------------------------------------------ test.py:283-394
+    def msi_render_equirect_hres(self, blend_weights, alphas, raw_hres_ref_image, raw_hres_src_image,
+                                 ref_pose, src_pose, tgt_pose_rt, tgt_pos, planes, intrinsics,
+                                 ref_pose_inv=None):
+        """High-res re-render of test.py:283-394 as ONE fused device pass: the reference loops over
+        the planes on the host (one sess.run + numpy composite per plane, to fit its GPU memory); with
+        288 GB of HBM the whole high-res sweep volume and layer stack stay resident.
+        blend_weights / alphas: the low-res [B,H,W,D] outputs of infer_msi(extra_outputs=
+        'blend_weights alphas') (test.py:264-271 saves them as .npy).  Returns (rgb, depth), both
+        [B,Hh,Wh,3] float (rgb in [-1,1], depth = composited plane index / D as test.py:374-382)."""
+        bw = self._f32(blend_weights)
+        al = self._f32(alphas)
+        b, h, w, d = bw.shape
+        hres_ref = self.preprocess_image(raw_hres_ref_image)
+        hres_src = self.preprocess_image(raw_hres_src_image)
+        hh, hw = hres_ref.shape[1], hres_ref.shape[2]
+        psv = self.format_network_input(hres_ref, hres_src, ref_pose, src_pose, planes, intrinsics,
+                                        ref_pose_inv=ref_pose_inv)
+        low = torch.cat([bw, al], dim=-1).contiguous()
+        up = torch.empty((b, hh, hw, 2 * d), dtype=torch.float32, device=self.device)
+        N.check(N.lib.msi_resize_bilinear_f32(low.data_ptr(), up.data_ptr(), b, h, w, 2 * d, hh, hw, self._stream()),
+                "msi_resize_bilinear_f32")
+        rgba = torch.empty((b, d, hh, hw, 4), dtype=torch.float32, device=self.device)
+        N.check(N.lib.msi_assemble_rgba_scaled_f32(psv.data_ptr(), up.data_ptr(), rgba.data_ptr(), b, hh, hw, d,
+                                                   self._stream()), "msi_assemble_rgba_scaled_f32")
+        return self.msi_render_equirect_view_and_depth(rgba.permute(0, 2, 3, 1, 4), tgt_pose_rt, tgt_pos, planes,
+                                                       intrinsics)

@@ -157,3 +157,47 @@ class MSI(object):
         layers = np.transpose(rgba_layers, (3, 0, 1, 2, 4))
         proj = G.projective_forward_sphere_to_perspective(layers, tgt_pos, depths, viewing_window, psp_height, psp_width)
         return G.over_composite([proj[i] for i in range(len(planes))])
+
+
+    # -- test.py:283-394: high-res re-render, plane by plane as the reference does ---------------
+    @staticmethod
+    def resize_bilinear_align_corners(x, out_h, out_w):
+        """tf.image.resize(..., BILINEAR, align_corners=True) [TF-knowledge], x [B,H,W,C]."""
+        x = np.asarray(x, dtype=F)
+        _, h, w, _ = x.shape
+        sy = F(h - 1) / F(out_h - 1) if out_h > 1 else F(0)
+        sx = F(w - 1) / F(out_w - 1) if out_w > 1 else F(0)
+        fy = (np.arange(out_h, dtype=F) * sy).astype(F)
+        fx = (np.arange(out_w, dtype=F) * sx).astype(F)
+        y0 = np.floor(fy).astype(int); y1 = np.minimum(np.ceil(fy).astype(int), h - 1)
+        x0 = np.floor(fx).astype(int); x1 = np.minimum(np.ceil(fx).astype(int), w - 1)
+        yl = (fy - y0.astype(F))[None, :, None, None]
+        xl = (fx - x0.astype(F))[None, None, :, None]
+        tl = x[:, y0][:, :, x0]; tr = x[:, y0][:, :, x1]
+        bl = x[:, y1][:, :, x0]; br = x[:, y1][:, :, x1]
+        top = tl + (tr - tl) * xl
+        bot = bl + (br - bl) * xl
+        return (top + (bot - top) * yl).astype(F)
+
+    def render_hres(self, blend_weights, alphas, raw_hres_ref_image, raw_hres_src_image, ref_pose, src_pose,
+                    tgt_pose_rt, tgt_pos, planes, intrinsics):
+        hres_ref = self.preprocess_image(raw_hres_ref_image)
+        hres_src = self.preprocess_image(raw_hres_src_image)
+        b, hh, hw, _ = hres_ref.shape
+        n = len(planes)
+        out, depth = None, None
+        for i in range(n):
+            net_in = self.format_network_input(hres_ref, hres_src, ref_pose, src_pose, planes[i:i + 1], intrinsics)
+            uw = self.resize_bilinear_align_corners(np.asarray(blend_weights)[..., i:i + 1], hh, hw)
+            ua = self.resize_bilinear_align_corners(np.asarray(alphas)[..., i:i + 1], hh, hw)
+            rgb = uw * net_in[..., 0:3] + (F(1) - uw) * net_in[..., 3:6]
+            layer = np.concatenate([rgb, ua], axis=3).reshape(b, hh, hw, 1, 4)
+            warped = self.msi_render_equirect_view_single(layer, tgt_pose_rt, tgt_pos, planes[i:i + 1], intrinsics)[0]
+            wrgb, walpha = warped[..., :3], warped[..., 3:]
+            a3 = np.tile(walpha, (1, 1, 1, 3))
+            if i == 0:
+                out, depth = wrgb, np.zeros_like(wrgb)
+            else:
+                out = out * (F(1.) - walpha) + wrgb * walpha
+                depth = F(i / n) * a3 + depth * (F(1.0) - a3)
+        return out.astype(F), depth.astype(F)

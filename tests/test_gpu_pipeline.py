@@ -74,3 +74,34 @@ def test_batch_elements_are_independent():
     for i in range(b):
         one = run(slice(i, i + 1))
         assert torch.equal(full[i:i + 1], one), i     # bit-identical: no cross-sample reduction anywhere
+
+
+def test_high_res_rerender_matches_plane_by_plane_oracle():
+    """test.py:283-394 (BASELINE configs[3] 'high_res'): low-res inference, then re-render at a
+    higher resolution from upsampled blend weights / alphas.  The oracle follows the reference's
+    per-plane host loop; the HIP path does it in one fused pass."""
+    import torch
+    from matryodshka_amd import MSI
+    from oracle import nets as onets
+    from oracle.msi import MSI as OracleMSI
+    b, h, w, d, ngf = 1, 16, 32, 8, 16
+    hh, hw = 40, 88                                     # non-integer scale on purpose
+    inp = make_inputs(31, b, h, w)
+    hres = make_inputs(32, b, hh, hw)
+    weights = onets.init_weights(6 * d, 2 * d, ngf=ngf, coord_net=True, seed=31, randomize_affine=True)
+    m, o = MSI(weights=weights), OracleMSI(weights=weights)
+    planes = m.inv_depths(1.0, 100.0, d)
+    pred, _ = m.infer_msi(torch.from_numpy(inp["src_image"]), torch.from_numpy(inp["ref_image"]), None, None,
+                          inp["ref_pose"], inp["src_pose"], inp["intrinsics"], "blend_psv", d, planes,
+                          extra_outputs="blend_weights alphas", ngf=ngf)
+    rgb, dep = m.msi_render_equirect_hres(pred["blend_weights"], pred["alphas"], torch.from_numpy(hres["ref_image"]),
+                                          torch.from_numpy(hres["src_image"]), inp["ref_pose"], inp["src_pose"],
+                                          inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    pred_o, _ = o.infer_msi(inp["src_image"], inp["ref_image"], None, None, inp["ref_pose"], inp["src_pose"],
+                            inp["intrinsics"], "blend_psv", d, planes, extra_outputs="blend_weights alphas", ngf=ngf)
+    rgb_o, dep_o = o.render_hres(pred_o["blend_weights"], pred_o["alphas"], hres["ref_image"], hres["src_image"],
+                                 inp["ref_pose"], inp["src_pose"], inp["tgt_pose_rt"], inp["tgt_pos"], planes,
+                                 inp["intrinsics"])
+    assert tuple(rgb.shape) == rgb_o.shape == (b, hh, hw, 3)
+    assert np.abs(rgb.cpu().numpy() - rgb_o).max() <= TOL
+    assert np.abs(dep.cpu().numpy() - dep_o).max() <= TOL
