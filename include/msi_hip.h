@@ -144,6 +144,22 @@ int msi_render_perspective_f32(const float *rgba_native, const float *pose, cons
                                int32_t num_planes, int32_t tgt_height, int32_t tgt_width, float *out_rgb,
                                msi_stream_t stream);
 
+/* ---- PP (perspective cube-face) path, BASELINE configs[4] ------------------------------------
+ * pj.perspective_plane_sweep (projector.py:221-223): sweep_one with spherical.uv_grid (:46-48),
+ * backproject_planar (:131-149), apply_pose (projector.py:275-291), project_perspective
+ * (spherical.py:248-266) and the wrap-around sampler.  intrinsics [B,3,3] = fx,cx / fy,cy. */
+int msi_perspective_plane_sweep_f32(const float *image, const float *pose, const float *intrinsics,
+                                    const float *depths, int32_t batch, int32_t height, int32_t width,
+                                    int32_t num_depths, float *psv, int32_t psv_channels,
+                                    int32_t channel_offset, msi_stream_t stream);
+/* MSI.mpi_render_view (msi.py:527-548): pj.projective_forward_homography (projector.py:343-373) ->
+ * homography.planar_transform (homography.py:35-157) -> tf.contrib.resampler (zero padding) ->
+ * pj.over_composite.  intrinsics_inv [B,3,3] replaces the hidden graph input `intrinsics_inv:0`
+ * (homography.py:52). */
+int msi_mpi_render_f32(const float *rgba_native, const float *tgt_pose, const float *intrinsics,
+                       const float *intrinsics_inv, const float *depths, int32_t batch, int32_t height,
+                       int32_t width, int32_t num_planes, float *out_rgb, msi_stream_t stream);
+
 /* ---- K2: encoder-decoder CNN -------------------------------------------------------
  * nets.msi_coord_train_net (nets.py:471-515; coord_net=1) and nets.msi_train_net
  * (nets.py:387-450; coord_net=0): 14x conv3x3 (+|sin(lat)| coordinate channel,

@@ -53,6 +53,8 @@ SIGNATURES = {
     "msi_project_layers_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "msi_render_ods_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "msi_render_perspective_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "msi_perspective_plane_sweep_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "msi_mpi_render_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "msi_net_layer_info": (_I, [POINTER(NetDesc), _I, POINTER(LayerInfo)]),
     "msi_net_param_floats": (c_size_t, [POINTER(NetDesc)]),
     "msi_net_packed_floats": (c_size_t, [POINTER(NetDesc)]),

@@ -435,6 +435,160 @@ __global__ void resize_bilinear_kernel(const float4 *__restrict__ in, float4 *__
   }
 }
 
+// ------------------------------------------------------------------------ PP path (config 5)
+// pj.perspective_plane_sweep (projector.py:221-223) = sweep_one with spherical.uv_grid (:46-48),
+// backproject_planar (:131-149), apply_pose, project_perspective (:248-266) and the SAME
+// wrap-around sampler as the ODS sweep.  Faithful to the reference, the pose is applied twice:
+// once by apply_pose (projector.py:155) and once inside project_perspective through
+// intrinsics @ pose (spherical.py:258-259); the 3x3 intrinsics are zero-padded to 4x4
+// (projector.py:145-148), so only rows 0..2 of the product are used.
+__global__ void __launch_bounds__(256)
+pp_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose,
+                const float *__restrict__ intrinsics, const float *__restrict__ depths, int batch,
+                int height, int width, int nd, float s0, float sstep, float t0, float tstep,
+                float *__restrict__ psv, int channels, int coff) {
+  const long total = (long)batch * height * width * nd;
+  const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= total) return;
+  const int d = (int)(item % nd);
+  const long p = item / nd;
+  const int j = (int)(p % width);
+  const int i = (int)((p / width) % height);
+  const int b = (int)(p / ((long)width * height));
+  const float S = s0 + sstep * (float)j, T = t0 + tstep * (float)i;
+  const float depth = depths[d];
+  const float *Kb = intrinsics + (size_t)b * 9;
+  const float fx = Kb[0], fy = Kb[4], cx = Kb[2], cy = Kb[5];
+  // backproject_planar (spherical.py:146-148): x = depth*S*cx/fx, y = depth*T*cy/fy, z = depth*1
+  float x = ((depth * S) * cx) / fx;
+  float y = ((depth * T) * cy) / fy;
+  float z = depth * 1.0f;
+  const float *P = pose + (size_t)b * 16;
+  {  // apply_pose (projector.py:275-291)
+    const float ax = ((P[0] * x + P[1] * y) + P[2] * z) + P[3] * 1.0f;
+    const float ay = ((P[4] * x + P[5] * y) + P[6] * z) + P[7] * 1.0f;
+    const float az = ((P[8] * x + P[9] * y) + P[10] * z) + P[11] * 1.0f;
+    x = ax; y = ay; z = az;
+  }
+  // project_perspective: M = K4 @ pose, rows 0..2; the padded column contributes 0 * pose[3][c]
+  float pr[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float m[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      m[c] = ((Kb[r * 3 + 0] * P[c] + Kb[r * 3 + 1] * P[4 + c]) + Kb[r * 3 + 2] * P[8 + c]) + 0.0f * P[12 + c];
+    pr[r] = ((m[0] * x + m[1] * y) + m[2] * z) + m[3] * 1.0f;
+  }
+  const float u = pr[0] / pr[2], v = pr[1] / pr[2];
+  const Taps t = make_taps(u, v, width, height);
+  const float *img = image + (size_t)b * height * width * 3;
+  const float *pa = img + ((size_t)t.y0 * width + t.x0) * 3;
+  const float *pb = img + ((size_t)t.y0 * width + t.x1) * 3;
+  const float *pc = img + ((size_t)t.y1 * width + t.x0) * 3;
+  const float *pd = img + ((size_t)t.y1 * width + t.x1) * 3;
+  float *o = psv + (size_t)p * channels + coff + d * 3;
+  o[0] = blend4(t, pa[0], pb[0], pc[0], pd[0]);
+  o[1] = blend4(t, pa[1], pb[1], pc[1], pd[1]);
+  o[2] = blend4(t, pa[2], pb[2], pc[2], pd[2]);
+}
+
+// MSI.mpi_render_view (msi.py:527-548): pj.projective_forward_homography (projector.py:343-373) ->
+// homography.planar_transform (homography.py:120-157: inv_homography :35-58, transform_points
+// :60-80, normalize_homogeneous :82-94, divide_safe :30-33) -> sampling.bilinear_wrapper =
+// tf.contrib.resampler (zero padding) -> pj.over_composite, fused.  The per-(layer, sample)
+// inverse homographies (a few dozen flops each) are computed once per workgroup into LDS.
+constexpr int MPI_MAX_PLANES = 128;
+
+__device__ __forceinline__ float4 fetch_or_zero(const float4 *L, int x, int y, int width, int height) {
+  if (x >= 0 && y >= 0 && x < width && y < height) return L[(size_t)y * width + x];
+  return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(256)
+mpi_render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ tgt_pose,
+                  const float *__restrict__ intrinsics, const float *__restrict__ intrinsics_inv,
+                  const float *__restrict__ depths, int batch, int height, int width, int nd,
+                  float *__restrict__ out_rgb) {
+  __shared__ float hom[MPI_MAX_PLANES][9];
+  const int b = blockIdx.z;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  if (tid < nd) {
+    const float *P = tgt_pose + (size_t)b * 16;
+    const float *Ks = intrinsics + (size_t)b * 9, *Ki = intrinsics_inv + (size_t)b * 9;
+    float rt[3][3], t[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rt[r][c] = P[c * 4 + r];  // rot_t = transpose(pose[:3,:3])
+      t[r] = P[r * 4 + 3];
+    }
+    const float a = -depths[tid];
+    // n_hat = [0,0,1]: n_hat @ rot_t = row 2 of rot_t
+    const float nrt_t = (rt[2][0] * t[0] + rt[2][1] * t[1]) + rt[2][2] * t[2];
+    float den = a - nrt_t;
+    den += 1e-8f * (den == 0.0f ? 1.0f : 0.0f);  // divide_safe
+    float m1[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float q = (rt[r][0] * t[0] + rt[r][1] * t[1]) + rt[r][2] * t[2];  // (rot_t @ t)[r]
+#pragma unroll
+      for (int c = 0; c < 3; ++c) m1[r][c] = rt[r][c] + (q * rt[2][c]) / den;
+    }
+    float m2[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        m2[r][c] = (Ks[r * 3 + 0] * m1[0][c] + Ks[r * 3 + 1] * m1[1][c]) + Ks[r * 3 + 2] * m1[2][c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        hom[tid][r * 3 + c] = (m2[r][0] * Ki[0 * 3 + c] + m2[r][1] * Ki[1 * 3 + c]) + m2[r][2] * Ki[2 * 3 + c];
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  if (j >= width || i >= height) return;
+  const float uu = (float)j, vv = (float)i;  // meshgrid_abs (projector.py:478-499)
+  const size_t hw = (size_t)height * width;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+  for (int d = 0; d < nd; ++d) {
+    const float *h = hom[d];
+    const float xs = (uu * h[0] + vv * h[1]) + 1.0f * h[2];
+    const float ys = (uu * h[3] + vv * h[4]) + 1.0f * h[5];
+    float ws = (uu * h[6] + vv * h[7]) + 1.0f * h[8];
+    ws += 1e-8f * (ws == 0.0f ? 1.0f : 0.0f);
+    const float x = xs / ws, y = ys / ws;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    // tf.contrib.resampler [TF-knowledge]: zero outside (-1, W) x (-1, H); missing corners are 0
+    if (x > -1.0f && y > -1.0f && x < (float)width && y < (float)height) {
+      const float fxf = floorf(x), fyf = floorf(y);
+      const int fx = (int)fxf, fy = (int)fyf, cx = fx + 1, cy = fy + 1;
+      const float dx = (float)cx - x, dy = (float)cy - y;
+      const float4 *L = rgba + ((size_t)b * nd + d) * hw;
+      const float4 a00 = fetch_or_zero(L, fx, fy, width, height), a11 = fetch_or_zero(L, cx, cy, width, height);
+      const float4 a01 = fetch_or_zero(L, fx, cy, width, height), a10 = fetch_or_zero(L, cx, fy, width, height);
+      const float w00 = dx * dy, w11 = (1.0f - dx) * (1.0f - dy), w01 = dx * (1.0f - dy), w10 = (1.0f - dx) * dy;
+      v.x = ((w00 * a00.x + w11 * a11.x) + w01 * a01.x) + w10 * a10.x;
+      v.y = ((w00 * a00.y + w11 * a11.y) + w01 * a01.y) + w10 * a10.y;
+      v.z = ((w00 * a00.z + w11 * a11.z) + w01 * a01.z) + w10 * a10.z;
+      v.w = ((w00 * a00.w + w11 * a11.w) + w01 * a01.w) + w10 * a10.w;
+    }
+    if (d == 0) {
+      o0 = v.x; o1 = v.y; o2 = v.z;
+    } else {
+      const float om = 1.0f - v.w;
+      o0 = v.x * v.w + o0 * om;
+      o1 = v.y * v.w + o1 * om;
+      o2 = v.z * v.w + o2 * om;
+    }
+  }
+  float *o = out_rgb + ((size_t)b * hw + (size_t)i * width + j) * 3;
+  o[0] = o0; o[1] = o1; o[2] = o2;
+}
+
 int grid_1d(size_t n) {
   size_t blocks = (n + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
@@ -644,6 +798,42 @@ int msi_project_layers_f32(const float *rgba_native, const float *tgt_pose_rt,
   MSI_REQUIRE(out_layers && tgt_pos && trig, "project_layers: null pointer");
   return render_common(RENDER_LAYERS, RAY_EQUIRECT, rgba_native, tgt_pose_rt, tgt_pos, nullptr, depths, trig, batch,
                        height, width, num_planes, same_size(height, width), nullptr, nullptr, out_layers, stream);
+}
+
+int msi_perspective_plane_sweep_f32(const float *image, const float *pose, const float *intrinsics,
+                                    const float *depths, int32_t batch, int32_t height, int32_t width,
+                                    int32_t num_depths, float *psv, int32_t psv_channels,
+                                    int32_t channel_offset, msi_stream_t stream) {
+  MSI_REQUIRE(image && pose && intrinsics && depths && psv, "perspective_plane_sweep: null pointer");
+  MSI_REQUIRE(batch >= 0 && height > 1 && width > 1 && num_depths > 0, "perspective_plane_sweep: bad dims");
+  MSI_REQUIRE(channel_offset >= 0 && channel_offset + 3 * num_depths <= psv_channels,
+              "perspective_plane_sweep: channel window outside %d channels", psv_channels);
+  const long total = (long)batch * height * width * num_depths;
+  if (total == 0) return MSI_OK;
+  const long blocks = (total + 255) / 256;
+  MSI_REQUIRE(blocks < 2147483647L, "perspective_plane_sweep: problem too large");
+  // spherical.uv_grid (spherical.py:46-48), tf.linspace fp32 semantics
+  const float s0 = (float)(-1.0 + 1.0 / width), s1 = (float)(1.0 - 1.0 / width);
+  const float t0 = (float)(-1.0 + 1.0 / height), t1 = (float)(1.0 - 1.0 / height);
+  hipLaunchKernelGGL(pp_sweep_kernel, dim3((unsigned)blocks), dim3(256), 0, msi::as_stream(stream), image, pose,
+                     intrinsics, depths, batch, height, width, num_depths, s0, (s1 - s0) / (float)(width - 1), t0,
+                     (t1 - t0) / (float)(height - 1), psv, psv_channels, channel_offset);
+  return msi::check_launch("perspective_plane_sweep");
+}
+
+int msi_mpi_render_f32(const float *rgba_native, const float *tgt_pose, const float *intrinsics,
+                       const float *intrinsics_inv, const float *depths, int32_t batch, int32_t height,
+                       int32_t width, int32_t num_planes, float *out_rgb, msi_stream_t stream) {
+  MSI_REQUIRE(rgba_native && tgt_pose && intrinsics && intrinsics_inv && depths && out_rgb, "mpi_render: null pointer");
+  MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_planes > 0, "mpi_render: bad dims");
+  if (num_planes > MPI_MAX_PLANES)
+    return msi::fail(MSI_E_UNSUPPORTED, "mpi_render: at most %d planes", MPI_MAX_PLANES);
+  if (batch == 0) return MSI_OK;
+  const dim3 grid((width + 63) / 64, (height + 3) / 4, batch), block(64, 4);
+  hipLaunchKernelGGL(mpi_render_kernel, grid, block, 0, msi::as_stream(stream),
+                     reinterpret_cast<const float4 *>(rgba_native), tgt_pose, intrinsics, intrinsics_inv, depths, batch,
+                     height, width, num_planes, out_rgb);
+  return msi::check_launch("mpi_render");
 }
 
 int msi_render_ods_f32(const float *rgba_native, const float *pose, const float *intrinsics,

@@ -29,11 +29,14 @@ def _ptr(t):
 class MSI(object):
     """Class definition for the MSI inference module (reference: msi.py:33-38)."""
 
-    def __init__(self, weights=None, coord_net=True, device=None):
+    def __init__(self, weights=None, coord_net=True, device=None, input_type='ODS'):
         if not torch.cuda.is_available():
             raise RuntimeError("matryodshka_amd.MSI needs a HIP device (no CPU fallback)")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.coord_net = bool(coord_net)
+        if input_type not in ('ODS', 'PP'):
+            raise ValueError("input_type must be 'ODS' or 'PP' (FLAGS.input_type, msi.py:1157-1161)")
+        self.input_type = input_type
         self._weights = None
         self._blob_cache = {}     # (in_channels, num_outputs, ngf) -> np blob
         self._packed_cache = {}   # desc key -> device tensor
@@ -173,10 +176,16 @@ class MSI(object):
         for i, (img, pose) in enumerate(((ref_image, ref_pose), (src_image, src_pose))):
             curr_pose = self._f32(torch.matmul(pose, ref_pose_inv))            # msi.py:1125
             order = 1 if (i % 2) == 0 else -1
-            N.check(N.lib.msi_ods_sphere_sweep_f32(
-                img.data_ptr(), curr_pose.data_ptr(), intr.data_ptr(), depths.data_ptr(), trig.data_ptr(),
-                b, h, w, nd, order, psv.data_ptr(), 6 * nd, i * 3 * nd, self._stream()),
-                "msi_ods_sphere_sweep_f32")
+            if self.input_type == 'ODS':
+                N.check(N.lib.msi_ods_sphere_sweep_f32(
+                    img.data_ptr(), curr_pose.data_ptr(), intr.data_ptr(), depths.data_ptr(), trig.data_ptr(),
+                    b, h, w, nd, order, psv.data_ptr(), 6 * nd, i * 3 * nd, self._stream()),
+                    "msi_ods_sphere_sweep_f32")
+            else:   # sweep_src for perspective inputs (msi.py:1157-1161); ref_pose_inv = interp_pose_inv (:1113)
+                N.check(N.lib.msi_perspective_plane_sweep_f32(
+                    img.data_ptr(), curr_pose.data_ptr(), intr.data_ptr(), depths.data_ptr(),
+                    b, h, w, nd, psv.data_ptr(), 6 * nd, i * 3 * nd, self._stream()),
+                    "msi_perspective_plane_sweep_f32")
         return psv
 
     # ------------------------------------------------------------------ msi.py:40-289
@@ -368,3 +377,26 @@ class MSI(object):
                                                    self._stream()), "msi_assemble_rgba_scaled_f32")
         return self.msi_render_equirect_view_and_depth(rgba.permute(0, 2, 3, 1, 4), tgt_pose_rt, tgt_pos, planes,
                                                        intrinsics)
+
+    # ------------------------------------------------------------------ msi.py:527-548
+    def mpi_render_view(self, rgba_layers, tgt_pose, planes, intrinsics, intrinsics_inv=None):
+        """Render a target perspective view from plane layers by per-plane inverse homographies
+        (zero-padding bilinear) -> [B,H,W,3].  `intrinsics_inv` replaces the hidden graph input
+        `intrinsics_inv:0` (homography.py:52); default inverse(intrinsics)."""
+        native = self._native_layers(rgba_layers)
+        b, d, h, w, _ = native.shape
+        pose = self._f32(tgt_pose).reshape(-1, 4, 4)
+        intr = self._f32(intrinsics).reshape(-1, 3, 3)
+        if intrinsics_inv is None:
+            intrinsics_inv = torch.linalg.inv(intr.cpu().double()).float()
+        intr_inv = self._f32(intrinsics_inv).reshape(-1, 3, 3)
+        if pose.shape[0] != b or intr.shape[0] != b or intr_inv.shape[0] != b:
+            raise ValueError("tgt_pose / intrinsics batch must match rgba_layers")
+        depths = self._planes(planes)
+        if depths.numel() != d:
+            raise ValueError("len(planes) != number of layers")
+        out = torch.empty((b, h, w, 3), dtype=torch.float32, device=self.device)
+        N.check(N.lib.msi_mpi_render_f32(native.data_ptr(), pose.data_ptr(), intr.data_ptr(), intr_inv.data_ptr(),
+                                         depths.data_ptr(), b, h, w, d, out.data_ptr(), self._stream()),
+                "msi_mpi_render_f32")
+        return out

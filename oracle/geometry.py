@@ -440,3 +440,127 @@ def over_composite_depth(rgbas):
         else:
             output = F(i / n) * alpha + output * (F(1.0) - alpha)
     return output.astype(F)
+
+
+# ----------------------------------------------------------------------------
+# PP (perspective cube-face) path -- BASELINE configs[4]
+# ----------------------------------------------------------------------------
+def perspective_plane_sweep(image, depths, pose, intrinsics):
+    """projector.perspective_plane_sweep (projector.py:221-223) = sweep_one with uv_grid
+    (spherical.py:46-48), backproject_planar (:131-149), apply_pose, project_perspective (:248-266:
+    matmul(intrinsics4x4, pose) applied to the ALREADY posed points -- the pose enters twice, as in
+    the reference) and the wrap-around sampler.  image [B,H,W,C]; returns [B,H,W,C*D]."""
+    image = _f(image)
+    pose = _f(pose)
+    intrinsics = _f(intrinsics)
+    depths = _f(depths)
+    batch, height, width, ch = image.shape
+    nd = depths.shape[0]
+    s, t = uv_axes(height, width)
+    S, T = np.meshgrid(s, t)
+    S = S.astype(F)[None]
+    T = T.astype(F)[None]
+    dep = depths.reshape(-1, 1, 1)
+    out = np.empty((batch, height, width, ch * nd), dtype=F)
+    one = F(1)
+    for i in range(batch):
+        K = intrinsics[i]
+        fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+        with np.errstate(all="ignore"):
+            x = ((dep * S) * cx) / fx
+            y = ((dep * T) * cy) / fy
+            z = dep * np.ones_like(x)
+            x, y, z = apply_pose((x.astype(F), y.astype(F), z.astype(F)), pose[i])
+            P = pose[i]
+            pr = []
+            for r in range(3):
+                m = [F(F(F(K[r, 0] * P[0, c] + K[r, 1] * P[1, c]) + K[r, 2] * P[2, c]) + F(0) * P[3, c]) for c in range(4)]
+                pr.append(((m[0] * x + m[1] * y) + m[2] * z) + m[3] * one)
+            u = pr[0] / pr[2]
+            v = pr[1] / pr[2]
+        uv = np.stack([u, v], axis=-1).astype(F)
+        tiled = np.broadcast_to(image[i:i + 1], (nd, height, width, ch))
+        res = np.transpose(resample(tiled, uv), (1, 2, 0, 3))
+        out[i] = res.reshape(height, width, ch * nd)
+    return out
+
+
+def resampler_zero_pad(image, coords):
+    """tf.contrib.resampler.resampler (sampling.py:51) [TF-knowledge]: bilinear with zero padding;
+    zero outside (-1, W) x (-1, H); sum order fxfy + cxcy + fxcy + cxfy."""
+    image = _f(image)
+    coords = _f(coords)
+    n, height, width, ch = image.shape
+    x = coords[..., 0]
+    y = coords[..., 1]
+    with np.errstate(all="ignore"):
+        inside = (x > F(-1)) & (y > F(-1)) & (x < F(width)) & (y < F(height))
+        xs = np.where(inside, x, F(0))
+        ys = np.where(inside, y, F(0))
+        fx = np.floor(xs).astype(np.int64)
+        fy = np.floor(ys).astype(np.int64)
+        cx, cy = fx + 1, fy + 1
+        dx = cx.astype(F) - xs
+        dy = cy.astype(F) - ys
+    b = np.arange(n).reshape(n, 1, 1)
+
+    def get(ix, iy):
+        ok = (ix >= 0) & (iy >= 0) & (ix < width) & (iy < height)
+        v = image[b, np.clip(iy, 0, height - 1), np.clip(ix, 0, width - 1)]
+        return np.where(ok[..., None], v, F(0))
+
+    one = F(1)
+    out = (((dx * dy)[..., None] * get(fx, fy) + ((one - dx) * (one - dy))[..., None] * get(cx, cy))
+           + (dx * (one - dy))[..., None] * get(fx, cy)) + ((one - dx) * dy)[..., None] * get(cx, fy)
+    return np.where(inside[..., None], out, F(0)).astype(F)
+
+
+def _mm3(a, b):
+    """3x3 fp32 matmul, dot products summed left to right."""
+    a = _f(a)
+    b = _f(b)
+    out = np.empty((3, 3), dtype=F)
+    for r in range(3):
+        for c in range(3):
+            out[r, c] = F(F(a[r, 0] * b[0, c] + a[r, 1] * b[1, c]) + a[r, 2] * b[2, c])
+    return out
+
+
+def inv_homography(k_s, k_t_inv, rot, t, a):
+    """homography.inv_homography (homography.py:35-58) with n_hat = [0,0,1]
+    (projector.py:365-366); k_t_inv is the hidden graph input `intrinsics_inv:0`."""
+    rot_t = _f(rot).T.copy()
+    t = _f(t).reshape(3)
+    nrt = rot_t[2]                                            # n_hat @ rot_t
+    den = F(a) - F(F(nrt[0] * t[0] + nrt[1] * t[1]) + nrt[2] * t[2])
+    den = F(den + F(1e-8) * F(1.0 if den == 0 else 0.0))      # divide_safe (homography.py:30-33)
+    q = np.array([F(F(rot_t[r, 0] * t[0] + rot_t[r, 1] * t[1]) + rot_t[r, 2] * t[2]) for r in range(3)], dtype=F)
+    m1 = np.empty((3, 3), dtype=F)
+    for r in range(3):
+        for c in range(3):
+            m1[r, c] = F(rot_t[r, c] + F(F(q[r] * rot_t[2, c]) / den))
+    return _mm3(_mm3(k_s, m1), k_t_inv)
+
+
+def projective_forward_homography(src_images, intrinsics, intrinsics_inv, pose, depths):
+    """projector.projective_forward_homography (projector.py:343-373) -> homography.planar_transform
+    (homography.py:96-157).  src_images [D,B,H,W,C]; returns the warped layers."""
+    src_images = _f(src_images)
+    n_layers, n_batch, height, width, _ = src_images.shape
+    pose = _f(pose)
+    depths = _f(depths)
+    xs, ys = np.meshgrid(np.arange(width, dtype=F), np.arange(height, dtype=F))   # meshgrid_abs
+    out = np.empty_like(src_images)
+    one = F(1)
+    for l in range(n_layers):
+        coords = []
+        for bb in range(n_batch):
+            h = inv_homography(intrinsics[bb], intrinsics_inv[bb], pose[bb, :3, :3], pose[bb, :3, 3], -depths[l, bb])
+            with np.errstate(all="ignore"):
+                px = (xs * h[0, 0] + ys * h[0, 1]) + one * h[0, 2]
+                py = (xs * h[1, 0] + ys * h[1, 1]) + one * h[1, 2]
+                pw = (xs * h[2, 0] + ys * h[2, 1]) + one * h[2, 2]
+                pw = pw + F(1e-8) * (pw == 0).astype(F)
+                coords.append(np.stack([px / pw, py / pw], axis=-1).astype(F))
+        out[l] = resampler_zero_pad(src_images[l], np.stack(coords, axis=0))
+    return out

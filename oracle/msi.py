@@ -22,9 +22,10 @@ F = np.float32
 
 
 class MSI(object):
-    def __init__(self, weights=None, coord_net=True):
+    def __init__(self, weights=None, coord_net=True, input_type='ODS'):
         self.weights = weights
         self.coord_net = coord_net
+        self.input_type = input_type     # FLAGS.input_type: 'ODS' | 'PP' (msi.py:1157-1161)
 
     # -- msi.py:1196-1217 ---------------------------------------------------
     def inv_depths(self, start_depth, end_depth, num_depths):
@@ -79,7 +80,10 @@ class MSI(object):
         for i, (img, pose) in enumerate(((ref_image, ref_pose), (src_image, src_pose))):
             curr_pose = np.matmul(pose.astype(F), ref_pose_inv.astype(F)).astype(F)
             order = 1 if (i % 2) == 0 else -1
-            net_input.append(G.ods_sphere_sweep(img, order, planes, curr_pose, intrinsics))
+            if self.input_type == 'ODS':
+                net_input.append(G.ods_sphere_sweep(img, order, planes, curr_pose, intrinsics))
+            else:   # sweep_src, msi.py:1157-1161 (ref_pose_inv is `interp_pose_inv:0` there, :1113)
+                net_input.append(G.perspective_plane_sweep(img, planes, curr_pose, intrinsics))
         return np.concatenate(net_input, axis=3)
 
     # -- msi.py:40-289 (blend_psv) -------------------------------------------
@@ -201,3 +205,17 @@ class MSI(object):
                 out = out * (F(1.) - walpha) + wrgb * walpha
                 depth = F(i / n) * a3 + depth * (F(1.0) - a3)
         return out.astype(F), depth.astype(F)
+
+
+    # -- msi.py:527-548 -------------------------------------------------------------
+    def mpi_render_view(self, rgba_layers, tgt_pose, planes, intrinsics, intrinsics_inv=None):
+        rgba_layers = np.asarray(rgba_layers, dtype=F)
+        tgt_pose = np.asarray(tgt_pose, dtype=F).reshape(-1, 4, 4)
+        intrinsics = np.asarray(intrinsics, dtype=F)
+        if intrinsics_inv is None:
+            intrinsics_inv = np.linalg.inv(intrinsics.astype(np.float64)).astype(F)
+        batch_size = tgt_pose.shape[0]
+        depths = np.tile(np.asarray(planes, dtype=F).reshape(-1, 1), (1, batch_size))
+        layers = np.transpose(rgba_layers, (3, 0, 1, 2, 4))
+        proj = G.projective_forward_homography(layers, intrinsics, np.asarray(intrinsics_inv, dtype=F), tgt_pose, depths)
+        return G.over_composite([proj[i] for i in range(len(planes))])
