@@ -317,15 +317,44 @@ conv_igemm_kernel(const ConvParams p) {
 #undef MSI_SUPERSTEP
 
   // ---- epilogue: store + LayerNorm partial ------------------------------------------------
+  // The accumulators go through LDS so that the tile leaves as 16-byte-per-lane stores of whole
+  // 256-byte channel rows (per-lane 4-byte stores of the MFMA C layout reached only 1.4 TB/s on the
+  // 52 MB layers; this form streams like a copy).
   // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  constexpr int LDW = BN + 4;  // floats per staged row: 16-byte aligned, breaks the power-of-two stride
+  static_assert((size_t)BM * LDW * 4 <= (size_t)NSTAGE * KPB * STAGE_BYTES, "epilogue tile must fit the k-loop LDS");
+  float *ct = reinterpret_cast<float *>(smem);  // all LDS reads of the main loop are behind the last barrier
   const int col = lane & 31, rowq = 4 * (lane >> 5);
   float lsum = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
-      if (m >= mtot) continue;
+      const int lrow = wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
+      const bool mok = tile_m * BM + lrow < mtot;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int lcol = wn * (NT * 32) + j * 32 + col;
+        const int n = tile_n * BN + lcol;
+        float v = acc[i][j][r];
+        if (MODE == MODE_HEAD) v = tanhf(v + p.bias[min(n, p.Cout - 1)]);
+        ct[lrow * LDW + lcol] = v;
+        lsum += (mok && n < p.Cout) ? v : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int C4 = BN / 4;                       // float4 per staged row
+    constexpr int PASSES = BM * C4 / 256;
+    const bool vec_ok = (p.Cout & 3) == 0;
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      const int idx = tid + 256 * k;
+      const int lrow = idx / C4, c4 = idx - lrow * C4;
+      const int m = tile_m * BM + lrow;
+      const int n = tile_n * BN + c4 * 4;
+      if (m >= mtot || n >= p.Cout) continue;
       size_t opix;
       if (MODE == MODE_CONVT) {
         const int mh = m / p.Mw, mw = m - mh * p.Mw;
@@ -333,14 +362,15 @@ conv_igemm_kernel(const ConvParams p) {
       } else {
         opix = (size_t)b * mtot + m;
       }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = tile_n * BN + wn * (NT * 32) + j * 32 + col;
-        if (n >= p.Cout) continue;
-        float v = acc[i][j][r];
-        if (MODE == MODE_HEAD) v = tanhf(v + p.bias[n]);
-        p.y[opix * p.Cout + n] = v;
-        lsum += v;
+      const v4f v = *reinterpret_cast<const v4f *>(ct + lrow * LDW + c4 * 4);
+      float *dst = p.y + opix * p.Cout + n;
+      if (vec_ok) {
+        *reinterpret_cast<v4f *>(dst) = v;
+      } else {
+        dst[0] = v.x;
+        if (n + 1 < p.Cout) dst[1] = v.y;
+        if (n + 2 < p.Cout) dst[2] = v.z;
+        if (n + 3 < p.Cout) dst[3] = v.w;
       }
     }
   }
@@ -348,7 +378,7 @@ conv_igemm_kernel(const ConvParams p) {
 
   // block mean, then M2 about the block mean (two-pass inside the block: the values
   // are still in registers), reduced in a fixed order.
-  float *red = reinterpret_cast<float *>(smem);  // all LDS reads of the main loop are behind the last barrier
+  __shared__ float red[4];
   auto block_sum = [&](float v) __attribute__((always_inline)) -> float {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
