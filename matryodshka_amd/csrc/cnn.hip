@@ -121,7 +121,16 @@ conv_igemm_kernel(const ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  // XCD-aware tile order: workgroup b of a launch runs on XCD b % 8 (observed, speed only), and each
+  // XCD has a private L2.  Consecutive M tiles share their 3x3 halo rows (and all share the weights),
+  // so every XCD gets a CONTIGUOUS range of M tiles instead of every eighth one (bijective remap).
+  int tile_m;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int tile_n = blockIdx.y;
   const int cls = blockIdx.z % p.nclass, b = blockIdx.z / p.nclass;
   const int ph = cls >> 1, pw = cls & 1;
   const int mtot = p.Mh * p.Mw;
