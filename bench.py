@@ -100,6 +100,7 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         raise SystemExit("--gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
+    local_rank = local_rank % torch.cuda.device_count()   # (ranks may share a GPU in the gloo functional test)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

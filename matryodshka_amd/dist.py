@@ -15,7 +15,9 @@ def init_process_group(backend=None):
     if dist.is_initialized():
         return
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # MSI_DIST_BACKEND=gloo lets two ranks share one GPU (functional test of the N>1 path on a
+        # 1-GPU box; RCCL refuses duplicate devices)
+        backend = os.environ.get("MSI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     kwargs = {}
@@ -31,8 +33,14 @@ def shard_frames(num_frames, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _coll_device(device):
+    """Collectives run on the GPU with nccl (RCCL) and on the host with gloo."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else device
+
+
 def broadcast_blob(blob, numel, device, src=0):
     """Broadcast a flat fp32 parameter blob (numpy on `src`, ignored elsewhere)."""
+    device = _coll_device(device)
     if dist.get_rank() == src:
         t = torch.from_numpy(np.ascontiguousarray(blob, dtype=np.float32)).to(device)
         assert t.numel() == numel
@@ -59,6 +67,6 @@ def barrier():
 
 
 def max_over_ranks(value, device):
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
