@@ -1,0 +1,47 @@
+"""The test.py-equivalent harness (matryodshka_amd/harness.py): a synthetic 'Replica-style' sample
+(camera .txt line + three .jpeg files at 2x the working resolution) must produce the reference's
+output files (test.py:209-281), and the written PNGs must equal the direct API results."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import make_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_harness_writes_reference_outputs(tmp_path):
+    from PIL import Image
+    from matryodshka_amd import harness
+    h, w, d, ngf = 16, 32, 4, 8
+    inp = make_inputs(3, 1, 2 * h, 2 * w)
+    img_dir = tmp_path / "images"; img_dir.mkdir()
+    rng = np.random.RandomState(0)
+    for name in ("000", "001", "002"):
+        arr = np.clip(rng.uniform(0, 255, size=(2 * h, 2 * w, 3)), 0, 255).astype(np.uint8)
+        Image.fromarray(arr).save(str(img_dir / ("room_0_pos%s.jpeg" % name)), quality=95)
+    cam = tmp_path / "cams.txt"
+    cam.write_text("room_0 000 001 002 0.032 0.01 -0.02 0.03\n")
+    out_root = tmp_path / "out"
+    n = harness.main(["--cameras_glob", str(cam), "--image_dir", str(img_dir), "--output_root", str(out_root),
+                      "--experiment_name", "exp", "--height", str(h), "--width", str(w), "--num_msi_planes", str(d),
+                      "--ngf", str(ngf)])
+    assert n == 1
+    sample = out_root / "exp" / "room_0_000001002"
+    expected = ["tgt_image_room_0_000001002.png", "output_tgt_room_0_000001002.png", "output_depth_room_0_000001002.png",
+                "src_image_room_0_000001002.png", "ref_image_room_0_000001002.png", "blend_weights.npy", "alphas.npy"]
+    expected += ["psv_plane_%.3d.png" % j for j in range(d)] + ["blend_weight_%.3d.png" % j for j in range(d)]
+    expected += ["msi_alpha_%.2d.png" % j for j in range(d)] + ["msi_rgb_%.2d.png" % j for j in range(d)]
+    for f in expected:
+        assert (sample / f).exists(), f
+    assert (out_root / "exp" / "step.txt").read_text() == "0"
+    bw = np.load(str(sample / "blend_weights.npy"))
+    assert bw.shape == (1, h, w, d) and 0.0 <= bw.min() and bw.max() <= 1.0
+    out = np.asarray(Image.open(str(sample / "output_tgt_room_0_000001002.png")))
+    assert out.shape == (h, w, 3) and out.dtype == np.uint8
+    # the area resize of the harness: ref_image png == box mean of the 2x jpeg
+    ref_png = np.asarray(Image.open(str(sample / "ref_image_room_0_000001002.png"))).astype(int)
+    jpg = np.asarray(Image.open(str(img_dir / "room_0_pos000.jpeg")).convert("RGB"), dtype=np.float32)
+    box = jpg.reshape(h, 2, w, 2, 3).mean(axis=(1, 3))
+    assert np.abs(ref_png - np.clip(box, 0, 255).astype("uint8").astype(int)).max() <= 1
