@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--no-coord-net", action="store_true", help="msi_train_net instead of msi_coord_train_net")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams consecutive frames are issued on (1 = strictly one frame at a time, the "
+                         "default and the configuration BASELINE quotes; 2 = software-pipeline independent frames, "
+                         "each still batch 1, to fill the tile-quantisation tails of the small layers)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,7 +119,9 @@ def main():
     # weights: rank 0 initialises, everyone receives them over RCCL (xGMI)
     weights = nets.init_weights(cin, nout, NGF, coord, seed=8964) if rank == 0 else None
     weights = mdist.broadcast_weights(weights, cin, nout, NGF, coord, dev, src=0) if world > 1 else weights
-    model = MSI(weights=weights, coord_net=coord, device=dev)
+    models = [MSI(weights=weights, coord_net=coord, device=dev) for _ in range(max(1, args.streams))]
+    model = models[0]
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(args.streams - 1)]
     planes = model.inv_depths(1.0, 100.0, D)
 
     # synthetic ODS pair, seeded per rank (each rank renders its own frames)
@@ -132,7 +138,7 @@ def main():
 
     stage_names = ["preprocess", "sweep", "cnn", "assemble", "render", "deprocess"]
 
-    def frame(events=None):
+    def frame(events=None, model=model):
         def mark():
             if events is not None:
                 e = torch.cuda.Event(enable_timing=True)
@@ -155,17 +161,23 @@ def main():
         mark()
         return rgb, dep, rgb8, dep8, out
 
-    for _ in range(args.warmup):
-        frame()
+    def step(k, events=None):
+        if args.streams == 1:
+            return frame(events)
+        with torch.cuda.stream(streams[k % args.streams]):      # frame k and k+1 overlap on the device
+            return frame(None, models[k % args.streams])
+
+    for k in range(max(args.warmup, args.streams)):
+        step(k)
     torch.cuda.synchronize()
     if world > 1:
         mdist.barrier()
     torch.cuda.synchronize()
     all_events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         ev = []
-        result = frame(ev)
+        result = step(k, ev)
         all_events.append(ev)
     torch.cuda.synchronize()
     if world > 1:
@@ -177,6 +189,15 @@ def main():
     if rank != 0:
         return
 
+    if args.streams > 1:
+        # per-stage HIP events are only meaningful when frames do not overlap: time one frame alone
+        torch.cuda.synchronize()
+        all_events = []
+        for _ in range(5):
+            ev = []
+            frame(ev)
+            all_events.append(ev)
+        torch.cuda.synchronize()
     stage_ms = {}
     for si, name in enumerate(stage_names):
         stage_ms[name] = float(np.mean([ev[si].elapsed_time(ev[si + 1]) for ev in all_events]))
@@ -203,7 +224,8 @@ def main():
         "config": {"workload": "BASELINE configs[1]: 640x320 ODS pair, 32 spheres, batch=1 per GPU, fp32, "
                                + ("CoordNet" if coord else "wrap-pad net") + ", infer + RGB&depth render",
                    "height": H, "width": W, "num_spheres": D, "ngf": NGF, "frames_per_step_per_gpu": 1,
-                   "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world},
+                   "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world,
+                   "streams_per_gpu": args.streams},
         "roofline": {"kernel": "conv_igemm_kernel (18 launches/frame, fp32 MFMA implicit GEMM; + 17 ln_finish)",
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": cnn_traffic(),
