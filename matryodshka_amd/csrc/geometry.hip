@@ -36,7 +36,12 @@ PixConsts make_consts(int height, int width) {
   return k;
 }
 
+// tf.mod on int32 = floor-mod.  Pixel coordinates that come out of the angle formulas lie in
+// [-1, n], so the index (a = x + n) is in [n-1, 2n]: one conditional subtract; anything else (only
+// reachable through NaN/inf garbage) takes the generic integer-division path (~20 instructions,
+// which used to be paid 4x per bilinear lookup).
 __device__ __forceinline__ int floor_mod(int a, int n) {
+  if (a >= 0 && a < 2 * n) return a >= n ? a - n : a;
   int m = a % n;
   return m < 0 ? m + n : m;
 }
@@ -111,14 +116,13 @@ ods_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose
                  const float *__restrict__ intrinsics, const float *__restrict__ depths,
                  const float *__restrict__ trig, int batch, int height, int width, int nd,
                  float order, float *__restrict__ psv, int channels, int coff, PixConsts K) {
-  const long total = (long)batch * height * width * nd;
-  const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= total) return;
-  const int d = (int)(item % nd);
-  const long p = item / nd;
-  const int j = (int)(p % width);
-  const int i = (int)((p / width) % height);
-  const int b = (int)(p / ((long)width * height));
+  // grid = (ceil(W*D / 256), H, B): 32-bit index math only (64-bit div/mod are emulated in ~100
+  // VALU instructions each and used to dominate this kernel)
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= width * nd) return;
+  const int j = idx / nd, d = idx - j * nd;
+  const int i = blockIdx.y, b = blockIdx.z;
+  const long p = ((long)b * height + i) * width + j;
 
   const float cs = trig[j], ss = trig[width + j];
   const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
@@ -447,14 +451,13 @@ pp_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose,
                 const float *__restrict__ intrinsics, const float *__restrict__ depths, int batch,
                 int height, int width, int nd, float s0, float sstep, float t0, float tstep,
                 float *__restrict__ psv, int channels, int coff) {
-  const long total = (long)batch * height * width * nd;
-  const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= total) return;
-  const int d = (int)(item % nd);
-  const long p = item / nd;
-  const int j = (int)(p % width);
-  const int i = (int)((p / width) % height);
-  const int b = (int)(p / ((long)width * height));
+  // grid = (ceil(W*D / 256), H, B): 32-bit index math only (64-bit div/mod are emulated in ~100
+  // VALU instructions each and used to dominate this kernel)
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= width * nd) return;
+  const int j = idx / nd, d = idx - j * nd;
+  const int i = blockIdx.y, b = blockIdx.z;
+  const long p = ((long)b * height + i) * width + j;
   const float S = s0 + sstep * (float)j, T = t0 + tstep * (float)i;
   const float depth = depths[d];
   const float *Kb = intrinsics + (size_t)b * 9;
@@ -675,11 +678,11 @@ int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float 
   MSI_REQUIRE(channel_offset >= 0 && channel_offset + 3 * num_depths <= psv_channels,
               "ods_sphere_sweep: channel window [%d,%d) outside %d channels", channel_offset,
               channel_offset + 3 * num_depths, psv_channels);
-  const long total = (long)batch * height * width * num_depths;
-  if (total == 0) return MSI_OK;
-  const long blocks = (total + 255) / 256;
-  MSI_REQUIRE(blocks < 2147483647L, "ods_sphere_sweep: problem too large");
-  hipLaunchKernelGGL(ods_sweep_kernel, dim3((unsigned)blocks), dim3(256), 0, msi::as_stream(stream),
+  if (batch == 0) return MSI_OK;
+  MSI_REQUIRE((long)width * num_depths < 2147483647L && height <= 65535 && batch <= 65535,
+              "ods_sphere_sweep: problem too large");
+  const dim3 grid((unsigned)(((long)width * num_depths + 255) / 256), height, batch);
+  hipLaunchKernelGGL(ods_sweep_kernel, grid, dim3(256), 0, msi::as_stream(stream),
                      image, pose, intrinsics, depths, trig, batch, height, width, num_depths,
                      (float)order, psv, psv_channels, channel_offset, make_consts(height, width));
   return msi::check_launch("ods_sphere_sweep");
@@ -808,14 +811,14 @@ int msi_perspective_plane_sweep_f32(const float *image, const float *pose, const
   MSI_REQUIRE(batch >= 0 && height > 1 && width > 1 && num_depths > 0, "perspective_plane_sweep: bad dims");
   MSI_REQUIRE(channel_offset >= 0 && channel_offset + 3 * num_depths <= psv_channels,
               "perspective_plane_sweep: channel window outside %d channels", psv_channels);
-  const long total = (long)batch * height * width * num_depths;
-  if (total == 0) return MSI_OK;
-  const long blocks = (total + 255) / 256;
-  MSI_REQUIRE(blocks < 2147483647L, "perspective_plane_sweep: problem too large");
+  if (batch == 0) return MSI_OK;
+  MSI_REQUIRE((long)width * num_depths < 2147483647L && height <= 65535 && batch <= 65535,
+              "perspective_plane_sweep: problem too large");
+  const dim3 grid((unsigned)(((long)width * num_depths + 255) / 256), height, batch);
   // spherical.uv_grid (spherical.py:46-48), tf.linspace fp32 semantics
   const float s0 = (float)(-1.0 + 1.0 / width), s1 = (float)(1.0 - 1.0 / width);
   const float t0 = (float)(-1.0 + 1.0 / height), t1 = (float)(1.0 - 1.0 / height);
-  hipLaunchKernelGGL(pp_sweep_kernel, dim3((unsigned)blocks), dim3(256), 0, msi::as_stream(stream), image, pose,
+  hipLaunchKernelGGL(pp_sweep_kernel, grid, dim3(256), 0, msi::as_stream(stream), image, pose,
                      intrinsics, depths, batch, height, width, num_depths, s0, (s1 - s0) / (float)(width - 1), t0,
                      (t1 - t0) / (float)(height - 1), psv, psv_channels, channel_offset);
   return msi::check_launch("perspective_plane_sweep");
