@@ -61,6 +61,9 @@ constexpr int NSTAGE = MSI_NSTAGE;  // LDS ring depth: NSTAGE-1 k-steps of DMA i
 constexpr int NPAD_ALIGN = 128;
 constexpr int COORD_CLASSES = 5;    // column border classes of the CoordNet table: 0,1 | interior | W-2,W-1
 constexpr unsigned OOB = 0x80000000u;  // per-lane offset that is out of range of every descriptor
+constexpr int NUM_CUS = 256;
+constexpr int MAX_SPLIT = 8;
+constexpr size_t PARTIAL_BYTES = (size_t)NUM_CUS * MAX_SPLIT * 128 * 64 * sizeof(float);  // < 256 split tiles x 8 ranges
 constexpr double LN_EPS = 1e-12;  // slim.layer_norm variance epsilon [TF-knowledge]
 
 enum { MODE_CONV = 0, MODE_CONVT = 1, MODE_HEAD = 2 };
@@ -72,6 +75,9 @@ struct ConvParams {
   const float *bias;         // head only
   float *y;                  // raw output NHWC [B,Hout,Wout,Cout]
   float *stats;              // [B][nparts][4] (count, mean, M2, -) or null
+  float *partial;            // [split tiles][split][BM*BN] partial accumulators
+  int tiles_m, tiles_n, ntiles;  // output tiles per (sample, class) and in the whole launch
+  int n_main, split;         // tiles computed whole | K-ranges per remaining tile
   int C0, C1;
   int Hin, Win, Hout, Wout, Cout, npad;
   int Mh, Mw;                // GEMM row grid per sample (output grid; input grid for convT)
@@ -121,17 +127,46 @@ conv_igemm_kernel(const ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: workgroup b of a launch runs on XCD b % 8 (observed, speed only), and each
-  // XCD has a private L2.  Consecutive M tiles share their 3x3 halo rows (and all share the weights),
-  // so every XCD gets a CONTIGUOUS range of M tiles instead of every eighth one (bijective remap).
-  int tile_m;
+  // ---- work decomposition: "tail split" ----------------------------------------------------------
+  // All output tiles of a layer are co-resident (five workgroups fit a CU), so the launch takes as
+  // long as the busiest CU: with T tiles on 256 CUs that is ceil(T/256) tile-times although the
+  // average is T/256 (800 tiles: 4 vs 3.125 -> 78 %).  The first n_main = 256*floor(T/256) tiles are
+  // therefore computed whole (every CU gets the same number), and each of the remaining tiles is cut
+  // into `split` K-ranges computed by separate, short workgroups of the SAME launch whose partial
+  // accumulators conv_fixup_kernel sums in k order.
+  // XCD-aware order for the whole tiles: workgroup b runs on XCD b % 8 (observed, speed only) and
+  // each XCD has a private L2; consecutive tiles share halo rows and weights, so every XCD gets a
+  // CONTIGUOUS range of tiles instead of every eighth one (bijective remap).
+  const int S = p.ksteps;
+  int t, k0 = 0, k1 = S, ks = 0;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-    tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    const int bid = blockIdx.x;
+    if (bid < p.n_main) {
+      const int q = p.n_main >> 3, r = p.n_main & 7, xcd = bid & 7, local = bid >> 3;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    } else {
+      const int r = bid - p.n_main;
+      const int tl = r / p.split;
+      ks = r - tl * p.split;
+      t = p.n_main + tl;
+      k0 = ks * S / p.split;
+      k1 = (ks + 1) * S / p.split;
+    }
   }
-  const int tile_n = blockIdx.y;
-  const int cls = blockIdx.z % p.nclass, b = blockIdx.z / p.nclass;
+  const bool full = (k0 == 0) & (k1 == S);
+  int tile_m, tile_n, cls, b;
+  {
+    // tile order: M tiles fastest (measured on the same box: 3.03 ms per frame vs 3.11 ms with N tiles
+    // fastest and 3.09 ms for the previous 3-D grid without the tail split)
+    int r = t;
+    const int q1 = r / p.tiles_m;
+    tile_m = r - q1 * p.tiles_m; r = q1;
+    const int q2 = r / p.tiles_n;
+    tile_n = r - q2 * p.tiles_n; r = q2;
+    const int q3 = r / p.nclass;
+    cls = r - q3 * p.nclass;
+    b = q3;
+  }
   const int ph = cls >> 1, pw = cls & 1;
   const int mtot = p.Mh * p.Mw;
   const int wrap_w = p.wrap ? p.Win : 0;
@@ -162,7 +197,7 @@ conv_igemm_kernel(const ConvParams p) {
 
   const size_t in_pix = (size_t)p.Hin * p.Win;
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(p.wpk + (size_t)cls * p.ksteps * p.npad * BK), 0, (int)((size_t)p.ksteps * p.npad * ROW_BYTES), 0x00020000);
+      (void *)(p.wpk + (size_t)cls * S * p.npad * BK), 0, (int)((size_t)S * p.npad * ROW_BYTES), 0x00020000);
   const char *src0 = (const char *)(p.x0 + (size_t)b * in_pix * p.C0);
   const long d_src = (const char *)(p.x1 + (size_t)b * in_pix * p.C1) - src0;  // integer select, see gen below
   const int bytes0 = (int)(in_pix * p.C0 * 4), bytes1 = (int)(in_pix * p.C1 * 4);
@@ -172,8 +207,15 @@ conv_igemm_kernel(const ConvParams p) {
   unsigned a_voff[AI];       // byte offset of (pixel, data chunk) inside the source, or OOB
   unsigned a_voff_tail[AI];  // same with lanes beyond the source's channel count disabled (last chunk)
   __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, bytes0, 0x00020000);
-  int g_step = 0, g_tap = 0, g_src = 0, g_chunk = 0, g_C = p.C0;
   const int nreg = p.ntaps * (p.cpt0 + p.cpt1);  // regular k-steps; + 1 coord step when p.coord_tab
+  int g_step = k0, g_tap = 0, g_src = 0, g_chunk = 0, g_C = p.C0;
+  if (k0 > 0 && k0 < nreg) {   // a K-range of a split tile starts in the middle of the k-step list
+    const int cpt = p.cpt0 + p.cpt1;
+    g_tap = k0 / cpt;
+    const int within = k0 - g_tap * cpt;
+    g_src = within >= p.cpt0 ? 1 : 0;
+    g_chunk = g_src ? within - p.cpt0 : within;
+  }
 
   auto new_segment = [&]() __attribute__((always_inline)) {
     int dh, dw;
@@ -293,13 +335,13 @@ conv_igemm_kernel(const ConvParams p) {
   // whose grid is too small to hide the barrier with occupancy.  Unrolled by two with literal
   // buffer indices (a run-time index would send the ds_read address arrays to scratch).
   static_assert(NSTAGE == 2, "the main loop is written for a double buffer");
-  const int nsteps = p.ksteps;
+  const int nsteps = k1 - k0;
   const int nsuper = (nsteps + KPB - 1) / KPB;
   new_segment();
   auto issue_super = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < KPB; ++kk)
-      if (g_step < nsteps) issue(buf * KPB + kk);
+      if (g_step < k1) issue(buf * KPB + kk);
   };
   issue_super(0);
   wait_vmcnt<0>();
@@ -346,16 +388,27 @@ conv_igemm_kernel(const ConvParams p) {
         const int lcol = wn * (NT * 32) + j * 32 + col;
         const int n = tile_n * BN + lcol;
         float v = acc[i][j][r];
-        if (MODE == MODE_HEAD) v = tanhf(v + p.bias[min(n, p.Cout - 1)]);
+        if (MODE == MODE_HEAD && full) v = tanhf(v + p.bias[min(n, p.Cout - 1)]);
         ct[lrow * LDW + lcol] = v;
         lsum += (mok && n < p.Cout) ? v : 0.f;
       }
     }
   }
   __syncthreads();
+  constexpr int C4 = BN / 4;                       // float4 per staged row
+  constexpr int PASSES = BM * C4 / 256;
+  if (!full) {
+    // K-range of a split tile: raw accumulators, row-major [BM][BN], into slot (tile, range)
+    float *dst = p.partial + ((size_t)(t - p.n_main) * p.split + ks) * (BM * BN);
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      const int idx = tid + 256 * k;
+      const int lrow = idx / C4, c4 = idx - lrow * C4;
+      *reinterpret_cast<v4f *>(dst + lrow * BN + c4 * 4) = *reinterpret_cast<const v4f *>(ct + lrow * LDW + c4 * 4);
+    }
+    return;
+  }
   {
-    constexpr int C4 = BN / 4;                       // float4 per staged row
-    constexpr int PASSES = BM * C4 / 256;
     const bool vec_ok = (p.Cout & 3) == 0;
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
@@ -418,8 +471,8 @@ conv_igemm_kernel(const ConvParams p) {
   }
   const float bm2 = block_sum(lm2);
   if (tid == 0) {
-    const int nparts = gridDim.x * gridDim.y * p.nclass;
-    const int part = (cls * gridDim.y + tile_n) * gridDim.x + tile_m;
+    const int nparts = p.tiles_m * p.tiles_n * p.nclass;
+    const int part = (cls * p.tiles_n + tile_n) * p.tiles_m + tile_m;
     float *o = p.stats + ((size_t)b * nparts + part) * 4;
     o[0] = bcnt;
     o[1] = bmean;
@@ -427,6 +480,114 @@ conv_igemm_kernel(const ConvParams p) {
     o[3] = 0.f;
   }
 #endif  // __HIP_DEVICE_COMPILE__
+}
+
+// Fix-up of the split tiles: sums the `split` partial accumulators of a tile in k order
+// (deterministic) and performs the epilogue no single workgroup could (bias + tanh for the head,
+// store, LayerNorm partial).  One workgroup per split tile.
+template <int BM, int BN, int MODE>
+__global__ void __launch_bounds__(256)
+conv_fixup_kernel(const ConvParams p) {
+  __shared__ float red[4];
+  constexpr int C4 = BN / 4;
+  constexpr int PASSES = BM * C4 / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = p.n_main + blockIdx.x;
+  int tile_m, tile_n, cls, b;
+  {
+    int r = t;   // same order as conv_igemm_kernel: M tiles fastest
+    tile_m = r % p.tiles_m; r /= p.tiles_m;
+    tile_n = r % p.tiles_n; r /= p.tiles_n;
+    cls = r % p.nclass;
+    b = r / p.nclass;
+  }
+  const int ph = cls >> 1, pw = cls & 1;
+  const int mtot = p.Mh * p.Mw;
+  v4f v[PASSES];
+#pragma unroll
+  for (int k = 0; k < PASSES; ++k) v[k] = v4f{0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < p.split; ++ks) {
+    const float *src = p.partial + ((size_t)blockIdx.x * p.split + ks) * (BM * BN);
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      const v4f a = *reinterpret_cast<const v4f *>(src + (size_t)(tid + 256 * k) * 4);
+      v[k].x += a.x; v[k].y += a.y; v[k].z += a.z; v[k].w += a.w;
+    }
+  }
+  const bool vec_ok = (p.Cout & 3) == 0;
+  float lsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < PASSES; ++k) {
+    const int idx = tid + 256 * k;
+    const int lrow = idx / C4, c4 = idx - lrow * C4;
+    const int m = tile_m * BM + lrow;
+    const int n = tile_n * BN + c4 * 4;
+    float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+    if (MODE == MODE_HEAD) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = tanhf(e[q] + p.bias[min(n + q, p.Cout - 1)]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      e[q] = (m < mtot && n + q < p.Cout) ? e[q] : 0.f;
+      lsum += e[q];
+    }
+    v[k] = v4f{e[0], e[1], e[2], e[3]};
+    if (m >= mtot || n >= p.Cout) continue;
+    size_t opix;
+    if (MODE == MODE_CONVT) {
+      const int mh = m / p.Mw, mw = m - mh * p.Mw;
+      opix = ((size_t)b * p.Hout + (2 * mh + ph)) * p.Wout + (2 * mw + pw);
+    } else {
+      opix = (size_t)b * mtot + m;
+    }
+    float *dst = p.y + opix * p.Cout + n;
+    if (vec_ok) {
+      *reinterpret_cast<v4f *>(dst) = v[k];
+    } else {
+      dst[0] = e[0];
+      if (n + 1 < p.Cout) dst[1] = e[1];
+      if (n + 2 < p.Cout) dst[2] = e[2];
+      if (n + 3 < p.Cout) dst[3] = e[3];
+    }
+  }
+  if (MODE == MODE_HEAD || p.stats == nullptr) return;
+  auto block_sum = [&](float x) __attribute__((always_inline)) -> float {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    __syncthreads();
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  const float bsum = block_sum(lsum);
+  const float bcnt = (float)(min(BM, mtot - tile_m * BM) * min(BN, p.Cout - tile_n * BN));
+  const float bmean = bcnt > 0.f ? bsum / bcnt : 0.f;
+  float lm2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < PASSES; ++k) {
+    const int idx = tid + 256 * k;
+    const int lrow = idx / C4, c4 = idx - lrow * C4;
+    const int m = tile_m * BM + lrow;
+    const int n = tile_n * BN + c4 * 4;
+    const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (m < mtot && n + q < p.Cout) {
+        const float dlt = e[q] - bmean;
+        lm2 += dlt * dlt;
+      }
+  }
+  const float bm2 = block_sum(lm2);
+  if (tid == 0) {
+    const int nparts = p.tiles_m * p.tiles_n * p.nclass;
+    const int part = (cls * p.tiles_n + tile_n) * p.tiles_m + tile_m;
+    float *o = p.stats + ((size_t)b * nparts + part) * 4;
+    o[0] = bcnt;
+    o[1] = bmean;
+    o[2] = bm2;
+    o[3] = 0.f;
+  }
 }
 
 // LayerNorm finish + apply in ONE launch.  Every workgroup first merges the per-workgroup (count,
@@ -523,7 +684,7 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Net {
   std::vector<Layer> layers;
-  size_t param_floats = 0, packed_floats = 0, ws_bytes = 0, stats_off = 0, stats_bytes = 0;
+  size_t param_floats = 0, packed_floats = 0, ws_bytes = 0, stats_off = 0, stats_bytes = 0, partial_off = 0;
 };
 
 int build_net(const msi_net_desc *d, Net &net) {
@@ -629,14 +790,34 @@ int build_net(const msi_net_desc *d, Net &net) {
   net.packed_floats = koff;
   net.stats_off = woff;
   net.stats_bytes = round_up((size_t)d->batch * max_parts * 4 * sizeof(float), 256);
-  net.ws_bytes = woff + net.stats_bytes;
+  net.partial_off = woff + net.stats_bytes;
+  net.ws_bytes = net.partial_off + PARTIAL_BYTES;
   return MSI_OK;
 }
 
 template <int BM, int BN, int MODE, int KPB>
-int launch_conv_mode(const ConvParams &p, int batch, hipStream_t stream, int *nparts) {
+int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   const int mtot = p.Mh * p.Mw;
-  const dim3 grid((mtot + BM - 1) / BM, (p.Cout + BN - 1) / BN, batch * p.nclass);
+  p.tiles_m = (mtot + BM - 1) / BM;
+  p.tiles_n = (p.Cout + BN - 1) / BN;
+  p.ntiles = p.tiles_m * p.tiles_n * p.nclass * batch;
+  *nparts = p.tiles_m * p.tiles_n * p.nclass;
+  // tail split (see the kernel): whole tiles in multiples of the CU count, the remainder cut into
+  // `split` K-ranges so that (remainder x split) is again close to a multiple of the CU count
+  p.n_main = p.ntiles;
+  p.split = 1;
+  static const char *ts = getenv("MSI_CONV_TAILSPLIT");   // debug: 0 disables
+  const int rem = p.ntiles % NUM_CUS;
+  if (rem != 0 && p.ntiles > NUM_CUS / 2 && p.ksteps >= 2 * MAX_SPLIT && !(ts && atoi(ts) == 0)) {
+    int best = 1;
+    double best_cost = 1.0;   // time of the tail in tile-times: ceil(rem*s/CUs)/s
+    for (int sp = 2; sp <= MAX_SPLIT; ++sp) {
+      const double cost = (double)((rem * sp + NUM_CUS - 1) / NUM_CUS) / sp;
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+    }
+    if (best > 1) { p.split = best; p.n_main = p.ntiles - rem; }
+  }
+  const int nblocks = p.n_main + (p.ntiles - p.n_main) * p.split;
   const size_t lds = (size_t)NSTAGE * KPB * (BM + BN) * ROW_BYTES;
   if (lds > 64 * 1024) {
     static thread_local bool done = false;
@@ -647,9 +828,11 @@ int launch_conv_mode(const ConvParams &p, int batch, hipStream_t stream, int *np
       done = true;
     }
   }
-  *nparts = grid.x * grid.y * p.nclass;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, KPB>), grid, dim3(256), lds, stream, p);
-  return msi::check_launch("conv_igemm");
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, KPB>), dim3(nblocks), dim3(256), lds, stream, p);
+  int rc = msi::check_launch("conv_igemm");
+  if (rc || p.split == 1) return rc;
+  hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, MODE>), dim3(p.ntiles - p.n_main), dim3(256), 0, stream, p);
+  return msi::check_launch("conv_fixup");
 }
 
 template <int BM, int BN, int KPB>
@@ -830,6 +1013,7 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
     p.bias = L.kind == MODE_HEAD ? packed + L.gamma_off : nullptr;
     p.y = L.kind == MODE_HEAD ? pred : reinterpret_cast<float *>(ws + L.raw_off);
     p.stats = L.kind == MODE_HEAD ? nullptr : stats;
+    p.partial = reinterpret_cast<float *>(ws + net.partial_off);
     p.Hin = L.in_h; p.Win = L.in_w; p.Hout = L.out_h; p.Wout = L.out_w;
     p.Cout = L.cout; p.npad = L.npad;
     p.ntaps = L.ntaps; p.cpt0 = L.cpt0; p.cpt1 = L.cpt1; p.ksteps = L.ksteps;
