@@ -34,27 +34,38 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak F
 PEAK_HBM_GBS = 8000.0           # HBM3E spec peak, same guide
 
 
-def cnn_flops(h, w, cin, nout, ngf, coord):
-    """2*MACs of the 18 layers (SURVEY.md 8d: 302.4 GFLOP at 640x320, D=32, CoordNet)."""
+def cnn_layer_flops(h, w, cin, nout, ngf, coord):
+    """2*MACs of each of the 18 layers in graph order (conv1_1 ... conv8_2, color_pred)."""
     ex = 1 if coord else 0
-    total = 0
     def conv(hh, ww, ci, co, k=9, e=ex):
         return 2 * hh * ww * co * (k * (ci + e))
-    total += conv(h, w, cin, ngf)
-    total += conv(h // 2, w // 2, ngf, ngf * 2)
-    total += conv(h // 2, w // 2, ngf * 2, ngf * 2)
-    total += conv(h // 4, w // 4, ngf * 2, ngf * 4)
-    total += 2 * conv(h // 4, w // 4, ngf * 4, ngf * 4)
-    total += conv(h // 8, w // 8, ngf * 4, ngf * 8)
-    total += 3 * conv(h // 8, w // 8, ngf * 8, ngf * 8)
-    total += 2 * (h // 4) * (w // 4) * (ngf * 4) * 4 * (ngf * 16)      # conv6_1: 2x2 taps per output pixel
-    total += 2 * conv(h // 4, w // 4, ngf * 4, ngf * 4)
-    total += 2 * (h // 2) * (w // 2) * (ngf * 2) * 4 * (ngf * 8)       # conv7_1
-    total += conv(h // 2, w // 2, ngf * 2, ngf * 2)
-    total += 2 * h * w * ngf * 4 * (ngf * 4)                          # conv8_1
-    total += conv(h, w, ngf, ngf)
-    total += 2 * h * w * ngf * nout                                    # head
-    return total
+    def convt(hh, ww, ci, co):                   # 4x4 stride-2 transpose: 2x2 taps per OUTPUT pixel (hh, ww)
+        return 2 * hh * ww * co * 4 * ci
+    return [
+        conv(h, w, cin, ngf),                                   # conv1_1
+        conv(h // 2, w // 2, ngf, ngf * 2),                     # conv1_2 (stride 2)
+        conv(h // 2, w // 2, ngf * 2, ngf * 2),                 # conv2_1
+        conv(h // 4, w // 4, ngf * 2, ngf * 4),                 # conv2_2 (stride 2)
+        conv(h // 4, w // 4, ngf * 4, ngf * 4),                 # conv3_1
+        conv(h // 4, w // 4, ngf * 4, ngf * 4),                 # conv3_2
+        conv(h // 8, w // 8, ngf * 4, ngf * 8),                 # conv3_3 (stride 2)
+        conv(h // 8, w // 8, ngf * 8, ngf * 8),                 # conv4_1
+        conv(h // 8, w // 8, ngf * 8, ngf * 8),                 # conv4_2
+        conv(h // 8, w // 8, ngf * 8, ngf * 8),                 # conv4_3
+        convt(h // 4, w // 4, ngf * 16, ngf * 4),               # conv6_1 (skip concat in)
+        conv(h // 4, w // 4, ngf * 4, ngf * 4),                 # conv6_2
+        conv(h // 4, w // 4, ngf * 4, ngf * 4),                 # conv6_3
+        convt(h // 2, w // 2, ngf * 8, ngf * 2),                # conv7_1
+        conv(h // 2, w // 2, ngf * 2, ngf * 2),                 # conv7_2
+        convt(h, w, ngf * 4, ngf),                              # conv8_1
+        conv(h, w, ngf, ngf),                                   # conv8_2
+        2 * h * w * ngf * nout,                                 # color_pred (1x1 + bias + tanh)
+    ]
+
+
+def cnn_flops(h, w, cin, nout, ngf, coord):
+    """2*MACs of the 18 layers (SURVEY.md 8d: 302.4 GFLOP at 640x320, D=32, CoordNet)."""
+    return sum(cnn_layer_flops(h, w, cin, nout, ngf, coord))
 
 
 def cnn_traffic():

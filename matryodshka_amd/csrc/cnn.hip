@@ -84,7 +84,7 @@ struct ConvParams {
   int ntaps, cpt0, cpt1, ksteps;  // taps, 32-channel chunks per tap of each source, total k-steps
   int stride, rate, pad_t, pad_l;
   int mode, wrap, nclass;
-  int ablate;                // debug only (MSI_CONV_ABLATE): 1 = skip DMA, 2 = skip MFMAs
+  int ablate;                // debug only (MSI_CONV_ABLATE): 1 = skip the k-loop DMA (results are garbage)
 };
 
 template <int MODE>
@@ -114,8 +114,30 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// LDS operand fetch / wait as inline asm: hipcc schedules builtin LDS loads for minimum register
+// pressure (fetch a quarter, wait lgkmcnt(0), 4 MFMAs, fetch the next quarter ...) and re-adds the
+// stage offset per read with VALU.  Here the order is the source order, the stage / sub-tile offset
+// is the instruction's immediate, and the waits are counted (LDS reads return in order; any other
+// lgkm operation in flight only makes a counted wait more conservative).
+template <int OFF>
+__device__ __forceinline__ v4f lds_read128(unsigned addr) {
+  v4f v;
+  if constexpr (OFF < 65536) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  } else {  // beyond the 16-bit immediate (only the experimental big tiles): one VALU add
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr + (OFF & ~0xffff)), "n"(OFF & 0xffff) : "memory");
+  }
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm(v4f &x, v4f &y) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N) : "memory");
+}
+
+// amdgpu_waves_per_eu: with a dynamic LDS size hipcc cannot see that five 32 KB workgroups share a CU
+// and spends registers freely (116 for the 64x64 tile => four waves per SIMD); five need <= 96.
 template <int BM, int BN, int MODE, int KPB>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM * BN <= 64 * 64 ? 5 : 2)))
 conv_igemm_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (the body uses device-only types)
   constexpr int MT = BM / 64, NT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
@@ -290,15 +312,17 @@ conv_igemm_kernel(const ConvParams p) {
   // lives in slot (h*4+q) ^ ((row>>1)&7).
   const int frow = lane & 31, fh = lane >> 5;
   const int fswz = (frow >> 1) & 7;
-  unsigned a_rd[NSTAGE * KPB][4], b_rd[NSTAGE * KPB][4];
-#pragma unroll
-  for (int st = 0; st < NSTAGE * KPB; ++st)
+  // Only the eight stage-0 addresses live in VGPRs; stage and sub-tile offsets are ds_read immediates.
+  unsigned a_q[4], b_q[4];
+  {
+    const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int slot = ((fh * 4 + q) ^ fswz) * 16;
-      a_rd[st][q] = st * STAGE_BYTES + (wm * (MT * 32) + frow) * ROW_BYTES + slot;
-      b_rd[st][q] = st * STAGE_BYTES + BM * ROW_BYTES + (wn * (NT * 32) + frow) * ROW_BYTES + slot;
+      a_q[q] = lds_base + (wm * (MT * 32) + frow) * ROW_BYTES + slot;
+      b_q[q] = lds_base + BM * ROW_BYTES + (wn * (NT * 32) + frow) * ROW_BYTES + slot;
     }
+  }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -308,24 +332,41 @@ conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](const unsigned (&ard)[4], const unsigned (&brd)[4]) __attribute__((always_inline)) {
+  // One k-step = fetch (all eight operand quarters, 32 VGPRs per MFMA tile row/column) + mma (16
+  // MFMAs per MFMA tile, each quarter waiting only for its own two fetches).  A wave keeps its MFMA
+  // stream fed on its own instead of relying on the other waves of the SIMD to cover every ds_read
+  // round trip; whatever is placed between fetch and mma (the DMA issue of the next k-step) runs
+  // in the shadow of the LDS latency.
+  struct Frag { v4f a[4][MT], b[4][NT]; };
+#define MSI_FETCH(F, ST)                                                                              \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                 \
+      F.a[q_][i_] = i_ == 0 ? lds_read128<(ST) * STAGE_BYTES>(a_q[q_])                                \
+                            : lds_read128<(ST) * STAGE_BYTES + (MT - 1) * 32 * ROW_BYTES>(a_q[q_]);    \
+    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                 \
+      F.b[q_][j_] = j_ == 0 ? lds_read128<(ST) * STAGE_BYTES>(b_q[q_])                                \
+                            : lds_read128<(ST) * STAGE_BYTES + (NT - 1) * 32 * ROW_BYTES>(b_q[q_]);    \
+  }
+  static_assert(MT <= 2 && NT <= 2, "MSI_FETCH addresses at most two MFMA tiles per direction");
+  auto mma_quarter = [&](Frag &f, const int q) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v4f a[MT], bb[NT];
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const v4f *>(smem + ard[q] + i * 32 * ROW_BYTES);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bb[j] = *reinterpret_cast<const v4f *>(smem + brd[q] + j * 32 * ROW_BYTES);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, bb[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, bb[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, bb[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, bb[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].x, f.b[q][j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].y, f.b[q][j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].z, f.b[q][j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].w, f.b[q][j].w, acc[i][j], 0, 0, 0);
+      }
+  };
+  // counted waits: quarter q needs the first (q+1)*(MT+NT) fetches of the 4*(MT+NT) issued
+  auto mma = [&](Frag &f) __attribute__((always_inline)) {
+    constexpr int PER = MT + NT;
+    // (sched_barrier: the MFMAs are not volatile -- without it all four waits are hoisted above them)
+    wait_lgkm<3 * PER>(f.a[0][MT - 1], f.b[0][NT - 1]); mma_quarter(f, 0); __builtin_amdgcn_sched_barrier(0);
+    wait_lgkm<2 * PER>(f.a[1][MT - 1], f.b[1][NT - 1]); mma_quarter(f, 1); __builtin_amdgcn_sched_barrier(0);
+    wait_lgkm<1 * PER>(f.a[2][MT - 1], f.b[2][NT - 1]); mma_quarter(f, 2); __builtin_amdgcn_sched_barrier(0);
+    wait_lgkm<0>(f.a[3][MT - 1], f.b[3][NT - 1]);       mma_quarter(f, 3); __builtin_amdgcn_sched_barrier(0);
   };
 
   // ---- main loop: double-buffered LDS, KPB k-steps per barrier -----------------------------------
@@ -349,11 +390,16 @@ conv_igemm_kernel(const ConvParams p) {
 
 #define MSI_SUPERSTEP(U, S)                                                               \
   {                                                                                       \
+    Frag f0_;                                                                             \
+    MSI_FETCH(f0_, (U) * KPB)                                                             \
     if ((S) + 1 < nsuper && !(p.ablate & 1)) issue_super((U) ^ 1);                        \
-    if (!(p.ablate & 2)) {                                                                \
-      compute(a_rd[(U) * KPB], b_rd[(U) * KPB]);                                          \
+    {                                                                                     \
+      mma(f0_);                                                                           \
       if constexpr (KPB > 1) {                                                            \
-        if ((S) * KPB + 1 < nsteps) compute(a_rd[(U) * KPB + 1], b_rd[(U) * KPB + 1]);    \
+        if ((S) * KPB + 1 < nsteps) {                                                     \
+          MSI_FETCH(f0_, (U) * KPB + 1)                                                   \
+          mma(f0_);                                                                       \
+        }                                                                                 \
       }                                                                                   \
     }                                                                                     \
     wait_vmcnt<0>();                                                                      \
@@ -366,6 +412,7 @@ conv_igemm_kernel(const ConvParams p) {
     MSI_SUPERSTEP(1, S + 1);
   }
 #undef MSI_SUPERSTEP
+#undef MSI_FETCH
 
   // ---- epilogue: store + LayerNorm partial ------------------------------------------------
   // The accumulators go through LDS so that the tile leaves as 16-byte-per-lane stores of whole

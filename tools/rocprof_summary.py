@@ -33,10 +33,25 @@ def main():
         print("\n# conv_igemm launches of the last frame (18 layers, graph order)")
         names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2",
                  "conv4_3", "conv6_1", "conv6_2", "conv6_3", "conv7_1", "conv7_2", "conv8_1", "conv8_2", "color_pred"]
-        for nm, r in zip(names, conv[-18:]):
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        flops = bench.cnn_layer_flops(320, 640, 192, 64, 64, True)      # BASELINE config
+        fix = c.execute("select start, end from kernels where name like '%conv_fixup%' order by start").fetchall()
+        tot_us = 0.0
+        for nm, r, fl in zip(names, conv[-18:], flops):
             tmpl = r[0].split("<")[1].split(">")[0] if "<" in r[0] else "?"
-            print("%-10s tile<%s> blocks=(%d,%d,%d) lds=%d vgpr=%d agpr=%d  %9.1f us" % (
-                nm, tmpl, r[3] // r[6], r[4], r[5], r[7], r[8], r[9], (r[2] - r[1]) / 1e3))
+            us = (r[2] - r[1]) / 1e3
+            # a fix-up launch (tail split) directly follows its conv launch
+            fx = [(e - s0) / 1e3 for s0, e in fix if r[2] <= s0 < r[2] + 200000]
+            nxt = [q[1] for q in conv if q[1] > r[1]]
+            fx = [f for (s0, e), f in zip([x for x in fix if r[2] <= x[0] < r[2] + 200000], fx) if not nxt or s0 < nxt[0]]
+            fus = sum(fx[:1])
+            tot_us += us + fus
+            print("%-10s tile<%s> blocks=%d lds=%d vgpr=%d agpr=%d  %8.1f us + fixup %5.1f us  %6.1f TFLOP/s (%4.1f%%, BASELINE shapes)" % (
+                nm, tmpl, (r[3] // r[6]) * r[4] * r[5], r[7], r[8], r[9], us, fus, fl / (us + fus) / 1e6,
+                100 * fl / (us + fus) / 1e6 / bench.PEAK_FP32_MFMA_TFLOPS))
+        print("sum %.1f us -> %.1f TFLOP/s" % (tot_us, sum(flops) / tot_us / 1e6))
 
 
 if __name__ == "__main__":
