@@ -81,28 +81,21 @@ struct ConvParams {
   int C0, C1;
   int Hin, Win, Hout, Wout, Cout, npad;
   int Mh, Mw;                // GEMM row grid per sample (output grid; input grid for convT)
+  unsigned mg_mw;            // floor(2^32 / Mw) (clamped): m / Mw by multiply-high + one correction
   int ntaps, cpt0, cpt1, ksteps;  // taps, 32-channel chunks per tap of each source, total k-steps
   int stride, rate, pad_t, pad_l;
   int mode, wrap, nclass;
   int ablate;                // debug only (MSI_CONV_ABLATE): 1 = skip the k-loop DMA (results are garbage)
 };
 
+// Input offset (rows or columns) of tap-row / tap-column variant v.
 template <int MODE>
-__device__ __forceinline__ void tap_offset(int rate, int tap, int ph, int pw, int &dh, int &dw) {
-  if (MODE == MODE_CONV) {
-    const int kh = tap / 3, kw = tap - kh * 3;
-    dh = kh * rate;
-    dw = kw * rate;
-  } else if (MODE == MODE_CONVT) {
-    // y[2i + k - 1] += x[i] w[k]: even outputs use k=1 (i = o/2) and k=3 (i = o/2 - 1),
-    // odd outputs k=2 (i = (o-1)/2) and k=0 (i = (o+1)/2).
-    const int th = tap >> 1, tw = tap & 1;
-    dh = th == 0 ? 0 : (ph ? 1 : -1);
-    dw = tw == 0 ? 0 : (pw ? 1 : -1);
-  } else {
-    dh = 0;
-    dw = 0;
-  }
+__device__ __forceinline__ int tap_delta(int v, int parity, int rate) {
+  if (MODE == MODE_CONV) return v * rate;
+  // conv-transpose, y[2i + k - 1] += x[i] w[k]: even outputs use k=1 (i = o/2) and k=3 (i = o/2 - 1),
+  // odd outputs k=2 (i = (o-1)/2) and k=0 (i = (o+1)/2).
+  if (MODE == MODE_CONVT) return v == 0 ? 0 : (parity ? 1 : -1);
+  return 0;
 }
 
 __device__ __forceinline__ int coord_class(int mw, int Mw) {
@@ -136,8 +129,8 @@ __device__ __forceinline__ void wait_lgkm(v4f &x, v4f &y) {
 
 // amdgpu_waves_per_eu: with a dynamic LDS size hipcc cannot see that five 32 KB workgroups share a CU
 // and spends registers freely (116 for the 64x64 tile => four waves per SIMD); five need <= 96.
-template <int BM, int BN, int MODE, int KPB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM * BN <= 64 * 64 ? 5 : 2)))
+template <int BM, int BN, int MODE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5)))
 conv_igemm_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (the body uses device-only types)
   constexpr int MT = BM / 64, NT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
@@ -196,26 +189,49 @@ conv_igemm_kernel(const ConvParams p) {
   // ---- DMA lane mapping: instruction i of this wave fills LDS rows [wave*BM/4 + 8i, +8);
   // lane -> (row = lane>>3, 16-byte slot = lane&7); the slot holds data chunk slot ^ ((row>>1)&7).
   const int drow = lane >> 3, dslot = lane & 7;
-  int r_ih[AI], r_iw[AI], r_mh[AI], r_cls[AI];
-  unsigned r_ok = 0;
-  int a_chunk[AI];   // data chunk (0..7) this lane fetches for A row i
+  // Per A row: everything a (tap, source) segment switch needs, so that the switch itself -- VALU work
+  // inside the MFMA loop, paid in matrix throughput -- is ~7 instructions per row: the input row
+  // base, the (wrapped) input column for each of the NV tap columns, and one validity bit per tap.
+  constexpr int NV = MODE == MODE_CONV ? 3 : (MODE == MODE_CONVT ? 2 : 1);  // tap rows = tap columns
+  int rowbase[AI], colw0[AI], colw1[AI], colw2[AI];  // (three arrays: a [AI][NV] array selected by
+                                                                           // the tap column ends up indexed in scratch)
+  unsigned vmask[AI], a_chunk16[AI];
+  unsigned c_voff[AI];       // CoordNet k-step: byte offset into the (row, column class) table, or OOB
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int r = wave * (BM / 4) + i * 8 + drow;
     const int m = tile_m * BM + r;
-    const int mh = m / p.Mw, mw = m - mh * p.Mw;
-    r_ih[i] = mh * p.stride - p.pad_t;
-    r_iw[i] = mw * p.stride - p.pad_l;
-    r_mh[i] = mh;
-    r_cls[i] = coord_class(mw, p.Mw);
-    if (m < mtot) r_ok |= 1u << i;
-    a_chunk[i] = dslot ^ ((r >> 1) & 7);
+    int mh = (int)__umulhi((unsigned)m, p.mg_mw);
+    int mw = m - mh * p.Mw;
+    if (mw >= p.Mw) { ++mh; mw -= p.Mw; }
+    const int ih0 = mh * p.stride - p.pad_t, iw0 = mw * p.stride - p.pad_l;
+    rowbase[i] = ih0 * p.Win;
+    const bool mok = m < mtot;
+    unsigned rowok = 0, colok = 0;
+    colw1[i] = colw2[i] = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int ih = ih0 + tap_delta<MODE>(v, ph, p.rate);
+      int iw = iw0 + tap_delta<MODE>(v, pw, p.rate);
+      iw = iw < 0 ? iw + wrap_w : (iw >= p.Win ? iw - wrap_w : iw);  // wrap_w = 0: plain zero padding
+      if (v == 0) colw0[i] = iw;
+      if (v == 1) colw1[i] = iw;
+      if (v == 2) colw2[i] = iw;
+      if (ih >= 0 && ih < p.Hin) rowok |= 1u << v;
+      if (iw >= 0 && iw < p.Win) colok |= 1u << v;
+    }
+    unsigned vm = 0;
+#pragma unroll
+    for (int vr = 0; vr < NV; ++vr)
+#pragma unroll
+      for (int vc = 0; vc < NV; ++vc)
+        if (mok && ((rowok >> vr) & 1u) && ((colok >> vc) & 1u)) vm |= 1u << (vr * NV + vc);
+    vmask[i] = vm;
+    a_chunk16[i] = (unsigned)((dslot ^ ((r >> 1) & 7)) * 16);  // byte offset of the data chunk this lane fetches
+    c_voff[i] = mok ? (unsigned)((mh * COORD_CLASSES + coord_class(mw, p.Mw)) * ROW_BYTES) + a_chunk16[i] : OOB;
   }
   // B: rows [wave*BN/4 + 8i, +8) of the weight tile; the packed blob is already swizzled
-  unsigned b_voff[BI];
-#pragma unroll
-  for (int i = 0; i < BI; ++i)
-    b_voff[i] = (unsigned)(((tile_n * BN + wave * (BN / 4) + i * 8 + drow) * BK + dslot * 4) * 4);
+  const unsigned b_voff = (unsigned)(((tile_n * BN + wave * (BN / 4) + drow) * BK + dslot * 4) * 4);
 
   const size_t in_pix = (size_t)p.Hin * p.Win;
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
@@ -227,7 +243,6 @@ conv_igemm_kernel(const ConvParams p) {
   // ---- k-step generator: (tap, source, chunk) segments ------------------------------------------
   // Per segment the per-lane A offsets are fixed; the channel walk is the scalar soffset.
   unsigned a_voff[AI];       // byte offset of (pixel, data chunk) inside the source, or OOB
-  unsigned a_voff_tail[AI];  // same with lanes beyond the source's channel count disabled (last chunk)
   __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, bytes0, 0x00020000);
   const int nreg = p.ntaps * (p.cpt0 + p.cpt1);  // regular k-steps; + 1 coord step when p.coord_tab
   int g_step = k0, g_tap = 0, g_src = 0, g_chunk = 0, g_C = p.C0;
@@ -239,73 +254,85 @@ conv_igemm_kernel(const ConvParams p) {
     g_chunk = g_src ? within - p.cpt0 : within;
   }
 
-  auto new_segment = [&]() __attribute__((always_inline)) {
-    int dh, dw;
-    tap_offset<MODE>(p.rate, g_tap, ph, pw, dh, dw);
-    g_C = g_src ? p.C1 : p.C0;
-    rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(src0 + (g_src ? d_src : 0L)), 0, g_src ? bytes1 : bytes0,
-                                               0x00020000);
-    const int ctail = g_C & (BK - 1);  // channels in the last (partial) chunk, 0 = full
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int ih = r_ih[i] + dh;
-      int iw = r_iw[i] + dw;
-      iw = iw < 0 ? iw + wrap_w : (iw >= p.Win ? iw - wrap_w : iw);  // wrap_w = 0: plain zero padding
-      const bool ok = ((r_ok >> i) & 1u) & (ih >= 0) & (ih < p.Hin) & (iw >= 0) & (iw < p.Win);
-      const unsigned off = (unsigned)(((ih * p.Win + iw) * g_C + a_chunk[i] * 4) * 4);
-      a_voff[i] = ok ? off : OOB;
-      a_voff_tail[i] = (ok && (ctail == 0 || a_chunk[i] * 4 < ctail)) ? off : OOB;
-    }
-  };
-
-  auto issue = [&](int stage) __attribute__((always_inline)) {
-    // A and B tiles of k-step g_step -> LDS stage; then advance the generator by one k-step.
-    char *sA = smem + stage * STAGE_BYTES + wave * (BM / 4) * ROW_BYTES;
-    char *sB = smem + stage * STAGE_BYTES + BM * ROW_BYTES + wave * (BN / 4) * ROW_BYTES;
-    const int soff_b = g_step * p.npad * ROW_BYTES;
-    if (g_step < nreg) {
-      const int soff_a = g_chunk * ROW_BYTES;
-      const bool tail = (g_chunk + 1) * BK > g_C;  // wave-uniform; only when C % 32 != 0
-      if (!tail) {
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void *)(sA + i * 8 * ROW_BYTES), 16, a_voff[i], soff_a, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void *)(sA + i * 8 * ROW_BYTES), 16, a_voff_tail[i], soff_a, 0, 0);
-      }
-    } else {
-      // CoordNet k-step: row m reads table[mh][column class][32]
-      const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)p.coord_tab, 0, p.Mh * COORD_CLASSES * ROW_BYTES, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        const unsigned off = (unsigned)(((r_mh[i] * COORD_CLASSES + r_cls[i]) * BK + a_chunk[i] * 4) * 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_void *)(sA + i * 8 * ROW_BYTES), 16,
-                                                 ((r_ok >> i) & 1u) ? off : OOB, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB + i * 8 * ROW_BYTES), 16, b_voff[i], soff_b, 0, 0);
-    // advance (wave-uniform scalar state)
-    ++g_step;
-    if (g_step < nreg) {
-      ++g_chunk;
-      const int cpt = g_src ? p.cpt1 : p.cpt0;
-      if (g_chunk == cpt) {
-        g_chunk = 0;
-        if (g_src == 0 && p.cpt1 > 0) {
-          g_src = 1;
-        } else {
-          g_src = 0;
-          ++g_tap;
-        }
-        new_segment();
-      }
-    }
-  };
+  // The k-step issue is a macro, not a lambda: a by-reference closure keeps pointers to colw0/1/2 in
+  // adjacent fields, hipcc turns the tap-column select into an INDEXED load from the closure, and
+  // everything the closure references (the kernel arguments included) then lives in scratch.
+  bool g_new = true;  // the per-lane offsets of the current (tap, source) segment are not computed yet
+  // A and B tiles of k-step g_step -> LDS stage; then advance the generator by one k-step.
+#define MSI_ISSUE(stage)                                                                                  \
+  {                                                                                                                              \
+    /* A and B tiles of k-step g_step -> LDS stage; then advance the generator by one k-step. */                                 \
+    char *sA = smem + (stage) * STAGE_BYTES + wave * (BM / 4) * ROW_BYTES;                                                         \
+    char *sB = smem + (stage) * STAGE_BYTES + BM * ROW_BYTES + wave * (BN / 4) * ROW_BYTES;                                        \
+    const int soff_b = g_step * p.npad * ROW_BYTES;                                                                              \
+    if (g_step < nreg) {                                                                                                         \
+      if (g_new) {                                                                                                               \
+        /* segment switch: tap -> (tap row, tap column) variant, all scalar; ~7 VALU per row */                                  \
+        g_new = false;                                                                                                           \
+        int vr, vc;                                                                                                              \
+        if (MODE == MODE_CONV) { vr = g_tap / 3; vc = g_tap - vr * 3; }                                                          \
+        else if (MODE == MODE_CONVT) { vr = g_tap >> 1; vc = g_tap & 1; }                                                        \
+        else { vr = 0; vc = 0; }                                                                                                 \
+        const int srow = tap_delta<MODE>(vr, ph, p.rate) * p.Win;                                                                \
+        const unsigned bit = 1u << (vr * NV + vc);                                                                               \
+        g_C = g_src ? p.C1 : p.C0;                                                                                               \
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(src0 + (g_src ? d_src : 0L)), 0, g_src ? bytes1 : bytes0,            \
+                                                   0x00020000);                                                                  \
+        const unsigned pix_bytes = (unsigned)g_C * 4u;                                                                           \
+_Pragma("unroll")                                                                                                                \
+        for (int i = 0; i < AI; ++i) {                                                                                           \
+          int iw = colw0[i];                                                                                                     \
+          if (NV > 1) iw = vc == 1 ? colw1[i] : iw;                                                                              \
+          if (NV > 2) iw = vc == 2 ? colw2[i] : iw;                                                                              \
+          /* pixel index < 2^24 and bytes per pixel < 2^24 (checked on the host): the 24-bit multiply is */                      \
+          /* full rate, a 32-bit multiply a quarter */                                                                           \
+          const unsigned off = __umul24((unsigned)(rowbase[i] + srow + iw), pix_bytes) + a_chunk16[i];                           \
+          a_voff[i] = (vmask[i] & bit) != 0 ? off : OOB;                                                                         \
+        }                                                                                                                        \
+      }                                                                                                                          \
+      const int soff_a = g_chunk * ROW_BYTES;                                                                                    \
+      const int cleft = g_C - g_chunk * BK;  /* channels from this chunk on; < 32 only when C % 32 != 0 (wave-uniform) */        \
+      if (cleft >= BK) {                                                                                                         \
+_Pragma("unroll")                                                                                                                \
+        for (int i = 0; i < AI; ++i)                                                                                             \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void *)(sA + i * 8 * ROW_BYTES), 16, a_voff[i], soff_a, 0, 0);   \
+      } else {                                                                                                                   \
+        /* channel tail: lanes whose 16-byte chunk starts beyond the source's channels fetch zeros */                            \
+_Pragma("unroll")                                                                                                                \
+        for (int i = 0; i < AI; ++i)                                                                                             \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void *)(sA + i * 8 * ROW_BYTES), 16,                             \
+                                                   a_chunk16[i] < (unsigned)cleft * 4u ? a_voff[i] : OOB, soff_a, 0, 0);         \
+      }                                                                                                                          \
+    } else {                                                                                                                     \
+      /* CoordNet k-step: row m reads table[mh][column class][32] */                                                             \
+      const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(                                                   \
+          (void *)p.coord_tab, 0, p.Mh * COORD_CLASSES * ROW_BYTES, 0x00020000);                                                 \
+_Pragma("unroll")                                                                                                                \
+      for (int i = 0; i < AI; ++i)                                                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_void *)(sA + i * 8 * ROW_BYTES), 16, c_voff[i], 0, 0, 0);          \
+    }                                                                                                                            \
+    /* B rows [wave*BN/4 + 8i, +8): the instruction's immediate offset advances BOTH the source and the LDS address */                                        \
+    static_assert(BI <= 2, "B rows per wave: written out for immediate offsets");                                                \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 0, 0);                                  \
+    if (BI > 1)                                                                                                                  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 8 * ROW_BYTES, 0);  \
+    /* advance (wave-uniform scalar state) */                                                                                    \
+    ++g_step;                                                                                                                    \
+    if (g_step < nreg) {                                                                                                         \
+      ++g_chunk;                                                                                                                 \
+      const int cpt = g_src ? p.cpt1 : p.cpt0;                                                                                   \
+      if (g_chunk == cpt) {                                                                                                      \
+        g_chunk = 0;                                                                                                             \
+        if (g_src == 0 && p.cpt1 > 0) {                                                                                          \
+          g_src = 1;                                                                                                             \
+        } else {                                                                                                                 \
+          g_src = 0;                                                                                                             \
+          ++g_tap;                                                                                                               \
+        }                                                                                                                        \
+        g_new = true;                                                                                                            \
+      }                                                                                                                          \
+    }                                                                                                                            \
+  }
 
   // ---- MFMA side: precomputed ds_read addresses (no VALU in the loop) --------------------------
   // lane reads row (lane&31) of its wave tile, k-quarter q of half h = lane>>5: data chunk h*4+q
@@ -359,59 +386,48 @@ conv_igemm_kernel(const ConvParams p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].w, f.b[q][j].w, acc[i][j], 0, 0, 0);
       }
   };
-  // counted waits: quarter q needs the first (q+1)*(MT+NT) fetches of the 4*(MT+NT) issued
-  auto mma = [&](Frag &f) __attribute__((always_inline)) {
-    constexpr int PER = MT + NT;
-    // (sched_barrier: the MFMAs are not volatile -- without it all four waits are hoisted above them)
-    wait_lgkm<3 * PER>(f.a[0][MT - 1], f.b[0][NT - 1]); mma_quarter(f, 0); __builtin_amdgcn_sched_barrier(0);
-    wait_lgkm<2 * PER>(f.a[1][MT - 1], f.b[1][NT - 1]); mma_quarter(f, 1); __builtin_amdgcn_sched_barrier(0);
-    wait_lgkm<1 * PER>(f.a[2][MT - 1], f.b[2][NT - 1]); mma_quarter(f, 2); __builtin_amdgcn_sched_barrier(0);
-    wait_lgkm<0>(f.a[3][MT - 1], f.b[3][NT - 1]);       mma_quarter(f, 3); __builtin_amdgcn_sched_barrier(0);
-  };
+  // Quarter Q of a fetched k-step.  Counted wait: LDS reads return in order, quarter Q needs the
+  // first (Q+1)*(MT+NT) of the 4*(MT+NT) fetches.  sched_barrier: the MFMAs are not volatile --
+  // without it hipcc hoists all waits above them.
+#define MSI_MMA_Q(F, Q)                                                                           \
+  wait_lgkm<(3 - (Q)) * (MT + NT)>(F.a[Q][MT - 1], F.b[Q][NT - 1]);                                \
+  mma_quarter(F, Q);                                                                              \
+  __builtin_amdgcn_sched_barrier(0);
 
-  // ---- main loop: double-buffered LDS, KPB k-steps per barrier -----------------------------------
-  //   super-step S: issue the DMA of super-step S+1 into the other buffer | MFMAs of the KPB k-steps
-  //   of super-step S | s_waitcnt vmcnt(0) | barrier.
-  // KPB = 2 doubles the MFMA work per barrier (and the LDS per workgroup): used for the layers
-  // whose grid is too small to hide the barrier with occupancy.  Unrolled by two with literal
-  // buffer indices (a run-time index would send the ds_read address arrays to scratch).
+  // ---- main loop: double-buffered LDS, one barrier per k-step ------------------------------------
+  //   k-step s:  fetch the operands of s | first MFMA quarter | issue the DMA of s+1 into the other
+  //   buffer | remaining quarters | s_waitcnt vmcnt(0) | barrier.
+  // Occupancy (five workgroups per CU) covers the barrier.  Measured alternatives, all slower on the
+  // BASELINE network: 3- and 4-stage rings, 128x64 / 128x128 tiles, two k-steps per barrier (with and
+  // without prefetching the second k-step's operands); the DMA issue before the first MFMA quarter
+  // (2.91 ms per frame vs 2.88) or after the second (2.89).
+  // Unrolled by two with literal buffer indices (stage offsets are ds_read immediates).
   static_assert(NSTAGE == 2, "the main loop is written for a double buffer");
   const int nsteps = k1 - k0;
-  const int nsuper = (nsteps + KPB - 1) / KPB;
-  new_segment();
-  auto issue_super = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kk = 0; kk < KPB; ++kk)
-      if (g_step < k1) issue(buf * KPB + kk);
-  };
-  issue_super(0);
+  MSI_ISSUE(0)
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-#define MSI_SUPERSTEP(U, S)                                                               \
+#define MSI_KSTEP(U, S)                                                                   \
   {                                                                                       \
-    Frag f0_;                                                                             \
-    MSI_FETCH(f0_, (U) * KPB)                                                             \
-    if ((S) + 1 < nsuper && !(p.ablate & 1)) issue_super((U) ^ 1);                        \
-    {                                                                                     \
-      mma(f0_);                                                                           \
-      if constexpr (KPB > 1) {                                                            \
-        if ((S) * KPB + 1 < nsteps) {                                                     \
-          MSI_FETCH(f0_, (U) * KPB + 1)                                                   \
-          mma(f0_);                                                                       \
-        }                                                                                 \
-      }                                                                                   \
-    }                                                                                     \
+    Frag f_;                                                                              \
+    MSI_FETCH(f_, U)                                                                      \
+    MSI_MMA_Q(f_, 0)                                                                      \
+    if ((S) + 1 < nsteps && !p.ablate) MSI_ISSUE((U) ^ 1)                                 \
+    MSI_MMA_Q(f_, 1)                                                                      \
+    MSI_MMA_Q(f_, 2)                                                                      \
+    MSI_MMA_Q(f_, 3)                                                                      \
     wait_vmcnt<0>();                                                                      \
     __builtin_amdgcn_s_barrier();                                                         \
   }
-  static_assert(KPB == 1 || KPB == 2, "k-steps per barrier");
-  for (int S = 0; S < nsuper; S += 2) {
-    MSI_SUPERSTEP(0, S);
-    if (S + 1 >= nsuper) break;
-    MSI_SUPERSTEP(1, S + 1);
+  for (int S = 0; S < nsteps; S += 2) {
+    MSI_KSTEP(0, S);
+    if (S + 1 >= nsteps) break;
+    MSI_KSTEP(1, S + 1);
   }
-#undef MSI_SUPERSTEP
+#undef MSI_KSTEP
+#undef MSI_ISSUE
+#undef MSI_MMA_Q
 #undef MSI_FETCH
 
   // ---- epilogue: store + LayerNorm partial ------------------------------------------------
@@ -420,7 +436,7 @@ conv_igemm_kernel(const ConvParams p) {
   // 52 MB layers; this form streams like a copy).
   // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   constexpr int LDW = BN + 4;  // floats per staged row: 16-byte aligned, breaks the power-of-two stride
-  static_assert((size_t)BM * LDW * 4 <= (size_t)NSTAGE * KPB * STAGE_BYTES, "epilogue tile must fit the k-loop LDS");
+  static_assert((size_t)BM * LDW * 4 <= (size_t)NSTAGE * STAGE_BYTES, "epilogue tile must fit the k-loop LDS");
   float *ct = reinterpret_cast<float *>(smem);  // all LDS reads of the main loop are behind the last barrier
   const int col = lane & 31, rowq = 4 * (lane >> 5);
   float lsum = 0.f;
@@ -744,6 +760,8 @@ int build_net(const msi_net_desc *d, Net &net) {
                      d->height, d->width);
   if (d->in_channels % 4 || d->ngf % 4)
     return msi::fail(MSI_E_UNSUPPORTED, "net: in_channels and ngf must be multiples of 4");
+  if ((long)d->height * d->width >= (1L << 24))
+    return msi::fail(MSI_E_UNSUPPORTED, "net: more than 2^24 pixels per sample (24-bit pixel index in the conv kernel)");
   const int ngf = d->ngf, ex = d->coord_net ? 1 : 0;
   struct Spec { const char *name; int kind, src0, src1, cout, stride, rate; };
   const Spec specs[MSI_NET_NUM_LAYERS] = {
@@ -842,10 +860,11 @@ int build_net(const msi_net_desc *d, Net &net) {
   return MSI_OK;
 }
 
-template <int BM, int BN, int MODE, int KPB>
+template <int BM, int BN, int MODE>
 int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   const int mtot = p.Mh * p.Mw;
   p.tiles_m = (mtot + BM - 1) / BM;
+  p.mg_mw = p.Mw == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)p.Mw);
   p.tiles_n = (p.Cout + BN - 1) / BN;
   p.ntiles = p.tiles_m * p.tiles_n * p.nclass * batch;
   *nparts = p.tiles_m * p.tiles_n * p.nclass;
@@ -865,44 +884,36 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
     if (best > 1) { p.split = best; p.n_main = p.ntiles - rem; }
   }
   const int nblocks = p.n_main + (p.ntiles - p.n_main) * p.split;
-  const size_t lds = (size_t)NSTAGE * KPB * (BM + BN) * ROW_BYTES;
+  const size_t lds = (size_t)NSTAGE * (BM + BN) * ROW_BYTES;
   if (lds > 64 * 1024) {
     static thread_local bool done = false;
     if (!done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, MODE, KPB>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, MODE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "conv: %s", hipGetErrorString(e));
       done = true;
     }
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, KPB>), dim3(nblocks), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE>), dim3(nblocks), dim3(256), lds, stream, p);
   int rc = msi::check_launch("conv_igemm");
   if (rc || p.split == 1) return rc;
   hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, MODE>), dim3(p.ntiles - p.n_main), dim3(256), 0, stream, p);
   return msi::check_launch("conv_fixup");
 }
 
-template <int BM, int BN, int KPB>
+template <int BM, int BN>
 int launch_conv(const ConvParams &p, int batch, hipStream_t stream, int *nparts) {
   switch (p.mode) {
-    case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, KPB>(p, batch, stream, nparts);
-    case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, KPB>(p, batch, stream, nparts);
-    default: return launch_conv_mode<BM, BN, MODE_HEAD, KPB>(p, batch, stream, nparts);
+    case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV>(p, batch, stream, nparts);
+    case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT>(p, batch, stream, nparts);
+    default: return launch_conv_mode<BM, BN, MODE_HEAD>(p, batch, stream, nparts);
   }
 }
 
-// Tile choice.  Measured on the BASELINE network (profiles/r01_*): with the DMA-fed loop the 64x64
-// tile wins on every layer (3.17 ms vs 3.29 ms mixed vs 3.85 ms all-128x128): its 32 KB of LDS lets
-// five workgroups share a CU, and occupancy hides the per-k-step barrier better than a larger
-// tile's higher arithmetic intensity helps.  The larger tiles stay available (MSI_CONV_TILE).
-// k-steps per barrier: 2 when the grid cannot put ~4 workgroups on every CU (the barrier is then
-// hidden by more MFMA work per wave instead of by occupancy), else 1.
-void choose_tile(int mtot, int cout, int zdim, int &bm, int &bn, int &kpb) {
-  bm = 64;
-  bn = 64;
-  const long blocks = (long)((mtot + bm - 1) / bm) * ((cout + bn - 1) / bn) * zdim;
-  kpb = blocks < 4 * 256 ? 2 : 1;
-}
+// Tile: 64x64 on every layer.  Its 32 KB of LDS lets five workgroups share a CU, and occupancy
+// hides the per-k-step barrier better than a larger tile's arithmetic intensity helps (measured on
+// the BASELINE network, profiles/r01_*: 128x64 +4 %, 128x128 +20 % time).
+constexpr int TILE_M = 64, TILE_N = 64;
 
 }  // namespace
 
@@ -1084,20 +1095,12 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
     } else {
       p.Mh = L.out_h; p.Mw = L.out_w; p.stride = 1;
     }
-    int bm, bn, kpb, nparts = 0;
-    choose_tile(p.Mh * p.Mw, L.cout, desc->batch * L.nclass, bm, bn, kpb);
-    {  // debug knobs, read once
+    int nparts = 0;
+    {  // debug knob, read once
       static const char *abl = getenv("MSI_CONV_ABLATE");
-      static const char *til = getenv("MSI_CONV_TILE");
-      static const char *kp = getenv("MSI_CONV_KPB");
       p.ablate = abl ? atoi(abl) : 0;
-      if (til) { int a = 0, c = 0; if (sscanf(til, "%dx%d", &a, &c) == 2) { bm = a; bn = c; } }
-      if (kp) kpb = atoi(kp);
     }
-    if (bm == 128 && kpb == 2) rc = launch_conv<128, 64, 2>(p, desc->batch, stream, &nparts);
-    else if (bm == 128) rc = launch_conv<128, 64, 1>(p, desc->batch, stream, &nparts);
-    else if (kpb == 2) rc = launch_conv<64, 64, 2>(p, desc->batch, stream, &nparts);
-    else rc = launch_conv<64, 64, 1>(p, desc->batch, stream, &nparts);
+    rc = launch_conv<TILE_M, TILE_N>(p, desc->batch, stream, &nparts);
     if (rc) return rc;
     if (L.kind != MODE_HEAD) {
       const size_t per_sample = (size_t)L.out_h * L.out_w * L.cout;
