@@ -566,15 +566,26 @@ conv_fixup_kernel(const ConvParams p) {
   }
   const int ph = cls >> 1, pw = cls & 1;
   const int mtot = p.Mh * p.Mw;
+  // All `split` partial tiles are requested before the first one is used: one memory round trip
+  // instead of `split` dependent ones (the loop over a run-time count waited per K-range).  Ranges
+  // beyond `split` re-read the last one and are masked out of the sum, which stays in k order.
+  v4f a[MAX_SPLIT][PASSES];
+#pragma unroll
+  for (int ks = 0; ks < MAX_SPLIT; ++ks) {
+    const float *src = p.partial + ((size_t)blockIdx.x * p.split + min(ks, p.split - 1)) * (BM * BN);
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) a[ks][k] = *reinterpret_cast<const v4f *>(src + (size_t)(tid + 256 * k) * 4);
+  }
   v4f v[PASSES];
 #pragma unroll
-  for (int k = 0; k < PASSES; ++k) v[k] = v4f{0.f, 0.f, 0.f, 0.f};
-  for (int ks = 0; ks < p.split; ++ks) {
-    const float *src = p.partial + ((size_t)blockIdx.x * p.split + ks) * (BM * BN);
+  for (int k = 0; k < PASSES; ++k) v[k] = a[0][k];
+#pragma unroll
+  for (int ks = 1; ks < MAX_SPLIT; ++ks) {
+    const bool on = ks < p.split;
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
-      const v4f a = *reinterpret_cast<const v4f *>(src + (size_t)(tid + 256 * k) * 4);
-      v[k].x += a.x; v[k].y += a.y; v[k].z += a.z; v[k].w += a.w;
+      v[k].x += on ? a[ks][k].x : 0.f; v[k].y += on ? a[ks][k].y : 0.f;
+      v[k].z += on ? a[ks][k].z : 0.f; v[k].w += on ? a[ks][k].w : 0.f;
     }
   }
   const bool vec_ok = (p.Cout & 3) == 0;
