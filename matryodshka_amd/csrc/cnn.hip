@@ -130,7 +130,7 @@ __device__ __forceinline__ void wait_lgkm(v4f &x, v4f &y) {
 // amdgpu_waves_per_eu: with a dynamic LDS size hipcc cannot see that five 32 KB workgroups share a CU
 // and spends registers freely (116 for the 64x64 tile => four waves per SIMD); five need <= 96.
 template <int BM, int BN, int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NSTAGE == 2 ? 5 : 3)))
 conv_igemm_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (the body uses device-only types)
   constexpr int MT = BM / 64, NT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
@@ -220,12 +220,14 @@ conv_igemm_kernel(const ConvParams p) {
       if (ih >= 0 && ih < p.Hin) rowok |= 1u << v;
       if (iw >= 0 && iw < p.Win) colok |= 1u << v;
     }
-    unsigned vm = 0;
+    // bit (vr*NV + vc) = rowok[vr] & colok[vc]: replicate colok into every NV-bit group, keep the groups of valid rows
+    unsigned colrep = 0, rowrep = 0;
 #pragma unroll
-    for (int vr = 0; vr < NV; ++vr)
-#pragma unroll
-      for (int vc = 0; vc < NV; ++vc)
-        if (mok && ((rowok >> vr) & 1u) && ((colok >> vc) & 1u)) vm |= 1u << (vr * NV + vc);
+    for (int vr = 0; vr < NV; ++vr) {
+      colrep |= colok << (vr * NV);
+      rowrep |= ((rowok >> vr) & 1u) * (((1u << NV) - 1u) << (vr * NV));
+    }
+    const unsigned vm = mok ? (colrep & rowrep) : 0u;
     vmask[i] = vm;
     a_chunk16[i] = (unsigned)((dslot ^ ((r >> 1) & 7)) * 16);  // byte offset of the data chunk this lane fetches
     c_voff[i] = mok ? (unsigned)((mh * COORD_CLASSES + coord_class(mw, p.Mw)) * ROW_BYTES) + a_chunk16[i] : OOB;
@@ -402,28 +404,42 @@ _Pragma("unroll")                                                               
   // without prefetching the second k-step's operands); the DMA issue before the first MFMA quarter
   // (2.91 ms per frame vs 2.88) or after the second (2.89).
   // Unrolled by two with literal buffer indices (stage offsets are ds_read immediates).
-  static_assert(NSTAGE == 2, "the main loop is written for a double buffer");
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "the main loop is unrolled for a 2- or 3-stage ring");
+  constexpr int PD = NSTAGE - 1;          // prefetch distance in k-steps
+  constexpr int DMA_PER_STEP = AI + BI;   // buffer_load ... lds instructions per wave per k-step
   const int nsteps = k1 - k0;
   MSI_ISSUE(0)
-  wait_vmcnt<0>();
+  if (PD > 1 && nsteps > 1) {
+    MSI_ISSUE(1)
+    wait_vmcnt<DMA_PER_STEP>();           // k-step 0 landed, k-step 1 in flight
+  } else {
+    wait_vmcnt<0>();
+  }
   __builtin_amdgcn_s_barrier();
 
+  // k-step S in stage U: issue k-step S+PD into the stage freed by the previous barrier; before the
+  // closing barrier k-step S+1 must have landed (the youngest PD-1 k-steps may stay in flight).
 #define MSI_KSTEP(U, S)                                                                   \
   {                                                                                       \
     Frag f_;                                                                              \
     MSI_FETCH(f_, U)                                                                      \
     MSI_MMA_Q(f_, 0)                                                                      \
-    if ((S) + 1 < nsteps && !p.ablate) MSI_ISSUE((U) ^ 1)                                 \
+    const bool more_ = (S) + PD < nsteps;                                                 \
+    if (more_ && !p.ablate) MSI_ISSUE(((U) + PD) % NSTAGE)                                \
     MSI_MMA_Q(f_, 1)                                                                      \
     MSI_MMA_Q(f_, 2)                                                                      \
     MSI_MMA_Q(f_, 3)                                                                      \
-    wait_vmcnt<0>();                                                                      \
+    if (PD > 1 && more_) wait_vmcnt<(PD - 1) * DMA_PER_STEP>(); else wait_vmcnt<0>();     \
     __builtin_amdgcn_s_barrier();                                                         \
   }
-  for (int S = 0; S < nsteps; S += 2) {
+  for (int S = 0; S < nsteps; S += NSTAGE) {
     MSI_KSTEP(0, S);
     if (S + 1 >= nsteps) break;
     MSI_KSTEP(1, S + 1);
+    if (NSTAGE > 2) {
+      if (S + 2 >= nsteps) break;
+      MSI_KSTEP(NSTAGE - 1, S + 2);
+    }
   }
 #undef MSI_KSTEP
 #undef MSI_ISSUE
@@ -439,21 +455,28 @@ _Pragma("unroll")                                                               
   static_assert((size_t)BM * LDW * 4 <= (size_t)NSTAGE * STAGE_BYTES, "epilogue tile must fit the k-loop LDS");
   float *ct = reinterpret_cast<float *>(smem);  // all LDS reads of the main loop are behind the last barrier
   const int col = lane & 31, rowq = 4 * (lane >> 5);
+  // interior tile (the common case): no row / channel masks anywhere in the epilogue -- its VALU work is
+  // paid in matrix throughput of the co-resident workgroups
+  const bool interior = (tile_m + 1) * BM <= mtot && (tile_n + 1) * BN <= p.Cout;
   float lsum = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int lrow = wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
-      const bool mok = tile_m * BM + lrow < mtot;
+    for (int j = 0; j < NT; ++j) {
+      const int lcol = wn * (NT * 32) + j * 32 + col;
+      const int n = tile_n * BN + lcol;
+      float bias = 0.f;
+      if (MODE == MODE_HEAD && full) bias = p.bias[min(n, p.Cout - 1)];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int lcol = wn * (NT * 32) + j * 32 + col;
-        const int n = tile_n * BN + lcol;
+      for (int r = 0; r < 16; ++r) {
+        const int lrow = wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
         float v = acc[i][j][r];
-        if (MODE == MODE_HEAD && full) v = tanhf(v + p.bias[min(n, p.Cout - 1)]);
+        if (MODE == MODE_HEAD && full) v = tanhf(v + bias);
         ct[lrow * LDW + lcol] = v;
-        lsum += (mok && n < p.Cout) ? v : 0.f;
+        if (MODE != MODE_HEAD) {
+          if (interior) lsum += v;
+          else lsum += (tile_m * BM + lrow < mtot && n < p.Cout) ? v : 0.f;
+        }
       }
     }
   }
@@ -479,10 +502,12 @@ _Pragma("unroll")                                                               
       const int lrow = idx / C4, c4 = idx - lrow * C4;
       const int m = tile_m * BM + lrow;
       const int n = tile_n * BN + c4 * 4;
-      if (m >= mtot || n >= p.Cout) continue;
+      if (!interior && (m >= mtot || n >= p.Cout)) continue;
       size_t opix;
       if (MODE == MODE_CONVT) {
-        const int mh = m / p.Mw, mw = m - mh * p.Mw;
+        int mh = (int)__umulhi((unsigned)m, p.mg_mw);   // m / Mw by multiply-high + one correction
+        int mw = m - mh * p.Mw;
+        if (mw >= p.Mw) { ++mh; mw -= p.Mw; }
         opix = ((size_t)b * p.Hout + (2 * mh + ph)) * p.Wout + (2 * mw + pw);
       } else {
         opix = (size_t)b * mtot + m;
@@ -522,13 +547,12 @@ _Pragma("unroll")                                                               
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
-      if (m >= mtot) continue;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = tile_n * BN + wn * (NT * 32) + j * 32 + col;
-        if (n >= p.Cout) continue;
         const float dlt = acc[i][j][r] - bmean;
-        lm2 += dlt * dlt;
+        if (interior) lm2 += dlt * dlt;
+        else lm2 += (m < mtot && n < p.Cout) ? dlt * dlt : 0.f;
       }
     }
   }
