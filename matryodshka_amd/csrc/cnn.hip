@@ -85,6 +85,9 @@ struct ConvParams {
   int ntaps, cpt0, cpt1, ksteps;  // taps, 32-channel chunks per tap of each source, total k-steps
   int stride, rate, pad_t, pad_l;
   int mode, wrap, nclass;
+#ifdef MSI_CONV_TIMING
+  unsigned long long *dbg;   // [block][6]: s_memtime at start, loop start, loop end, end; HW_ID; XCC_ID (tools/conv_timing.py)
+#endif
   int ablate;                // debug only (MSI_CONV_ABLATE): 1 = skip the k-loop DMA (results are garbage)
 };
 
@@ -139,6 +142,9 @@ conv_igemm_kernel(const ConvParams p) {
   constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -432,6 +438,9 @@ _Pragma("unroll")                                                               
     if (PD > 1 && more_) wait_vmcnt<(PD - 1) * DMA_PER_STEP>(); else wait_vmcnt<0>();     \
     __builtin_amdgcn_s_barrier();                                                         \
   }
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
   for (int S = 0; S < nsteps; S += NSTAGE) {
     MSI_KSTEP(0, S);
     if (S + 1 >= nsteps) break;
@@ -442,6 +451,17 @@ _Pragma("unroll")                                                               
     }
   }
 #undef MSI_KSTEP
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if (p.dbg && tid == 0) {
+      unsigned long long *o = p.dbg + (size_t)blockIdx.x * 6;
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
+      o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: wave, simd, cu, sh, se ...
+      o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // XCC_ID
+    }
+  };
+#endif
 #undef MSI_ISSUE
 #undef MSI_MMA_Q
 #undef MSI_FETCH
@@ -492,6 +512,9 @@ _Pragma("unroll")                                                               
       const int lrow = idx / C4, c4 = idx - lrow * C4;
       *reinterpret_cast<v4f *>(dst + lrow * BN + c4 * 4) = *reinterpret_cast<const v4f *>(ct + lrow * LDW + c4 * 4);
     }
+#ifdef MSI_CONV_TIMING
+    stamp();
+#endif
     return;
   }
   {
@@ -524,11 +547,18 @@ _Pragma("unroll")                                                               
       }
     }
   }
+#ifdef MSI_CONV_TIMING
+  if (MODE == MODE_HEAD || p.stats == nullptr) { stamp(); return; }
+#else
   if (MODE == MODE_HEAD || p.stats == nullptr) return;
+#endif
 
   // block mean, then M2 about the block mean (two-pass inside the block: the values
   // are still in registers), reduced in a fixed order.
-  __shared__ float red[4];
+  // (the four wave sums live in the dynamic LDS behind the staged tile: a separate 16-byte __shared__
+  // array makes the workgroup 32784 B and a CU then holds four of them instead of five)
+  static_assert((size_t)BM * LDW * 4 + 16 <= (size_t)NSTAGE * STAGE_BYTES, "wave sums behind the staged tile");
+  float *red = ct + BM * LDW;
   auto block_sum = [&](float v) __attribute__((always_inline)) -> float {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -566,6 +596,9 @@ _Pragma("unroll")                                                               
     o[2] = bm2;
     o[3] = 0.f;
   }
+#ifdef MSI_CONV_TIMING
+  stamp();
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -952,6 +985,21 @@ constexpr int TILE_M = 64, TILE_N = 64;
 
 }  // namespace
 
+#ifdef MSI_CONV_TIMING
+// tools/conv_timing.py: per-workgroup phase stamps of one layer's conv launch (debug builds only)
+static unsigned long long *g_timing_buf = nullptr;
+static int g_timing_layer = -1;
+extern "C" int msi_debug_conv_occupancy(int lds_bytes) {
+  int n = -1;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<TILE_M, TILE_N, MODE_CONV>, 256, (size_t)lds_bytes);
+  return n;
+}
+extern "C" void msi_debug_conv_timing(void *device_buffer, int layer) {
+  g_timing_buf = static_cast<unsigned long long *>(device_buffer);
+  g_timing_layer = layer;
+}
+#endif
+
 extern "C" {
 
 int msi_net_layer_info(const msi_net_desc *desc, int32_t layer, msi_layer_info *out) {
@@ -1135,6 +1183,9 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
       static const char *abl = getenv("MSI_CONV_ABLATE");
       p.ablate = abl ? atoi(abl) : 0;
     }
+#ifdef MSI_CONV_TIMING
+    p.dbg = (li == g_timing_layer) ? g_timing_buf : nullptr;
+#endif
     rc = launch_conv<TILE_M, TILE_N>(p, desc->batch, stream, &nparts);
     if (rc) return rc;
     if (L.kind != MODE_HEAD) {

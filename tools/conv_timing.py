@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Per-workgroup phase timing of one conv layer (needs a library built with -DMSI_CONV_TIMING,
+e.g. tools/_variants/libmsi_timing.so installed as matryodshka_amd/libmsi_hip.so):
+s_memtime stamps at kernel entry, k-loop start, k-loop end and exit of every workgroup.
+
+    python tools/conv_timing.py [layer ...]
+"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from matryodshka_amd import MSI, nets, _native
+
+lib = _native.lib
+lib.msi_debug_conv_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.msi_debug_conv_timing.restype = None
+names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3",
+         "conv6_1", "conv6_2", "conv6_3", "conv7_1", "conv7_2", "conv8_1", "conv8_2", "color_pred"]
+layers = [int(a) for a in sys.argv[1:]] or [0, 1, 4, 7, 16]
+m = MSI(weights=nets.init_weights(192, 64, 64, True), coord_net=True)
+x = torch.rand((1, 320, 640, 192), device="cuda") * 2 - 1
+for _ in range(3):
+    m.run_net(x, 64, 64)
+buf = torch.zeros((8192, 6), dtype=torch.int64, device="cuda")
+for li in layers:
+    buf.zero_()
+    lib.msi_debug_conv_timing(ctypes.c_void_p(buf.data_ptr()), li)
+    m.run_net(x, 64, 64)
+    torch.cuda.synchronize()
+    lib.msi_debug_conv_timing(None, -1)
+    t = buf.cpu().numpy().astype(np.int64)
+    t = t[t[:, 0] != 0]
+    pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+    span = t[:, 3].max() - t[:, 0].min()
+    dur = t[:, 3] - t[:, 0]
+    print("%-10s blocks %5d  span %8d ticks | per block: prologue %6.0f  loop %8.0f  epilogue %6.0f  total %8.0f (min %d max %d) | sum(block time)/span = %.2f resident blocks" % (
+        names[li], len(t), span, pro.mean(), loop.mean(), epi.mean(), dur.mean(), dur.min(), dur.max(), dur.sum() / span))
+    # per CU (XCC_ID, HW_ID se/sh/cu): time-average number of resident workgroups and of workgroups inside the k-loop
+    hw, xcc = t[:, 4], t[:, 5] & 0xf
+    cu_key = (xcc << 16) | (((hw >> 13) & 0x7) << 12) | (((hw >> 12) & 0x1) << 8) | ((hw >> 8) & 0xf)   # se[15:13] sh[12] cu[11:8]
+    res, inl, spans, nblk = [], [], [], []
+    for k in np.unique(cu_key):
+        b = t[cu_key == k]
+        sp = b[:, 3].max() - b[:, 0].min()
+        res.append((b[:, 3] - b[:, 0]).sum() / sp)
+        inl.append((b[:, 2] - b[:, 1]).sum() / sp)
+        spans.append(sp)
+        nblk.append(len(b))
+    print("           %d CUs seen; blocks per CU %d..%d; per-CU span %.0f..%.0f ticks; resident workgroups %.2f (avg), in k-loop %.2f (avg)" % (
+        len(res), min(nblk), max(nblk), min(spans), max(spans), np.mean(res), np.mean(inl)))
+lib.msi_debug_conv_occupancy.argtypes = [ctypes.c_int]
+lib.msi_debug_conv_occupancy.restype = ctypes.c_int
+for lds in (32768, 32784, 40960, 49152):
+    print("occupancy API: %d B dynamic LDS -> %d workgroups per CU" % (lds, lib.msi_debug_conv_occupancy(lds)))
