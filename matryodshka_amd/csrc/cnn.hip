@@ -722,8 +722,8 @@ conv_fixup_kernel(const ConvParams p) {
 }
 
 // LayerNorm finish + apply in ONE launch.  Every workgroup first merges the per-workgroup (count,
-// mean, M2) partials of its sample in fp64 (Chan's pairwise update in a fixed order => identical
-// in every workgroup and deterministic) into the affine of slim.layer_norm,
+// mean, M2) partials of its sample in fp64 (two parallel passes in a fixed order => identical in
+// every workgroup and deterministic) into the affine of slim.layer_norm,
 //   scale = gamma * rsqrt(var + eps), shift = beta - mean * scale,
 // keeps it in LDS, and then applies x = max(x*scale[c] + shift[c], 0) IN PLACE to its grid-stride
 // slice (nets.py:401,485 arg_scope: normalizer, then the default ReLU).  Merging redundantly
@@ -734,37 +734,42 @@ ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int npar
                 const float *__restrict__ gamma, const float *__restrict__ beta, size_t per_sample, int C,
                 float *__restrict__ aff) {
   extern __shared__ __attribute__((aligned(16))) float s_aff[];  // scale[C] shift[C]
-  __shared__ double s_n[256], s_mean[256], s_m2[256];
-  const int b = blockIdx.y, tid = threadIdx.x;
+  __shared__ double s_red[2][4];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float *st = stats + (size_t)b * nparts * 4;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int i = tid; i < nparts; i += 256) {
-    const v4f pr = *reinterpret_cast<const v4f *>(st + (size_t)i * 4);
-    const double nb = pr.x, mb = pr.y, m2b = pr.z;
-    if (nb > 0.0) {
-      const double nt = n + nb, dl = mb - mean;
-      mean += dl * (nb / nt);
-      m2 += m2b + dl * dl * (n * nb / nt);
-      n = nt;
-    }
-  }
-  s_n[tid] = n; s_mean[tid] = mean; s_m2[tid] = m2;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) {
-      const double na = s_n[tid], nb = s_n[tid + off];
-      if (nb > 0.0) {
-        const double nt = na + nb, dl = s_mean[tid + off] - s_mean[tid];
-        s_mean[tid] += dl * (nb / nt);
-        s_m2[tid] += s_m2[tid + off] + dl * dl * (na * nb / nt);
-        s_n[tid] = nt;
-      }
+  // fixed-order block sum of two doubles: wave shuffle tree, then the four wave sums
+  auto block_sum2 = [&](double &x, double &y) __attribute__((always_inline)) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      x += __shfl_down(x, off, 64);
+      y += __shfl_down(y, off, 64);
     }
     __syncthreads();
+    if (lane == 0) { s_red[0][wave] = x; s_red[1][wave] = y; }
+    __syncthreads();
+    x = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+    y = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+  };
+  // pass 1: N = sum n_i, mean = sum n_i mean_i / N;  pass 2: M2 = sum (M2_i + n_i (mean_i - mean)^2).
+  // Same result as Chan's sequential update, without its two fp64 divisions per partial on the
+  // critical path of every layer (this merge sits between two conv launches 17 times per frame).
+  double sn = 0.0, sm = 0.0;
+  for (int i = tid; i < nparts; i += 256) {
+    const v4f pr = *reinterpret_cast<const v4f *>(st + (size_t)i * 4);
+    sn += (double)pr.x;
+    sm += (double)pr.x * (double)pr.y;
   }
-  const double var = s_m2[0] / s_n[0];
+  block_sum2(sn, sm);
+  const double mu = sm / sn;
+  double s2 = 0.0, dummy = 0.0;
+  for (int i = tid; i < nparts; i += 256) {
+    const v4f pr = *reinterpret_cast<const v4f *>(st + (size_t)i * 4);
+    const double dl = (double)pr.y - mu;
+    s2 += (double)pr.z + (double)pr.x * dl * dl;
+  }
+  block_sum2(s2, dummy);
+  const double var = s2 / sn;
   const double inv = 1.0 / sqrt(var + LN_EPS);
-  const double mu = s_mean[0];
   for (int c = tid; c < C; c += 256) {
     const double sc = inv * (double)gamma[c];
     const float fs = (float)sc, ft = (float)((double)beta[c] - mu * sc);
@@ -780,16 +785,24 @@ ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int npar
   v4f *xv = reinterpret_cast<v4f *>(x + (size_t)b * per_sample);
   const size_t nvec = per_sample / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < nvec; i += stride) {
-    const int c = (int)((i * 4) % C);
-    const v4f s4 = *reinterpret_cast<const v4f *>(s_aff + c);
-    const v4f t4 = *reinterpret_cast<const v4f *>(s_aff + C + c);
-    v4f v = xv[i];
+  auto apply = [](v4f v, const v4f s4, const v4f t4) __attribute__((always_inline)) -> v4f {
     v.x = fmaxf(v.x * s4.x + t4.x, 0.f);
     v.y = fmaxf(v.y * s4.y + t4.y, 0.f);
     v.z = fmaxf(v.z * s4.z + t4.z, 0.f);
     v.w = fmaxf(v.w * s4.w + t4.w, 0.f);
-    xv[i] = v;
+    return v;
+  };
+  if ((256 * 4) % C == 0) {
+    // every grid-stride step advances a thread by a multiple of C floats: its four channels are fixed
+    const int c = (tid * 4) % C;
+    const v4f s4 = *reinterpret_cast<const v4f *>(s_aff + c);
+    const v4f t4 = *reinterpret_cast<const v4f *>(s_aff + C + c);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < nvec; i += stride) xv[i] = apply(xv[i], s4, t4);
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < nvec; i += stride) {
+      const int c = (int)((i * 4) % C);
+      xv[i] = apply(xv[i], *reinterpret_cast<const v4f *>(s_aff + c), *reinterpret_cast<const v4f *>(s_aff + C + c));
+    }
   }
 }
 
