@@ -138,8 +138,8 @@ def main():
     # synthetic ODS pair, seeded per rank (each rank renders its own frames)
     from tests.util import make_inputs
     inp = make_inputs(8964 + rank, 1, H, W)
-    src_u8 = torch.from_numpy(inp["src_image"]).to(dev)
-    ref_u8 = torch.from_numpy(inp["ref_image"]).to(dev)
+    src_u8 = torch.from_numpy(np.ascontiguousarray(inp["src_image"])).to(dev).contiguous()   # resident, in the
+    ref_u8 = torch.from_numpy(np.ascontiguousarray(inp["ref_image"])).to(dev).contiguous()   # layout the API takes
     ref_pose = torch.from_numpy(inp["ref_pose"]).to(dev)
     src_pose = torch.from_numpy(inp["src_pose"]).to(dev)
     ref_pose_inv = torch.linalg.inv(torch.from_numpy(inp["ref_pose"])).to(dev)

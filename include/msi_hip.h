@@ -71,6 +71,12 @@ int msi_preprocess_f32(const float *in, float *out, size_t n, msi_stream_t strea
 int msi_deprocess_f32_u8(const float *in, uint8_t *out, size_t n, int32_t is_depth,
                          msi_stream_t stream);
 
+/* out[b] = lhs[b] @ rhs[b] for [B,4,4] row-major poses, terms summed k = 0..3 without fma:
+ * curr_pose = psv_src_pose @ ref_pose_inv (msi.py:1125), tgt_pose @ interp_pose_inv (msi.py:644-646).
+ * One 16-thread-per-sample launch instead of a BLAS call in the frame loop. */
+int msi_compose_poses_f32(const float *lhs, const float *rhs, float *out, int32_t batch,
+                          msi_stream_t stream);
+
 /* ---- K1: ODS sphere sweep -----------------------------------------------------
  * pj.ods_sphere_sweep -> sweep_one (projector.py:209-211, 129-170) with
  * backproject_spherical (spherical.py:116-129), apply_pose (projector.py:275-291),

@@ -45,6 +45,7 @@ SIGNATURES = {
     "msi_preprocess_u8_f32": (_I, [_P, _P, c_size_t, _P]),
     "msi_preprocess_f32": (_I, [_P, _P, c_size_t, _P]),
     "msi_deprocess_f32_u8": (_I, [_P, _P, c_size_t, _I, _P]),
+    "msi_compose_poses_f32": (_I, [_P, _P, _P, _I, _P]),
     "msi_ods_sphere_sweep_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "msi_assemble_rgba_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msi_resize_bilinear_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

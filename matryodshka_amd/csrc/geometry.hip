@@ -111,6 +111,21 @@ __global__ void deprocess_kernel(const float *__restrict__ in, uint8_t *__restri
 // One work item = (pixel, depth); depth is the fastest index so a wavefront's 64
 // lanes write 64 consecutive 12-byte texels of the NHWC volume (768 contiguous
 // bytes at D=32 per source).  The source image (2.4 MB) stays L2-resident.
+// [B,4,4] @ [B,4,4], one thread per output element, products summed k = 0..3 (no fma: this file is
+// compiled with -ffp-contract=off), like a plain fp32 matmul loop.
+__global__ void __launch_bounds__(256)
+compose_poses_kernel(const float *__restrict__ lhs, const float *__restrict__ rhs, float *__restrict__ out, int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * 16) return;
+  const int b = i >> 4, r = (i >> 2) & 3, c = i & 3;
+  const float *A = lhs + b * 16 + r * 4, *Bm = rhs + b * 16 + c;
+  float acc = A[0] * Bm[0];
+  acc = acc + A[1] * Bm[4];
+  acc = acc + A[2] * Bm[8];
+  acc = acc + A[3] * Bm[12];
+  out[i] = acc;
+}
+
 __global__ void __launch_bounds__(256)
 ods_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose,
                  const float *__restrict__ intrinsics, const float *__restrict__ depths,
@@ -665,6 +680,16 @@ int msi_deprocess_f32_u8(const float *in, uint8_t *out, size_t n, int32_t is_dep
   hipLaunchKernelGGL(deprocess_kernel, dim3(grid_1d(n)), dim3(256), 0, msi::as_stream(stream), in,
                      out, n, (int)is_depth);
   return msi::check_launch("deprocess");
+}
+
+int msi_compose_poses_f32(const float *lhs, const float *rhs, float *out, int32_t batch,
+                          msi_stream_t stream) {
+  MSI_REQUIRE(lhs && rhs && out, "compose_poses: null pointer");
+  MSI_REQUIRE(batch >= 0, "compose_poses: bad batch");
+  if (batch == 0) return MSI_OK;
+  hipLaunchKernelGGL(compose_poses_kernel, dim3(grid_1d((size_t)batch * 16)), dim3(256), 0, msi::as_stream(stream),
+                     lhs, rhs, out, (int)batch);
+  return msi::check_launch("compose_poses");
 }
 
 int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float *intrinsics,

@@ -149,6 +149,20 @@ class MSI(object):
         """float [0,1] -> uint8 without the (x+1)/2 (msi.py:1186-1194)."""
         return self._deprocess(image, 1)
 
+    def _compose(self, lhs, rhs):
+        """[B,4,4] @ [B,4,4] on the device (msi_compose_poses_f32)."""
+        lhs, rhs = self._f32(lhs), self._f32(rhs)
+        if lhs.dim() == 2:
+            lhs = lhs[None]
+        if rhs.dim() == 2:
+            rhs = rhs[None]
+        if rhs.shape[0] != lhs.shape[0]:
+            rhs = rhs.expand(lhs.shape[0], 4, 4).contiguous()
+        out = torch.empty((lhs.shape[0], 4, 4), dtype=torch.float32, device=self.device)
+        N.check(N.lib.msi_compose_poses_f32(lhs.data_ptr(), rhs.data_ptr(), out.data_ptr(), lhs.shape[0], self._stream()),
+                "msi_compose_poses_f32")
+        return out
+
     # ------------------------------------------------------------------ msi.py:1094-1130
     def format_network_input(self, ref_image, src_image, ref_pose, src_pose, planes, intrinsics,
                              ref_pose_inv=None):
@@ -159,14 +173,10 @@ class MSI(object):
         b, h, w, c = ref_image.shape
         if c != 3 or src_image.shape != ref_image.shape:
             raise ValueError("format_network_input: images must be [B,H,W,3] and agree")
-        # 4x4 pose composition stays on whatever device the poses live on; only a missing
-        # ref_pose_inv is computed on the host (pass it explicitly to avoid the round trip)
-        ref_pose = torch.as_tensor(ref_pose, dtype=torch.float32)
-        pdev = ref_pose.device
-        src_pose = torch.as_tensor(src_pose, dtype=torch.float32).to(pdev)
+        # a missing ref_pose_inv is computed on the host (pass it explicitly to avoid the round trip)
         if ref_pose_inv is None:
-            ref_pose_inv = torch.linalg.inv(ref_pose.cpu().double()).float()   # test.py:111
-        ref_pose_inv = torch.as_tensor(ref_pose_inv, dtype=torch.float32).to(pdev)
+            ref_pose_inv = torch.linalg.inv(torch.as_tensor(ref_pose, dtype=torch.float32).cpu().double()).float()   # test.py:111
+        ref_pose, src_pose, ref_pose_inv = self._f32(ref_pose), self._f32(src_pose), self._f32(ref_pose_inv)
         depths = self._planes(planes)
         nd = depths.numel()
         intr = self._f32(intrinsics)
@@ -174,7 +184,7 @@ class MSI(object):
         psv = torch.empty((b, h, w, 6 * nd), dtype=torch.float32, device=self.device)
         # order = +1 for the reference image (i = 0), -1 for the source (i = 1), msi.py:1127
         for i, (img, pose) in enumerate(((ref_image, ref_pose), (src_image, src_pose))):
-            curr_pose = self._f32(torch.matmul(pose, ref_pose_inv))            # msi.py:1125
+            curr_pose = self._compose(pose, ref_pose_inv)                      # msi.py:1125
             order = 1 if (i % 2) == 0 else -1
             if self.input_type == 'ODS':
                 N.check(N.lib.msi_ods_sphere_sweep_f32(

@@ -67,6 +67,21 @@ def test_sweep_float_input_and_nonidentity_pose(gpu):
     assert np.percentile(err, 99.9) < 1e-3
 
 
+def test_compose_poses_matches_matmul(gpu):
+    """msi_compose_poses_f32 = the fp32 4x4 product of msi.py:1125, summed k = 0..3 without fma."""
+    torch, m, o = gpu
+    rng = np.random.RandomState(3)
+    a = rng.uniform(-2, 2, (5, 4, 4)).astype(np.float32)
+    bm = rng.uniform(-2, 2, (5, 4, 4)).astype(np.float32)
+    got = _np(m._compose(torch.from_numpy(a), torch.from_numpy(bm)))
+    want = np.zeros_like(a)
+    for k in range(4):                                       # same order, plain fp32 mul + add
+        want = (want + a[:, :, k:k + 1] * bm[:, k:k + 1, :]).astype(np.float32) if k else (a[:, :, :1] * bm[:, :1, :])
+    assert np.array_equal(got, want)
+    eye = np.eye(4, dtype=np.float32)[None]
+    assert np.array_equal(_np(m._compose(torch.from_numpy(a[:1]), torch.from_numpy(eye))), a[:1])   # identity is exact
+
+
 @pytest.mark.parametrize("b,h,w,d", [(1, 32, 64, 4), (2, 24, 96, 8), (1, 20, 50, 12)])
 def test_assemble_matches_oracle(gpu, b, h, w, d):
     torch, m, o = gpu
