@@ -70,13 +70,13 @@ def cnn_flops(h, w, cin, nout, ngf, coord):
 
 def cnn_traffic():
     """HBM bytes per frame of the conv kernels (18 launches) from the committed PMC passes
-    (profiles/r01_c_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH
+    (profiles/r01_g_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH
     doubled per the gfx950 note of MI355X_MICROARCH.md); None if the profile is not present."""
-    path = os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_g_hbm_traffic.json")
     try:
         with open(path) as f:
             k = json.load(f)["kernels"]["conv_igemm_kernel"]
-        return {"hbm_bytes_per_frame": k["hbm_bytes"], "source": "profiles/r01_c_hbm_traffic.json (separate --pmc passes)"}
+        return {"hbm_bytes_per_frame": k["hbm_bytes"], "source": "profiles/r01_g_hbm_traffic.json (separate --pmc passes)"}
     except Exception:
         return None
 
@@ -142,7 +142,7 @@ def main():
     ref_u8 = torch.from_numpy(np.ascontiguousarray(inp["ref_image"])).to(dev).contiguous()   # layout the API takes
     ref_pose = torch.from_numpy(inp["ref_pose"]).to(dev)
     src_pose = torch.from_numpy(inp["src_pose"]).to(dev)
-    ref_pose_inv = torch.linalg.inv(torch.from_numpy(inp["ref_pose"])).to(dev)
+    ref_pose_inv = torch.linalg.inv(torch.from_numpy(inp["ref_pose"])).contiguous().to(dev)   # (LAPACK returns a transposed view)
     intr = torch.from_numpy(inp["intrinsics"]).to(dev)
     tgt_pose_rt = torch.from_numpy(inp["tgt_pose_rt"]).to(dev)
     tgt_pos = torch.from_numpy(inp["tgt_pos"]).to(dev)

@@ -15,9 +15,10 @@
 //   * the LDS image is linear per row (128 B = 32 channels) with the 16-byte slot XOR-swizzled by
 //     (row>>1)&7 -- applied to the per-lane SOURCE offset for A and baked into the packed
 //     weights for B -- which makes the ds_read_b128 operand fetch bank-conflict free;
-//   * ds_read addresses are precomputed per (stage, quarter) so the loop needs no address VALU;
-//   * a 3-stage LDS ring with counted vmcnt keeps two k-steps of DMA in flight across the
-//     single barrier per k-step.
+//   * the operand fetch is inline asm: eight address VGPRs, the stage offset is the ds_read
+//     immediate, all eight reads of a k-step are issued before its MFMAs (counted lgkmcnt waits);
+//   * a 2-stage LDS ring (32 KB => five workgroups per CU), one barrier per k-step, the next
+//     k-step's DMA issued after the first MFMA quarter.
 // Consequence: the producer's LayerNorm + ReLU can no longer be applied in the operand loader;
 // it is applied once, in place, by ln_apply_kernel (HBM-bound, ~1 read + 1 write per activation)
 // instead of 9 x Cout/BN times in VALU.
@@ -35,7 +36,8 @@
 //     per workgroup; ln_apply_kernel merges the partials in fp64 in a fixed order (Chan)
 //     into the per-channel scale/shift and normalises in place.
 //
-// Tiling: 256 threads = 4 wavefronts (2x2), wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, BK=32.
+// Tiling: 256 threads = 4 wavefronts (2x2), wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, BK=32;
+// work decomposition ("tail split") and the measured alternatives: DESIGN.md section 4.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
