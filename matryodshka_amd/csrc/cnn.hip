@@ -83,7 +83,7 @@ struct ConvParams {
   int C0, C1;
   int Hin, Win, Hout, Wout, Cout, npad;
   int Mh, Mw;                // GEMM row grid per sample (output grid; input grid for convT)
-  unsigned mg_mw;            // floor(2^32 / Mw) (clamped): m / Mw by multiply-high + one correction
+  unsigned mg_mw, mg_tm, mg_tn, mg_nc, mg_sp;  // udiv_magic multipliers of Mw, tiles_m, tiles_n, nclass, split
   int ntaps, cpt0, cpt1, ksteps;  // taps, 32-channel chunks per tap of each source, total k-steps
   int stride, rate, pad_t, pad_l;
   int mode, wrap, nclass;
@@ -101,6 +101,15 @@ __device__ __forceinline__ int tap_delta(int v, int parity, int rate) {
   // odd outputs k=2 (i = (o-1)/2) and k=0 (i = (o+1)/2).
   if (MODE == MODE_CONVT) return v == 0 ? 0 : (parity ? 1 : -1);
   return 0;
+}
+
+// x / d by multiply-high with mg = floor(2^32 / d) (0xffffffff for d = 1) and one correction step:
+// exact for every 32-bit x; on wave-uniform values this is two scalar multiplies instead of the
+// ~35-instruction division sequence.
+__device__ __forceinline__ unsigned udiv_magic(unsigned x, unsigned d, unsigned mg) {
+  unsigned q = __umulhi(x, mg);
+  if (x - q * d >= d) ++q;
+  return q;
 }
 
 __device__ __forceinline__ int coord_class(int mw, int Mw) {
@@ -169,11 +178,11 @@ conv_igemm_kernel(const ConvParams p) {
       t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     } else {
       const int r = bid - p.n_main;
-      const int tl = r / p.split;
+      const int tl = (int)udiv_magic((unsigned)r, (unsigned)p.split, p.mg_sp);
       ks = r - tl * p.split;
       t = p.n_main + tl;
-      k0 = ks * S / p.split;
-      k1 = (ks + 1) * S / p.split;
+      k0 = (int)udiv_magic((unsigned)(ks * S), (unsigned)p.split, p.mg_sp);
+      k1 = (int)udiv_magic((unsigned)((ks + 1) * S), (unsigned)p.split, p.mg_sp);
     }
   }
   const bool full = (k0 == 0) & (k1 == S);
@@ -182,11 +191,11 @@ conv_igemm_kernel(const ConvParams p) {
     // tile order: M tiles fastest (measured on the same box: 3.03 ms per frame vs 3.11 ms with N tiles
     // fastest and 3.09 ms for the previous 3-D grid without the tail split)
     int r = t;
-    const int q1 = r / p.tiles_m;
+    const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
     tile_m = r - q1 * p.tiles_m; r = q1;
-    const int q2 = r / p.tiles_n;
+    const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
     tile_n = r - q2 * p.tiles_n; r = q2;
-    const int q3 = r / p.nclass;
+    const int q3 = (int)udiv_magic((unsigned)r, (unsigned)p.nclass, p.mg_nc);
     cls = r - q3 * p.nclass;
     b = q3;
   }
@@ -209,9 +218,8 @@ conv_igemm_kernel(const ConvParams p) {
   for (int i = 0; i < AI; ++i) {
     const int r = wave * (BM / 4) + i * 8 + drow;
     const int m = tile_m * BM + r;
-    int mh = (int)__umulhi((unsigned)m, p.mg_mw);
-    int mw = m - mh * p.Mw;
-    if (mw >= p.Mw) { ++mh; mw -= p.Mw; }
+    const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);
+    const int mw = m - mh * p.Mw;
     const int ih0 = mh * p.stride - p.pad_t, iw0 = mw * p.stride - p.pad_l;
     rowbase[i] = ih0 * p.Win;
     const bool mok = m < mtot;
@@ -344,6 +352,11 @@ _Pragma("unroll")                                                               
     }                                                                                                                            \
   }
 
+  // the first k-step's DMA goes out before the rest of the set-up: its latency (HBM under load) is the
+  // longest single wait of the prologue
+  const int nsteps = k1 - k0;
+  MSI_ISSUE(0)
+
   // ---- MFMA side: precomputed ds_read addresses (no VALU in the loop) --------------------------
   // lane reads row (lane&31) of its wave tile, k-quarter q of half h = lane>>5: data chunk h*4+q
   // lives in slot (h*4+q) ^ ((row>>1)&7).
@@ -415,8 +428,6 @@ _Pragma("unroll")                                                               
   static_assert(NSTAGE == 2 || NSTAGE == 3, "the main loop is unrolled for a 2- or 3-stage ring");
   constexpr int PD = NSTAGE - 1;          // prefetch distance in k-steps
   constexpr int DMA_PER_STEP = AI + BI;   // buffer_load ... lds instructions per wave per k-step
-  const int nsteps = k1 - k0;
-  MSI_ISSUE(0)
   if (PD > 1 && nsteps > 1) {
     MSI_ISSUE(1)
     wait_vmcnt<DMA_PER_STEP>();           // k-step 0 landed, k-step 1 in flight
@@ -480,6 +491,7 @@ _Pragma("unroll")                                                               
   // interior tile (the common case): no row / channel masks anywhere in the epilogue -- its VALU work is
   // paid in matrix throughput of the co-resident workgroups
   const bool interior = (tile_m + 1) * BM <= mtot && (tile_n + 1) * BN <= p.Cout;
+  const bool want_stats = MODE != MODE_HEAD && full && p.stats != nullptr;
   float lsum = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -500,6 +512,43 @@ _Pragma("unroll")                                                               
           else lsum += (tile_m * BM + lrow < mtot && n < p.Cout) ? v : 0.f;
         }
       }
+    }
+  }
+  // LayerNorm partial, per WAVE first (no workgroup barrier): mean of the wave's (MT*32)x(NT*32) block, then
+  // M2 about that mean (two-pass: the values are still in registers); lane 0 parks (count, mean, M2) behind
+  // the staged tile and thread 0 merges the four after the one barrier this epilogue has.
+  static_assert((size_t)BM * LDW * 4 + 64 <= (size_t)NSTAGE * STAGE_BYTES, "wave partials behind the staged tile");
+  float *wpart = ct + BM * LDW;   // [4 waves][4]
+  if (want_stats) {
+    auto wave_sum = [&](float v) __attribute__((always_inline)) -> float {   // butterfly: every lane gets the total
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      return v;
+    };
+    const int rv = min(max(mtot - (tile_m * BM + wm * (MT * 32)), 0), MT * 32);
+    const int cv = min(max(p.Cout - (tile_n * BN + wn * (NT * 32)), 0), NT * 32);
+    const float wcnt = (float)(rv * cv);
+    const float wmean = wcnt > 0.f ? wave_sum(lsum) / wcnt : 0.f;
+    float lm2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = tile_n * BN + wn * (NT * 32) + j * 32 + col;
+          const float dlt = acc[i][j][r] - wmean;
+          if (interior) lm2 += dlt * dlt;
+          else lm2 += (m < mtot && n < p.Cout) ? dlt * dlt : 0.f;
+        }
+      }
+    }
+    const float wm2 = wave_sum(lm2);
+    if (lane == 0) {
+      wpart[wave * 4 + 0] = wcnt;
+      wpart[wave * 4 + 1] = wmean;
+      wpart[wave * 4 + 2] = wm2;
     }
   }
   __syncthreads();
@@ -530,9 +579,8 @@ _Pragma("unroll")                                                               
       if (!interior && (m >= mtot || n >= p.Cout)) continue;
       size_t opix;
       if (MODE == MODE_CONVT) {
-        int mh = (int)__umulhi((unsigned)m, p.mg_mw);   // m / Mw by multiply-high + one correction
-        int mw = m - mh * p.Mw;
-        if (mw >= p.Mw) { ++mh; mw -= p.Mw; }
+        const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);
+        const int mw = m - mh * p.Mw;
         opix = ((size_t)b * p.Hout + (2 * mh + ph)) * p.Wout + (2 * mw + pw);
       } else {
         opix = (size_t)b * mtot + m;
@@ -549,53 +597,28 @@ _Pragma("unroll")                                                               
       }
     }
   }
-#ifdef MSI_CONV_TIMING
-  if (MODE == MODE_HEAD || p.stats == nullptr) { stamp(); return; }
-#else
-  if (MODE == MODE_HEAD || p.stats == nullptr) return;
-#endif
-
-  // block mean, then M2 about the block mean (two-pass inside the block: the values
-  // are still in registers), reduced in a fixed order.
-  // (the four wave sums live in the dynamic LDS behind the staged tile: a separate 16-byte __shared__
-  // array makes the workgroup 32784 B and a CU then holds four of them instead of five)
-  static_assert((size_t)BM * LDW * 4 + 16 <= (size_t)NSTAGE * STAGE_BYTES, "wave sums behind the staged tile");
-  float *red = ct + BM * LDW;
-  auto block_sum = [&](float v) __attribute__((always_inline)) -> float {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-  };
-  const float bsum = block_sum(lsum);
-  // the count of valid outputs of this tile is known analytically (one reduction less)
-  const float bcnt = (float)(min(BM, mtot - tile_m * BM) * min(BN, p.Cout - tile_n * BN));
-  const float bmean = bcnt > 0.f ? bsum / bcnt : 0.f;
-  float lm2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = tile_n * BN + wn * (NT * 32) + j * 32 + col;
-        const float dlt = acc[i][j][r] - bmean;
-        if (interior) lm2 += dlt * dlt;
-        else lm2 += (m < mtot && n < p.Cout) ? dlt * dlt : 0.f;
+  if (want_stats && tid == 0) {
+    // Chan's merge of the four wave partials in a fixed order: (0,1), (2,3), then the pair
+    auto merge = [](float &na, float &ma, float &sa, float nb, float mb, float sb) __attribute__((always_inline)) {
+      const float nt = na + nb;
+      if (nb > 0.f) {
+        const float dl = mb - ma, f = nb / nt;
+        ma += dl * f;
+        sa += sb + dl * dl * (na * f);
+        na = nt;
       }
-    }
-  }
-  const float bm2 = block_sum(lm2);
-  if (tid == 0) {
+    };
+    float n0 = wpart[0], m0 = wpart[1], s0 = wpart[2];
+    float n2 = wpart[8], m2 = wpart[9], s2 = wpart[10];
+    merge(n0, m0, s0, wpart[4], wpart[5], wpart[6]);
+    merge(n2, m2, s2, wpart[12], wpart[13], wpart[14]);
+    merge(n0, m0, s0, n2, m2, s2);
     const int nparts = p.tiles_m * p.tiles_n * p.nclass;
     const int part = (cls * p.tiles_n + tile_n) * p.tiles_m + tile_m;
     float *o = p.stats + ((size_t)b * nparts + part) * 4;
-    o[0] = bcnt;
-    o[1] = bmean;
-    o[2] = bm2;
+    o[0] = n0;
+    o[1] = m0;
+    o[2] = s0;
     o[3] = 0.f;
   }
 #ifdef MSI_CONV_TIMING
@@ -947,7 +970,6 @@ template <int BM, int BN, int MODE>
 int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   const int mtot = p.Mh * p.Mw;
   p.tiles_m = (mtot + BM - 1) / BM;
-  p.mg_mw = p.Mw == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)p.Mw);
   p.tiles_n = (p.Cout + BN - 1) / BN;
   p.ntiles = p.tiles_m * p.tiles_n * p.nclass * batch;
   *nparts = p.tiles_m * p.tiles_n * p.nclass;
@@ -966,6 +988,9 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
     }
     if (best > 1) { p.split = best; p.n_main = p.ntiles - rem; }
   }
+  auto magic = [](int d) { return d == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)d); };
+  p.mg_mw = magic(p.Mw); p.mg_tm = magic(p.tiles_m); p.mg_tn = magic(p.tiles_n); p.mg_nc = magic(p.nclass);
+  p.mg_sp = magic(p.split);
   const int nblocks = p.n_main + (p.ntiles - p.n_main) * p.split;
   const size_t lds = (size_t)NSTAGE * (BM + BN) * ROW_BYTES;
   if (lds > 64 * 1024) {
