@@ -79,11 +79,12 @@ struct ConvParams {
   float *stats;              // [B][nparts][4] (count, mean, M2, -) or null
   float *partial;            // [split tiles][split][BM*BN] partial accumulators
   int tiles_m, tiles_n, ntiles;  // output tiles per (sample, class) and in the whole launch
-  int n_main, split;         // tiles computed whole | K-ranges per remaining tile
+  int n_main, split0, split; // the first n_main tiles are cut into split0 K-ranges each (1 = whole), the rest into split
+  int nb_main;               // n_main * split0: workgroups of the first group
   int C0, C1;
   int Hin, Win, Hout, Wout, Cout, npad;
   int Mh, Mw;                // GEMM row grid per sample (output grid; input grid for convT)
-  unsigned mg_mw, mg_tm, mg_tn, mg_nc, mg_sp;  // udiv_magic multipliers of Mw, tiles_m, tiles_n, nclass, split
+  unsigned mg_mw, mg_tm, mg_tn, mg_nc, mg_sp0, mg_sp;  // udiv_magic multipliers of Mw, tiles_m, tiles_n, nclass, split0, split
   int ntaps, cpt0, cpt1, ksteps;  // taps, 32-channel chunks per tap of each source, total k-steps
   int stride, rate, pad_t, pad_l;
   int mode, wrap, nclass;
@@ -170,19 +171,23 @@ conv_igemm_kernel(const ConvParams p) {
   // each XCD has a private L2; consecutive tiles share halo rows and weights, so every XCD gets a
   // CONTIGUOUS range of tiles instead of every eighth one (bijective remap).
   const int S = p.ksteps;
-  int t, k0 = 0, k1 = S, ks = 0;
+  int t, k0 = 0, k1 = S, ks = 0, slot = 0;   // slot: index of this K-range's partial accumulator
   {
     const int bid = blockIdx.x;
-    if (bid < p.n_main) {
+    if (bid < p.nb_main && p.split0 == 1) {
       const int q = p.n_main >> 3, r = p.n_main & 7, xcd = bid & 7, local = bid >> 3;
       t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     } else {
-      const int r = bid - p.n_main;
-      const int tl = (int)udiv_magic((unsigned)r, (unsigned)p.split, p.mg_sp);
-      ks = r - tl * p.split;
-      t = p.n_main + tl;
-      k0 = (int)udiv_magic((unsigned)(ks * S), (unsigned)p.split, p.mg_sp);
-      k1 = (int)udiv_magic((unsigned)((ks + 1) * S), (unsigned)p.split, p.mg_sp);
+      int sp, r, tbase;
+      unsigned mg;
+      if (bid < p.nb_main) { sp = p.split0; mg = p.mg_sp0; r = bid; tbase = 0; }
+      else { sp = p.split; mg = p.mg_sp; r = bid - p.nb_main; tbase = p.n_main; }
+      const int tl = (int)udiv_magic((unsigned)r, (unsigned)sp, mg);
+      ks = r - tl * sp;
+      t = tbase + tl;
+      k0 = (int)udiv_magic((unsigned)(ks * S), (unsigned)sp, mg);
+      k1 = (int)udiv_magic((unsigned)((ks + 1) * S), (unsigned)sp, mg);
+      slot = bid - (p.split0 == 1 ? p.nb_main : 0);
     }
   }
   const bool full = (k0 == 0) & (k1 == S);
@@ -556,7 +561,7 @@ _Pragma("unroll")                                                               
   constexpr int PASSES = BM * C4 / 256;
   if (!full) {
     // K-range of a split tile: raw accumulators, row-major [BM][BN], into slot (tile, range)
-    float *dst = p.partial + ((size_t)(t - p.n_main) * p.split + ks) * (BM * BN);
+    float *dst = p.partial + (size_t)slot * (BM * BN);
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
       const int idx = tid + 256 * k;
@@ -637,7 +642,12 @@ conv_fixup_kernel(const ConvParams p) {
   constexpr int C4 = BN / 4;
   constexpr int PASSES = BM * C4 / 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = p.n_main + blockIdx.x;
+  // split tiles: [0, ntiles) when the first group is split too, else [n_main, ntiles); their partial
+  // slots are consecutive in workgroup order of conv_igemm_kernel
+  const int t = (p.split0 == 1 ? p.n_main : 0) + blockIdx.x;
+  const int nsp = t < p.n_main ? p.split0 : p.split;
+  const int slot0 = p.split0 == 1 ? (t - p.n_main) * p.split
+                                  : (t < p.n_main ? t * p.split0 : p.nb_main + (t - p.n_main) * p.split);
   int tile_m, tile_n, cls, b;
   {
     int r = t;   // same order as conv_igemm_kernel: M tiles fastest
@@ -654,7 +664,7 @@ conv_fixup_kernel(const ConvParams p) {
   v4f a[MAX_SPLIT][PASSES];
 #pragma unroll
   for (int ks = 0; ks < MAX_SPLIT; ++ks) {
-    const float *src = p.partial + ((size_t)blockIdx.x * p.split + min(ks, p.split - 1)) * (BM * BN);
+    const float *src = p.partial + (size_t)(slot0 + min(ks, nsp - 1)) * (BM * BN);
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) a[ks][k] = *reinterpret_cast<const v4f *>(src + (size_t)(tid + 256 * k) * 4);
   }
@@ -663,7 +673,7 @@ conv_fixup_kernel(const ConvParams p) {
   for (int k = 0; k < PASSES; ++k) v[k] = a[0][k];
 #pragma unroll
   for (int ks = 1; ks < MAX_SPLIT; ++ks) {
-    const bool on = ks < p.split;
+    const bool on = ks < nsp;
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
       v[k].x += on ? a[ks][k].x : 0.f; v[k].y += on ? a[ks][k].y : 0.f;
@@ -976,6 +986,7 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   // tail split (see the kernel): whole tiles in multiples of the CU count, the remainder cut into
   // `split` K-ranges so that (remainder x split) is again close to a multiple of the CU count
   p.n_main = p.ntiles;
+  p.split0 = 1;
   p.split = 1;
   static const char *ts = getenv("MSI_CONV_TAILSPLIT");   // debug: 0 disables
   const int rem = p.ntiles % NUM_CUS;
@@ -987,11 +998,31 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
       if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
     }
     if (best > 1) { p.split = best; p.n_main = p.ntiles - rem; }
+    // One whole tile per CU next to four short K-ranges ends with that tile running alone (one wave per
+    // SIMD, nothing to hide its barriers behind): such layers (256 <= tiles < 512: the 40x80 ones) also cut
+    // the first group in two.  Measured: 2.750 -> 2.72 ms per frame, flat over 2..4 x 5..8
+    // (debug override MSI_CONV_SPLIT01="s0xs1").
+    if (p.n_main == NUM_CUS && p.split > 1 && p.ksteps >= 4 * MAX_SPLIT) {
+      p.split0 = 2;
+      p.split = p.split > 6 ? 6 : p.split;   // remainder ranges not much shorter than the halves
+    }
+    static const char *s01 = getenv("MSI_CONV_SPLIT01");
+    int a0 = 0, a1 = 0;
+    if (s01 && p.n_main == NUM_CUS && sscanf(s01, "%dx%d", &a0, &a1) == 2 && a0 >= 1 && a0 <= MAX_SPLIT && a1 >= 2 &&
+        a1 <= MAX_SPLIT && p.ksteps >= 2 * a0 && p.ksteps >= 2 * a1) {
+      p.split0 = a0;
+      p.split = a1;
+    }
   }
+  p.nb_main = p.n_main * p.split0;
   auto magic = [](int d) { return d == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)d); };
   p.mg_mw = magic(p.Mw); p.mg_tm = magic(p.tiles_m); p.mg_tn = magic(p.tiles_n); p.mg_nc = magic(p.nclass);
+  p.mg_sp0 = magic(p.split0);
   p.mg_sp = magic(p.split);
-  const int nblocks = p.n_main + (p.ntiles - p.n_main) * p.split;
+  const int nblocks = p.nb_main + (p.ntiles - p.n_main) * p.split;
+  const int nfix = (p.split0 > 1 ? p.n_main : 0) + (p.split > 1 ? p.ntiles - p.n_main : 0);
+  if ((size_t)(nblocks - (p.split0 == 1 ? p.nb_main : 0)) * BM * BN * sizeof(float) > PARTIAL_BYTES)
+    return msi::fail(MSI_E_WORKSPACE, "conv: %d partial accumulators exceed the workspace", nblocks);
   const size_t lds = (size_t)NSTAGE * (BM + BN) * ROW_BYTES;
   if (lds > 64 * 1024) {
     static thread_local bool done = false;
@@ -1004,8 +1035,8 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE>), dim3(nblocks), dim3(256), lds, stream, p);
   int rc = msi::check_launch("conv_igemm");
-  if (rc || p.split == 1) return rc;
-  hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, MODE>), dim3(p.ntiles - p.n_main), dim3(256), 0, stream, p);
+  if (rc || nfix == 0) return rc;
+  hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, MODE>), dim3(nfix), dim3(256), 0, stream, p);
   return msi::check_launch("conv_fixup");
 }
 
