@@ -76,7 +76,7 @@ def cnn_traffic():
     try:
         with open(path) as f:
             k = json.load(f)["kernels"]["conv_igemm_kernel"]
-        return {"hbm_bytes_per_frame": k["hbm_bytes"], "source": "profiles/r01_g_hbm_traffic.json (separate --pmc passes)"}
+        return int(k["hbm_bytes"])
     except Exception:
         return None
 
@@ -240,7 +240,12 @@ def main():
         "roofline": {"kernel": "conv_igemm_kernel (18 launches/frame, fp32 MFMA implicit GEMM; + 17 ln_finish)",
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": cnn_traffic(),
-                     "algorithmic_flops_per_frame": flops, "ms_per_frame": round(stage_ms["cnn"], 4)},
+                     "traffic_note": "HBM bytes per frame of the 18 conv launches, profiles/r01_g_hbm_traffic.json "
+                                     "(separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH correction)",
+                     "launches_per_frame": 18, "algorithmic_flops_per_frame": flops,
+                     "ms_per_frame": round(stage_ms["cnn"], 4),
+                     "timed": "HIP events around msi_net_forward_f32 on the launch stream inside the timed region "
+                              "(18 conv + 17 fix-up + 17 ln_apply launches: conservative for the conv kernel alone)"},
         "stages": stages,
     }
 
