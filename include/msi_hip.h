@@ -92,6 +92,14 @@ int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float 
                              float *psv, int32_t psv_channels, int32_t channel_offset,
                              msi_stream_t stream);
 
+/* Same sweep with a bf16 volume (round to nearest even): the network input of BASELINE
+ * configs[2]; everything up to the final store is the fp32 arithmetic above. */
+int msi_ods_sphere_sweep_bf16(const float *image, const float *pose, const float *intrinsics,
+                              const float *depths, const float *trig, int32_t batch,
+                              int32_t height, int32_t width, int32_t num_depths, int32_t order,
+                              void *psv_bf16, int32_t psv_channels, int32_t channel_offset,
+                              msi_stream_t stream);
+
 /* ---- K3: RGBA layer assembly ----------------------------------------------------
  * infer_msi "layer_prediction", which_color_pred = blend_psv (msi.py:130-147):
  * w=(pred[..,d]+1)/2, a=(pred[..,D+d]+1)/2, rgb = w*psv_ref_d + (1-w)*psv_src_d.
@@ -100,6 +108,11 @@ int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float 
 int msi_assemble_rgba_f32(const float *psv, const float *pred, float *rgba_native,
                           float *blend_weights, float *alphas, int32_t batch, int32_t height,
                           int32_t width, int32_t num_planes, msi_stream_t stream);
+
+/* msi_assemble_rgba_f32 reading the bf16 PSV of the bf16 path (pred, outputs fp32). */
+int msi_assemble_rgba_bf16psv_f32(const void *psv_bf16, const float *pred, float *rgba_native,
+                                  float *blend_weights, float *alphas, int32_t batch, int32_t height,
+                                  int32_t width, int32_t num_planes, msi_stream_t stream);
 
 /* High-res re-render (test.py:283-394): the per-plane loop there is (a) the high-res sphere
  * sweep (msi_ods_sphere_sweep_f32 at the high resolution), (b) tf.image.resize(BILINEAR,
@@ -179,7 +192,11 @@ typedef struct msi_net_desc {
   int32_t num_outputs;          /* 2*D for blend_psv */
   int32_t ngf;                  /* 64 in the reference */
   int32_t coord_net;            /* 1: msi_coord_train_net, 0: msi_train_net */
+  int32_t dtype;                /* MSI_DTYPE_F32 (0) or MSI_DTYPE_BF16 (1): operand type of the convolutions */
 } msi_net_desc;
+
+#define MSI_DTYPE_F32 0
+#define MSI_DTYPE_BF16 1
 
 #define MSI_NET_NUM_LAYERS 18
 
@@ -213,6 +230,15 @@ size_t msi_net_workspace_bytes(const msi_net_desc *desc);
 int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const float *net_input,
                         float *pred, void *workspace, size_t workspace_bytes,
                         msi_stream_t stream);
+/* BASELINE configs[2] (bf16): desc->dtype = MSI_DTYPE_BF16.  net_input [B,H,W,in_channels] bf16
+ * (msi_ods_sphere_sweep_bf16 writes it), weights and activations bf16 (round to nearest even),
+ * products accumulated in fp32 on v_mfma_f32_32x32x16_bf16, LayerNorm statistics and affine in
+ * fp32 on the fp32 accumulators, pred [B,H,W,num_outputs] fp32.  in_channels and ngf must be
+ * multiples of 8.  The packed blob (same size query / packer, keyed by desc->dtype) holds bf16
+ * weights and fp32 gamma / beta / bias. */
+int msi_net_forward_bf16(const msi_net_desc *desc, const float *packed, const void *net_input_bf16,
+                         float *pred, void *workspace, size_t workspace_bytes,
+                         msi_stream_t stream);
 
 #ifdef __cplusplus
 }

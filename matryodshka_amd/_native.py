@@ -22,7 +22,10 @@ class MsiError(RuntimeError):
 class NetDesc(Structure):
     _fields_ = [("batch", c_int32), ("height", c_int32), ("width", c_int32),
                 ("in_channels", c_int32), ("num_outputs", c_int32), ("ngf", c_int32),
-                ("coord_net", c_int32)]
+                ("coord_net", c_int32), ("dtype", c_int32)]
+
+
+MSI_DTYPE_F32, MSI_DTYPE_BF16 = 0, 1
 
 
 class LayerInfo(Structure):
@@ -47,7 +50,9 @@ SIGNATURES = {
     "msi_deprocess_f32_u8": (_I, [_P, _P, c_size_t, _I, _P]),
     "msi_compose_poses_f32": (_I, [_P, _P, _P, _I, _P]),
     "msi_ods_sphere_sweep_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "msi_ods_sphere_sweep_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "msi_assemble_rgba_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msi_assemble_rgba_bf16psv_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msi_resize_bilinear_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msi_assemble_rgba_scaled_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "msi_render_equirect_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
@@ -62,6 +67,7 @@ SIGNATURES = {
     "msi_net_pack_weights_host": (_I, [POINTER(NetDesc), _P, _P]),
     "msi_net_workspace_bytes": (c_size_t, [POINTER(NetDesc)]),
     "msi_net_forward_f32": (_I, [POINTER(NetDesc), _P, _P, _P, _P, c_size_t, _P]),
+    "msi_net_forward_bf16": (_I, [POINTER(NetDesc), _P, _P, _P, _P, c_size_t, _P]),
 }
 
 

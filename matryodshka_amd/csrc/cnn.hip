@@ -71,9 +71,10 @@ constexpr double LN_EPS = 1e-12;  // slim.layer_norm variance epsilon [TF-knowle
 enum { MODE_CONV = 0, MODE_CONVT = 1, MODE_HEAD = 2 };
 
 struct ConvParams {
-  const float *x0, *x1;      // NHWC sources, already normalised (x1 = second half of a skip concat)
-  const float *wpk;          // packed weights [nclass][ksteps][npad][32], slots pre-swizzled
-  const float *coord_tab;    // CoordNet table [Mh][COORD_CLASSES][32] or null
+  // element-typed buffers (fp32, or bf16 in the BF16 instantiation) are addressed in bytes
+  const char *x0, *x1;       // NHWC sources, already normalised (x1 = second half of a skip concat)
+  const char *wpk;           // packed weights [nclass][ksteps][npad][128 B], slots pre-swizzled
+  const char *coord_tab;     // CoordNet table [Mh][COORD_CLASSES][128 B] or null
   const float *bias;         // head only
   float *y;                  // raw output NHWC [B,Hout,Wout,Cout]
   float *stats;              // [B][nparts][4] (count, mean, M2, -) or null
@@ -144,10 +145,15 @@ __device__ __forceinline__ void wait_lgkm(v4f &x, v4f &y) {
 
 // amdgpu_waves_per_eu: with a dynamic LDS size hipcc cannot see that five 32 KB workgroups share a CU
 // and spends registers freely (116 for the 64x64 tile => four waves per SIMD); five need <= 96.
-template <int BM, int BN, int MODE>
+// BF16 = 0: fp32 operands, 32 channels per k-step, v_mfma_f32_32x32x2_f32 (16 per k-step and wave);
+// BF16 = 1: bf16 operands (fp32 accumulate, fp32 raw output), 64 channels per k-step -- the same 128-byte
+// rows, swizzle and DMA -- and v_mfma_f32_32x32x16_bf16 (4 per k-step and wave).
+template <int BM, int BN, int MODE, int BF16>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NSTAGE == 2 ? 5 : 3)))
 conv_igemm_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (the body uses device-only types)
+  constexpr int ESZ = BF16 ? 2 : 4;          // bytes per operand element
+  constexpr int BKE = ROW_BYTES / ESZ;       // channels per k-step: 32 (fp32) / 64 (bf16)
   constexpr int MT = BM / 64, NT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
   constexpr int AI = BM / 32, BI = BN / 32;  // DMA wave-instructions (8 rows x 128 B each) per wave per k-step
   constexpr int ND = AI + BI;
@@ -254,14 +260,14 @@ conv_igemm_kernel(const ConvParams p) {
     c_voff[i] = mok ? (unsigned)((mh * COORD_CLASSES + coord_class(mw, p.Mw)) * ROW_BYTES) + a_chunk16[i] : OOB;
   }
   // B: rows [wave*BN/4 + 8i, +8) of the weight tile; the packed blob is already swizzled
-  const unsigned b_voff = (unsigned)(((tile_n * BN + wave * (BN / 4) + drow) * BK + dslot * 4) * 4);
+  const unsigned b_voff = (unsigned)((tile_n * BN + wave * (BN / 4) + drow) * ROW_BYTES + dslot * 16);
 
   const size_t in_pix = (size_t)p.Hin * p.Win;
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(p.wpk + (size_t)cls * S * p.npad * BK), 0, (int)((size_t)S * p.npad * ROW_BYTES), 0x00020000);
-  const char *src0 = (const char *)(p.x0 + (size_t)b * in_pix * p.C0);
-  const long d_src = (const char *)(p.x1 + (size_t)b * in_pix * p.C1) - src0;  // integer select, see gen below
-  const int bytes0 = (int)(in_pix * p.C0 * 4), bytes1 = (int)(in_pix * p.C1 * 4);
+      (void *)(p.wpk + (size_t)cls * S * p.npad * ROW_BYTES), 0, (int)((size_t)S * p.npad * ROW_BYTES), 0x00020000);
+  const char *src0 = p.x0 + (size_t)b * in_pix * p.C0 * ESZ;
+  const long d_src = (p.x1 + (size_t)b * in_pix * p.C1 * ESZ) - src0;  // integer select, see gen below
+  const int bytes0 = (int)(in_pix * p.C0 * ESZ), bytes1 = (int)(in_pix * p.C1 * ESZ);
 
   // ---- k-step generator: (tap, source, chunk) segments ------------------------------------------
   // Per segment the per-lane A offsets are fixed; the channel walk is the scalar soffset.
@@ -301,7 +307,7 @@ conv_igemm_kernel(const ConvParams p) {
         g_C = g_src ? p.C1 : p.C0;                                                                                               \
         rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(src0 + (g_src ? d_src : 0L)), 0, g_src ? bytes1 : bytes0,            \
                                                    0x00020000);                                                                  \
-        const unsigned pix_bytes = (unsigned)g_C * 4u;                                                                           \
+        const unsigned pix_bytes = (unsigned)g_C * (unsigned)ESZ;                                                                           \
 _Pragma("unroll")                                                                                                                \
         for (int i = 0; i < AI; ++i) {                                                                                           \
           int iw = colw0[i];                                                                                                     \
@@ -314,8 +320,8 @@ _Pragma("unroll")                                                               
         }                                                                                                                        \
       }                                                                                                                          \
       const int soff_a = g_chunk * ROW_BYTES;                                                                                    \
-      const int cleft = g_C - g_chunk * BK;  /* channels from this chunk on; < 32 only when C % 32 != 0 (wave-uniform) */        \
-      if (cleft >= BK) {                                                                                                         \
+      const int cleft = g_C - g_chunk * BKE; /* channels from this chunk on; < BKE only when C % BKE != 0 (wave-uniform) */        \
+      if (cleft >= BKE) {                                                                                                        \
 _Pragma("unroll")                                                                                                                \
         for (int i = 0; i < AI; ++i)                                                                                             \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void *)(sA + i * 8 * ROW_BYTES), 16, a_voff[i], soff_a, 0, 0);   \
@@ -324,7 +330,7 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                                \
         for (int i = 0; i < AI; ++i)                                                                                             \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void *)(sA + i * 8 * ROW_BYTES), 16,                             \
-                                                   a_chunk16[i] < (unsigned)cleft * 4u ? a_voff[i] : OOB, soff_a, 0, 0);         \
+                                                   a_chunk16[i] < (unsigned)(cleft * ESZ) ? a_voff[i] : OOB, soff_a, 0, 0);         \
       }                                                                                                                          \
     } else {                                                                                                                     \
       /* CoordNet k-step: row m reads table[mh][column class][32] */                                                             \
@@ -373,7 +379,9 @@ _Pragma("unroll")                                                               
     const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int slot = ((fh * 4 + q) ^ fswz) * 16;
+      // quarter q of the k-step, lane half fh: fp32 -> channels 16 fh + 4q .. +4 (chunk 4 fh + q, one per
+      // four 32x32x2 MFMAs); bf16 -> channels 16q + 8 fh .. +8 (chunk 2q + fh, the A/B fragment of one 32x32x16)
+      const int slot = ((BF16 ? 2 * q + fh : fh * 4 + q) ^ fswz) * 16;
       a_q[q] = lds_base + (wm * (MT * 32) + frow) * ROW_BYTES + slot;
       b_q[q] = lds_base + BM * ROW_BYTES + (wn * (NT * 32) + frow) * ROW_BYTES + slot;
     }
@@ -403,15 +411,21 @@ _Pragma("unroll")                                                               
                             : lds_read128<(ST) * STAGE_BYTES + (NT - 1) * 32 * ROW_BYTES>(b_q[q_]);    \
   }
   static_assert(MT <= 2 && NT <= 2, "MSI_FETCH addresses at most two MFMA tiles per direction");
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   auto mma_quarter = [&](Frag &f, const int q) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].x, f.b[q][j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].y, f.b[q][j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].z, f.b[q][j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].w, f.b[q][j].w, acc[i][j], 0, 0, 0);
+        if constexpr (BF16) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[q][i]),
+                                                              __builtin_bit_cast(bf16x8, f.b[q][j]), acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].x, f.b[q][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].y, f.b[q][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].z, f.b[q][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].w, f.b[q][j].w, acc[i][j], 0, 0, 0);
+        }
       }
   };
   // Quarter Q of a fetched k-step.  Counted wait: LDS reads return in order, quarter Q needs the
@@ -764,10 +778,13 @@ conv_fixup_kernel(const ConvParams p) {
 // slice (nets.py:401,485 arg_scope: normalizer, then the default ReLU).  Merging redundantly
 // (<= 3200 partials = 51 KB from L2 per workgroup) is cheaper than a separate single-block launch
 // plus a kernel boundary per layer.  Workgroup 0 also publishes the affine (debug / tests).
+// BF16OUT: the normalised activation is written as bf16 to `yb` (the operand buffer of the bf16 path)
+// and the fp32 raw output is left alone; otherwise x is normalised in place.
+template <int BF16OUT>
 __global__ void __launch_bounds__(256)
 ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int nparts,
                 const float *__restrict__ gamma, const float *__restrict__ beta, size_t per_sample, int C,
-                float *__restrict__ aff) {
+                float *__restrict__ aff, unsigned short *__restrict__ yb) {
   extern __shared__ __attribute__((aligned(16))) float s_aff[];  // scale[C] shift[C]
   __shared__ double s_red[2][4];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -827,16 +844,27 @@ ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int npar
     v.w = fmaxf(v.w * s4.w + t4.w, 0.f);
     return v;
   };
+  // fp32 -> bf16, round to nearest even (finite inputs: the LayerNorm output)
+  auto bf16_bits = [](float f) __attribute__((always_inline)) -> unsigned {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  };
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  v2u *yv = reinterpret_cast<v2u *>(yb + (size_t)b * per_sample);
+  auto put = [&](size_t i, const v4f v) __attribute__((always_inline)) {
+    if (BF16OUT) yv[i] = v2u{bf16_bits(v.x) | (bf16_bits(v.y) << 16), bf16_bits(v.z) | (bf16_bits(v.w) << 16)};
+    else xv[i] = v;
+  };
   if ((256 * 4) % C == 0) {
     // every grid-stride step advances a thread by a multiple of C floats: its four channels are fixed
     const int c = (tid * 4) % C;
     const v4f s4 = *reinterpret_cast<const v4f *>(s_aff + c);
     const v4f t4 = *reinterpret_cast<const v4f *>(s_aff + C + c);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < nvec; i += stride) xv[i] = apply(xv[i], s4, t4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < nvec; i += stride) put(i, apply(xv[i], s4, t4));
   } else {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < nvec; i += stride) {
       const int c = (int)((i * 4) % C);
-      xv[i] = apply(xv[i], *reinterpret_cast<const v4f *>(s_aff + c), *reinterpret_cast<const v4f *>(s_aff + C + c));
+      put(i, apply(xv[i], *reinterpret_cast<const v4f *>(s_aff + c), *reinterpret_cast<const v4f *>(s_aff + C + c)));
     }
   }
 }
@@ -857,6 +885,7 @@ struct Layer {
   size_t packed_w_floats;
   size_t gamma_off, beta_off, coord_off;  // floats inside the packed blob
   size_t raw_off, aff_off;                // bytes inside the workspace
+  size_t act_off;                         // bf16 path: normalised bf16 activation (the next layer's operand)
 };
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -876,6 +905,12 @@ int build_net(const msi_net_desc *d, Net &net) {
                      d->height, d->width);
   if (d->in_channels % 4 || d->ngf % 4)
     return msi::fail(MSI_E_UNSUPPORTED, "net: in_channels and ngf must be multiples of 4");
+  if (d->dtype != MSI_DTYPE_F32 && d->dtype != MSI_DTYPE_BF16)
+    return msi::fail(MSI_E_BADARG, "net: dtype %d (MSI_DTYPE_F32 or MSI_DTYPE_BF16)", d->dtype);
+  const int bf16 = d->dtype == MSI_DTYPE_BF16;
+  const int esz = bf16 ? 2 : 4, bke = ROW_BYTES / esz;   // operand bytes, channels per k-step
+  if (bf16 && (d->in_channels % 8 || d->ngf % 8))
+    return msi::fail(MSI_E_UNSUPPORTED, "net: bf16 needs in_channels and ngf in multiples of 8 (16-byte channel chunks)");
   if ((long)d->height * d->width >= (1L << 24))
     return msi::fail(MSI_E_UNSUPPORTED, "net: more than 2^24 pixels per sample (24-bit pixel index in the conv kernel)");
   const int ngf = d->ngf, ex = d->coord_net ? 1 : 0;
@@ -931,10 +966,10 @@ int build_net(const msi_net_desc *d, Net &net) {
       L.ntaps = 1;
       L.nclass = 1;
     }
-    if ((size_t)sh * sw * (size_t)(L.c0 > L.c1 ? L.c0 : L.c1) * 4 >= ((size_t)1 << 31))
+    if ((size_t)sh * sw * (size_t)(L.c0 > L.c1 ? L.c0 : L.c1) * esz >= ((size_t)1 << 31))
       return msi::fail(MSI_E_UNSUPPORTED, "net: %s input exceeds 2 GiB per sample", s.name);
-    L.cpt0 = (L.c0 + BK - 1) / BK;
-    L.cpt1 = (L.c1 + BK - 1) / BK;
+    L.cpt0 = (L.c0 + bke - 1) / bke;
+    L.cpt1 = (L.c1 + bke - 1) / bke;
     L.ksteps = L.ntaps * (L.cpt0 + L.cpt1) + (L.has_coord ? 1 : 0);
     L.npad = (int)round_up(L.cout, NPAD_ALIGN);
     // parameter blob (reference layout)
@@ -946,11 +981,11 @@ int build_net(const msi_net_desc *d, Net &net) {
     poff += L.param_floats;
     // packed blob
     L.packed_off = koff;
-    L.packed_w_floats = (size_t)L.nclass * L.ksteps * L.npad * BK;
+    L.packed_w_floats = (size_t)L.nclass * L.ksteps * L.npad * (ROW_BYTES / 4);   // 128-byte rows in both types
     L.gamma_off = L.packed_off + L.packed_w_floats;
     L.beta_off = L.gamma_off + round_up(L.cout, 4);
     L.coord_off = L.beta_off + round_up(L.cout, 4);
-    koff = L.coord_off + (L.has_coord ? (size_t)L.out_h * COORD_CLASSES * BK : 0);
+    koff = L.coord_off + (L.has_coord ? (size_t)L.out_h * COORD_CLASSES * (ROW_BYTES / 4) : 0);
     koff = round_up(koff, 64);
     // workspace
     if (s.kind != MODE_HEAD) {
@@ -958,6 +993,10 @@ int build_net(const msi_net_desc *d, Net &net) {
       woff += round_up((size_t)d->batch * L.out_h * L.out_w * L.cout * sizeof(float), 256);
       L.aff_off = woff;
       woff += round_up((size_t)d->batch * 2 * L.cout * sizeof(float), 256);
+      if (bf16) {
+        L.act_off = woff;
+        woff += round_up((size_t)d->batch * L.out_h * L.out_w * L.cout * 2, 256);
+      }
     } else {
       L.raw_off = (size_t)-1;
       L.aff_off = (size_t)-1;
@@ -976,7 +1015,7 @@ int build_net(const msi_net_desc *d, Net &net) {
   return MSI_OK;
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int BF16>
 int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   const int mtot = p.Mh * p.Mw;
   p.tiles_m = (mtot + BM - 1) / BM;
@@ -1027,13 +1066,13 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   if (lds > 64 * 1024) {
     static thread_local bool done = false;
     if (!done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, MODE>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, MODE, BF16>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "conv: %s", hipGetErrorString(e));
       done = true;
     }
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE>), dim3(nblocks), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, BF16>), dim3(nblocks), dim3(256), lds, stream, p);
   int rc = msi::check_launch("conv_igemm");
   if (rc || nfix == 0) return rc;
   hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, MODE>), dim3(nfix), dim3(256), 0, stream, p);
@@ -1041,11 +1080,18 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
 }
 
 template <int BM, int BN>
-int launch_conv(const ConvParams &p, int batch, hipStream_t stream, int *nparts) {
+int launch_conv(const ConvParams &p, int bf16, int batch, hipStream_t stream, int *nparts) {
+  if (bf16) {
+    switch (p.mode) {
+      case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 1>(p, batch, stream, nparts);
+      case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 1>(p, batch, stream, nparts);
+      default: return launch_conv_mode<BM, BN, MODE_HEAD, 1>(p, batch, stream, nparts);
+    }
+  }
   switch (p.mode) {
-    case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV>(p, batch, stream, nparts);
-    case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT>(p, batch, stream, nparts);
-    default: return launch_conv_mode<BM, BN, MODE_HEAD>(p, batch, stream, nparts);
+    case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 0>(p, batch, stream, nparts);
+    case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 0>(p, batch, stream, nparts);
+    default: return launch_conv_mode<BM, BN, MODE_HEAD, 0>(p, batch, stream, nparts);
   }
 }
 
@@ -1062,7 +1108,7 @@ static unsigned long long *g_timing_buf = nullptr;
 static int g_timing_layer = -1;
 extern "C" int msi_debug_conv_occupancy(int lds_bytes) {
   int n = -1;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<TILE_M, TILE_N, MODE_CONV>, 256, (size_t)lds_bytes);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<TILE_M, TILE_N, MODE_CONV, 0>, 256, (size_t)lds_bytes);
   return n;
 }
 extern "C" void msi_debug_conv_timing(void *device_buffer, int layer) {
@@ -1110,6 +1156,19 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
   if (rc) return rc;
   MSI_REQUIRE(params && packed, "net_pack_weights: null pointer");
   memset(packed, 0, net.packed_floats * sizeof(float));
+  const int bf16 = desc->dtype == MSI_DTYPE_BF16;
+  const int bke = bf16 ? 64 : 32;
+  // element kk of a 128-byte row: 16-byte chunk (kk * esz / 16) goes to slot chunk ^ swz
+  auto put_elem = [bf16](char *row, int kk, int swz, float v) {
+    if (bf16) {
+      uint32_t u;
+      memcpy(&u, &v, 4);
+      const uint16_t h = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);   // round to nearest even
+      memcpy(row + (((kk >> 3) ^ swz) << 4) + (kk & 7) * 2, &h, 2);
+    } else {
+      memcpy(row + (((kk >> 2) ^ swz) << 4) + (kk & 3) * 4, &v, 4);
+    }
+  };
   for (const Layer &L : net.layers) {
     const float *w = params + L.param_off;
     float *o = packed + L.packed_off;
@@ -1126,12 +1185,12 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
         const int chunk = src ? within - L.cpt0 : within;
         const int csrc = src ? L.c1 : L.c0, cbase = src ? L.c0 : 0;
         for (int n = 0; n < L.cout; ++n) {
-          float *row = o + (((size_t)cls * L.ksteps + s) * L.npad + n) * BK;
+          char *row = reinterpret_cast<char *>(o) + (((size_t)cls * L.ksteps + s) * L.npad + n) * ROW_BYTES;
           const int swz = (n >> 1) & 7;  // LDS slot j of row n holds data chunk j ^ swz (see the kernel)
-          for (int kk = 0; kk < BK; ++kk) {
+          for (int kk = 0; kk < bke; ++kk) {
             int tap, c;
             if (coord_step) { tap = kk; c = L.cin; if (tap >= L.ntaps) continue; }
-            else { tap = tap_s; if (chunk * BK + kk >= csrc) continue; c = cbase + chunk * BK + kk; }
+            else { tap = tap_s; if (chunk * bke + kk >= csrc) continue; c = cbase + chunk * bke + kk; }
             float v;
             if (L.kind == MODE_CONV) {            // [3,3,cin_w,cout]
               v = w[((size_t)tap * cin_w + c) * L.cout + n];
@@ -1143,7 +1202,7 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
             } else {                              // [1,1,cin,cout]
               v = w[(size_t)c * L.cout + n];
             }
-            row[(((kk >> 2) ^ swz) << 2) + (kk & 3)] = v;
+            put_elem(row, kk, swz, v);
           }
         }
       }
@@ -1182,7 +1241,8 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
             const int kh = tap / 3, kw = tap % 3;
             const int ih = mh * L.stride - pad_t + kh * L.rate, iw = mw * L.stride - pad_l + kw * L.rate;
             const bool ok = ih >= 0 && ih < L.in_h && iw >= 0 && iw < L.in_w;
-            tab[((size_t)mh * COORD_CLASSES + cc) * BK + tap] = ok ? coord[ih] : 0.0f;
+            put_elem(reinterpret_cast<char *>(tab) + ((size_t)mh * COORD_CLASSES + cc) * ROW_BYTES, tap, 0,
+                     ok ? coord[ih] : 0.0f);
           }
         }
     }
@@ -1190,11 +1250,12 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
   return MSI_OK;
 }
 
-int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const float *net_input,
-                        float *pred, void *workspace, size_t workspace_bytes, msi_stream_t stream_) {
+static int net_forward(const msi_net_desc *desc, const float *packed, const void *net_input,
+                       float *pred, void *workspace, size_t workspace_bytes, msi_stream_t stream_) {
   Net net;
   int rc = build_net(desc, net);
   if (rc) return rc;
+  const int bf16 = desc->dtype == MSI_DTYPE_BF16;
   MSI_REQUIRE(packed && net_input && pred && workspace, "net_forward: null pointer");
   if (workspace_bytes < net.ws_bytes)
     return msi::fail(MSI_E_WORKSPACE, "net_forward: workspace %zu B < required %zu B", workspace_bytes,
@@ -1208,9 +1269,11 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
     const Layer &L = net.layers[li];
     ConvParams p;
     memset(&p, 0, sizeof(p));
-    // sources are the in-place normalised outputs of their producers (or the raw network input)
-    auto src_ptr = [&](int s) -> const float * {
-      return s < 0 ? net_input : reinterpret_cast<const float *>(ws + net.layers[s].raw_off);
+    // sources: the network input, or the normalised output of the producer -- in place in its raw
+    // buffer (fp32) or the bf16 copy ln_apply wrote next to it
+    auto src_ptr = [&](int s) -> const char * {
+      if (s < 0) return static_cast<const char *>(net_input);
+      return ws + (bf16 ? net.layers[s].act_off : net.layers[s].raw_off);
     };
     p.x0 = src_ptr(L.src0);
     p.C0 = L.c0;
@@ -1220,8 +1283,8 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
       p.x1 = src_ptr(L.src1);
       p.C1 = L.c1;
     }
-    p.wpk = packed + L.packed_off;
-    p.coord_tab = L.has_coord ? packed + L.coord_off : nullptr;
+    p.wpk = reinterpret_cast<const char *>(packed + L.packed_off);
+    p.coord_tab = L.has_coord ? reinterpret_cast<const char *>(packed + L.coord_off) : nullptr;
     p.bias = L.kind == MODE_HEAD ? packed + L.gamma_off : nullptr;
     p.y = L.kind == MODE_HEAD ? pred : reinterpret_cast<float *>(ws + L.raw_off);
     p.stats = L.kind == MODE_HEAD ? nullptr : stats;
@@ -1257,21 +1320,38 @@ int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const flo
 #ifdef MSI_CONV_TIMING
     p.dbg = (li == g_timing_layer) ? g_timing_buf : nullptr;
 #endif
-    rc = launch_conv<TILE_M, TILE_N>(p, desc->batch, stream, &nparts);
+    rc = launch_conv<TILE_M, TILE_N>(p, bf16, desc->batch, stream, &nparts);
     if (rc) return rc;
     if (L.kind != MODE_HEAD) {
       const size_t per_sample = (size_t)L.out_h * L.out_w * L.cout;
       size_t blocks = (per_sample / 4 + 255) / 256;
       if (blocks > 512) blocks = 512;  // grid-stride: keeps the redundant partial merge cheap
-      hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)blocks, desc->batch), dim3(256),
-                         (size_t)2 * L.cout * sizeof(float), stream, reinterpret_cast<float *>(ws + L.raw_off), stats,
-                         nparts, packed + L.gamma_off, packed + L.beta_off, per_sample, L.cout,
-                         reinterpret_cast<float *>(ws + L.aff_off));
+      float *raw = reinterpret_cast<float *>(ws + L.raw_off), *aff = reinterpret_cast<float *>(ws + L.aff_off);
+      const dim3 grid((unsigned)blocks, desc->batch);
+      const size_t lds = (size_t)2 * L.cout * sizeof(float);
+      if (bf16)
+        hipLaunchKernelGGL(ln_apply_kernel<1>, grid, dim3(256), lds, stream, raw, stats, nparts, packed + L.gamma_off,
+                           packed + L.beta_off, per_sample, L.cout, aff, reinterpret_cast<unsigned short *>(ws + L.act_off));
+      else
+        hipLaunchKernelGGL(ln_apply_kernel<0>, grid, dim3(256), lds, stream, raw, stats, nparts, packed + L.gamma_off,
+                           packed + L.beta_off, per_sample, L.cout, aff, static_cast<unsigned short *>(nullptr));
       rc = msi::check_launch("ln_apply");
       if (rc) return rc;
     }
   }
   return MSI_OK;
+}
+
+int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const float *net_input,
+                        float *pred, void *workspace, size_t workspace_bytes, msi_stream_t stream) {
+  MSI_REQUIRE(desc && desc->dtype == MSI_DTYPE_F32, "net_forward_f32: desc->dtype must be MSI_DTYPE_F32");
+  return net_forward(desc, packed, net_input, pred, workspace, workspace_bytes, stream);
+}
+
+int msi_net_forward_bf16(const msi_net_desc *desc, const float *packed, const void *net_input_bf16,
+                         float *pred, void *workspace, size_t workspace_bytes, msi_stream_t stream) {
+  MSI_REQUIRE(desc && desc->dtype == MSI_DTYPE_BF16, "net_forward_bf16: desc->dtype must be MSI_DTYPE_BF16");
+  return net_forward(desc, packed, net_input_bf16, pred, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -107,10 +107,6 @@ __global__ void deprocess_kernel(const float *__restrict__ in, uint8_t *__restri
   }
 }
 
-// ------------------------------------------------------------------------ K1
-// One work item = (pixel, depth); depth is the fastest index so a wavefront's 64
-// lanes write 64 consecutive 12-byte texels of the NHWC volume (768 contiguous
-// bytes at D=32 per source).  The source image (2.4 MB) stays L2-resident.
 // [B,4,4] @ [B,4,4], one thread per output element, products summed k = 0..3 (no fma: this file is
 // compiled with -ffp-contract=off), like a plain fp32 matmul loop.
 __global__ void __launch_bounds__(256)
@@ -126,11 +122,28 @@ compose_poses_kernel(const float *__restrict__ lhs, const float *__restrict__ rh
   out[i] = acc;
 }
 
+// fp32 <-> bf16 (round to nearest even; the values stored here are finite)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  const unsigned u = __builtin_bit_cast(unsigned, f);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+  return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+__device__ __forceinline__ void store_elem(float *p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void store_elem(unsigned short *p, size_t i, float v) { p[i] = f32_to_bf16(v); }
+
+// ------------------------------------------------------------------------ K1
+// One work item = (pixel, depth); depth is the fastest index so a wavefront's 64
+// lanes write 64 consecutive 12-byte texels of the NHWC volume (768 contiguous
+// bytes at D=32 per source).  The source image (2.4 MB) stays L2-resident.
+// OutT = float, or unsigned short = bf16 bits (the bf16 network input of BASELINE configs[2]).
+template <typename OutT>
 __global__ void __launch_bounds__(256)
 ods_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose,
                  const float *__restrict__ intrinsics, const float *__restrict__ depths,
                  const float *__restrict__ trig, int batch, int height, int width, int nd,
-                 float order, float *__restrict__ psv, int channels, int coff, PixConsts K) {
+                 float order, OutT *__restrict__ psv, int channels, int coff, PixConsts K) {
   // grid = (ceil(W*D / 256), H, B): 32-bit index math only (64-bit div/mod are emulated in ~100
   // VALU instructions each and used to dominate this kernel)
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -196,10 +209,10 @@ ods_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose
   const float *pb = img + ((size_t)t.y0 * width + t.x1) * 3;
   const float *pc = img + ((size_t)t.y1 * width + t.x0) * 3;
   const float *pd = img + ((size_t)t.y1 * width + t.x1) * 3;
-  float *o = psv + (size_t)p * channels + coff + d * 3;
-  o[0] = blend4(t, pa[0], pb[0], pc[0], pd[0]);
-  o[1] = blend4(t, pa[1], pb[1], pc[1], pd[1]);
-  o[2] = blend4(t, pa[2], pb[2], pc[2], pd[2]);
+  const size_t o = (size_t)p * channels + coff + d * 3;
+  store_elem(psv, o + 0, blend4(t, pa[0], pb[0], pc[0], pd[0]));
+  store_elem(psv, o + 1, blend4(t, pa[1], pb[1], pc[1], pd[1]));
+  store_elem(psv, o + 2, blend4(t, pa[2], pb[2], pc[2], pd[2]));
 }
 
 // ------------------------------------------------------------------------ K3
@@ -210,8 +223,10 @@ ods_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose
 // of the D-major stack: 512 contiguous bytes per (half-wave, layer).
 constexpr int K3_TP = 32;
 
+// PSV_BF16: the PSV is the bf16 network input (converted to fp32 on its way into LDS).
+template <int PSV_BF16>
 __global__ void __launch_bounds__(256)
-assemble_kernel(const float *__restrict__ psv, const float *__restrict__ pred,
+assemble_kernel(const void *__restrict__ psv_, const float *__restrict__ pred,
                 float4 *__restrict__ rgba, float *__restrict__ bw_out,
                 float *__restrict__ al_out, long npix_total, int hw, int nd, int pred_scaled) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -224,8 +239,23 @@ assemble_kernel(const float *__restrict__ psv, const float *__restrict__ pred,
   const int npx = (int)((npix_total - p0) < K3_TP ? (npix_total - p0) : K3_TP);
   const int tid = threadIdx.x;
 
-  {
-    const float4 *g = reinterpret_cast<const float4 *>(psv + p0 * c_psv);
+  if (PSV_BF16) {
+    const uint4 *g = reinterpret_cast<const uint4 *>(static_cast<const unsigned short *>(psv_) + p0 * c_psv);
+    const int nv = npx * c_psv / 8;
+    for (int v = tid; v < nv; v += 256) {
+      const uint4 q = g[v];
+      const int e = v * 8;
+      const int row = e / c_psv, col = e - row * c_psv;  // c_psv % 8 == 0 (D % 4 == 0): no row straddle
+      float *dst = l_psv + row * s_psv + col;
+      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dst[2 * k] = bf16_to_f32((unsigned short)(w[k] & 0xffffu));
+        dst[2 * k + 1] = bf16_to_f32((unsigned short)(w[k] >> 16));
+      }
+    }
+  } else {
+    const float4 *g = reinterpret_cast<const float4 *>(static_cast<const float *>(psv_) + p0 * c_psv);
     const int nv = npx * c_psv / 4;
     for (int v = tid; v < nv; v += 256) {
       const float4 q = g[v];
@@ -692,11 +722,11 @@ int msi_compose_poses_f32(const float *lhs, const float *rhs, float *out, int32_
   return msi::check_launch("compose_poses");
 }
 
-int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float *intrinsics,
-                             const float *depths, const float *trig, int32_t batch,
-                             int32_t height, int32_t width, int32_t num_depths, int32_t order,
-                             float *psv, int32_t psv_channels, int32_t channel_offset,
-                             msi_stream_t stream) {
+static int sweep_common(const float *image, const float *pose, const float *intrinsics,
+                        const float *depths, const float *trig, int32_t batch,
+                        int32_t height, int32_t width, int32_t num_depths, int32_t order,
+                        void *psv, int psv_bf16, int32_t psv_channels, int32_t channel_offset,
+                        msi_stream_t stream) {
   MSI_REQUIRE(image && pose && intrinsics && depths && trig && psv, "ods_sphere_sweep: null pointer");
   MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_depths > 0, "ods_sphere_sweep: bad dims");
   MSI_REQUIRE(order == 1 || order == -1, "ods_sphere_sweep: order must be +1 or -1");
@@ -707,13 +737,38 @@ int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float 
   MSI_REQUIRE((long)width * num_depths < 2147483647L && height <= 65535 && batch <= 65535,
               "ods_sphere_sweep: problem too large");
   const dim3 grid((unsigned)(((long)width * num_depths + 255) / 256), height, batch);
-  hipLaunchKernelGGL(ods_sweep_kernel, grid, dim3(256), 0, msi::as_stream(stream),
-                     image, pose, intrinsics, depths, trig, batch, height, width, num_depths,
-                     (float)order, psv, psv_channels, channel_offset, make_consts(height, width));
+  if (psv_bf16)
+    hipLaunchKernelGGL(ods_sweep_kernel<unsigned short>, grid, dim3(256), 0, msi::as_stream(stream),
+                       image, pose, intrinsics, depths, trig, batch, height, width, num_depths,
+                       (float)order, static_cast<unsigned short *>(psv), psv_channels, channel_offset,
+                       make_consts(height, width));
+  else
+    hipLaunchKernelGGL(ods_sweep_kernel<float>, grid, dim3(256), 0, msi::as_stream(stream),
+                       image, pose, intrinsics, depths, trig, batch, height, width, num_depths,
+                       (float)order, static_cast<float *>(psv), psv_channels, channel_offset,
+                       make_consts(height, width));
   return msi::check_launch("ods_sphere_sweep");
 }
 
-static int assemble_common(const float *psv, const float *pred, float *rgba_native,
+int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float *intrinsics,
+                             const float *depths, const float *trig, int32_t batch,
+                             int32_t height, int32_t width, int32_t num_depths, int32_t order,
+                             float *psv, int32_t psv_channels, int32_t channel_offset,
+                             msi_stream_t stream) {
+  return sweep_common(image, pose, intrinsics, depths, trig, batch, height, width, num_depths, order, psv, 0,
+                      psv_channels, channel_offset, stream);
+}
+
+int msi_ods_sphere_sweep_bf16(const float *image, const float *pose, const float *intrinsics,
+                              const float *depths, const float *trig, int32_t batch,
+                              int32_t height, int32_t width, int32_t num_depths, int32_t order,
+                              void *psv_bf16, int32_t psv_channels, int32_t channel_offset,
+                              msi_stream_t stream) {
+  return sweep_common(image, pose, intrinsics, depths, trig, batch, height, width, num_depths, order, psv_bf16, 1,
+                      psv_channels, channel_offset, stream);
+}
+
+static int assemble_common(const void *psv, int psv_bf16, const float *pred, float *rgba_native,
                            float *blend_weights, float *alphas, int32_t batch, int32_t height,
                            int32_t width, int32_t num_planes, int pred_scaled, msi_stream_t stream) {
   MSI_REQUIRE(psv && pred && rgba_native, "assemble_rgba: null pointer");
@@ -729,26 +784,39 @@ static int assemble_common(const float *psv, const float *pred, float *rgba_nati
   if (npix == 0) return MSI_OK;
   const long blocks = (npix + K3_TP - 1) / K3_TP;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(assemble_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(
+        psv_bf16 ? reinterpret_cast<const void *>(assemble_kernel<1>) : reinterpret_cast<const void *>(assemble_kernel<0>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "assemble_rgba: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), lds, msi::as_stream(stream),
-                     psv, pred, reinterpret_cast<float4 *>(rgba_native), blend_weights, alphas, npix,
-                     height * width, num_planes, pred_scaled);
+  if (psv_bf16)
+    hipLaunchKernelGGL(assemble_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, msi::as_stream(stream),
+                       psv, pred, reinterpret_cast<float4 *>(rgba_native), blend_weights, alphas, npix,
+                       height * width, num_planes, pred_scaled);
+  else
+    hipLaunchKernelGGL(assemble_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, msi::as_stream(stream),
+                       psv, pred, reinterpret_cast<float4 *>(rgba_native), blend_weights, alphas, npix,
+                       height * width, num_planes, pred_scaled);
   return msi::check_launch("assemble_rgba");
 }
 
 int msi_assemble_rgba_f32(const float *psv, const float *pred, float *rgba_native,
                           float *blend_weights, float *alphas, int32_t batch, int32_t height,
                           int32_t width, int32_t num_planes, msi_stream_t stream) {
-  return assemble_common(psv, pred, rgba_native, blend_weights, alphas, batch, height, width, num_planes, 0, stream);
+  return assemble_common(psv, 0, pred, rgba_native, blend_weights, alphas, batch, height, width, num_planes, 0, stream);
+}
+
+int msi_assemble_rgba_bf16psv_f32(const void *psv_bf16, const float *pred, float *rgba_native,
+                                  float *blend_weights, float *alphas, int32_t batch, int32_t height,
+                                  int32_t width, int32_t num_planes, msi_stream_t stream) {
+  return assemble_common(psv_bf16, 1, pred, rgba_native, blend_weights, alphas, batch, height, width, num_planes, 0,
+                         stream);
 }
 
 int msi_assemble_rgba_scaled_f32(const float *psv, const float *weights_alphas, float *rgba_native,
                                  int32_t batch, int32_t height, int32_t width, int32_t num_planes,
                                  msi_stream_t stream) {
-  return assemble_common(psv, weights_alphas, rgba_native, nullptr, nullptr, batch, height, width, num_planes, 1,
+  return assemble_common(psv, 0, weights_alphas, rgba_native, nullptr, nullptr, batch, height, width, num_planes, 1,
                          stream);
 }
 

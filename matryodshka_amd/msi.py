@@ -29,7 +29,7 @@ def _ptr(t):
 class MSI(object):
     """Class definition for the MSI inference module (reference: msi.py:33-38)."""
 
-    def __init__(self, weights=None, coord_net=True, device=None, input_type='ODS'):
+    def __init__(self, weights=None, coord_net=True, device=None, input_type='ODS', dtype='f32'):
         if not torch.cuda.is_available():
             raise RuntimeError("matryodshka_amd.MSI needs a HIP device (no CPU fallback)")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
@@ -37,6 +37,13 @@ class MSI(object):
         if input_type not in ('ODS', 'PP'):
             raise ValueError("input_type must be 'ODS' or 'PP' (FLAGS.input_type, msi.py:1157-1161)")
         self.input_type = input_type
+        # 'bf16' = BASELINE configs[2]: the sweep volume, the weights and the activations of the network are
+        # bf16 (fp32 accumulate, fp32 LayerNorm statistics, fp32 prediction); geometry stays fp32
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        if dtype == 'bf16' and input_type != 'ODS':
+            raise NotImplementedError("dtype='bf16' is built for the ODS path only")
+        self.dtype = dtype
         self._weights = None
         self._blob_cache = {}     # (in_channels, num_outputs, ngf) -> np blob
         self._packed_cache = {}   # desc key -> device tensor
@@ -84,8 +91,8 @@ class MSI(object):
     def _net(self, batch, height, width, in_channels, num_outputs, ngf):
         if self._weights is None:
             raise RuntimeError("MSI: no network weights loaded (load_weights / weights=...)")
-        key = (batch, height, width, in_channels, num_outputs, ngf, self.coord_net)
-        desc = nets.make_desc(batch, height, width, in_channels, num_outputs, ngf, self.coord_net)
+        key = (batch, height, width, in_channels, num_outputs, ngf, self.coord_net, self.dtype)
+        desc = nets.make_desc(batch, height, width, in_channels, num_outputs, ngf, self.coord_net, self.dtype)
         pkey = key[1:]  # packing does not depend on the batch size
         packed = self._packed_cache.get(pkey)
         if packed is None:
@@ -181,16 +188,18 @@ class MSI(object):
         nd = depths.numel()
         intr = self._f32(intrinsics)
         trig = self._trig(h, w)
-        psv = torch.empty((b, h, w, 6 * nd), dtype=torch.float32, device=self.device)
+        bf16 = self.dtype == 'bf16'
+        psv = torch.empty((b, h, w, 6 * nd), dtype=torch.bfloat16 if bf16 else torch.float32, device=self.device)
         # order = +1 for the reference image (i = 0), -1 for the source (i = 1), msi.py:1127
         for i, (img, pose) in enumerate(((ref_image, ref_pose), (src_image, src_pose))):
             curr_pose = self._compose(pose, ref_pose_inv)                      # msi.py:1125
             order = 1 if (i % 2) == 0 else -1
             if self.input_type == 'ODS':
-                N.check(N.lib.msi_ods_sphere_sweep_f32(
+                sweep = N.lib.msi_ods_sphere_sweep_bf16 if bf16 else N.lib.msi_ods_sphere_sweep_f32
+                N.check(sweep(
                     img.data_ptr(), curr_pose.data_ptr(), intr.data_ptr(), depths.data_ptr(), trig.data_ptr(),
                     b, h, w, nd, order, psv.data_ptr(), 6 * nd, i * 3 * nd, self._stream()),
-                    "msi_ods_sphere_sweep_f32")
+                    "msi_ods_sphere_sweep")
             else:   # sweep_src for perspective inputs (msi.py:1157-1161); ref_pose_inv = interp_pose_inv (:1113)
                 N.check(N.lib.msi_perspective_plane_sweep_f32(
                     img.data_ptr(), curr_pose.data_ptr(), intr.data_ptr(), depths.data_ptr(),
@@ -221,9 +230,13 @@ class MSI(object):
         """msi_net(net_input, num_outputs) (msi.py:95-125): [B,H,W,Cin] -> [B,H,W,num_outputs]."""
         b, h, w, cin = net_input.shape
         desc, packed, ws = self._net(b, h, w, cin, num_outputs, ngf)
+        want = torch.bfloat16 if self.dtype == 'bf16' else torch.float32
+        if net_input.dtype != want or not net_input.is_contiguous():
+            net_input = net_input.to(want).contiguous()
         pred = torch.empty((b, h, w, num_outputs), dtype=torch.float32, device=self.device)
-        N.check(N.lib.msi_net_forward_f32(desc, packed.data_ptr(), net_input.data_ptr(), pred.data_ptr(),
-                                          ws.data_ptr(), ws.numel(), self._stream()), "msi_net_forward_f32")
+        fwd = N.lib.msi_net_forward_bf16 if self.dtype == 'bf16' else N.lib.msi_net_forward_f32
+        N.check(fwd(desc, packed.data_ptr(), net_input.data_ptr(), pred.data_ptr(),
+                    ws.data_ptr(), ws.numel(), self._stream()), "msi_net_forward")
         return pred
 
     def assemble_layers(self, net_input, msi_pred, num_msi_planes, extra_outputs=''):
@@ -233,9 +246,10 @@ class MSI(object):
         rgba = torch.empty((b, d, h, w, 4), dtype=torch.float32, device=self.device)
         bw = torch.empty((b, h, w, d), dtype=torch.float32, device=self.device) if 'blend_weights' in extra_outputs else None
         al = torch.empty((b, h, w, d), dtype=torch.float32, device=self.device) if 'alpha' in extra_outputs else None
-        N.check(N.lib.msi_assemble_rgba_f32(net_input.data_ptr(), msi_pred.data_ptr(), rgba.data_ptr(),
-                                            _ptr(bw), _ptr(al), b, h, w, d, self._stream()),
-                "msi_assemble_rgba_f32")
+        asm = N.lib.msi_assemble_rgba_bf16psv_f32 if net_input.dtype == torch.bfloat16 else N.lib.msi_assemble_rgba_f32
+        N.check(asm(net_input.data_ptr(), msi_pred.data_ptr(), rgba.data_ptr(),
+                    _ptr(bw), _ptr(al), b, h, w, d, self._stream()),
+                "msi_assemble_rgba")
         pred = {'rgba_layers': rgba.permute(0, 2, 3, 1, 4)}
         if bw is not None:
             pred['blend_weights'] = bw

@@ -19,9 +19,12 @@ LAYER_NAMES = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2",
 KIND_CONV, KIND_CONVT, KIND_HEAD = 0, 1, 2
 
 
-def make_desc(batch, height, width, in_channels, num_outputs, ngf=64, coord_net=True):
+def make_desc(batch, height, width, in_channels, num_outputs, ngf=64, coord_net=True, dtype="f32"):
+    """dtype: "f32" (BASELINE configs 1, 2, 4, 5) or "bf16" (configs[2]: bf16 operands, fp32 accumulate)."""
+    if dtype not in ("f32", "bf16"):
+        raise ValueError("dtype must be 'f32' or 'bf16'")
     return N.NetDesc(int(batch), int(height), int(width), int(in_channels), int(num_outputs),
-                     int(ngf), 1 if coord_net else 0)
+                     int(ngf), 1 if coord_net else 0, N.MSI_DTYPE_BF16 if dtype == "bf16" else N.MSI_DTYPE_F32)
 
 
 def layer_infos(desc):

@@ -22,9 +22,12 @@ F = np.float32
 
 
 class MSI(object):
-    def __init__(self, weights=None, coord_net=True, input_type='ODS'):
+    def __init__(self, weights=None, coord_net=True, input_type='ODS', dtype='f32'):
         self.weights = weights
         self.coord_net = coord_net
+        # 'bf16': BASELINE configs[2] as the build defines it (the reference has no bf16 code): the sweep
+        # volume is rounded to bf16 and the network uses bf16 operands (oracle/nets.py forward(bf16=True))
+        self.dtype = dtype
         self.input_type = input_type     # FLAGS.input_type: 'ODS' | 'PP' (msi.py:1157-1161)
 
     # -- msi.py:1196-1217 ---------------------------------------------------
@@ -84,7 +87,8 @@ class MSI(object):
                 net_input.append(G.ods_sphere_sweep(img, order, planes, curr_pose, intrinsics))
             else:   # sweep_src, msi.py:1157-1161 (ref_pose_inv is `interp_pose_inv:0` there, :1113)
                 net_input.append(G.perspective_plane_sweep(img, planes, curr_pose, intrinsics))
-        return np.concatenate(net_input, axis=3)
+        net_input = np.concatenate(net_input, axis=3)
+        return nets.bf16_round(net_input) if self.dtype == 'bf16' else net_input
 
     # -- msi.py:40-289 (blend_psv) -------------------------------------------
     def infer_msi(self, raw_src_image, raw_ref_image, raw_hres_src_image, raw_hres_ref_image,
@@ -95,7 +99,7 @@ class MSI(object):
         ref_image = self.preprocess_image(raw_ref_image)
         net_input = self.format_network_input(ref_image, src_image, ref_pose, src_pose,
                                               psv_planes, intrinsics, ref_pose_inv=ref_pose_inv)
-        msi_pred = nets.forward(self.weights, net_input, coord_net=self.coord_net)
+        msi_pred = nets.forward(self.weights, net_input, coord_net=self.coord_net, bf16=self.dtype == 'bf16')
         pred = self.assemble(net_input, msi_pred, num_msi_planes, extra_outputs)
         return pred, net_input
 

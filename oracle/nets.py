@@ -131,16 +131,29 @@ def wrap_pad(x, lp, rp):
     return TF.pad(x, (0, 0, lp, rp))
 
 
-def forward(weights, net_input, coord_net=True, return_activations=False):
+def bf16_round(t):
+    """fp32 -> bf16 -> fp32 (round to nearest even), torch tensor or numpy array."""
+    if isinstance(t, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(t, dtype=F32)).bfloat16().float().numpy()
+    return t.bfloat16().float()
+
+
+def forward(weights, net_input, coord_net=True, return_activations=False, bf16=False):
     """msi_coord_train_net (nets.py:471-515) / msi_train_net (:387-450).
-    net_input: np [B,H,W,Cin] fp32.  Returns np [B,H,W,num_outputs] fp32."""
-    x = torch.from_numpy(np.ascontiguousarray(np.transpose(net_input, (0, 3, 1, 2)))).float()
+    net_input: np [B,H,W,Cin] fp32.  Returns np [B,H,W,num_outputs] fp32.
+
+    bf16=True models BASELINE configs[2] (the reference has no bf16 code: this defines the variant the
+    build implements): every convolution OPERAND is rounded to bf16 -- the network input, the weights,
+    the coordinate channel, each LayerNorm+ReLU output -- while products are accumulated in fp32 and the
+    LayerNorm statistics / affine, the head bias and tanh stay fp32 on the unrounded accumulators."""
+    rnd = bf16_round if bf16 else (lambda t: t)
+    x = rnd(torch.from_numpy(np.ascontiguousarray(np.transpose(net_input, (0, 3, 1, 2)))).float())
     acts = {}
 
     def conv(name, x, stride=1, rate=1):
-        w = _conv_w(weights[name + "/weights"])
+        w = rnd(_conv_w(weights[name + "/weights"]))
         if coord_net:
-            x = add_sph_coords(x)
+            x = rnd(add_sph_coords(x))
             _, _, h, wd = x.shape
             pt, pb = _same_pad(h, 2 * rate + 1, stride)
             pl, pr = _same_pad(wd, 2 * rate + 1, stride)
@@ -149,19 +162,19 @@ def forward(weights, net_input, coord_net=True, return_activations=False):
             x = wrap_pad(x, rate, rate)
         y = TF.conv2d(x, w, stride=stride, dilation=rate)
         acts[name + "/raw"] = y
-        y = layer_norm_relu(y, weights[name + "/LayerNorm/gamma"], weights[name + "/LayerNorm/beta"])
+        y = rnd(layer_norm_relu(y, weights[name + "/LayerNorm/gamma"], weights[name + "/LayerNorm/beta"]))
         acts[name] = y
         return y
 
     def convT(name, x):
-        w = _convT_w(weights[name + "/weights"])
+        w = rnd(_convT_w(weights[name + "/weights"]))
         if coord_net:
             y = TF.conv_transpose2d(x, w, stride=2, padding=1)
         else:
             y = TF.conv_transpose2d(wrap_pad(x, 2, 2), w, stride=2, padding=0)
             y = y[:, :, 5:-5, 5:-5]
         acts[name + "/raw"] = y
-        y = layer_norm_relu(y, weights[name + "/LayerNorm/gamma"], weights[name + "/LayerNorm/beta"])
+        y = rnd(layer_norm_relu(y, weights[name + "/LayerNorm/gamma"], weights[name + "/LayerNorm/beta"]))
         acts[name] = y
         return y
 
@@ -183,7 +196,7 @@ def forward(weights, net_input, coord_net=True, return_activations=False):
         c72 = conv("conv7_2", c71)
         c81 = convT("conv8_1", torch.cat([c72, c12], dim=1))
         c82 = conv("conv8_2", c81)
-        w = _conv_w(weights["color_pred/weights"])
+        w = rnd(_conv_w(weights["color_pred/weights"]))
         b = torch.from_numpy(weights["color_pred/biases"])
         pred = torch.tanh(TF.conv2d(c82, w, bias=b))
     out = np.ascontiguousarray(pred.permute(0, 2, 3, 1).numpy())

@@ -1,0 +1,98 @@
+"""GPU parity of the bf16 network path (BASELINE configs[2]: bf16 operands, fp32 accumulate) against
+the oracle's bf16 emulation (oracle/nets.py forward(bf16=True): operands rounded to bf16 at the same
+points, everything else fp32).
+
+Tolerances (stated here because north_star's 1e-3 is the fp32 gate):
+  * first-layer raw output (fp32 accumulators of identical bf16 operands): 1e-4 of the layer's scale --
+    only the fp32 summation order differs;
+  * deeper layers / the tanh prediction: both sides round activations to bf16 (2^-8 relative), and a
+    summation-order difference can flip a rounding, so agreement is a few bf16 ulps of the layer scale:
+    max-abs <= 4e-2, mean-abs <= 3e-3 on the prediction in [-1, 1];
+  * against the fp32 oracle the bf16 path is reported, and bounded loosely (mean-abs <= 2e-2)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from matryodshka_amd import MSI, nets
+    from oracle import nets as onets
+    from oracle.msi import MSI as OracleMSI
+    return torch, MSI, nets, onets, OracleMSI
+
+
+@pytest.mark.parametrize("coord", [True, False])
+@pytest.mark.parametrize("b,h,w,cin,nout,ngf", [(1, 32, 64, 96, 32, 16), (2, 16, 40, 24, 8, 16), (1, 16, 32, 48, 16, 64)])
+def test_bf16_net_matches_bf16_oracle(env, coord, b, h, w, cin, nout, ngf):
+    torch, MSI, nets, onets, _ = env
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=3, randomize_affine=True)
+    rng = np.random.RandomState(4)
+    x = onets.bf16_round(rng.uniform(-1, 1, size=(b, h, w, cin)).astype(np.float32))
+    m = MSI(weights=weights, coord_net=coord, dtype='bf16')
+    pred = m.run_net(torch.from_numpy(x).cuda().bfloat16(), nout, ngf).cpu().numpy()
+    ref, acts = onets.forward(weights, x, coord_net=coord, return_activations=True, bf16=True)
+    ref32 = onets.forward(weights, x, coord_net=coord)
+    desc, _, ws = m._net(b, h, w, cin, nout, ngf)
+    infos = nets.layer_infos(desc)
+    first = infos[0]
+    n = b * first.out_h * first.out_w * first.cout
+    raw = ws[first.raw_offset:first.raw_offset + 4 * n].view(torch.float32).reshape(b, first.out_h, first.out_w, first.cout)
+    o = acts["conv1_1/raw"]
+    assert np.abs(raw.cpu().numpy() - o).max() <= 1e-4 * np.abs(o).max()
+    err = np.abs(pred - ref)
+    assert err.max() <= 4e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+    assert np.abs(pred - ref32).mean() <= 2e-2
+
+
+def test_bf16_sweep_is_rounded_fp32_sweep(env):
+    torch, MSI, nets, onets, OracleMSI = env
+    from tests.util import make_inputs
+    b, h, w, d = 1, 32, 64, 8
+    inp = make_inputs(11, b, h, w)
+    m = MSI(dtype='bf16')
+    o = OracleMSI(dtype='bf16')
+    planes = m.inv_depths(1.0, 100.0, d)
+    ref = m.preprocess_image(torch.from_numpy(inp["ref_image"]))
+    src = m.preprocess_image(torch.from_numpy(inp["src_image"]))
+    psv = m.format_network_input(ref, src, inp["ref_pose"], inp["src_pose"], planes, inp["intrinsics"])
+    assert psv.dtype == torch.bfloat16
+    psv_o = o.format_network_input(o.preprocess_image(inp["ref_image"]), o.preprocess_image(inp["src_image"]),
+                                   inp["ref_pose"], inp["src_pose"], planes, inp["intrinsics"])
+    diff = np.abs(psv.float().cpu().numpy() - psv_o)
+    # identical up to fp32 differences that cross a bf16 rounding boundary (one bf16 ulp <= 2^-8 below 1)
+    assert diff.max() <= 2.0 ** -7 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+
+
+def test_bf16_pipeline_config3_shapes(env):
+    """D = 64 (Cin = 384, 128 head channels), batch 2, reduced image: infer + render through the bf16 path."""
+    torch, MSI, nets, onets, OracleMSI = env
+    from tests.util import make_inputs
+    b, h, w, d, ngf = 2, 32, 64, 64, 16
+    inp = make_inputs(21, b, h, w)
+    weights = onets.init_weights(6 * d, 2 * d, ngf=ngf, coord_net=True, seed=2, randomize_affine=True)
+    m = MSI(weights=weights, dtype='bf16')
+    o = OracleMSI(weights=weights, dtype='bf16')
+    planes = m.inv_depths(1.0, 100.0, d)
+    out, net_input = m.infer_msi(torch.from_numpy(inp["src_image"]), torch.from_numpy(inp["ref_image"]), None, None,
+                                 inp["ref_pose"], inp["src_pose"], inp["intrinsics"], 'blend_psv', d, planes, ngf=ngf)
+    out_o, _ = o.infer_msi(inp["src_image"], inp["ref_image"], None, None, inp["ref_pose"], inp["src_pose"],
+                           inp["intrinsics"], 'blend_psv', d, planes, ngf=ngf)
+    rgba = out["rgba_layers"].cpu().numpy()
+    err = np.abs(rgba - out_o["rgba_layers"])
+    assert err.max() <= 4e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+    rgb = m.msi_render_equirect_view(out["rgba_layers"], inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    rgb_o = o.msi_render_equirect_view(out_o["rgba_layers"], inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    e2 = np.abs(rgb.cpu().numpy() - rgb_o)
+    assert e2.max() <= 6e-2 and e2.mean() <= 3e-3, (e2.max(), e2.mean())
+    assert np.isfinite(rgb.cpu().numpy()).all()
+
+
+def test_bf16_rejects_unsupported_channels(env):
+    torch, MSI, nets, onets, _ = env
+    from matryodshka_amd import _native as N
+    desc = nets.make_desc(1, 16, 32, 12, 4, 12, True, dtype="bf16")      # 12 channels: not a multiple of 8
+    assert N.lib.msi_net_workspace_bytes(desc) == 0 and b"multiples of 8" in N.lib.msi_last_error_string()

@@ -76,25 +76,32 @@ def test_variable_table_matches_oracle_and_reference_count(native_lib):
     assert all(np.array_equal(back[k], ow[k]) for k in ow)
 
 
-def _unswizzle_row(row, n):
-    """Packed rows store data chunk j^((n>>1)&7) in 16-byte slot j (bank-conflict-free LDS image)."""
+def _unswizzle_row(row, n, dtype="f32"):
+    """Packed rows store data chunk j^((n>>1)&7) in 16-byte slot j (bank-conflict-free LDS image).
+    `row` is the 128-byte row as 32 float32 words; bf16 rows come back as 64 fp32 values."""
     swz = (n >> 1) & 7
     out = np.empty_like(row)
     for j in range(8):
         out[(j ^ swz) * 4:(j ^ swz) * 4 + 4] = row[j * 4:j * 4 + 4]
+    if dtype == "bf16":
+        return (out.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
     return out
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("coord", [True, False])
-def test_weight_packing_index_level(native_lib, coord):
+def test_weight_packing_index_level(native_lib, coord, dtype):
     """msi_net_pack_weights_host against an index-level restatement of the documented layout
-    [class][k-step][npad][32]: k-steps are tap-major, then source-0 chunks, then source-1 chunks,
-    then (CoordNet) one step holding the 9 taps of the coordinate channel."""
+    [class][k-step][npad][128 bytes]: k-steps are tap-major, then source-0 chunks, then source-1 chunks,
+    then (CoordNet) one step holding the 9 taps of the coordinate channel.  A row holds 32 fp32 or
+    64 bf16 (round to nearest even) channels."""
     from matryodshka_amd import nets
     cin, nout, ngf = 24, 8, 16
+    bke = 64 if dtype == "bf16" else 32
     w = onets.init_weights(cin, nout, ngf, coord, seed=3, randomize_affine=True)
-    desc = nets.make_desc(1, 16, 32, cin, nout, ngf, coord)
+    desc = nets.make_desc(1, 16, 32, cin, nout, ngf, coord, dtype=dtype)
     packed = nets.pack_params(desc, nets.flatten_params(w, cin, nout, ngf, coord))
+    rnd = onets.bf16_round if dtype == "bf16" else (lambda a: a)
     infos = nets.layer_infos(desc)
     off = 0
     skips = {"conv6_1": (ngf * 8, ngf * 8), "conv7_1": (ngf * 4, ngf * 4), "conv8_1": (ngf * 2, ngf * 2)}
@@ -102,7 +109,7 @@ def test_weight_packing_index_level(native_lib, coord):
         name = info.name.decode()
         wt = w[name + "/weights"]
         c0, c1 = skips.get(name, (info.cin, 0))
-        cpt0, cpt1 = -(-c0 // 32), -(-c1 // 32)
+        cpt0, cpt1 = -(-c0 // bke), -(-c1 // bke)
         ntaps = {0: 9, 1: 4, 2: 1}[info.kind]
         ncls = 4 if info.kind == 1 else 1
         ksteps = ntaps * (cpt0 + cpt1) + (1 if info.has_coord else 0)
@@ -111,8 +118,8 @@ def test_weight_packing_index_level(native_lib, coord):
         rng = np.random.RandomState(hash(name) % 1000)
         for _ in range(40):
             cls, s, n = rng.randint(ncls), rng.randint(ksteps), rng.randint(info.cout)
-            row = _unswizzle_row(wp[cls, s, n], n)
-            exp = np.zeros(32, np.float32)
+            row = _unswizzle_row(wp[cls, s, n], n, dtype)
+            exp = np.zeros(bke, np.float32)
             if info.has_coord and s == ksteps - 1:
                 for tap in range(9):
                     exp[tap] = wt[tap // 3, tap % 3, info.cin, n]
@@ -120,10 +127,10 @@ def test_weight_packing_index_level(native_lib, coord):
                 tap, within = divmod(s, cpt0 + cpt1)
                 src, chunk = (0, within) if within < cpt0 else (1, within - cpt0)
                 base, csrc = (0, c0) if src == 0 else (c0, c1)
-                for kk in range(32):
-                    if chunk * 32 + kk >= csrc:
+                for kk in range(bke):
+                    if chunk * bke + kk >= csrc:
                         continue
-                    c = base + chunk * 32 + kk
+                    c = base + chunk * bke + kk
                     if info.kind == 0:
                         exp[kk] = wt[tap // 3, tap % 3, c, n]
                     elif info.kind == 1:
@@ -134,7 +141,7 @@ def test_weight_packing_index_level(native_lib, coord):
                         exp[kk] = wt[kh, kw, n, c]
                     else:
                         exp[kk] = wt[0, 0, c, n]
-            assert np.array_equal(row, exp), (name, cls, s, n)
+            assert np.array_equal(row, rnd(exp)), (name, cls, s, n)
         assert not wp[:, :, info.cout:, :].any()          # N padding is zero
         off_next = off + wp.size
         # gamma/beta (or bias) follow the weights

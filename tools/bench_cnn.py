@@ -20,13 +20,16 @@ ap.add_argument("--height", type=int, default=320)
 ap.add_argument("--width", type=int, default=640)
 ap.add_argument("--planes", type=int, default=32)
 ap.add_argument("--no-coord-net", action="store_true")
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
 a = ap.parse_args()
 
 from matryodshka_amd import MSI, nets
 coord = not a.no_coord_net
 cin, nout = 6 * a.planes, 2 * a.planes
-m = MSI(weights=nets.init_weights(cin, nout, 64, coord), coord_net=coord)
+m = MSI(weights=nets.init_weights(cin, nout, 64, coord), coord_net=coord, dtype=a.dtype)
 x = torch.rand((a.batch, a.height, a.width, cin), device="cuda") * 2 - 1
+if a.dtype == "bf16":
+    x = x.bfloat16()
 for _ in range(a.warmup):
     m.run_net(x, nout, 64)
 torch.cuda.synchronize()
@@ -38,5 +41,6 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.steps
 fl = bench.cnn_flops(a.height, a.width, cin, nout, 64, coord) * a.batch
-print("cnn forward: %.3f ms/call (batch %d)  %.1f TFLOP/s  (%.1f%% of %.1f)" % (
-    ms, a.batch, fl / ms / 1e9, 100 * fl / ms / 1e9 / bench.PEAK_FP32_MFMA_TFLOPS, bench.PEAK_FP32_MFMA_TFLOPS))
+peak = 2500.0 if a.dtype == "bf16" else bench.PEAK_FP32_MFMA_TFLOPS
+print("cnn forward: %.3f ms/call (batch %d, %s)  %.1f TFLOP/s  (%.1f%% of %.1f)" % (
+    ms, a.batch, a.dtype, fl / ms / 1e9, 100 * fl / ms / 1e9 / peak, peak))
