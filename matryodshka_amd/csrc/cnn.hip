@@ -149,7 +149,7 @@ __device__ __forceinline__ void wait_lgkm(v4f &x, v4f &y) {
 // BF16 = 1: bf16 operands (fp32 accumulate, fp32 raw output), 64 channels per k-step -- the same 128-byte
 // rows, swizzle and DMA -- and v_mfma_f32_32x32x16_bf16 (4 per k-step and wave).
 template <int BM, int BN, int MODE, int BF16>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NSTAGE == 2 ? 5 : 3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM * BN >= 128 * 128 ? 2 : (BM * BN > 64 * 64 || NSTAGE > 2 ? 3 : 5))))
 conv_igemm_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (the body uses device-only types)
   constexpr int ESZ = BF16 ? 2 : 4;          // bytes per operand element
@@ -341,10 +341,11 @@ _Pragma("unroll")                                                               
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_void *)(sA + i * 8 * ROW_BYTES), 16, c_voff[i], 0, 0, 0);          \
     }                                                                                                                            \
     /* B rows [wave*BN/4 + 8i, +8): the instruction's immediate offset advances BOTH the source and the LDS address */                                        \
-    static_assert(BI <= 2, "B rows per wave: written out for immediate offsets");                                                \
+    static_assert(BI <= 4, "B rows per wave: written out for immediate offsets");                                                \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 0, 0);                                  \
-    if (BI > 1)                                                                                                                  \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 8 * ROW_BYTES, 0);  \
+    if (BI > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 8 * ROW_BYTES, 0);          \
+    if (BI > 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 16 * ROW_BYTES, 0);         \
+    if (BI > 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 24 * ROW_BYTES, 0);         \
     /* advance (wave-uniform scalar state) */                                                                                    \
     ++g_step;                                                                                                                    \
     if (g_step < nreg) {                                                                                                         \
@@ -500,57 +501,60 @@ _Pragma("unroll")                                                               
 
   // ---- epilogue: store + LayerNorm partial ------------------------------------------------
   // The accumulators go through LDS so that the tile leaves as 16-byte-per-lane stores of whole
-  // 256-byte channel rows (per-lane 4-byte stores of the MFMA C layout reached only 1.4 TB/s on the
-  // 52 MB layers; this form streams like a copy).
-  // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // channel rows (per-lane 4-byte stores of the MFMA C layout reached only 1.4 TB/s on the 52 MB
+  // layers; this form streams like a copy).  One staging pass per MFMA-tile row i of the wave tile:
+  // 64 tile rows (32 of each wave row wm) x BN channels at a time.
+  // C/D layout of v_mfma_f32_32x32x2_f32 / _32x32x16_bf16: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   constexpr int LDW = BN + 4;  // floats per staged row: 16-byte aligned, breaks the power-of-two stride
-  static_assert((size_t)BM * LDW * 4 <= (size_t)NSTAGE * STAGE_BYTES, "epilogue tile must fit the k-loop LDS");
+  constexpr int SROWS = 64;    // staged rows per pass
+  static_assert((size_t)SROWS * LDW * 4 + 64 <= (size_t)NSTAGE * STAGE_BYTES, "staged rows + wave partials must fit the k-loop LDS");
   float *ct = reinterpret_cast<float *>(smem);  // all LDS reads of the main loop are behind the last barrier
+  float *wpart = ct + SROWS * LDW;              // [4 waves][4] LayerNorm partials
   const int col = lane & 31, rowq = 4 * (lane >> 5);
   // interior tile (the common case): no row / channel masks anywhere in the epilogue -- its VALU work is
   // paid in matrix throughput of the co-resident workgroups
   const bool interior = (tile_m + 1) * BM <= mtot && (tile_n + 1) * BN <= p.Cout;
   const bool want_stats = MODE != MODE_HEAD && full && p.stats != nullptr;
-  float lsum = 0.f;
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  if (MODE == MODE_HEAD && full) {   // bias + tanh in registers
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int lcol = wn * (NT * 32) + j * 32 + col;
-      const int n = tile_n * BN + lcol;
-      float bias = 0.f;
-      if (MODE == MODE_HEAD && full) bias = p.bias[min(n, p.Cout - 1)];
+      const int n = tile_n * BN + wn * (NT * 32) + j * 32 + col;
+      const float bias = p.bias[min(n, p.Cout - 1)];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lrow = wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
-        float v = acc[i][j][r];
-        if (MODE == MODE_HEAD && full) v = tanhf(v + bias);
-        ct[lrow * LDW + lcol] = v;
-        if (MODE != MODE_HEAD) {
-          if (interior) lsum += v;
-          else lsum += (tile_m * BM + lrow < mtot && n < p.Cout) ? v : 0.f;
-        }
-      }
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = tanhf(acc[i][j][r] + bias);
     }
   }
   // LayerNorm partial, per WAVE first (no workgroup barrier): mean of the wave's (MT*32)x(NT*32) block, then
   // M2 about that mean (two-pass: the values are still in registers); lane 0 parks (count, mean, M2) behind
-  // the staged tile and thread 0 merges the four after the one barrier this epilogue has.
-  static_assert((size_t)BM * LDW * 4 + 64 <= (size_t)NSTAGE * STAGE_BYTES, "wave partials behind the staged tile");
-  float *wpart = ct + BM * LDW;   // [4 waves][4]
+  // the staged rows and thread 0 merges the four after the first barrier of the epilogue.
   if (want_stats) {
     auto wave_sum = [&](float v) __attribute__((always_inline)) -> float {   // butterfly: every lane gets the total
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
       return v;
     };
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = tile_n * BN + wn * (NT * 32) + j * 32 + col;
+          if (interior) lsum += acc[i][j][r];
+          else lsum += (m < mtot && n < p.Cout) ? acc[i][j][r] : 0.f;
+        }
+      }
     const int rv = min(max(mtot - (tile_m * BM + wm * (MT * 32)), 0), MT * 32);
     const int cv = min(max(p.Cout - (tile_n * BN + wn * (NT * 32)), 0), NT * 32);
     const float wcnt = (float)(rv * cv);
     const float wmean = wcnt > 0.f ? wave_sum(lsum) / wcnt : 0.f;
     float lm2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
@@ -562,7 +566,6 @@ _Pragma("unroll")                                                               
           else lm2 += (m < mtot && n < p.Cout) ? dlt * dlt : 0.f;
         }
       }
-    }
     const float wm2 = wave_sum(lm2);
     if (lane == 0) {
       wpart[wave * 4 + 0] = wcnt;
@@ -570,29 +573,29 @@ _Pragma("unroll")                                                               
       wpart[wave * 4 + 2] = wm2;
     }
   }
-  __syncthreads();
   constexpr int C4 = BN / 4;                       // float4 per staged row
-  constexpr int PASSES = BM * C4 / 256;
-  if (!full) {
-    // K-range of a split tile: raw accumulators, row-major [BM][BN], into slot (tile, range)
-    float *dst = p.partial + (size_t)slot * (BM * BN);
+  constexpr int PASSES = SROWS * C4 / 256;
+  const bool vec_ok = (p.Cout & 3) == 0;
+  float *pdst = full ? nullptr : p.partial + (size_t)slot * (BM * BN);   // K-range of a split tile: raw accumulators, row-major [BM][BN]
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    if (i > 0) __syncthreads();                    // the previous pass has been read out
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ct[(wm * 32 + (r & 3) + 8 * (r >> 2) + rowq) * LDW + wn * (NT * 32) + j * 32 + col] = acc[i][j][r];
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
       const int idx = tid + 256 * k;
-      const int lrow = idx / C4, c4 = idx - lrow * C4;
-      *reinterpret_cast<v4f *>(dst + lrow * BN + c4 * 4) = *reinterpret_cast<const v4f *>(ct + lrow * LDW + c4 * 4);
-    }
-#ifdef MSI_CONV_TIMING
-    stamp();
-#endif
-    return;
-  }
-  {
-    const bool vec_ok = (p.Cout & 3) == 0;
-#pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-      const int idx = tid + 256 * k;
-      const int lrow = idx / C4, c4 = idx - lrow * C4;
+      const int srow = idx / C4, c4 = idx - srow * C4;
+      const int lrow = (srow >> 5) * (MT * 32) + i * 32 + (srow & 31);   // staged row -> tile row
+      const v4f v = *reinterpret_cast<const v4f *>(ct + srow * LDW + c4 * 4);
+      if (!full) {
+        *reinterpret_cast<v4f *>(pdst + lrow * BN + c4 * 4) = v;
+        continue;
+      }
       const int m = tile_m * BM + lrow;
       const int n = tile_n * BN + c4 * 4;
       if (!interior && (m >= mtot || n >= p.Cout)) continue;
@@ -604,7 +607,6 @@ _Pragma("unroll")                                                               
       } else {
         opix = (size_t)b * mtot + m;
       }
-      const v4f v = *reinterpret_cast<const v4f *>(ct + lrow * LDW + c4 * 4);
       float *dst = p.y + opix * p.Cout + n;
       if (vec_ok) {
         *reinterpret_cast<v4f *>(dst) = v;
@@ -1029,7 +1031,8 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   p.split = 1;
   static const char *ts = getenv("MSI_CONV_TAILSPLIT");   // debug: 0 disables
   const int rem = p.ntiles % NUM_CUS;
-  if (rem != 0 && p.ntiles > NUM_CUS / 2 && p.ksteps >= 2 * MAX_SPLIT && !(ts && atoi(ts) == 0)) {
+  if (BM * BN == 64 * 64 &&   // (the fix-up kernel is written for the 64x64 tile; big tiles are only chosen for big grids)
+      rem != 0 && p.ntiles > NUM_CUS / 2 && p.ksteps >= 2 * MAX_SPLIT && !(ts && atoi(ts) == 0)) {
     int best = 1;
     double best_cost = 1.0;   // time of the tail in tile-times: ceil(rem*s/CUs)/s
     for (int sp = 2; sp <= MAX_SPLIT; ++sp) {
@@ -1088,10 +1091,14 @@ int launch_conv(const ConvParams &p, int bf16, int batch, hipStream_t stream, in
       default: return launch_conv_mode<BM, BN, MODE_HEAD, 1>(p, batch, stream, nparts);
     }
   }
-  switch (p.mode) {
-    case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 0>(p, batch, stream, nparts);
-    case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 0>(p, batch, stream, nparts);
-    default: return launch_conv_mode<BM, BN, MODE_HEAD, 0>(p, batch, stream, nparts);
+  if constexpr (BM * BN == 64 * 64) {
+    switch (p.mode) {
+      case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 0>(p, batch, stream, nparts);
+      case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 0>(p, batch, stream, nparts);
+      default: return launch_conv_mode<BM, BN, MODE_HEAD, 0>(p, batch, stream, nparts);
+    }
+  } else {
+    return msi::fail(MSI_E_UNSUPPORTED, "conv: the fp32 path is built for the 64x64 tile");
   }
 }
 
@@ -1320,7 +1327,17 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
 #ifdef MSI_CONV_TIMING
     p.dbg = (li == g_timing_layer) ? g_timing_buf : nullptr;
 #endif
-    rc = launch_conv<TILE_M, TILE_N>(p, bf16, desc->batch, stream, &nparts);
+    // bf16: at 4 MFMAs per k-step the 64x64 tile is bound by its LDS traffic; where the grid stays large
+    // (>= 4 tiles per CU) and Cout allows, the 128x128 tile (64x64 per wave) halves that traffic per flop
+    const long tiles_big = (long)((p.Mh * p.Mw + 127) / 128) * ((L.cout + 127) / 128) * L.nclass * desc->batch;
+    const char *bigenv = getenv("MSI_CONV_BIGTILE");   // debug / tests: 0 = never, 2 = whenever Cout allows (read per call)
+    const int bigmode = bigenv ? atoi(bigenv) : 1;
+    if (bf16 && L.cout % 128 == 0 && bigmode != 0 && (tiles_big >= 4 * NUM_CUS || bigmode == 2))
+      rc = launch_conv<128, 128>(p, bf16, desc->batch, stream, &nparts);
+    else if (bf16 && L.cout % 64 == 0 && bigmode != 0 && (2 * tiles_big >= 4 * NUM_CUS || bigmode == 2))
+      rc = launch_conv<128, 64>(p, bf16, desc->batch, stream, &nparts);   // Cout = 64 layers: 64x32 per wave
+    else
+      rc = launch_conv<TILE_M, TILE_N>(p, bf16, desc->batch, stream, &nparts);
     if (rc) return rc;
     if (L.kind != MODE_HEAD) {
       const size_t per_sample = (size_t)L.out_h * L.out_w * L.cout;

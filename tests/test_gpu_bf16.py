@@ -48,6 +48,25 @@ def test_bf16_net_matches_bf16_oracle(env, coord, b, h, w, cin, nout, ngf):
     assert np.abs(pred - ref32).mean() <= 2e-2
 
 
+def test_bf16_big_tile_matches_small_tile(env, monkeypatch):
+    """The 128x128 tile (chosen for large grids) forced on a small problem: same accumulators as the 64x64
+    tile up to fp32 summation order, hence the same prediction up to isolated bf16 rounding flips."""
+    torch, MSI, nets, onets, _ = env
+    b, h, w, cin, nout, ngf = 2, 32, 64, 48, 16, 64
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=9, randomize_affine=True)
+    x = torch.from_numpy(np.random.RandomState(1).uniform(-1, 1, (b, h, w, cin)).astype(np.float32)).cuda().bfloat16()
+    m = MSI(weights=weights, dtype='bf16')
+    monkeypatch.setenv("MSI_CONV_BIGTILE", "0")
+    small = m.run_net(x, nout, ngf).cpu().numpy()
+    monkeypatch.setenv("MSI_CONV_BIGTILE", "2")
+    big = m.run_net(x, nout, ngf).cpu().numpy()
+    ref = onets.forward(weights, x.float().cpu().numpy(), coord_net=True, bf16=True)
+    d = np.abs(big - small)
+    assert d.max() <= 4e-2 and d.mean() <= 3e-3, (d.max(), d.mean())
+    e = np.abs(big - ref)
+    assert e.max() <= 4e-2 and e.mean() <= 3e-3, (e.max(), e.mean())
+
+
 def test_bf16_sweep_is_rounded_fp32_sweep(env):
     torch, MSI, nets, onets, OracleMSI = env
     from tests.util import make_inputs
