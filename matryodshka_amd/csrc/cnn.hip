@@ -1334,8 +1334,9 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
     const int bigmode = bigenv ? atoi(bigenv) : 1;
     if (bf16 && L.cout % 128 == 0 && bigmode != 0 && (tiles_big >= 4 * NUM_CUS || bigmode == 2))
       rc = launch_conv<128, 128>(p, bf16, desc->batch, stream, &nparts);
-    else if (bf16 && L.cout % 64 == 0 && bigmode != 0 && (2 * tiles_big >= 4 * NUM_CUS || bigmode == 2))
-      rc = launch_conv<128, 64>(p, bf16, desc->batch, stream, &nparts);   // Cout = 64 layers: 64x32 per wave
+    else if (bf16 && L.cout % 64 == 0 && bigmode != 0 && ((tiles_big >= 4 * NUM_CUS && L.cin <= 128) || bigmode == 2))
+      rc = launch_conv<128, 64>(p, bf16, desc->batch, stream, &nparts);   // Cout = 64, short K (conv8_2: 495 vs 599 us;
+                                                                           // conv1_1 / conv8_1 are faster at 64x64)
     else
       rc = launch_conv<TILE_M, TILE_N>(p, bf16, desc->batch, stream, &nparts);
     if (rc) return rc;
