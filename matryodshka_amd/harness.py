@@ -10,7 +10,8 @@ to --height x --width (datasets.py:513-515), runs infer_msi + the equirect RGB /
   <output_root>/<experiment>/<scene>_<ref><src><tgt>/{tgt_image,output_tgt,output_depth}_<dir>.png,
   src_image/ref_image, psv_plane_%.3d.png, blend_weights.npy, blend_weight_%.3d.png, alphas.npy,
   msi_alpha_%.2d.png, msi_rgb_%.2d.png, and <output_root>/<experiment>/step.txt.
-`--weights` is an .npz of the TF variables (see nets.variable_shapes); without it Xavier-initialised
+`--checkpoint` reads a TF V2 checkpoint directly (tf_checkpoint.py), `--weights` an .npz of the TF variables
+(see nets.variable_shapes); without either Xavier-initialised
 weights are used (there is no network access for the pretrained checkpoint), step.txt then says 0.
 Host I/O only: all arithmetic is in libmsi_hip.so.
 """
@@ -120,6 +121,8 @@ def main(argv=None):
     ap.add_argument("--output_root", default="results")
     ap.add_argument("--experiment_name", default="msi-hip")
     ap.add_argument("--weights", default="", help=".npz of TF variables (net/<layer>/weights ...)")
+    ap.add_argument("--checkpoint", default="", help="TF checkpoint prefix or directory (test.py:192-202: "
+                    "<checkpoint_dir>/<experiment_name>); read without TensorFlow (matryodshka_amd/tf_checkpoint.py)")
     ap.add_argument("--step", type=int, default=0, help="global step recorded in step.txt (test.py:225-229)")
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=640)
@@ -135,7 +138,10 @@ def main(argv=None):
     from . import MSI, nets
     d = args.num_msi_planes
     coord = not args.no_coord_net
-    if args.weights:
+    if args.checkpoint:
+        from . import tf_checkpoint
+        weights, args.step = tf_checkpoint.network_weights(args.checkpoint)
+    elif args.weights:
         weights = dict(np.load(args.weights))
     else:
         weights = nets.init_weights(6 * d, 2 * d, args.ngf, coord)
