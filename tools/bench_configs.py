@@ -75,6 +75,33 @@ def ods(cfg, B, H, W, D, dtype):
             "network": {"ms_per_step": round(ms_net, 3), "TFLOPps": round(fl / ms_net / 1e9, 1)}}
 
 
+def hres(cfg, B, H, W, HH, HW, D):
+    """The reference's high-res mode (test.py:283-394): network at HxW, layers re-assembled and rendered at HHxHW."""
+    inp, hinp = make_inputs(8964, B, H, W), make_inputs(8965, B, HH, HW)
+    model = MSI(weights=nets.init_weights(6 * D, 2 * D, 64, True), coord_net=True)
+    planes = model.inv_depths(1.0, 100.0, D)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).contiguous()
+    src_u8, ref_u8, hsrc_u8, href_u8 = g(inp["src_image"]), g(inp["ref_image"]), g(hinp["src_image"]), g(hinp["ref_image"])
+    t = {k: g(inp[k]) for k in ("ref_pose", "src_pose", "intrinsics", "tgt_pose_rt", "tgt_pos")}
+    rpi = torch.linalg.inv(torch.from_numpy(inp["ref_pose"])).contiguous().to(dev)
+
+    def step():
+        src, ref = model.preprocess_image(src_u8), model.preprocess_image(ref_u8)
+        net_input = model.format_network_input(ref, src, t["ref_pose"], t["src_pose"], planes, t["intrinsics"], ref_pose_inv=rpi)
+        pred = model.run_net(net_input, 2 * D, 64)
+        out = model.assemble_layers(net_input, pred, D, extra_outputs="blend_weights alphas")
+        rgb, dep = model.msi_render_equirect_hres(out["blend_weights"], out["alphas"], href_u8, hsrc_u8, t["ref_pose"], t["src_pose"],
+                                                  t["tgt_pose_rt"], t["tgt_pos"], planes, t["intrinsics"], ref_pose_inv=rpi)
+        return model.deprocess_image(rgb), model.deprocess_depth_image(dep)
+
+    ms = timed(step)
+    return {"metric": "novel-view frames/sec, %dx%d network -> %dx%d high-res re-render, %d spheres" % (W, H, HW, HH, D),
+            "value": round(B * 1e3 / ms, 2), "unit": "frames/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg, "height": H, "width": W, "hres_height": HH, "hres_width": HW, "num_spheres": D,
+                       "frames_per_step_per_gpu": B}}
+
+
 def pp(cfg, B, N, D):
     rng = np.random.RandomState(8964)
     ref, src = smooth_noise(rng, B, N, N), smooth_noise(rng, B, N, N)
@@ -107,5 +134,7 @@ for c in a.configs:
         print(json.dumps(ods("BASELINE configs[2]: 640x320 ODS, 64 spheres + CoordNet, batch 16, bf16 network", 16, 320, 640, 64, "bf16")), flush=True)
     elif c == 3:
         print(json.dumps(ods("BASELINE configs[3]: 1280x640 ODS, 32 spheres, 4 frames per GPU (batch 32 over 8 GPUs), fp32", 4, 640, 1280, 32, "f32")), flush=True)
+        print(json.dumps(hres("BASELINE configs[3], the reference's high-res mode (test.py:283-394): network at 640x320, re-render at 1280x640, "
+                              "4 frames per GPU, fp32", 4, 320, 640, 640, 1280, 32)), flush=True)
     elif c == 4:
         print(json.dumps(pp("BASELINE configs[4]: input_type=PP, 256x256 cube faces, 32 planes, 8 faces per GPU (batch 64 over 8 GPUs), fp32", 8, 256, 32)), flush=True)
