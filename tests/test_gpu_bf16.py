@@ -110,6 +110,21 @@ def test_bf16_pipeline_config3_shapes(env):
     assert np.isfinite(rgb.cpu().numpy()).all()
 
 
+def test_bf16_full_size_network_matches_bf16_oracle(env):
+    """BASELINE configs[1] shapes (640x320, D = 32, ngf = 64, batch 1) through the bf16 network: the grid sizes at
+    which the tail split, the two-level split of the 40x80 layers and the fix-up kernel are active."""
+    torch, MSI, nets, onets, _ = env
+    cin, nout, ngf = 192, 64, 64
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=8964, randomize_affine=True)
+    rng = np.random.RandomState(5)
+    x = onets.bf16_round(rng.uniform(-1, 1, size=(1, 320, 640, cin)).astype(np.float32))
+    m = MSI(weights=weights, coord_net=True, dtype='bf16')
+    pred = m.run_net(torch.from_numpy(x).cuda().bfloat16(), nout, ngf).cpu().numpy()
+    ref = onets.forward(weights, x, coord_net=True, bf16=True)
+    err = np.abs(pred - ref)
+    assert err.max() <= 6e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+
+
 def test_bf16_rejects_unsupported_channels(env):
     torch, MSI, nets, onets, _ = env
     from matryodshka_amd import _native as N
