@@ -74,3 +74,14 @@ def test_workspace_too_small_is_an_error(env):
     ws = torch.zeros(1024, dtype=torch.uint8, device="cuda")
     rc = N.lib.msi_net_forward_f32(desc, packed.data_ptr(), x.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), None)
     assert rc == -4 and b"workspace" in N.lib.msi_last_error_string()
+
+
+def test_forward_is_bitwise_deterministic(env):
+    """Fixed summation orders everywhere (k order in the fix-up, fixed-order LayerNorm merges, no atomics):
+    the same input gives the same bits, at the grid sizes where the tail split is active."""
+    torch, MSI, nets, N, onets = env
+    m = MSI(weights=nets.init_weights(96, 32, 64, True), coord_net=True)
+    x = torch.rand((1, 160, 320, 96), device="cuda") * 2 - 1
+    ref = m.run_net(x, 32, 64).clone()
+    for _ in range(3):
+        assert torch.equal(m.run_net(x, 32, 64), ref)
