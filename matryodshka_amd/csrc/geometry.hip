@@ -10,6 +10,7 @@
 // trig tables, every branch below is bit-reproducible against the CPU oracle.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "msi_common.h"
 
@@ -138,81 +139,96 @@ __device__ __forceinline__ void store_elem(unsigned short *p, size_t i, float v)
 // lanes write 64 consecutive 12-byte texels of the NHWC volume (768 contiguous
 // bytes at D=32 per source).  The source image (2.4 MB) stays L2-resident.
 // OutT = float, or unsigned short = bf16 bits (the bf16 network input of BASELINE configs[2]).
-template <typename OutT>
+// NS = samples (consecutive depths of one pixel) per thread: with two, the per-pixel work (trigonometry,
+// index arithmetic) is shared and hipcc pairs the independent multiplies / adds of the two samples into
+// v_pk_mul_f32 / v_pk_add_f32 (IEEE, same roundings as the scalar forms) -- this kernel is VALU-bound.
+template <typename OutT, int NS>
 __global__ void __launch_bounds__(256)
 ods_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose,
                  const float *__restrict__ intrinsics, const float *__restrict__ depths,
                  const float *__restrict__ trig, int batch, int height, int width, int nd,
                  float order, OutT *__restrict__ psv, int channels, int coff, PixConsts K) {
-  // grid = (ceil(W*D / 256), H, B): 32-bit index math only (64-bit div/mod are emulated in ~100
+  // grid = (ceil(W*(D/NS) / 256), H, B): 32-bit index math only (64-bit div/mod are emulated in ~100
   // VALU instructions each and used to dominate this kernel)
+  const int ng = nd / NS;                       // depth groups per pixel (nd % NS == 0, checked on the host)
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= width * nd) return;
-  const int j = idx / nd, d = idx - j * nd;
+  if (idx >= width * ng) return;
+  const int j = idx / ng, d0 = (idx - j * ng) * NS;
   const int i = blockIdx.y, b = blockIdx.z;
   const long p = ((long)b * height + i) * width + j;
 
   const float cs = trig[j], ss = trig[width + j];
   const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
-  const float depth = depths[d];
-
-  // backproject_spherical (spherical.py:125-128)
-  float x = depth * (cs * ct);
-  float y = depth * st;
-  float z = depth * (ss * ct);
-
-  // apply_pose (projector.py:275-291): pose @ [x,y,z,1], terms summed left to right
   const float *P = pose + (size_t)b * 16;
-  const float px_ = ((P[0] * x + P[1] * y) + P[2] * z) + P[3] * 1.0f;
-  const float py_ = ((P[4] * x + P[5] * y) + P[6] * z) + P[7] * 1.0f;
-  const float pz_ = ((P[8] * x + P[9] * y) + P[10] * z) + P[11] * 1.0f;
-  x = px_;
-  y = py_;
-  z = pz_;
-
-  // project_ods (spherical.py:181-229)
   const float r = intrinsics[(size_t)b * 9];
-  const float f = r * r - (x * x + z * z);
-  const bool zlx = fabsf(z) > fabsf(x);
-  const float px = zlx ? x : z;
-  const float pz = zlx ? z : x;
-  const float pz2 = pz * pz;
-  const float a = 1.0f + (px * px) / pz2;
-  const float bq = ((-2.0f * f) * px) / pz2;
-  const float c = f + (f * f) / pz2;
-  const float disc = bq * bq - (4.0f * a) * c;
-  const float sgn = (pz > 0.0f) ? 1.0f : ((pz < 0.0f) ? -1.0f : pz);
-  float s = ((-order) * sgn) * sqrtf(disc);
-  s = zlx ? s : -s;
-  float dx = (-bq + s) / (2.0f * a);
-  float dz = (f - px * dx) / pz;
-  const float dxf = zlx ? -dx : -dz;
-  const float dzf = zlx ? -dz : -dx;
-  dx = dxf;
-  dz = dzf;
-  const float theta = -atan2f(dz, dx);
-  float phi = atan2f(y, sqrtf(dx * dx + dz * dz));
-  if (phi != phi) phi = 1.0f;
-  phi = (phi <= K.half_pi) ? phi : K.half_pi;
-  phi = (phi >= -K.half_pi) ? phi : -K.half_pi;
-  float u = (((theta + K.pi) - K.pi_over_w) / K.u_den) * K.wm1;
-  float v = (((phi + K.half_pi) - K.half_pi_over_h) / K.v_den) * K.hm1;
-  if (!(disc >= 0.0f)) {
-    u = 1.0f;
-    v = 1.0f;
-  }
-
-  // resample (sampling.py:135-197)
-  const Taps t = make_taps(u, v, width, height);
   const float *img = image + (size_t)b * height * width * 3;
-  const float *pa = img + ((size_t)t.y0 * width + t.x0) * 3;
-  const float *pb = img + ((size_t)t.y0 * width + t.x1) * 3;
-  const float *pc = img + ((size_t)t.y1 * width + t.x0) * 3;
-  const float *pd = img + ((size_t)t.y1 * width + t.x1) * 3;
-  const size_t o = (size_t)p * channels + coff + d * 3;
-  store_elem(psv, o + 0, blend4(t, pa[0], pb[0], pc[0], pd[0]));
-  store_elem(psv, o + 1, blend4(t, pa[1], pb[1], pc[1], pd[1]));
-  store_elem(psv, o + 2, blend4(t, pa[2], pb[2], pc[2], pd[2]));
+  const float csct = cs * ct, ssct = ss * ct;
+  float out[NS][3];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const float depth = depths[d0 + q];
+
+    // backproject_spherical (spherical.py:125-128)
+    float x = depth * csct;
+    float y = depth * st;
+    float z = depth * ssct;
+
+    // apply_pose (projector.py:275-291): pose @ [x,y,z,1], terms summed left to right
+    const float px_ = ((P[0] * x + P[1] * y) + P[2] * z) + P[3] * 1.0f;
+    const float py_ = ((P[4] * x + P[5] * y) + P[6] * z) + P[7] * 1.0f;
+    const float pz_ = ((P[8] * x + P[9] * y) + P[10] * z) + P[11] * 1.0f;
+    x = px_;
+    y = py_;
+    z = pz_;
+
+    // project_ods (spherical.py:181-229)
+    const float f = r * r - (x * x + z * z);
+    const bool zlx = fabsf(z) > fabsf(x);
+    const float px = zlx ? x : z;
+    const float pz = zlx ? z : x;
+    const float pz2 = pz * pz;
+    const float a = 1.0f + (px * px) / pz2;
+    const float bq = ((-2.0f * f) * px) / pz2;
+    const float c = f + (f * f) / pz2;
+    const float disc = bq * bq - (4.0f * a) * c;
+    const float sgn = (pz > 0.0f) ? 1.0f : ((pz < 0.0f) ? -1.0f : pz);
+    float s = ((-order) * sgn) * sqrtf(disc);
+    s = zlx ? s : -s;
+    float dx = (-bq + s) / (2.0f * a);
+    float dz = (f - px * dx) / pz;
+    const float dxf = zlx ? -dx : -dz;
+    const float dzf = zlx ? -dz : -dx;
+    dx = dxf;
+    dz = dzf;
+    const float theta = -atan2f(dz, dx);
+    float phi = atan2f(y, sqrtf(dx * dx + dz * dz));
+    if (phi != phi) phi = 1.0f;
+    phi = (phi <= K.half_pi) ? phi : K.half_pi;
+    phi = (phi >= -K.half_pi) ? phi : -K.half_pi;
+    float u = (((theta + K.pi) - K.pi_over_w) / K.u_den) * K.wm1;
+    float v = (((phi + K.half_pi) - K.half_pi_over_h) / K.v_den) * K.hm1;
+    if (!(disc >= 0.0f)) {
+      u = 1.0f;
+      v = 1.0f;
+    }
+
+    // resample (sampling.py:135-197)
+    const Taps t = make_taps(u, v, width, height);
+    const float *pa = img + ((size_t)t.y0 * width + t.x0) * 3;
+    const float *pb = img + ((size_t)t.y0 * width + t.x1) * 3;
+    const float *pc = img + ((size_t)t.y1 * width + t.x0) * 3;
+    const float *pd = img + ((size_t)t.y1 * width + t.x1) * 3;
+    out[q][0] = blend4(t, pa[0], pb[0], pc[0], pd[0]);
+    out[q][1] = blend4(t, pa[1], pb[1], pc[1], pd[1]);
+    out[q][2] = blend4(t, pa[2], pb[2], pc[2], pd[2]);
+  }
+  const size_t o = (size_t)p * channels + coff + d0 * 3;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    store_elem(psv, o + q * 3 + 0, out[q][0]);
+    store_elem(psv, o + q * 3 + 1, out[q][1]);
+    store_elem(psv, o + q * 3 + 2, out[q][2]);
+  }
 }
 
 // ------------------------------------------------------------------------ K3
@@ -722,6 +738,9 @@ int msi_compose_poses_f32(const float *lhs, const float *rhs, float *out, int32_
   return msi::check_launch("compose_poses");
 }
 
+#ifndef MSI_SWEEP_NS_DEFAULT
+#define MSI_SWEEP_NS_DEFAULT 2
+#endif
 static int sweep_common(const float *image, const float *pose, const float *intrinsics,
                         const float *depths, const float *trig, int32_t batch,
                         int32_t height, int32_t width, int32_t num_depths, int32_t order,
@@ -736,17 +755,21 @@ static int sweep_common(const float *image, const float *pose, const float *intr
   if (batch == 0) return MSI_OK;
   MSI_REQUIRE((long)width * num_depths < 2147483647L && height <= 65535 && batch <= 65535,
               "ods_sphere_sweep: problem too large");
-  const dim3 grid((unsigned)(((long)width * num_depths + 255) / 256), height, batch);
-  if (psv_bf16)
-    hipLaunchKernelGGL(ods_sweep_kernel<unsigned short>, grid, dim3(256), 0, msi::as_stream(stream),
-                       image, pose, intrinsics, depths, trig, batch, height, width, num_depths,
-                       (float)order, static_cast<unsigned short *>(psv), psv_channels, channel_offset,
-                       make_consts(height, width));
-  else
-    hipLaunchKernelGGL(ods_sweep_kernel<float>, grid, dim3(256), 0, msi::as_stream(stream),
-                       image, pose, intrinsics, depths, trig, batch, height, width, num_depths,
-                       (float)order, static_cast<float *>(psv), psv_channels, channel_offset,
-                       make_consts(height, width));
+  // NS depths per thread (bit-identical results for every NS; MSI_SWEEP_NS=1/2/4 overrides the default)
+  const char *nsenv = getenv("MSI_SWEEP_NS");
+  int ns = nsenv ? atoi(nsenv) : MSI_SWEEP_NS_DEFAULT;
+  if (ns != 1 && ns != 2 && ns != 4) ns = MSI_SWEEP_NS_DEFAULT;
+  while (num_depths % ns != 0) ns >>= 1;
+  const dim3 grid((unsigned)(((long)width * (num_depths / ns) + 255) / 256), height, batch);
+#define MSI_LAUNCH_SWEEP(T, NS_)                                                                         \
+  hipLaunchKernelGGL((ods_sweep_kernel<T, NS_>), grid, dim3(256), 0, msi::as_stream(stream), image, pose, \
+                     intrinsics, depths, trig, batch, height, width, num_depths, (float)order,           \
+                     static_cast<T *>(psv), psv_channels, channel_offset, make_consts(height, width))
+#define MSI_LAUNCH_SWEEP_T(T)                                                            \
+  { if (ns == 4) MSI_LAUNCH_SWEEP(T, 4); else if (ns == 2) MSI_LAUNCH_SWEEP(T, 2); else MSI_LAUNCH_SWEEP(T, 1); }
+  if (psv_bf16) MSI_LAUNCH_SWEEP_T(unsigned short) else MSI_LAUNCH_SWEEP_T(float)
+#undef MSI_LAUNCH_SWEEP_T
+#undef MSI_LAUNCH_SWEEP
   return msi::check_launch("ods_sphere_sweep");
 }
 

@@ -67,6 +67,24 @@ def test_sweep_float_input_and_nonidentity_pose(gpu):
     assert np.percentile(err, 99.9) < 1e-3
 
 
+def test_sweep_depths_per_thread_variants_are_bit_identical(gpu, monkeypatch):
+    """K1 processes NS consecutive depths per thread (default 2): the per-sample arithmetic is untouched, so
+    NS = 1 / 2 / 4 must give the same bits (also with a depth count that only allows NS = 2)."""
+    torch, m, o = gpu
+    for b, h, w, d in ((1, 32, 64, 8), (2, 24, 40, 6)):
+        inp = make_inputs(3, b, h, w)
+        planes = m.inv_depths(1.0, 100.0, d)
+        pose = inp["src_pose"].copy()
+        pose[:, 0, 3] = 0.013
+        ref = m.preprocess_image(torch.from_numpy(inp["ref_image"]))
+        src = m.preprocess_image(torch.from_numpy(inp["src_image"]))
+        outs = []
+        for ns in ("1", "2", "4"):
+            monkeypatch.setenv("MSI_SWEEP_NS", ns)
+            outs.append(m.format_network_input(ref, src, inp["ref_pose"], pose, planes, inp["intrinsics"]).clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_compose_poses_matches_matmul(gpu):
     """msi_compose_poses_f32 = the fp32 4x4 product of msi.py:1125, summed k = 0..3 without fma."""
     torch, m, o = gpu
