@@ -1,0 +1,29 @@
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from matryodshka_amd import MSI, nets
+from tests.util import make_inputs
+dev = torch.device("cuda:0")
+H, W, D = 320, 640, 32
+model = MSI(weights=nets.init_weights(6 * D, 2 * D, 64, True), coord_net=True)
+inp = make_inputs(8964, 1, H, W)
+planes = model.inv_depths(1.0, 100.0, D)
+g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).contiguous()
+src_u8, ref_u8 = g(inp["src_image"]), g(inp["ref_image"])
+t = {k: g(inp[k]) for k in ("ref_pose", "src_pose", "intrinsics", "tgt_pose_rt", "tgt_pos")}
+rpi = torch.linalg.inv(torch.from_numpy(inp["ref_pose"])).contiguous().to(dev)
+def frame():
+    src, ref = model.preprocess_image(src_u8), model.preprocess_image(ref_u8)
+    ni = model.format_network_input(ref, src, t["ref_pose"], t["src_pose"], planes, t["intrinsics"], ref_pose_inv=rpi)
+    pred = model.run_net(ni, 2 * D, 64)
+    out = model.assemble_layers(ni, pred, D)
+    rgb, dep = model.msi_render_equirect_view_and_depth(out["rgba_layers"], t["tgt_pose_rt"], t["tgt_pos"], planes, t["intrinsics"])
+    return model.deprocess_image(rgb), model.deprocess_depth_image(dep)
+for _ in range(5): frame()
+torch.cuda.synchronize()
+ts = []
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); frame(); t1 = time.perf_counter()
+    ts.append((t1 - t0) * 1e3)
+print("CPU time to issue one frame (GPU idle at start): min %.3f ms median %.3f ms" % (min(ts), sorted(ts)[5]))
