@@ -62,7 +62,7 @@ constexpr int NSTAGE = MSI_NSTAGE;  // LDS ring depth: NSTAGE-1 k-steps of DMA i
                                      // (3.29 / 3.41 / 3.80 ms per frame): LDS-limited occupancy matters more than prefetch depth
 constexpr int NPAD_ALIGN = 128;
 constexpr int COORD_CLASSES = 5;    // column border classes of the CoordNet table: 0,1 | interior | W-2,W-1
-constexpr unsigned OOB = 0x80000000u;  // per-lane offset that is out of range of every descriptor
+[[maybe_unused]] constexpr unsigned OOB = 0x80000000u;  // per-lane offset that is out of range of every descriptor (device code)
 constexpr int NUM_CUS = 256;
 constexpr int MAX_SPLIT = 8;
 constexpr size_t PARTIAL_BYTES = (size_t)NUM_CUS * MAX_SPLIT * 128 * 64 * sizeof(float);  // < 256 split tiles x 8 ranges
@@ -156,7 +156,6 @@ conv_igemm_kernel(const ConvParams p) {
   constexpr int BKE = ROW_BYTES / ESZ;       // channels per k-step: 32 (fp32) / 64 (bf16)
   constexpr int MT = BM / 64, NT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
   constexpr int AI = BM / 32, BI = BN / 32;  // DMA wave-instructions (8 rows x 128 B each) per wave per k-step
-  constexpr int ND = AI + BI;
   constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
