@@ -75,6 +75,8 @@ struct ConvParams {
   const char *x0, *x1;       // NHWC sources, already normalised (x1 = second half of a skip concat)
   const char *wpk;           // packed weights [nclass][ksteps][npad][128 B], slots pre-swizzled
   const char *coord_tab;     // CoordNet table [Mh][COORD_CLASSES][128 B] or null
+  const float *ln_aff;       // head, fp32 only: [B][scale[C0] | shift[C0]] of the source's LayerNorm, applied (+ ReLU) while
+                             // loading (the source buffer then holds the RAW conv output); null = source already normalised
   const float *bias;         // head only
   float *y;                  // raw output NHWC [B,Hout,Wout,Cout]
   float *stats;              // [B][nparts][4] (count, mean, M2, -) or null
@@ -320,7 +322,22 @@ _Pragma("unroll")                                                               
       }                                                                                                                          \
       const int soff_a = g_chunk * ROW_BYTES;                                                                                    \
       const int cleft = g_C - g_chunk * BKE; /* channels from this chunk on; < BKE only when C % BKE != 0 (wave-uniform) */        \
-      if (cleft >= BKE) {                                                                                                        \
+      if (MODE == MODE_HEAD && !BF16 && p.ln_aff != nullptr) {                                                                   \
+        /* fused LayerNorm apply of the producer (head only: two k-steps, HBM-bound -- VALU is free here): the A rows go */      \
+        /* through registers, x -> max(x * scale[c] + shift[c], 0), and land in the LDS slots the DMA would have filled  */      \
+        const float *aff_ = p.ln_aff + (size_t)b * 2 * p.C0;                                                                     \
+_Pragma("unroll")                                                                                                                \
+        for (int i = 0; i < AI; ++i) {                                                                                           \
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));                                                            \
+          const v4f x = __builtin_bit_cast(v4f, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[i], soff_a, 0)); \
+          const int c0 = g_chunk * BKE + (int)(a_chunk16[i] >> 2);                                                               \
+          const v4f s4 = *reinterpret_cast<const v4f *>(aff_ + c0), t4 = *reinterpret_cast<const v4f *>(aff_ + p.C0 + c0);       \
+          v4f y;                                                                                                                 \
+          y.x = fmaxf(x.x * s4.x + t4.x, 0.f); y.y = fmaxf(x.y * s4.y + t4.y, 0.f);                                              \
+          y.z = fmaxf(x.z * s4.z + t4.z, 0.f); y.w = fmaxf(x.w * s4.w + t4.w, 0.f);                                              \
+          *reinterpret_cast<v4f *>(sA + i * 8 * ROW_BYTES + lane * 16) = y;                                                      \
+        }                                                                                                                        \
+      } else if (cleft >= BKE) {                                                                                                 \
 _Pragma("unroll")                                                                                                                \
         for (int i = 0; i < AI; ++i)                                                                                             \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void *)(sA + i * 8 * ROW_BYTES), 16, a_voff[i], soff_a, 0, 0);   \
@@ -453,6 +470,7 @@ _Pragma("unroll")                                                               
   } else {
     wait_vmcnt<0>();
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the head's fused-LayerNorm path fills its A rows with ds_write)
   __builtin_amdgcn_s_barrier();
 
   // k-step S in stage U: issue k-step S+PD into the stage freed by the previous barrier; before the
@@ -779,8 +797,9 @@ conv_fixup_kernel(const ConvParams p) {
 // slice (nets.py:401,485 arg_scope: normalizer, then the default ReLU).  Merging redundantly
 // (<= 3200 partials = 51 KB from L2 per workgroup) is cheaper than a separate single-block launch
 // plus a kernel boundary per layer.  Workgroup 0 also publishes the affine (debug / tests).
-// BF16OUT: the normalised activation is written as bf16 to `yb` (the operand buffer of the bf16 path)
-// and the fp32 raw output is left alone; otherwise x is normalised in place.
+// BF16OUT = 1: the normalised activation is written as bf16 to `yb` (the operand buffer of the bf16 path)
+// and the fp32 raw output is left alone; 0: x is normalised in place; 2: finish only -- the affine is
+// published to `aff` and x stays raw (the consumer applies it: the head's fused path).
 template <int BF16OUT>
 __global__ void __launch_bounds__(256)
 ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int nparts,
@@ -803,24 +822,24 @@ ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int npar
     x = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
     y = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
   };
-  // pass 1: N = sum n_i, mean = sum n_i mean_i / N;  pass 2: M2 = sum (M2_i + n_i (mean_i - mean)^2).
-  // Same result as Chan's sequential update, without its two fp64 divisions per partial on the
-  // critical path of every layer (this merge sits between two conv launches 17 times per frame).
-  double sn = 0.0, sm = 0.0;
+  // One pass over the partials, three fp64 sums: N = sum n_i, S = sum n_i mean_i, Q = sum (M2_i + n_i mean_i^2);
+  // mean = S / N, M2 = Q - N mean^2 (in fp64 the cancellation costs ~1e-16 (1 + mean^2/var): nothing at fp32
+  // outputs).  No division and no dependent second pass on the critical path between two conv launches; the
+  // loads of a thread's partials are independent (unrolled), so their latencies overlap.
+  double sn = 0.0, sm = 0.0, s2 = 0.0;
+#pragma unroll 4
   for (int i = tid; i < nparts; i += 256) {
     const v4f pr = *reinterpret_cast<const v4f *>(st + (size_t)i * 4);
-    sn += (double)pr.x;
-    sm += (double)pr.x * (double)pr.y;
+    const double n_i = (double)pr.x, m_i = (double)pr.y;
+    sn += n_i;
+    sm += n_i * m_i;
+    s2 += (double)pr.z + n_i * m_i * m_i;
   }
   block_sum2(sn, sm);
-  const double mu = sm / sn;
-  double s2 = 0.0, dummy = 0.0;
-  for (int i = tid; i < nparts; i += 256) {
-    const v4f pr = *reinterpret_cast<const v4f *>(st + (size_t)i * 4);
-    const double dl = (double)pr.y - mu;
-    s2 += (double)pr.z + (double)pr.x * dl * dl;
-  }
+  double dummy = 0.0;
   block_sum2(s2, dummy);
+  const double mu = sm / sn;
+  s2 -= sn * mu * mu;
   const double var = s2 / sn;
   const double inv = 1.0 / sqrt(var + LN_EPS);
   for (int c = tid; c < C; c += 256) {
@@ -834,6 +853,7 @@ ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int npar
     }
   }
   __syncthreads();
+  if (BF16OUT == 2) return;
 
   v4f *xv = reinterpret_cast<v4f *>(x + (size_t)b * per_sample);
   const size_t nvec = per_sample / 4;
@@ -853,7 +873,7 @@ ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int npar
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
   v2u *yv = reinterpret_cast<v2u *>(yb + (size_t)b * per_sample);
   auto put = [&](size_t i, const v4f v) __attribute__((always_inline)) {
-    if (BF16OUT) yv[i] = v2u{bf16_bits(v.x) | (bf16_bits(v.y) << 16), bf16_bits(v.z) | (bf16_bits(v.w) << 16)};
+    if (BF16OUT == 1) yv[i] = v2u{bf16_bits(v.x) | (bf16_bits(v.y) << 16), bf16_bits(v.z) | (bf16_bits(v.w) << 16)};
     else xv[i] = v;
   };
   if ((256 * 4) % C == 0) {
@@ -1271,6 +1291,11 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
   char *ws = static_cast<char *>(workspace);
   float *stats = reinterpret_cast<float *>(ws + net.stats_off);
 
+  // The head (1x1, two k-steps, HBM-bound) applies its producer's LayerNorm + ReLU itself: one HBM round trip of
+  // that activation less (MSI_HEAD_FUSE_LN=0 restores the separate pass; the bf16 path keeps it).
+  const char *fenv = getenv("MSI_HEAD_FUSE_LN");
+  const bool fuse_head_ln = !bf16 && !(fenv && atoi(fenv) == 0);
+  const int head_src = net.layers[MSI_NET_NUM_LAYERS - 1].src0;
   for (int li = 0; li < MSI_NET_NUM_LAYERS; ++li) {
     const Layer &L = net.layers[li];
     ConvParams p;
@@ -1292,6 +1317,8 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
     p.wpk = reinterpret_cast<const char *>(packed + L.packed_off);
     p.coord_tab = L.has_coord ? reinterpret_cast<const char *>(packed + L.coord_off) : nullptr;
     p.bias = L.kind == MODE_HEAD ? packed + L.gamma_off : nullptr;
+    // fp32 head: its producer's LayerNorm + ReLU is applied while loading (the producer's buffer holds the raw output)
+    p.ln_aff = (L.kind == MODE_HEAD && fuse_head_ln) ? reinterpret_cast<const float *>(ws + net.layers[L.src0].aff_off) : nullptr;
     p.y = L.kind == MODE_HEAD ? pred : reinterpret_cast<float *>(ws + L.raw_off);
     p.stats = L.kind == MODE_HEAD ? nullptr : stats;
     p.partial = reinterpret_cast<float *>(ws + net.partial_off);
@@ -1349,6 +1376,10 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
       if (bf16)
         hipLaunchKernelGGL(ln_apply_kernel<1>, grid, dim3(256), lds, stream, raw, stats, nparts, packed + L.gamma_off,
                            packed + L.beta_off, per_sample, L.cout, aff, reinterpret_cast<unsigned short *>(ws + L.act_off));
+      else if (fuse_head_ln && li == head_src)   // finish only: the head applies the affine
+        hipLaunchKernelGGL(ln_apply_kernel<2>, dim3(1, desc->batch), dim3(256), lds, stream, raw, stats, nparts,
+                           packed + L.gamma_off, packed + L.beta_off, per_sample, L.cout, aff,
+                           static_cast<unsigned short *>(nullptr));
       else
         hipLaunchKernelGGL(ln_apply_kernel<0>, grid, dim3(256), lds, stream, raw, stats, nparts, packed + L.gamma_off,
                            packed + L.beta_off, per_sample, L.cout, aff, static_cast<unsigned short *>(nullptr));
