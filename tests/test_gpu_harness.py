@@ -45,3 +45,33 @@ def test_harness_writes_reference_outputs(tmp_path):
     jpg = np.asarray(Image.open(str(img_dir / "room_0_pos000.jpeg")).convert("RGB"), dtype=np.float32)
     box = jpg.reshape(h, 2, w, 2, 3).mean(axis=(1, 3))
     assert np.abs(ref_png - np.clip(box, 0, 255).astype("uint8").astype(int)).max() <= 1
+
+
+def test_harness_restores_a_tf_checkpoint(tmp_path):
+    """--checkpoint: the variables come from a TF V2 checkpoint (written here by tf_checkpoint.write_checkpoint),
+    step.txt records its global step (test.py:225-229), and the outputs equal a run on the same weights via --weights."""
+    from PIL import Image
+    from matryodshka_amd import harness, nets, tf_checkpoint
+    h, w, d, ngf = 16, 32, 4, 8
+    img_dir = tmp_path / "images"; img_dir.mkdir()
+    rng = np.random.RandomState(1)
+    for name in ("000", "001", "002"):
+        Image.fromarray(rng.randint(0, 255, size=(h, w, 3)).astype(np.uint8)).save(str(img_dir / ("s_pos%s.jpeg" % name)), quality=95)
+    cam = tmp_path / "cams.txt"
+    cam.write_text("s 000 001 002 0.032 0.01 -0.02 0.03\n")
+    weights = nets.init_weights(6 * d, 2 * d, ngf, True, seed=5)
+    ckpt_dir = tmp_path / "ckpt"; ckpt_dir.mkdir()
+    tensors = {"net/" + k: v for k, v in weights.items()}
+    tensors["global_step"] = np.array(1234, np.int64)
+    tf_checkpoint.write_checkpoint(str(ckpt_dir / "model.ckpt-1234"), tensors)
+    np.savez(str(tmp_path / "w.npz"), **weights)
+    common = ["--cameras_glob", str(cam), "--image_dir", str(img_dir), "--height", str(h), "--width", str(w),
+              "--num_msi_planes", str(d), "--ngf", str(ngf), "--test_outputs", "tgt_image_alphas"]
+    assert harness.main(common + ["--output_root", str(tmp_path / "a"), "--experiment_name", "e", "--checkpoint", str(ckpt_dir)]) == 1
+    assert harness.main(common + ["--output_root", str(tmp_path / "b"), "--experiment_name", "e", "--weights", str(tmp_path / "w.npz")]) == 1
+    assert (tmp_path / "a" / "e" / "step.txt").read_text() == "1234"
+    fa = tmp_path / "a" / "e" / "s_000001002"
+    fb = tmp_path / "b" / "e" / "s_000001002"
+    assert np.array_equal(np.load(str(fa / "alphas.npy")), np.load(str(fb / "alphas.npy")))
+    assert np.array_equal(np.asarray(Image.open(str(fa / "output_tgt_s_000001002.png"))),
+                          np.asarray(Image.open(str(fb / "output_tgt_s_000001002.png"))))
