@@ -29,9 +29,9 @@
 //     taps each (blockIdx.z selects the parity class);
 //   * GEMM view: M = pixels of one sample, N = Cout, K = taps x Cin, walked in
 //     k-steps of 32 channels of one tap; two sources = skip concat by descriptor pair;
-//   * CoordNet's |sin(lat)| channel (nets.py:260-265) is constant along W: it is
-//     one extra k-step whose 32 "channels" are the <=9 taps of that channel, read from a small
-//     host-built table indexed by (output row, column border class);
+//   * CoordNet's |sin(lat)| channel (nets.py:260-265) is constant along W and independent of the image:
+//     its share of the convolution is a host-built table [out row][column border class][Cout] that the
+//     epilogue adds to the accumulators (no extra k-step);
 //   * the epilogue writes the raw conv output and one (count, mean, M2) partial
 //     per workgroup; ln_apply_kernel merges the partials in fp64 in a fixed order (Chan)
 //     into the per-channel scale/shift and normalises in place.
@@ -74,7 +74,8 @@ struct ConvParams {
   // element-typed buffers (fp32, or bf16 in the BF16 instantiation) are addressed in bytes
   const char *x0, *x1;       // NHWC sources, already normalised (x1 = second half of a skip concat)
   const char *wpk;           // packed weights [nclass][ksteps][npad][128 B], slots pre-swizzled
-  const char *coord_tab;     // CoordNet table [Mh][COORD_CLASSES][128 B] or null
+  const float *coord_bias;   // CoordNet: contribution of the |sin(lat)| channel, [Mh][COORD_CLASSES][cb_stride] fp32, or null
+  int cb_stride;
   const float *ln_aff;       // head, fp32 only: [B][scale[C0] | shift[C0]] of the source's LayerNorm, applied (+ ReLU) while
                              // loading (the source buffer then holds the RAW conv output); null = source already normalised
   const float *bias;         // head only
@@ -225,7 +226,6 @@ conv_igemm_kernel(const ConvParams p) {
   int rowbase[AI], colw0[AI], colw1[AI], colw2[AI];  // (three arrays: a [AI][NV] array selected by
                                                                            // the tap column ends up indexed in scratch)
   unsigned vmask[AI], a_chunk16[AI];
-  unsigned c_voff[AI];       // CoordNet k-step: byte offset into the (row, column class) table, or OOB
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int r = wave * (BM / 4) + i * 8 + drow;
@@ -258,7 +258,6 @@ conv_igemm_kernel(const ConvParams p) {
     const unsigned vm = mok ? (colrep & rowrep) : 0u;
     vmask[i] = vm;
     a_chunk16[i] = (unsigned)((dslot ^ ((r >> 1) & 7)) * 16);  // byte offset of the data chunk this lane fetches
-    c_voff[i] = mok ? (unsigned)((mh * COORD_CLASSES + coord_class(mw, p.Mw)) * ROW_BYTES) + a_chunk16[i] : OOB;
   }
   // B: rows [wave*BN/4 + 8i, +8) of the weight tile; the packed blob is already swizzled
   const unsigned b_voff = (unsigned)((tile_n * BN + wave * (BN / 4) + drow) * ROW_BYTES + dslot * 16);
@@ -274,7 +273,7 @@ conv_igemm_kernel(const ConvParams p) {
   // Per segment the per-lane A offsets are fixed; the channel walk is the scalar soffset.
   unsigned a_voff[AI];       // byte offset of (pixel, data chunk) inside the source, or OOB
   __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)src0, 0, bytes0, 0x00020000);
-  const int nreg = p.ntaps * (p.cpt0 + p.cpt1);  // regular k-steps; + 1 coord step when p.coord_tab
+  const int nreg = p.ntaps * (p.cpt0 + p.cpt1);  // = p.ksteps
   int g_step = k0, g_tap = 0, g_src = 0, g_chunk = 0, g_C = p.C0;
   if (k0 > 0 && k0 < nreg) {   // a K-range of a split tile starts in the middle of the k-step list
     const int cpt = p.cpt0 + p.cpt1;
@@ -348,13 +347,6 @@ _Pragma("unroll")                                                               
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void *)(sA + i * 8 * ROW_BYTES), 16,                             \
                                                    a_chunk16[i] < (unsigned)(cleft * ESZ) ? a_voff[i] : OOB, soff_a, 0, 0);         \
       }                                                                                                                          \
-    } else {                                                                                                                     \
-      /* CoordNet k-step: row m reads table[mh][column class][32] */                                                             \
-      const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(                                                   \
-          (void *)p.coord_tab, 0, p.Mh * COORD_CLASSES * ROW_BYTES, 0x00020000);                                                 \
-_Pragma("unroll")                                                                                                                \
-      for (int i = 0; i < AI; ++i)                                                                                               \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_void *)(sA + i * 8 * ROW_BYTES), 16, c_voff[i], 0, 0, 0);          \
     }                                                                                                                            \
     /* B rows [wave*BN/4 + 8i, +8): the instruction's immediate offset advances BOTH the source and the LDS address */                                        \
     static_assert(BI <= 4, "B rows per wave: written out for immediate offsets");                                                \
@@ -543,57 +535,18 @@ _Pragma("unroll")                                                               
         for (int r = 0; r < 16; ++r) acc[i][j][r] = tanhf(acc[i][j][r] + bias);
     }
   }
-  // LayerNorm partial, per WAVE first (no workgroup barrier): mean of the wave's (MT*32)x(NT*32) block, then
-  // M2 about that mean (two-pass: the values are still in registers); lane 0 parks (count, mean, M2) behind
-  // the staged rows and thread 0 merges the four after the first barrier of the epilogue.
-  if (want_stats) {
-    auto wave_sum = [&](float v) __attribute__((always_inline)) -> float {   // butterfly: every lane gets the total
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      return v;
-    };
-    float lsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n = tile_n * BN + wn * (NT * 32) + j * 32 + col;
-          if (interior) lsum += acc[i][j][r];
-          else lsum += (m < mtot && n < p.Cout) ? acc[i][j][r] : 0.f;
-        }
-      }
-    const int rv = min(max(mtot - (tile_m * BM + wm * (MT * 32)), 0), MT * 32);
-    const int cv = min(max(p.Cout - (tile_n * BN + wn * (NT * 32)), 0), NT * 32);
-    const float wcnt = (float)(rv * cv);
-    const float wmean = wcnt > 0.f ? wave_sum(lsum) / wcnt : 0.f;
-    float lm2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n = tile_n * BN + wn * (NT * 32) + j * 32 + col;
-          const float dlt = acc[i][j][r] - wmean;
-          if (interior) lm2 += dlt * dlt;
-          else lm2 += (m < mtot && n < p.Cout) ? dlt * dlt : 0.f;
-        }
-      }
-    const float wm2 = wave_sum(lm2);
-    if (lane == 0) {
-      wpart[wave * 4 + 0] = wcnt;
-      wpart[wave * 4 + 1] = wmean;
-      wpart[wave * 4 + 2] = wm2;
-    }
-  }
+  // The tile leaves through LDS in 64-row passes; what a thread reads back (16-byte pieces of whole channel
+  // rows) is also what it (a) adds the CoordNet contribution to -- the |sin(lat)| channel does not depend on
+  // the input, so its part of the convolution is a host-built table indexed by (output row, column border
+  // class, channel) instead of a 33rd k-step -- and (b) takes the LayerNorm partial from: per WAVE, mean
+  // first, then M2 about that mean over the same registers (two-pass), merged by thread 0.
   constexpr int C4 = BN / 4;                       // float4 per staged row
   constexpr int PASSES = SROWS * C4 / 256;
   const bool vec_ok = (p.Cout & 3) == 0;
+  const bool has_cb = MODE == MODE_CONV && full && p.coord_bias != nullptr;
   float *pdst = full ? nullptr : p.partial + (size_t)slot * (BM * BN);   // K-range of a split tile: raw accumulators, row-major [BM][BN]
+  v4f keep[MT][PASSES];
+  float lsum = 0.f, lcnt = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     if (i > 0) __syncthreads();                    // the previous pass has been read out
@@ -608,7 +561,8 @@ _Pragma("unroll")                                                               
       const int idx = tid + 256 * k;
       const int srow = idx / C4, c4 = idx - srow * C4;
       const int lrow = (srow >> 5) * (MT * 32) + i * 32 + (srow & 31);   // staged row -> tile row
-      const v4f v = *reinterpret_cast<const v4f *>(ct + srow * LDW + c4 * 4);
+      v4f v = *reinterpret_cast<const v4f *>(ct + srow * LDW + c4 * 4);
+      keep[i][k] = v4f{0.f, 0.f, 0.f, 0.f};
       if (!full) {
         *reinterpret_cast<v4f *>(pdst + lrow * BN + c4 * 4) = v;
         continue;
@@ -623,6 +577,12 @@ _Pragma("unroll")                                                               
         opix = ((size_t)b * p.Hout + (2 * mh + ph)) * p.Wout + (2 * mw + pw);
       } else {
         opix = (size_t)b * mtot + m;
+        if (has_cb) {
+          const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);
+          const int mw = m - mh * p.Mw;
+          const v4f cb = *reinterpret_cast<const v4f *>(p.coord_bias + (size_t)(mh * COORD_CLASSES + coord_class(mw, p.Mw)) * p.cb_stride + n);
+          v.x += cb.x; v.y += cb.y; v.z += cb.z; v.w += cb.w;
+        }
       }
       float *dst = p.y + opix * p.Cout + n;
       if (vec_ok) {
@@ -633,31 +593,81 @@ _Pragma("unroll")                                                               
         if (n + 2 < p.Cout) dst[2] = v.z;
         if (n + 3 < p.Cout) dst[3] = v.w;
       }
+      if (want_stats) {
+        if (interior || n + 3 < p.Cout) {
+          lcnt += 4.f;
+        } else {   // channel tail inside the last float4
+          if (n + 1 >= p.Cout) v.y = 0.f;
+          if (n + 2 >= p.Cout) v.z = 0.f;
+          if (n + 3 >= p.Cout) v.w = 0.f;
+          lcnt += (float)(p.Cout - n);
+        }
+        lsum += (v.x + v.y) + (v.z + v.w);
+        keep[i][k] = v;
+      }
     }
   }
-  if (want_stats && tid == 0) {
-    // Chan's merge of the four wave partials in a fixed order: (0,1), (2,3), then the pair
-    auto merge = [](float &na, float &ma, float &sa, float nb, float mb, float sb) __attribute__((always_inline)) {
-      const float nt = na + nb;
-      if (nb > 0.f) {
-        const float dl = mb - ma, f = nb / nt;
-        ma += dl * f;
-        sa += sb + dl * dl * (na * f);
-        na = nt;
-      }
+  if (want_stats) {
+    auto wave_sum = [&](float x) __attribute__((always_inline)) -> float {   // butterfly: every lane gets the total
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      return x;
     };
-    float n0 = wpart[0], m0 = wpart[1], s0 = wpart[2];
-    float n2 = wpart[8], m2 = wpart[9], s2 = wpart[10];
-    merge(n0, m0, s0, wpart[4], wpart[5], wpart[6]);
-    merge(n2, m2, s2, wpart[12], wpart[13], wpart[14]);
-    merge(n0, m0, s0, n2, m2, s2);
-    const int nparts = p.tiles_m * p.tiles_n * p.nclass;
-    const int part = (cls * p.tiles_n + tile_n) * p.tiles_m + tile_m;
-    float *o = p.stats + ((size_t)b * nparts + part) * 4;
-    o[0] = n0;
-    o[1] = m0;
-    o[2] = s0;
-    o[3] = 0.f;
+    const float wcnt = interior ? (float)(MT * PASSES * 4 * 64) : wave_sum(lcnt);
+    const float wmean = wcnt > 0.f ? wave_sum(lsum) / wcnt : 0.f;
+    float lm2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) {
+        const v4f v = keep[i][k];
+        const float dx = v.x - wmean, dy = v.y - wmean, dz = v.z - wmean, dw = v.w - wmean;
+        if (interior) {
+          lm2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        } else {   // re-derive which of the four values exist (skipped pieces were kept as zeros and must not count)
+          const int idx = tid + 256 * k;
+          const int srow = idx / C4, c4 = idx - srow * C4;
+          const int m = tile_m * BM + (srow >> 5) * (MT * 32) + i * 32 + (srow & 31);
+          const int n = tile_n * BN + c4 * 4;
+          if (m < mtot) {
+            if (n < p.Cout) lm2 += dx * dx;
+            if (n + 1 < p.Cout) lm2 += dy * dy;
+            if (n + 2 < p.Cout) lm2 += dz * dz;
+            if (n + 3 < p.Cout) lm2 += dw * dw;
+          }
+        }
+      }
+    const float wm2 = wave_sum(lm2);
+    if (lane == 0) {
+      wpart[wave * 4 + 0] = wcnt;
+      wpart[wave * 4 + 1] = wmean;
+      wpart[wave * 4 + 2] = wm2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      // Chan's merge of the four wave partials in a fixed order: (0,1), (2,3), then the pair
+      auto merge = [](float &na, float &ma, float &sa, float nb, float mb, float sb) __attribute__((always_inline)) {
+        const float nt = na + nb;
+        if (nb > 0.f) {
+          const float dl = mb - ma, f = nb / nt;
+          ma += dl * f;
+          sa += sb + dl * dl * (na * f);
+          na = nt;
+        }
+      };
+      float n0 = wpart[0], m0 = wpart[1], s0 = wpart[2];
+      float n2 = wpart[8], m2 = wpart[9], s2 = wpart[10];
+      merge(n0, m0, s0, wpart[4], wpart[5], wpart[6]);
+      merge(n2, m2, s2, wpart[12], wpart[13], wpart[14]);
+      merge(n0, m0, s0, n2, m2, s2);
+      const int nparts = p.tiles_m * p.tiles_n * p.nclass;
+      const int part = (cls * p.tiles_n + tile_n) * p.tiles_m + tile_m;
+      float *o = p.stats + ((size_t)b * nparts + part) * 4;
+      o[0] = n0;
+      o[1] = m0;
+      o[2] = s0;
+      o[3] = 0.f;
+    }
   }
 #ifdef MSI_CONV_TIMING
   stamp();
@@ -684,16 +694,34 @@ conv_fixup_kernel(const ConvParams p) {
   int tile_m, tile_n, cls, b;
   {
     int r = t;   // same order as conv_igemm_kernel: M tiles fastest
-    tile_m = r % p.tiles_m; r /= p.tiles_m;
-    tile_n = r % p.tiles_n; r /= p.tiles_n;
-    cls = r % p.nclass;
-    b = r / p.nclass;
+    const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
+    tile_m = r - q1 * p.tiles_m; r = q1;
+    const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
+    tile_n = r - q2 * p.tiles_n; r = q2;
+    const int q3 = (int)udiv_magic((unsigned)r, (unsigned)p.nclass, p.mg_nc);
+    cls = r - q3 * p.nclass;
+    b = q3;
   }
   const int ph = cls >> 1, pw = cls & 1;
   const int mtot = p.Mh * p.Mw;
   // All `split` partial tiles are requested before the first one is used: one memory round trip
   // instead of `split` dependent ones (the loop over a run-time count waited per K-range).  Ranges
   // beyond `split` re-read the last one and are masked out of the sum, which stays in k order.
+  // The CoordNet contribution of each piece (see the conv epilogue) is requested in the same round trip.
+  v4f cbv[PASSES];
+#pragma unroll
+  for (int k = 0; k < PASSES; ++k) {
+    cbv[k] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_CONV && p.coord_bias != nullptr) {
+      const int idx = tid + 256 * k;
+      const int m = tile_m * BM + idx / C4, n = tile_n * BN + (idx % C4) * 4;
+      if (m < mtot && n < p.Cout) {   // cb_stride is Cout rounded up to 4: the whole float4 is in range
+        const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);
+        const int mw = m - mh * p.Mw;
+        cbv[k] = *reinterpret_cast<const v4f *>(p.coord_bias + (size_t)(mh * COORD_CLASSES + coord_class(mw, p.Mw)) * p.cb_stride + n);
+      }
+    }
+  }
   v4f a[MAX_SPLIT][PASSES];
 #pragma unroll
   for (int ks = 0; ks < MAX_SPLIT; ++ks) {
@@ -722,6 +750,7 @@ conv_fixup_kernel(const ConvParams p) {
     const int m = tile_m * BM + lrow;
     const int n = tile_n * BN + c4 * 4;
     float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+    e[0] += cbv[k].x; e[1] += cbv[k].y; e[2] += cbv[k].z; e[3] += cbv[k].w;
     if (MODE == MODE_HEAD) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) e[q] = tanhf(e[q] + p.bias[min(n + q, p.Cout - 1)]);
@@ -902,7 +931,7 @@ struct Layer {
   int c0, c1;
   int ntaps, cpt0, cpt1, ksteps, nclass, npad;
   size_t param_off, param_floats;  // floats
-  size_t packed_off;               // floats: weights, then gamma, beta (or bias), then coord table
+  size_t packed_off;               // floats: weights, then gamma, beta (or bias), then the CoordNet bias table
   size_t packed_w_floats;
   size_t gamma_off, beta_off, coord_off;  // floats inside the packed blob
   size_t raw_off, aff_off;                // bytes inside the workspace
@@ -991,7 +1020,7 @@ int build_net(const msi_net_desc *d, Net &net) {
       return msi::fail(MSI_E_UNSUPPORTED, "net: %s input exceeds 2 GiB per sample", s.name);
     L.cpt0 = (L.c0 + bke - 1) / bke;
     L.cpt1 = (L.c1 + bke - 1) / bke;
-    L.ksteps = L.ntaps * (L.cpt0 + L.cpt1) + (L.has_coord ? 1 : 0);
+    L.ksteps = L.ntaps * (L.cpt0 + L.cpt1);   // (the CoordNet channel is not a k-step: see the bias table below)
     L.npad = (int)round_up(L.cout, NPAD_ALIGN);
     // parameter blob (reference layout)
     const size_t wf = (s.kind == MODE_CONV)    ? (size_t)9 * (L.cin + L.has_coord) * L.cout
@@ -1006,7 +1035,7 @@ int build_net(const msi_net_desc *d, Net &net) {
     L.gamma_off = L.packed_off + L.packed_w_floats;
     L.beta_off = L.gamma_off + round_up(L.cout, 4);
     L.coord_off = L.beta_off + round_up(L.cout, 4);
-    koff = L.coord_off + (L.has_coord ? (size_t)L.out_h * COORD_CLASSES * (ROW_BYTES / 4) : 0);
+    koff = L.coord_off + (L.has_coord ? (size_t)L.out_h * COORD_CLASSES * round_up(L.cout, 4) : 0);
     koff = round_up(koff, 64);
     // workspace
     if (s.kind != MODE_HEAD) {
@@ -1203,10 +1232,9 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
     for (int cls = 0; cls < L.nclass; ++cls) {
       const int ph = cls >> 1, pw = cls & 1;
       for (int s = 0; s < L.ksteps; ++s) {
-        const bool coord_step = L.has_coord && s == L.ksteps - 1;
         // k-step order of the kernel's generator: tap-major, then source 0 chunks, then source 1 chunks
-        const int tap_s = coord_step ? 0 : s / cpt;
-        const int within = coord_step ? 0 : s % cpt;
+        const int tap_s = s / cpt;
+        const int within = s % cpt;
         const int src = within < L.cpt0 ? 0 : 1;
         const int chunk = src ? within - L.cpt0 : within;
         const int csrc = src ? L.c1 : L.c0, cbase = src ? L.c0 : 0;
@@ -1214,9 +1242,8 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
           char *row = reinterpret_cast<char *>(o) + (((size_t)cls * L.ksteps + s) * L.npad + n) * ROW_BYTES;
           const int swz = (n >> 1) & 7;  // LDS slot j of row n holds data chunk j ^ swz (see the kernel)
           for (int kk = 0; kk < bke; ++kk) {
-            int tap, c;
-            if (coord_step) { tap = kk; c = L.cin; if (tap >= L.ntaps) continue; }
-            else { tap = tap_s; if (chunk * bke + kk >= csrc) continue; c = cbase + chunk * bke + kk; }
+            if (chunk * bke + kk >= csrc) continue;
+            const int tap = tap_s, c = cbase + chunk * bke + kk;
             float v;
             if (L.kind == MODE_CONV) {            // [3,3,cin_w,cout]
               v = w[((size_t)tap * cin_w + c) * L.cout + n];
@@ -1241,34 +1268,52 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
       memcpy(packed + L.beta_off, w + wf + L.cout, L.cout * sizeof(float));
     }
     if (L.has_coord) {
-      // nets.add_sph_coords (nets.py:260-265): abs(sin(np.linspace(-pi/2, pi/2, H))) in fp64 -> fp32,
-      // tabulated as the A rows of the CoordNet k-step: table[out_row][column class][tap] =
-      // coord[ih] where tap (kh,kw) lands inside the image, else 0 (zero padding).
+      // nets.add_sph_coords (nets.py:260-265): the extra input channel abs(sin(np.linspace(-pi/2, pi/2, H)))
+      // (fp64 -> fp32) is constant along W and independent of the image, so its share of the 3x3
+      // convolution is tabulated here instead of being computed per frame:
+      //   bias[out_row][column class][n] = sum over the taps (kh,kw) that land inside the image of
+      //   coord[ih] * w[kh][kw][cin][n]     (zero padding elsewhere; column classes = the two border
+      //   columns on each side | interior), accumulated in fp64, stored fp32 and added to the fp32
+      //   accumulators in the conv epilogue.  In the bf16 path both factors are rounded to bf16 first
+      //   (they are convolution operands there).
       const double PI = 3.14159265358979323846;
       const double start = -PI / 2.0, stop = PI / 2.0;
       const int h = L.in_h;
       const double step = h > 1 ? (stop - start) / (h - 1) : 0.0;
-      std::vector<float> coord(h);
+      auto operand = [bf16](float v) -> double {
+        if (!bf16) return (double)v;
+        uint32_t u;
+        memcpy(&u, &v, 4);
+        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+        float r;
+        memcpy(&r, &u, 4);
+        return (double)r;
+      };
+      std::vector<double> coord(h);
       for (int i = 0; i < h; ++i) {
         double a = (double)i * step + start;
         if (i == h - 1 && h > 1) a = stop;
-        coord[i] = (float)fabs(sin(a));
+        coord[i] = operand((float)fabs(sin(a)));
       }
       const int keff = 2 * L.rate + 1;
       const int th = (L.out_h - 1) * L.stride + keff - L.in_h, tw = (L.out_w - 1) * L.stride + keff - L.in_w;
       const int pad_t = (th > 0 ? th : 0) / 2, pad_l = (tw > 0 ? tw : 0) / 2;  // TF SAME (CoordNet only)
       const int reps[COORD_CLASSES] = {0, 1, 2, L.out_w - 2, L.out_w - 1};
+      const size_t cbs = round_up(L.cout, 4);
       float *tab = packed + L.coord_off;
       for (int mh = 0; mh < L.out_h; ++mh)
         for (int cc = 0; cc < COORD_CLASSES; ++cc) {
           const int mw = reps[cc];
           if (mw < 0 || mw >= L.out_w) continue;
-          for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap % 3;
-            const int ih = mh * L.stride - pad_t + kh * L.rate, iw = mw * L.stride - pad_l + kw * L.rate;
-            const bool ok = ih >= 0 && ih < L.in_h && iw >= 0 && iw < L.in_w;
-            put_elem(reinterpret_cast<char *>(tab) + ((size_t)mh * COORD_CLASSES + cc) * ROW_BYTES, tap, 0,
-                     ok ? coord[ih] : 0.0f);
+          for (int n = 0; n < L.cout; ++n) {
+            double acc = 0.0;
+            for (int tap = 0; tap < 9; ++tap) {
+              const int kh = tap / 3, kw = tap % 3;
+              const int ih = mh * L.stride - pad_t + kh * L.rate, iw = mw * L.stride - pad_l + kw * L.rate;
+              if (ih < 0 || ih >= L.in_h || iw < 0 || iw >= L.in_w) continue;
+              acc += coord[ih] * operand(w[((size_t)tap * cin_w + L.cin) * L.cout + n]);
+            }
+            tab[((size_t)mh * COORD_CLASSES + cc) * cbs + n] = (float)acc;
           }
         }
     }
@@ -1315,7 +1360,8 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
       p.C1 = L.c1;
     }
     p.wpk = reinterpret_cast<const char *>(packed + L.packed_off);
-    p.coord_tab = L.has_coord ? reinterpret_cast<const char *>(packed + L.coord_off) : nullptr;
+    p.coord_bias = L.has_coord ? packed + L.coord_off : nullptr;
+    p.cb_stride = (int)round_up(L.cout, 4);
     p.bias = L.kind == MODE_HEAD ? packed + L.gamma_off : nullptr;
     // fp32 head: its producer's LayerNorm + ReLU is applied while loading (the producer's buffer holds the raw output)
     p.ln_aff = (L.kind == MODE_HEAD && fuse_head_ln) ? reinterpret_cast<const float *>(ws + net.layers[L.src0].aff_off) : nullptr;

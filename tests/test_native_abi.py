@@ -92,9 +92,9 @@ def _unswizzle_row(row, n, dtype="f32"):
 @pytest.mark.parametrize("coord", [True, False])
 def test_weight_packing_index_level(native_lib, coord, dtype):
     """msi_net_pack_weights_host against an index-level restatement of the documented layout
-    [class][k-step][npad][128 bytes]: k-steps are tap-major, then source-0 chunks, then source-1 chunks,
-    then (CoordNet) one step holding the 9 taps of the coordinate channel.  A row holds 32 fp32 or
-    64 bf16 (round to nearest even) channels."""
+    [class][k-step][npad][128 bytes]: k-steps are tap-major, then source-0 chunks, then source-1 chunks.
+    A row holds 32 fp32 or 64 bf16 (round to nearest even) channels.  The CoordNet channel is not a k-step:
+    its contribution is the fp32 table [out_row][5 column classes][Cout] behind gamma / beta."""
     from matryodshka_amd import nets
     cin, nout, ngf = 24, 8, 16
     bke = 64 if dtype == "bf16" else 32
@@ -112,7 +112,7 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
         cpt0, cpt1 = -(-c0 // bke), -(-c1 // bke)
         ntaps = {0: 9, 1: 4, 2: 1}[info.kind]
         ncls = 4 if info.kind == 1 else 1
-        ksteps = ntaps * (cpt0 + cpt1) + (1 if info.has_coord else 0)
+        ksteps = ntaps * (cpt0 + cpt1)
         npad = -(-info.cout // 128) * 128
         wp = packed[off:off + ncls * ksteps * npad * 32].reshape(ncls, ksteps, npad, 32)
         rng = np.random.RandomState(hash(name) % 1000)
@@ -120,10 +120,7 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
             cls, s, n = rng.randint(ncls), rng.randint(ksteps), rng.randint(info.cout)
             row = _unswizzle_row(wp[cls, s, n], n, dtype)
             exp = np.zeros(bke, np.float32)
-            if info.has_coord and s == ksteps - 1:
-                for tap in range(9):
-                    exp[tap] = wt[tap // 3, tap % 3, info.cin, n]
-            else:
+            if True:
                 tap, within = divmod(s, cpt0 + cpt1)
                 src, chunk = (0, within) if within < cpt0 else (1, within - cpt0)
                 base, csrc = (0, c0) if src == 0 else (c0, c1)
@@ -151,6 +148,25 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
             assert np.array_equal(packed[off_next:off_next + info.cout], w[name + "/LayerNorm/gamma"])
         # next layer's packed offset: walk by the library's own rule (64-float alignment)
         r4 = -(-info.cout // 4) * 4
-        off = off_next + 2 * r4 + (info.out_h * 5 * 32 if info.has_coord else 0)
+        off = off_next + 2 * r4
+        if info.has_coord:
+            # CoordNet bias table: sum over the in-image taps of coord[ih] * w[kh, kw, cin, n]
+            tab = packed[off:off + info.out_h * 5 * r4].reshape(info.out_h, 5, r4)
+            coord = rnd(np.abs(np.sin(np.linspace(-np.pi / 2.0, np.pi / 2.0, info.in_h))).astype(np.float32)).astype(np.float64)
+            wc = rnd(wt[:, :, info.cin, :]).astype(np.float64)                     # [3,3,Cout]
+            keff = 2 * info.rate + 1
+            pad_t = max((info.out_h - 1) * info.stride + keff - info.in_h, 0) // 2
+            pad_l = max((info.out_w - 1) * info.stride + keff - info.in_w, 0) // 2
+            reps = [0, 1, 2, info.out_w - 2, info.out_w - 1]
+            for mh in (0, 1, info.out_h // 2, info.out_h - 1):
+                for cc, mw in enumerate(reps):
+                    exp = np.zeros(info.cout)
+                    for kh in range(3):
+                        for kw in range(3):
+                            ih, iw = mh * info.stride - pad_t + kh * info.rate, mw * info.stride - pad_l + kw * info.rate
+                            if 0 <= ih < info.in_h and 0 <= iw < info.in_w:
+                                exp += coord[ih] * wc[kh, kw]
+                    assert np.allclose(tab[mh, cc, :info.cout], exp, rtol=1e-6, atol=1e-7), (name, mh, cc)
+            off += tab.size
         off = -(-off // 64) * 64
     assert off == packed.size
