@@ -65,6 +65,7 @@ constexpr int COORD_CLASSES = 5;    // column border classes of the CoordNet tab
 [[maybe_unused]] constexpr unsigned OOB = 0x80000000u;  // per-lane offset that is out of range of every descriptor (device code)
 constexpr int NUM_CUS = 256;
 constexpr int MAX_SPLIT = 8;
+constexpr int CNT_PER_LAYER = 2 * NUM_CUS;   // split tiles per launch: < 256 remainder tiles, or < 512 when the first group is split too
 constexpr size_t PARTIAL_BYTES = (size_t)NUM_CUS * MAX_SPLIT * 128 * 64 * sizeof(float);  // < 256 split tiles x 8 ranges
 constexpr double LN_EPS = 1e-12;  // slim.layer_norm variance epsilon [TF-knowledge]
 
@@ -82,6 +83,7 @@ struct ConvParams {
   float *y;                  // raw output NHWC [B,Hout,Wout,Cout]
   float *stats;              // [B][nparts][4] (count, mean, M2, -) or null
   float *partial;            // [split tiles][split][BM*BN] partial accumulators
+  int *tile_cnt;             // [split tiles] arrival tickets of the in-launch fix-up (zeroed per forward), or null
   int tiles_m, tiles_n, ntiles;  // output tiles per (sample, class) and in the whole launch
   int n_main, split0, split; // the first n_main tiles are cut into split0 K-ranges each (1 = whole), the rest into split
   int nb_main;               // n_main * split0: workgroups of the first group
@@ -523,7 +525,7 @@ _Pragma("unroll")                                                               
   // interior tile (the common case): no row / channel masks anywhere in the epilogue -- its VALU work is
   // paid in matrix throughput of the co-resident workgroups
   const bool interior = (tile_m + 1) * BM <= mtot && (tile_n + 1) * BN <= p.Cout;
-  const bool want_stats = MODE != MODE_HEAD && full && p.stats != nullptr;
+  const bool want_stats = MODE != MODE_HEAD && p.stats != nullptr;   // (only workgroups that emit a tile get that far)
   if (MODE == MODE_HEAD && full) {   // bias + tanh in registers
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -543,10 +545,58 @@ _Pragma("unroll")                                                               
   constexpr int C4 = BN / 4;                       // float4 per staged row
   constexpr int PASSES = SROWS * C4 / 256;
   const bool vec_ok = (p.Cout & 3) == 0;
-  const bool has_cb = MODE == MODE_CONV && full && p.coord_bias != nullptr;
+  const bool has_cb = MODE == MODE_CONV && p.coord_bias != nullptr;
   float *pdst = full ? nullptr : p.partial + (size_t)slot * (BM * BN);   // K-range of a split tile: raw accumulators, row-major [BM][BN]
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(full ? p.partial : pdst), 0, BM * BN * 4, 0x00020000);   // this K-range's slab
   v4f keep[MT][PASSES];
   float lsum = 0.f, lcnt = 0.f;
+  // one 16-byte piece (tile row LROW_, channels 4*C4_..+4) of the finished tile: CoordNet table, store, statistics
+#define MSI_EMIT(V_, I_, K_, LROW_, C4_)                                                                      \
+  {                                                                                                           \
+    v4f v = (V_);                                                                                             \
+    const int m = tile_m * BM + (LROW_);                                                                      \
+    const int n = tile_n * BN + (C4_) * 4;                                                                    \
+    if (interior || (m < mtot && n < p.Cout)) {                                                               \
+      size_t opix;                                                                                            \
+      if (MODE == MODE_CONVT) {                                                                               \
+        const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);                                 \
+        const int mw = m - mh * p.Mw;                                                                         \
+        opix = ((size_t)b * p.Hout + (2 * mh + ph)) * p.Wout + (2 * mw + pw);                                 \
+      } else {                                                                                                \
+        opix = (size_t)b * mtot + m;                                                                          \
+        if (has_cb) {                                                                                         \
+          const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);                               \
+          const int mw = m - mh * p.Mw;                                                                       \
+          const v4f cb = *reinterpret_cast<const v4f *>(                                                      \
+              p.coord_bias + (size_t)(mh * COORD_CLASSES + coord_class(mw, p.Mw)) * p.cb_stride + n);         \
+          v.x += cb.x; v.y += cb.y; v.z += cb.z; v.w += cb.w;                                                 \
+        }                                                                                                     \
+      }                                                                                                       \
+      float *dst = p.y + opix * p.Cout + n;                                                                   \
+      if (vec_ok) {                                                                                           \
+        *reinterpret_cast<v4f *>(dst) = v;                                                                    \
+      } else {                                                                                                \
+        dst[0] = v.x;                                                                                         \
+        if (n + 1 < p.Cout) dst[1] = v.y;                                                                     \
+        if (n + 2 < p.Cout) dst[2] = v.z;                                                                     \
+        if (n + 3 < p.Cout) dst[3] = v.w;                                                                     \
+      }                                                                                                       \
+      if (want_stats) {                                                                                       \
+        if (interior || n + 3 < p.Cout) {                                                                     \
+          lcnt += 4.f;                                                                                        \
+        } else { /* channel tail inside the last float4 */                                                    \
+          if (n + 1 >= p.Cout) v.y = 0.f;                                                                     \
+          if (n + 2 >= p.Cout) v.z = 0.f;                                                                     \
+          if (n + 3 >= p.Cout) v.w = 0.f;                                                                     \
+          lcnt += (float)(p.Cout - n);                                                                        \
+        }                                                                                                     \
+        lsum += (v.x + v.y) + (v.z + v.w);                                                                    \
+        keep[I_][K_] = v;                                                                                     \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     if (i > 0) __syncthreads();                    // the previous pass has been read out
@@ -561,52 +611,79 @@ _Pragma("unroll")                                                               
       const int idx = tid + 256 * k;
       const int srow = idx / C4, c4 = idx - srow * C4;
       const int lrow = (srow >> 5) * (MT * 32) + i * 32 + (srow & 31);   // staged row -> tile row
-      v4f v = *reinterpret_cast<const v4f *>(ct + srow * LDW + c4 * 4);
+      const v4f sv = *reinterpret_cast<const v4f *>(ct + srow * LDW + c4 * 4);
       keep[i][k] = v4f{0.f, 0.f, 0.f, 0.f};
       if (!full) {
-        *reinterpret_cast<v4f *>(pdst + lrow * BN + c4 * 4) = v;
+        if (p.tile_cnt != nullptr)   // write-through (sc1): visible to the reducer on any XCD without a release fence
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, sv), rsrc_p, (unsigned)((lrow * BN + c4 * 4) * 4), 0, 16);
+        else
+          *reinterpret_cast<v4f *>(pdst + lrow * BN + c4 * 4) = sv;
         continue;
       }
-      const int m = tile_m * BM + lrow;
-      const int n = tile_n * BN + c4 * 4;
-      if (!interior && (m >= mtot || n >= p.Cout)) continue;
-      size_t opix;
-      if (MODE == MODE_CONVT) {
-        const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);
-        const int mw = m - mh * p.Mw;
-        opix = ((size_t)b * p.Hout + (2 * mh + ph)) * p.Wout + (2 * mw + pw);
-      } else {
-        opix = (size_t)b * mtot + m;
-        if (has_cb) {
-          const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);
-          const int mw = m - mh * p.Mw;
-          const v4f cb = *reinterpret_cast<const v4f *>(p.coord_bias + (size_t)(mh * COORD_CLASSES + coord_class(mw, p.Mw)) * p.cb_stride + n);
-          v.x += cb.x; v.y += cb.y; v.z += cb.z; v.w += cb.w;
-        }
-      }
-      float *dst = p.y + opix * p.Cout + n;
-      if (vec_ok) {
-        *reinterpret_cast<v4f *>(dst) = v;
-      } else {
-        dst[0] = v.x;
-        if (n + 1 < p.Cout) dst[1] = v.y;
-        if (n + 2 < p.Cout) dst[2] = v.z;
-        if (n + 3 < p.Cout) dst[3] = v.w;
-      }
-      if (want_stats) {
-        if (interior || n + 3 < p.Cout) {
-          lcnt += 4.f;
-        } else {   // channel tail inside the last float4
-          if (n + 1 >= p.Cout) v.y = 0.f;
-          if (n + 2 >= p.Cout) v.z = 0.f;
-          if (n + 3 >= p.Cout) v.w = 0.f;
-          lcnt += (float)(p.Cout - n);
-        }
-        lsum += (v.x + v.y) + (v.z + v.w);
-        keep[i][k] = v;
-      }
+      MSI_EMIT(sv, i, k, lrow, c4)
     }
   }
+  if (!full) {
+    // ---- K-range of a split tile: the LAST of the tile's workgroups to arrive sums the partial accumulators in k
+    // order (deterministic whoever is last) and emits the tile.  Hand-off per cdna_hip_programming.md (in-launch
+    // split-K, write-through form): sc1 slab stores -> vmcnt(0) -> workgroup barrier -> one lane takes a relaxed
+    // agent-scope ticket; the last arriver reads the slabs with sc1 loads.  (MSI_CONV_FIXUP=kernel: separate launch.)
+    if (p.tile_cnt == nullptr) {
+#ifdef MSI_CONV_TIMING
+      stamp();
+#endif
+      return;
+    }
+    if constexpr (MT == 1) {
+      const int nsp = t < p.n_main ? p.split0 : p.split;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have left (sc1: written through)
+      __syncthreads();
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+        reinterpret_cast<int *>(wpart)[15] = old;
+      }
+      __syncthreads();
+      const int old = reinterpret_cast<int *>(wpart)[15];
+      if (old != nsp - 1) {
+#ifdef MSI_CONV_TIMING
+        stamp();
+#endif
+        return;
+      }
+      // the last arriver reads every slab with sc1 loads (coherent with the sc1 stores: no acquire fence)
+      const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)(p.partial + (size_t)(slot - ks) * (BM * BN)), 0, nsp * BM * BN * 4, 0x00020000);
+      v4f sumv[PASSES];
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k)
+        sumv[k] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_t, (unsigned)((tid + 256 * k) * 16), 0, 16));
+      for (int s2 = 1; s2 < nsp; ++s2) {
+        v4f tv[PASSES];
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k)
+          tv[k] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_t, (unsigned)((tid + 256 * k) * 16), s2 * BM * BN * 4, 16));
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k) { sumv[k].x += tv[k].x; sumv[k].y += tv[k].y; sumv[k].z += tv[k].z; sumv[k].w += tv[k].w; }
+      }
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) {
+        const int idx = tid + 256 * k;
+        const int lrow = idx / C4, c4 = idx - lrow * C4;
+        if (MODE == MODE_HEAD) {
+          const int n = tile_n * BN + c4 * 4;
+          sumv[k].x = tanhf(sumv[k].x + p.bias[min(n, p.Cout - 1)]);
+          sumv[k].y = tanhf(sumv[k].y + p.bias[min(n + 1, p.Cout - 1)]);
+          sumv[k].z = tanhf(sumv[k].z + p.bias[min(n + 2, p.Cout - 1)]);
+          sumv[k].w = tanhf(sumv[k].w + p.bias[min(n + 3, p.Cout - 1)]);
+        }
+        MSI_EMIT(sumv[k], 0, k, lrow, c4)
+      }
+    } else {
+      return;   // (big tiles are never split)
+    }
+  }
+#undef MSI_EMIT
   if (want_stats) {
     auto wave_sum = [&](float x) __attribute__((always_inline)) -> float {   // butterfly: every lane gets the total
 #pragma unroll
@@ -943,6 +1020,7 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Net {
   std::vector<Layer> layers;
   size_t param_floats = 0, packed_floats = 0, ws_bytes = 0, stats_off = 0, stats_bytes = 0, partial_off = 0;
+  size_t cnt_off = 0;   // arrival tickets of the in-launch fix-up: [layer][CNT_PER_LAYER] ints, zeroed per forward
 };
 
 int build_net(const msi_net_desc *d, Net &net) {
@@ -1061,7 +1139,8 @@ int build_net(const msi_net_desc *d, Net &net) {
   net.stats_off = woff;
   net.stats_bytes = round_up((size_t)d->batch * max_parts * 4 * sizeof(float), 256);
   net.partial_off = woff + net.stats_bytes;
-  net.ws_bytes = net.partial_off + PARTIAL_BYTES;
+  net.cnt_off = net.partial_off + PARTIAL_BYTES;
+  net.ws_bytes = net.cnt_off + round_up((size_t)MSI_NET_NUM_LAYERS * CNT_PER_LAYER * sizeof(int), 256);
   return MSI_OK;
 }
 
@@ -1111,6 +1190,7 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   p.mg_sp = magic(p.split);
   const int nblocks = p.nb_main + (p.ntiles - p.n_main) * p.split;
   const int nfix = (p.split0 > 1 ? p.n_main : 0) + (p.split > 1 ? p.ntiles - p.n_main : 0);
+  if (nfix > CNT_PER_LAYER) p.tile_cnt = nullptr;   // (cannot happen with the split rules above; falls back to the fix-up launch)
   if ((size_t)(nblocks - (p.split0 == 1 ? p.nb_main : 0)) * BM * BN * sizeof(float) > PARTIAL_BYTES)
     return msi::fail(MSI_E_WORKSPACE, "conv: %d partial accumulators exceed the workspace", nblocks);
   const size_t lds = (size_t)NSTAGE * (BM + BN) * ROW_BYTES;
@@ -1125,7 +1205,7 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, BF16>), dim3(nblocks), dim3(256), lds, stream, p);
   int rc = msi::check_launch("conv_igemm");
-  if (rc || nfix == 0) return rc;
+  if (rc || nfix == 0 || p.tile_cnt != nullptr) return rc;
   hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, MODE>), dim3(nfix), dim3(256), 0, stream, p);
   return msi::check_launch("conv_fixup");
 }
@@ -1341,6 +1421,14 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
   const char *fenv = getenv("MSI_HEAD_FUSE_LN");
   const bool fuse_head_ln = !bf16 && !(fenv && atoi(fenv) == 0);
   const int head_src = net.layers[MSI_NET_NUM_LAYERS - 1].src0;
+  // in-launch fix-up of the split tiles (default) or the separate conv_fixup_kernel launch (MSI_CONV_FIXUP=kernel)
+  const char *fxenv = getenv("MSI_CONV_FIXUP");
+  const bool inlaunch_fixup = !(fxenv && strcmp(fxenv, "kernel") == 0);
+  int *cnt = reinterpret_cast<int *>(ws + net.cnt_off);
+  if (inlaunch_fixup) {
+    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)MSI_NET_NUM_LAYERS * CNT_PER_LAYER * sizeof(int), stream);
+    if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_forward: %s", hipGetErrorString(e));
+  }
   for (int li = 0; li < MSI_NET_NUM_LAYERS; ++li) {
     const Layer &L = net.layers[li];
     ConvParams p;
@@ -1368,6 +1456,7 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
     p.y = L.kind == MODE_HEAD ? pred : reinterpret_cast<float *>(ws + L.raw_off);
     p.stats = L.kind == MODE_HEAD ? nullptr : stats;
     p.partial = reinterpret_cast<float *>(ws + net.partial_off);
+    p.tile_cnt = inlaunch_fixup ? cnt + (size_t)li * CNT_PER_LAYER : nullptr;
     p.Hin = L.in_h; p.Win = L.in_w; p.Hout = L.out_h; p.Wout = L.out_w;
     p.Cout = L.cout; p.npad = L.npad;
     p.ntaps = L.ntaps; p.cpt0 = L.cpt0; p.cpt1 = L.cpt1; p.ksteps = L.ksteps;
