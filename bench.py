@@ -70,9 +70,9 @@ def cnn_flops(h, w, cin, nout, ngf, coord):
 
 def cnn_traffic():
     """HBM bytes per frame of the conv kernels (18 launches) from the committed PMC passes
-    (profiles/r01_k_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH
+    (profiles/r01_l_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH
     doubled per the gfx950 note of MI355X_MICROARCH.md); None if the profile is not present."""
-    path = os.path.join(ROOT, "profiles", "r01_k_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_l_hbm_traffic.json")
     try:
         with open(path) as f:
             k = json.load(f)["kernels"]["conv_igemm_kernel"]
@@ -240,7 +240,7 @@ def main():
         "roofline": {"kernel": "conv_igemm_kernel (18 launches/frame, fp32 MFMA implicit GEMM; + 17 ln_finish)",
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": cnn_traffic(),
-                     "traffic_note": "HBM bytes per frame of the 18 conv launches, profiles/r01_k_hbm_traffic.json "
+                     "traffic_note": "HBM bytes per frame of the 18 conv launches, profiles/r01_l_hbm_traffic.json "
                                      "(separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH correction)",
                      "launches_per_frame": 18, "algorithmic_flops_per_frame": flops,
                      "ms_per_frame": round(stage_ms["cnn"], 4),
