@@ -26,18 +26,21 @@
 // One kernel template serves every layer:
 //   * conv3x3 (stride 1/2, rate 1/2, SAME-zero or wrap padding), the 1x1 head,
 //     and conv-transpose 4x4 s2 as four output-parity sub-convolutions of 2x2
-//     taps each (blockIdx.z selects the parity class);
+//     taps each (a class index in the 1-D grid);
 //   * GEMM view: M = pixels of one sample, N = Cout, K = taps x Cin, walked in
 //     k-steps of 32 channels of one tap; two sources = skip concat by descriptor pair;
 //   * CoordNet's |sin(lat)| channel (nets.py:260-265) is constant along W and independent of the image:
 //     its share of the convolution is a host-built table [out row][column border class][Cout] that the
 //     epilogue adds to the accumulators (no extra k-step);
 //   * the epilogue writes the raw conv output and one (count, mean, M2) partial
-//     per workgroup; ln_apply_kernel merges the partials in fp64 in a fixed order (Chan)
-//     into the per-channel scale/shift and normalises in place.
+//     per workgroup; ln_apply_kernel merges the partials in fp64 in a fixed order
+//     into the per-channel scale/shift and normalises in place (the 1x1 head applies its
+//     producer's affine + ReLU itself while loading);
+//   * bf16 operands (BF16 = 1): the same 128-byte rows hold 64 channels, v_mfma_f32_32x32x16_bf16.
 //
 // Tiling: 256 threads = 4 wavefronts (2x2), wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, BK=32;
-// work decomposition ("tail split") and the measured alternatives: DESIGN.md section 4.
+// work decomposition ("tail split": the tiles of the partial last wave are cut along K inside the launch, the
+// last arriving workgroup of a tile sums the partial accumulators) and the measured alternatives: DESIGN.md 4.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
