@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+_HEAD_FUSED = __import__("os").environ.get("MSI_HEAD_FUSE_LN") != "0"   # debug knob: separate LayerNorm pass before the head
 
 
 @pytest.fixture(scope="module")
@@ -45,7 +46,7 @@ def _run(env, b, h, w, cin, nout, ngf, coord, seed=0):
 def test_net_matches_oracle(env, coord, b, h, w, cin, nout, ngf):
     pred, ref, raws, acts = _run(env, b, h, w, cin, nout, ngf, coord)
     for name, raw in raws.items():
-        o = acts[name + "/raw"] if name == "conv8_2" else acts[name]   # the head applies conv8_2's LayerNorm itself
+        o = acts[name + "/raw"] if name == "conv8_2" and _HEAD_FUSED else acts[name]   # the head applies conv8_2's LayerNorm itself
         assert raw.shape == o.shape, name
         scale = np.abs(o).max() + 1e-12
         err = np.abs(raw - o).max() / scale
@@ -59,7 +60,7 @@ def test_net_reference_width_channels(env):
     the two-source skip concat at 1024/512/256 channels and Cout=512 layers."""
     pred, ref, raws, acts = _run(env, 1, 16, 32, 48, 16, 64, True, seed=5)
     for name, raw in raws.items():
-        o = acts[name + "/raw"] if name == "conv8_2" else acts[name]
+        o = acts[name + "/raw"] if name == "conv8_2" and _HEAD_FUSED else acts[name]
         err = np.abs(raw - o).max() / (np.abs(o).max() + 1e-12)
         assert err < 2e-4, "%s: relative max err %g" % (name, err)
     assert np.abs(pred - ref).max() <= 1e-3
