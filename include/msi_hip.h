@@ -114,6 +114,21 @@ int msi_assemble_rgba_bf16psv_f32(const void *psv_bf16, const float *pred, float
                                   float *blend_weights, float *alphas, int32_t batch, int32_t height,
                                   int32_t width, int32_t num_planes, msi_stream_t stream);
 
+/* The other colour schemes of infer_msi (FLAGS.which_color_pred, test.py:55-56; msi.py:166-275).  pred holds
+ *   MSI_COLOR_BLEND_PSV    [w | alpha]                2D   channels  (= msi_assemble_rgba_f32)
+ *   MSI_COLOR_BLEND_BG     [w | alpha | bg rgb]       2D+3           rgb = w psv_ref + (1-w) bg          (msi.py:177-188)
+ *   MSI_COLOR_BLEND_BG_PSV [w | alpha | bw | bg rgb]  3D+3           rgb = bw (w psv_ref + (1-w) psv_src) + (1-bw) bg
+ *   MSI_COLOR_ALPHA_ONLY   [alpha]                    D              rgb = psv_ref                       (msi.py:258-268)
+ * with w, alpha, bw = (x+1)/2 and bg the raw tanh output.  psv [B,H,W,6D] fp32, or bf16 when psv_is_bf16 != 0;
+ * blend_weights / alphas / bg_blend_weights [B,H,W,D] may be NULL (msi.py:276-289). */
+#define MSI_COLOR_BLEND_PSV 0
+#define MSI_COLOR_BLEND_BG 1
+#define MSI_COLOR_BLEND_BG_PSV 2
+#define MSI_COLOR_ALPHA_ONLY 3
+int msi_assemble_rgba_color_f32(const void *psv, int32_t psv_is_bf16, const float *pred, int32_t which_color_pred,
+                                float *rgba_native, float *blend_weights, float *alphas, float *bg_blend_weights,
+                                int32_t batch, int32_t height, int32_t width, int32_t num_planes, msi_stream_t stream);
+
 /* High-res re-render (test.py:283-394): the per-plane loop there is (a) the high-res sphere
  * sweep (msi_ods_sphere_sweep_f32 at the high resolution), (b) tf.image.resize(BILINEAR,
  * align_corners=True) of the low-res blend weights / alphas (test.py:319-325), (c) the blend of
@@ -183,9 +198,10 @@ int msi_mpi_render_f32(const float *rgba_native, const float *tgt_pose, const fl
  * nets.msi_coord_train_net (nets.py:471-515; coord_net=1) and nets.msi_train_net
  * (nets.py:387-450; coord_net=0): 14x conv3x3 (+|sin(lat)| coordinate channel,
  * nets.py:260-270), 3x conv-transpose 4x4 s2, LayerNorm over (H,W,C) + ReLU after
- * each, 1x1 tanh head with bias.  Implicit-GEMM on fp32 MFMA; LayerNorm statistics
- * are produced by the conv epilogue and applied (with the ReLU) in the consumer's
- * operand loader. */
+ * each, 1x1 tanh head with bias.  Implicit-GEMM on fp32 MFMA; LayerNorm sums are produced by the conv
+ * epilogue (exact fixed-point accumulation) and applied with the ReLU by one in-place pass per layer (the
+ * head applies its source's itself).  msi_train_net's conv-transposes are normalised over their uncropped
+ * (2H+10) x (2W+10) VALID output, as nets.py:423-435 does, before the [5:-5] crop. */
 typedef struct msi_net_desc {
   int32_t batch, height, width; /* height, width multiples of 8 */
   int32_t in_channels;          /* 6*D */
@@ -226,7 +242,33 @@ size_t msi_net_packed_floats(const msi_net_desc *desc);
 int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params_host,
                               float *packed_host);
 size_t msi_net_workspace_bytes(const msi_net_desc *desc);
-/* net_input [B,H,W,in_channels] -> pred [B,H,W,num_outputs]. */
+
+/* A plan resolves everything about a descriptor that does not depend on the buffers -- layer table, tile
+ * choice and work decomposition per layer, workspace layout, the CU count of the current device
+ * (hipDeviceProp.multiProcessorCount) -- once, so that msi_net_plan_forward does no allocation and no
+ * per-layer set-up arithmetic.  The plan is host memory owned by the caller (create / destroy); forward takes
+ * it const and keeps all per-call state on the stack: concurrent forwards on one plan (different streams,
+ * different workspaces) are safe.  Options replace what used to be environment variables; they are per plan,
+ * never process-global, and changing one re-plans (query msi_net_plan_workspace_bytes again afterwards). */
+typedef struct msi_net_plan msi_net_plan;
+#define MSI_NET_OPT_FIXUP_KERNEL 0 /* 0 (default): split tiles are summed inside the conv launch (last arriver);  */
+                                   /* 1: by a separate conv_fixup_kernel launch (bitwise-identical results)       */
+#define MSI_NET_OPT_TAILSPLIT 1    /* 1 (default): cut the tiles of the partial last wave over the CUs along K    */
+#define MSI_NET_OPT_BIGTILE 2      /* bf16 tile choice: 0 never 128x128 / 128x64, 1 (default) by grid size, 2 always */
+#define MSI_NET_OPT_HEAD_FUSE_LN 3 /* 1 (default): the fp32 head applies its source's LayerNorm while loading      */
+#define MSI_NET_OPT_NUM_CUS 4      /* CUs the work decomposition balances over (default: the device's count)      */
+#define MSI_NET_OPT_COUNT 5
+int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
+void msi_net_plan_destroy(msi_net_plan *plan);
+int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);
+size_t msi_net_plan_workspace_bytes(const msi_net_plan *plan);
+/* net_input [B,H,W,in_channels] (fp32, or bf16 when desc.dtype = MSI_DTYPE_BF16) -> pred [B,H,W,num_outputs] fp32. */
+int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
+                         void *workspace, size_t workspace_bytes, msi_stream_t stream);
+
+/* Descriptor-level convenience: the two calls below build a transient plan per call (set-up time, tests); the
+ * frame loop uses msi_net_plan_forward.
+ * net_input [B,H,W,in_channels] -> pred [B,H,W,num_outputs]. */
 int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const float *net_input,
                         float *pred, void *workspace, size_t workspace_bytes,
                         msi_stream_t stream);

@@ -26,6 +26,8 @@ class NetDesc(Structure):
 
 
 MSI_DTYPE_F32, MSI_DTYPE_BF16 = 0, 1
+# msi_net_plan_set_option keys (include/msi_hip.h)
+NET_OPT_FIXUP_KERNEL, NET_OPT_TAILSPLIT, NET_OPT_BIGTILE, NET_OPT_HEAD_FUSE_LN, NET_OPT_NUM_CUS = 0, 1, 2, 3, 4
 
 
 class LayerInfo(Structure):
@@ -53,6 +55,7 @@ SIGNATURES = {
     "msi_ods_sphere_sweep_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "msi_assemble_rgba_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msi_assemble_rgba_bf16psv_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msi_assemble_rgba_color_f32": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msi_resize_bilinear_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msi_assemble_rgba_scaled_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "msi_render_equirect_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
@@ -66,6 +69,11 @@ SIGNATURES = {
     "msi_net_packed_floats": (c_size_t, [POINTER(NetDesc)]),
     "msi_net_pack_weights_host": (_I, [POINTER(NetDesc), _P, _P]),
     "msi_net_workspace_bytes": (c_size_t, [POINTER(NetDesc)]),
+    "msi_net_plan_create": (_I, [POINTER(NetDesc), POINTER(c_void_p)]),
+    "msi_net_plan_destroy": (None, [_P]),
+    "msi_net_plan_set_option": (_I, [_P, _I, _I]),
+    "msi_net_plan_workspace_bytes": (c_size_t, [_P]),
+    "msi_net_plan_forward": (_I, [_P, _P, _P, _P, _P, c_size_t, _P]),
     "msi_net_forward_f32": (_I, [POINTER(NetDesc), _P, _P, _P, _P, c_size_t, _P]),
     "msi_net_forward_bf16": (_I, [POINTER(NetDesc), _P, _P, _P, _P, c_size_t, _P]),
 }
@@ -96,6 +104,29 @@ lib = _load()
 
 def last_error():
     return lib.msi_last_error_string().decode("utf-8", "replace")
+
+
+class NetPlan(object):
+    """Owner of a msi_net_plan (host memory of the native library)."""
+
+    def __init__(self, desc, options=None):
+        h = c_void_p()
+        check(lib.msi_net_plan_create(desc, ctypes.byref(h)), "msi_net_plan_create")
+        self.handle = h
+        self._destroy = lib.msi_net_plan_destroy     # (module globals may be gone at interpreter shutdown)
+        for key, value in (options or {}).items():
+            self.set_option(key, value)
+
+    def set_option(self, key, value):
+        check(lib.msi_net_plan_set_option(self.handle, int(key), int(value)), "msi_net_plan_set_option")
+
+    def workspace_bytes(self):
+        return lib.msi_net_plan_workspace_bytes(self.handle)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self._destroy(h)
 
 
 def check(rc, what):

@@ -32,10 +32,14 @@
 //   * CoordNet's |sin(lat)| channel (nets.py:260-265) is constant along W and independent of the image:
 //     its share of the convolution is a host-built table [out row][column border class][Cout] that the
 //     epilogue adds to the accumulators (no extra k-step);
-//   * the epilogue writes the raw conv output and one (count, mean, M2) partial
-//     per workgroup; ln_apply_kernel merges the partials in fp64 in a fixed order
-//     into the per-channel scale/shift and normalises in place (the 1x1 head applies its
-//     producer's affine + ReLU itself while loading);
+//   * the accumulators are kept TRANSPOSED (weights are the MFMA's row operand): a lane owns one
+//     pixel and 16 channels in four runs of four, so the epilogue stores 16-byte pieces straight
+//     from registers (no LDS staging, no barrier) and takes the LayerNorm sums from the same registers;
+//   * LayerNorm statistics: every wave adds its (sum x, sum x^2) -- formed about a wave-uniform pivot in fp32,
+//     completed in fp64 -- to 64 sharded FIXED-POINT accumulators with integer atomics: integer addition is
+//     associative, so the totals are bit-identical whatever the arrival order, and the consumer
+//     (ln_apply_kernel, or the 1x1 head while loading) derives mean / variance from 64 x 4 words instead of
+//     merging thousands of per-workgroup partials;
 //   * bf16 operands (BF16 = 1): the same 128-byte rows hold 64 channels, v_mfma_f32_32x32x16_bf16.
 //
 // Tiling: 256 threads = 4 wavefronts (2x2), wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, BK=32;
@@ -46,6 +50,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "msi_common.h"
@@ -66,11 +71,14 @@ constexpr int NSTAGE = MSI_NSTAGE;  // LDS ring depth: NSTAGE-1 k-steps of DMA i
 constexpr int NPAD_ALIGN = 128;
 constexpr int COORD_CLASSES = 5;    // column border classes of the CoordNet table: 0,1 | interior | W-2,W-1
 [[maybe_unused]] constexpr unsigned OOB = 0x80000000u;  // per-lane offset that is out of range of every descriptor (device code)
-constexpr int NUM_CUS = 256;
+constexpr int DEFAULT_CUS = 256;  // MI355X; the plan queries hipDeviceProp.multiProcessorCount (option MSI_NET_OPT_NUM_CUS overrides)
 constexpr int MAX_SPLIT = 8;
-constexpr int CNT_PER_LAYER = 2 * NUM_CUS;   // split tiles per launch: < 256 remainder tiles, or < 512 when the first group is split too
-constexpr size_t PARTIAL_BYTES = (size_t)NUM_CUS * MAX_SPLIT * 128 * 64 * sizeof(float);  // < 256 split tiles x 8 ranges
 constexpr double LN_EPS = 1e-12;  // slim.layer_norm variance epsilon [TF-knowledge]
+// LayerNorm sums: [sample][LN_SHARDS][4] signed 64-bit fixed point {S1 hi, S1 lo, S2 hi, S2 lo},
+// value = hi * 2^-8 + lo * 2^-52 (hi carries the integer part and 8 fraction bits, lo the next 44)
+constexpr int LN_SHARDS = 64;
+constexpr double LN_HI_SCALE = 256.0, LN_LO_SCALE = 17592186044416.0 /* 2^44, applied to the residue of S * 2^8 */;
+constexpr int HEAD_MAX_C = 256;   // the head's fused LayerNorm keeps scale | shift of its source in LDS
 
 enum { MODE_CONV = 0, MODE_CONVT = 1, MODE_HEAD = 2 };
 
@@ -80,12 +88,14 @@ struct ConvParams {
   const char *wpk;           // packed weights [nclass][ksteps][npad][128 B], slots pre-swizzled
   const float *coord_bias;   // CoordNet: contribution of the |sin(lat)| channel, [Mh][COORD_CLASSES][cb_stride] fp32, or null
   int cb_stride;
-  const float *ln_aff;       // head, fp32 only: [B][scale[C0] | shift[C0]] of the source's LayerNorm, applied (+ ReLU) while
+  const long long *ln_sums;  // head, fp32 only: the LayerNorm sums of the source layer; its affine (+ ReLU) is applied while
                              // loading (the source buffer then holds the RAW conv output); null = source already normalised
+  const float *ln_gamma, *ln_beta;   // ... with the source layer's gamma / beta
+  double ln_inv_n;           // ... and 1 / (elements per sample)
   const float *bias;         // head only
   float *y;                  // raw output NHWC [B,Hout,Wout,Cout]
-  float *stats;              // [B][nparts][4] (count, mean, M2, -) or null
-  float *partial;            // [split tiles][split][BM*BN] partial accumulators
+  long long *sums;           // LayerNorm sums of THIS layer [B][LN_SHARDS][4] (zeroed per forward), or null
+  float *partial;            // [split tiles][split][BM*BN] partial accumulators (register order, see dump_acc)
   int *tile_cnt;             // [split tiles] arrival tickets of the in-launch fix-up (zeroed per forward), or null
   int tiles_m, tiles_n, ntiles;  // output tiles per (sample, class) and in the whole launch
   int n_main, split0, split; // the first n_main tiles are cut into split0 K-ranges each (1 = whole), the rest into split
@@ -100,16 +110,21 @@ struct ConvParams {
 #ifdef MSI_CONV_TIMING
   unsigned long long *dbg;   // [block][6]: s_memtime at start, loop start, loop end, end; HW_ID; XCC_ID (tools/conv_timing.py)
 #endif
-  int ablate;                // debug only (MSI_CONV_ABLATE): 1 = skip the k-loop DMA (results are garbage)
 };
 
 // Input offset (rows or columns) of tap-row / tap-column variant v.
+// wrapt (conv-transpose of msi_train_net only): the reference runs conv2d_transpose(wrap_pad(x, 2, 2), VALID) and
+// LayerNorm + ReLU over its FULL (2H+10) x (2W+10) output before cropping [5:-5] (nets.py:423-435), so the border
+// enters the statistics.  The GEMM rows of a parity class then cover the whole non-zero part of that output:
+// row (mh, mw), mh in [0, H], mw in [0, W+4]  <->  full output (2 (mh + 2) + ph, 2 mw + pw); tap v uses kernel index
+// parity + 2 v and input row mh - v (zero outside [0, H)), padded input column mw - v (valid in [0, W+4), i.e. image
+// column (mw - v - 2) mod W).  Rows 0..3 and 2H+6..2H+9 of the full output are exactly zero and only enter the count.
 template <int MODE>
-__device__ __forceinline__ int tap_delta(int v, int parity, int rate) {
+__device__ __forceinline__ int tap_delta(int v, int parity, int rate, bool wrapt) {
   if (MODE == MODE_CONV) return v * rate;
-  // conv-transpose, y[2i + k - 1] += x[i] w[k]: even outputs use k=1 (i = o/2) and k=3 (i = o/2 - 1),
+  // conv-transpose (SAME), y[2i + k - 1] += x[i] w[k]: even outputs use k=1 (i = o/2) and k=3 (i = o/2 - 1),
   // odd outputs k=2 (i = (o-1)/2) and k=0 (i = (o+1)/2).
-  if (MODE == MODE_CONVT) return v == 0 ? 0 : (parity ? 1 : -1);
+  if (MODE == MODE_CONVT) return wrapt ? -v : (v == 0 ? 0 : (parity ? 1 : -1));
   return 0;
 }
 
@@ -150,6 +165,215 @@ template <int N>
 __device__ __forceinline__ void wait_lgkm(v4f &x, v4f &y) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N) : "memory");
 }
+
+// ---- shared device helpers of the epilogue ----------------------------------------------------
+__device__ __forceinline__ float wave_sum(float x) {   // butterfly: every lane gets the total, fixed order
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+
+// One wave's exact share of a LayerNorm sum: S -> (hi, lo) fixed point, two integer atomics (no return value).
+__device__ __forceinline__ void ln_atomic_add(long long *dst, double S) {
+  const double sh = S * LN_HI_SCALE;             // exact (power of two)
+  const double r = rint(sh);
+  const long long hi = (long long)r;
+  const long long lo = (long long)rint((sh - r) * LN_LO_SCALE);   // residue in [-0.5, 0.5]: exact difference, |lo| <= 2^43
+  __hip_atomic_fetch_add(dst, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(dst + 1, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// mean and 1 / sqrt(var + eps) of one sample from its LN_SHARDS x 4 fixed-point sums -> s_stat[0..1] (LDS).
+// Called by all 256 threads (ends with a barrier); wave 0 adds the shards (integers: exact, any order).
+__device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n, double *s_stat, int tid) {
+  static_assert(LN_SHARDS == 64, "one shard per lane of wave 0");
+  if (tid < 64) {
+    const long long *s = sums + (size_t)tid * 4;
+    long long h1 = s[0], l1 = s[1], h2 = s[2], l2 = s[3];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      h1 += __shfl_xor(h1, off, 64);
+      l1 += __shfl_xor(l1, off, 64);
+      h2 += __shfl_xor(h2, off, 64);
+      l2 += __shfl_xor(l2, off, 64);
+    }
+    if (tid == 0) {
+      const double S1 = (double)h1 * (1.0 / LN_HI_SCALE) + (double)l1 * (1.0 / (LN_HI_SCALE * LN_LO_SCALE));
+      const double S2 = (double)h2 * (1.0 / LN_HI_SCALE) + (double)l2 * (1.0 / (LN_HI_SCALE * LN_LO_SCALE));
+      const double mu = S1 * inv_n;
+      double var = S2 * inv_n - mu * mu;
+      var = var > 0.0 ? var : 0.0;
+      s_stat[0] = mu;
+      s_stat[1] = 1.0 / sqrt(var + LN_EPS);
+    }
+  }
+  __syncthreads();
+}
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// Partial accumulators of a split tile travel in REGISTER order: piece ((i*NT + j)*4 + g) of thread tid at
+// 16-byte slot (piece * 256 + tid) of the slab -- 1 KB contiguous per wave instruction, no LDS staging.
+// aux = 16 (sc1): write-through store / L1-bypassing load, the in-launch hand-off form (cdna_hip_programming.md).
+template <int MT, int NT, int AUX>
+__device__ __forceinline__ void dump_acc(const f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int tid) {
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const v4f v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc,
+                                               (unsigned)((((i * NT + j) * 4 + g) * 256 + tid) * 16), 0, AUX);
+      }
+}
+
+// acc = slab 0 + slab 1 + ... + slab nsp-1, in ascending k whoever calls (deterministic)
+template <int MT, int NT, int AUX>
+__device__ __forceinline__ void sum_slabs(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int nsp, int slab_bytes, int tid) {
+  for (int s = 0; s < nsp; ++s) {
+    v4f t[MT][NT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          t[i][j][g] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(
+              rsrc, (unsigned)((((i * NT + j) * 4 + g) * 256 + tid) * 16), s * slab_bytes, AUX));
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (s == 0) {
+            acc[i][j][4 * g] = t[i][j][g].x; acc[i][j][4 * g + 1] = t[i][j][g].y;
+            acc[i][j][4 * g + 2] = t[i][j][g].z; acc[i][j][4 * g + 3] = t[i][j][g].w;
+          } else {
+            acc[i][j][4 * g] += t[i][j][g].x; acc[i][j][4 * g + 1] += t[i][j][g].y;
+            acc[i][j][4 * g + 2] += t[i][j][g].z; acc[i][j][4 * g + 3] += t[i][j][g].w;
+          }
+        }
+  }
+}
+
+// ---- epilogue of one finished tile: CoordNet table, bias + tanh (head), store, LayerNorm sums -----
+// Transposed accumulators (C/D layout of v_mfma_f32_32x32x2_f32 / _32x32x16_bf16 with the weights as row
+// operand): lane -> pixel (lane & 31) of the wave's 32-pixel block i; register r = 4g + e -> channel
+// 32 j + 8 g + 4 (lane >> 5) + e.  A lane therefore stores four 16-byte pieces per (i, j) straight from
+// registers (the two half-waves complete 32-byte runs, the four g a 128-byte line), adds the CoordNet
+// table -- the |sin(lat)| channel does not depend on the input, so its part of the convolution is a
+// host-built table indexed by (output row, column border class, channel) instead of a 33rd k-step -- and
+// accumulates the LayerNorm sums of what it stores.
+// Statistics: d = x - pivot with a wave-uniform sample pivot (no cancellation: |d| ~ sigma), s1 = sum d,
+// s2 = sum d^2 in fp32 over the wave's 1024 values, then sum x = n P + s1, sum x^2 = s2 + 2 P s1 + n P^2 in
+// fp64 and an exact fixed-point atomic add (ln_atomic_add).
+// INTERIOR: whole tile inside the output, no row / channel masks anywhere (the common case; epilogue VALU
+// is paid in matrix throughput of the co-resident workgroups).
+template <int BM, int BN, int MODE, bool INTERIOR>
+__device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m,
+                                               int tile_n, int cls, int b, int tid) {
+  constexpr int MT = BM / 64, NT = BN / 64;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5;
+  const int ph = cls >> 1, pw = cls & 1;
+  const int mtot = p.Mh * p.Mw;
+  const bool wrapt = MODE == MODE_CONVT && p.wrap != 0;
+  const bool vec_ok = (p.Cout & 3) == 0;
+  const bool has_cb = MODE == MODE_CONV && p.coord_bias != nullptr;
+  const bool want_stats = MODE != MODE_HEAD && p.sums != nullptr;
+  const float pivot = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0][0][0])));
+  float s1 = 0.f, s2 = 0.f, cnt = 0.f;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (lane & 31);
+    const bool mok = INTERIOR || m < mtot;
+    int mh = 0, mw = 0;
+    if (MODE == MODE_CONVT || has_cb) {
+      mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);
+      mw = m - mh * p.Mw;
+    }
+    size_t opix;
+    bool sok = mok;   // stored (wrapt: computed for the statistics, stored only inside the [5:-5] crop)
+    if (MODE == MODE_CONVT) {
+      int orow = 2 * mh + ph, ocol = 2 * mw + pw;
+      if (wrapt) {
+        orow -= 1; ocol -= 5;
+        sok = mok && orow >= 0 && orow < p.Hout && ocol >= 0 && ocol < p.Wout;
+      }
+      opix = ((size_t)b * p.Hout + orow) * p.Wout + ocol;
+    } else {
+      opix = (size_t)b * mtot + m;
+    }
+    const float *cbrow = has_cb ? p.coord_bias + (size_t)(mh * COORD_CLASSES + coord_class(mw, p.Mw)) * p.cb_stride : nullptr;
+    float *yrow = p.y + opix * p.Cout;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nb = tile_n * BN + wn * (NT * 32) + j * 32 + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nb + 8 * g;
+        const bool ok = mok && (INTERIOR || n < p.Cout);
+        v4f v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (ok) {
+          if (has_cb) {   // cb_stride is Cout rounded up to 4: the whole float4 is in range
+            const v4f cb = *reinterpret_cast<const v4f *>(cbrow + n);
+            v.x += cb.x; v.y += cb.y; v.z += cb.z; v.w += cb.w;
+          }
+          if (MODE == MODE_HEAD) {   // (the packed bias is padded to a multiple of 4 as well)
+            const v4f bs = *reinterpret_cast<const v4f *>(p.bias + n);
+            v.x = tanhf(v.x + bs.x); v.y = tanhf(v.y + bs.y); v.z = tanhf(v.z + bs.z); v.w = tanhf(v.w + bs.w);
+          }
+          if (sok) {
+            float *dst = yrow + n;
+            if (vec_ok) {
+              *reinterpret_cast<v4f *>(dst) = v;
+            } else {
+              dst[0] = v.x;
+              if (n + 1 < p.Cout) dst[1] = v.y;
+              if (n + 2 < p.Cout) dst[2] = v.z;
+              if (n + 3 < p.Cout) dst[3] = v.w;
+            }
+          }
+          if (want_stats) {
+            const float dx = v.x - pivot, dy = v.y - pivot, dz = v.z - pivot, dw = v.w - pivot;
+            if (INTERIOR || n + 3 < p.Cout) {
+              s1 += (dx + dy) + (dz + dw);
+              s2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+              cnt += 4.f;
+            } else {   // channel tail inside the last float4
+              s1 += dx; s2 += dx * dx; cnt += 1.f;
+              if (n + 1 < p.Cout) { s1 += dy; s2 += dy * dy; cnt += 1.f; }
+              if (n + 2 < p.Cout) { s1 += dz; s2 += dz * dz; cnt += 1.f; }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float wcnt = INTERIOR ? (float)(MT * NT * 16 * 64) : wave_sum(cnt);
+    if (lane == 0 && wcnt > 0.f) {
+      const double P = (double)pivot, n = (double)wcnt, a = (double)s1;
+      long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * 4;
+      ln_atomic_add(dst, n * P + a);
+      ln_atomic_add(dst + 2, (double)s2 + 2.0 * P * a + n * P * P);
+    }
+  }
+}
+
+template <int BM, int BN, int MODE>
+__device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n,
+                                          int cls, int b, int tid) {
+  const bool interior = !(MODE == MODE_CONVT && p.wrap != 0) && (tile_m + 1) * BM <= p.Mh * p.Mw &&
+                        (tile_n + 1) * BN <= p.Cout && (p.Cout & 3) == 0;
+  if (interior) emit_tile_impl<BM, BN, MODE, true>(p, acc, tile_m, tile_n, cls, b, tid);
+  else emit_tile_impl<BM, BN, MODE, false>(p, acc, tile_m, tile_n, cls, b, tid);
+}
+
 
 // amdgpu_waves_per_eu: with a dynamic LDS size hipcc cannot see that five 32 KB workgroups share a CU
 // and spends registers freely (116 for the 64x64 tile => four waves per SIMD); five need <= 96.
@@ -220,6 +444,7 @@ conv_igemm_kernel(const ConvParams p) {
   const int ph = cls >> 1, pw = cls & 1;
   const int mtot = p.Mh * p.Mw;
   const int wrap_w = p.wrap ? p.Win : 0;
+  const bool wrapt = MODE == MODE_CONVT && p.wrap != 0;
 
   // ---- DMA lane mapping: instruction i of this wave fills LDS rows [wave*BM/4 + 8i, +8);
   // lane -> (row = lane>>3, 16-byte slot = lane&7); the slot holds data chunk slot ^ ((row>>1)&7).
@@ -244,14 +469,14 @@ conv_igemm_kernel(const ConvParams p) {
     colw1[i] = colw2[i] = 0;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const int ih = ih0 + tap_delta<MODE>(v, ph, p.rate);
-      int iw = iw0 + tap_delta<MODE>(v, pw, p.rate);
-      iw = iw < 0 ? iw + wrap_w : (iw >= p.Win ? iw - wrap_w : iw);  // wrap_w = 0: plain zero padding
+      const int ih = ih0 + tap_delta<MODE>(v, ph, p.rate, wrapt);
+      const int iwu = iw0 + tap_delta<MODE>(v, pw, p.rate, wrapt);
+      const int iw = iwu < 0 ? iwu + wrap_w : (iwu >= p.Win ? iwu - wrap_w : iwu);  // wrap_w = 0: plain zero padding
       if (v == 0) colw0[i] = iw;
       if (v == 1) colw1[i] = iw;
       if (v == 2) colw2[i] = iw;
       if (ih >= 0 && ih < p.Hin) rowok |= 1u << v;
-      if (iw >= 0 && iw < p.Win) colok |= 1u << v;
+      if (iw >= 0 && iw < p.Win && !(wrapt && (iwu < -2 || iwu >= p.Win + 2))) colok |= 1u << v;
     }
     // bit (vr*NV + vc) = rowok[vr] & colok[vc]: replicate colok into every NV-bit group, keep the groups of valid rows
     unsigned colrep = 0, rowrep = 0;
@@ -307,7 +532,7 @@ conv_igemm_kernel(const ConvParams p) {
         if (MODE == MODE_CONV) { vr = g_tap / 3; vc = g_tap - vr * 3; }                                                          \
         else if (MODE == MODE_CONVT) { vr = g_tap >> 1; vc = g_tap & 1; }                                                        \
         else { vr = 0; vc = 0; }                                                                                                 \
-        const int srow = tap_delta<MODE>(vr, ph, p.rate) * p.Win;                                                                \
+        const int srow = tap_delta<MODE>(vr, ph, p.rate, wrapt) * p.Win;                                                         \
         const unsigned bit = 1u << (vr * NV + vc);                                                                               \
         g_C = g_src ? p.C1 : p.C0;                                                                                               \
         rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(src0 + (g_src ? d_src : 0L)), 0, g_src ? bytes1 : bytes0,            \
@@ -326,10 +551,10 @@ _Pragma("unroll")                                                               
       }                                                                                                                          \
       const int soff_a = g_chunk * ROW_BYTES;                                                                                    \
       const int cleft = g_C - g_chunk * BKE; /* channels from this chunk on; < BKE only when C % BKE != 0 (wave-uniform) */        \
-      if (MODE == MODE_HEAD && !BF16 && p.ln_aff != nullptr) {                                                                   \
+      if (MODE == MODE_HEAD && !BF16 && p.ln_sums != nullptr) {                                                                  \
         /* fused LayerNorm apply of the producer (head only: two k-steps, HBM-bound -- VALU is free here): the A rows go */      \
         /* through registers, x -> max(x * scale[c] + shift[c], 0), and land in the LDS slots the DMA would have filled  */      \
-        const float *aff_ = p.ln_aff + (size_t)b * 2 * p.C0;                                                                     \
+        const float *aff_ = s_haff;                                                                                              \
 _Pragma("unroll")                                                                                                                \
         for (int i = 0; i < AI; ++i) {                                                                                           \
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));                                                            \
@@ -375,6 +600,25 @@ _Pragma("unroll")                                                               
         g_new = true;                                                                                                            \
       }                                                                                                                          \
     }                                                                                                                            \
+  }
+
+  // fp32 head: the affine of its source's LayerNorm (scale | shift per channel) from the source's sums -> LDS; the
+  // k-step issue applies it (+ ReLU) while loading, so the source is read RAW and never normalised in memory
+  float *s_haff = nullptr;
+  if constexpr (MODE == MODE_HEAD && !BF16) {
+    __shared__ __attribute__((aligned(16))) float s_haff_store[2 * HEAD_MAX_C];
+    __shared__ double s_hstat[2];
+    s_haff = s_haff_store;
+    if (p.ln_sums != nullptr) {
+      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * 4, p.ln_inv_n, s_hstat, tid);
+      const double mu = s_hstat[0], inv = s_hstat[1];
+      for (int c = tid; c < p.C0; c += 256) {
+        const double sc = inv * (double)p.ln_gamma[c];
+        s_haff_store[c] = (float)sc;
+        s_haff_store[p.C0 + c] = (float)((double)p.ln_beta[c] - mu * sc);
+      }
+      __syncthreads();
+    }
   }
 
   // the first k-step's DMA goes out before the rest of the set-up: its latency (HBM under load) is the
@@ -432,13 +676,14 @@ _Pragma("unroll")                                                               
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if constexpr (BF16) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[q][i]),
-                                                              __builtin_bit_cast(bf16x8, f.b[q][j]), acc[i][j], 0, 0, 0);
+          // weights first: D = W^T-tile x pixels, i.e. D row = channel, D column = pixel (transposed accumulators)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[q][j]),
+                                                              __builtin_bit_cast(bf16x8, f.a[q][i]), acc[i][j], 0, 0, 0);
         } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].x, f.b[q][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].y, f.b[q][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].z, f.b[q][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i].w, f.b[q][j].w, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[q][j].x, f.a[q][i].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[q][j].y, f.a[q][i].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[q][j].z, f.a[q][i].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[q][j].w, f.a[q][i].w, acc[i][j], 0, 0, 0);
         }
       }
   };
@@ -478,7 +723,7 @@ _Pragma("unroll")                                                               
     MSI_FETCH(f_, U)                                                                      \
     MSI_MMA_Q(f_, 0)                                                                      \
     const bool more_ = (S) + PD < nsteps;                                                 \
-    if (more_ && !p.ablate) MSI_ISSUE(((U) + PD) % NSTAGE)                                \
+    if (more_) MSI_ISSUE(((U) + PD) % NSTAGE)                                             \
     MSI_MMA_Q(f_, 1)                                                                      \
     MSI_MMA_Q(f_, 2)                                                                      \
     MSI_MMA_Q(f_, 3)                                                                      \
@@ -513,258 +758,59 @@ _Pragma("unroll")                                                               
 #undef MSI_MMA_Q
 #undef MSI_FETCH
 
-  // ---- epilogue: store + LayerNorm partial ------------------------------------------------
-  // The accumulators go through LDS so that the tile leaves as 16-byte-per-lane stores of whole
-  // channel rows (per-lane 4-byte stores of the MFMA C layout reached only 1.4 TB/s on the 52 MB
-  // layers; this form streams like a copy).  One staging pass per MFMA-tile row i of the wave tile:
-  // 64 tile rows (32 of each wave row wm) x BN channels at a time.
-  // C/D layout of v_mfma_f32_32x32x2_f32 / _32x32x16_bf16: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  constexpr int LDW = BN + 4;  // floats per staged row: 16-byte aligned, breaks the power-of-two stride
-  constexpr int SROWS = 64;    // staged rows per pass
-  static_assert((size_t)SROWS * LDW * 4 + 64 <= (size_t)NSTAGE * STAGE_BYTES, "staged rows + wave partials must fit the k-loop LDS");
-  float *ct = reinterpret_cast<float *>(smem);  // all LDS reads of the main loop are behind the last barrier
-  float *wpart = ct + SROWS * LDW;              // [4 waves][4] LayerNorm partials
-  const int col = lane & 31, rowq = 4 * (lane >> 5);
-  // interior tile (the common case): no row / channel masks anywhere in the epilogue -- its VALU work is
-  // paid in matrix throughput of the co-resident workgroups
-  const bool interior = (tile_m + 1) * BM <= mtot && (tile_n + 1) * BN <= p.Cout;
-  const bool want_stats = MODE != MODE_HEAD && p.stats != nullptr;   // (only workgroups that emit a tile get that far)
-  if (MODE == MODE_HEAD && full) {   // bias + tanh in registers
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = tile_n * BN + wn * (NT * 32) + j * 32 + col;
-      const float bias = p.bias[min(n, p.Cout - 1)];
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = tanhf(acc[i][j][r] + bias);
-    }
-  }
-  // The tile leaves through LDS in 64-row passes; what a thread reads back (16-byte pieces of whole channel
-  // rows) is also what it (a) adds the CoordNet contribution to -- the |sin(lat)| channel does not depend on
-  // the input, so its part of the convolution is a host-built table indexed by (output row, column border
-  // class, channel) instead of a 33rd k-step -- and (b) takes the LayerNorm partial from: per WAVE, mean
-  // first, then M2 about that mean over the same registers (two-pass), merged by thread 0.
-  constexpr int C4 = BN / 4;                       // float4 per staged row
-  constexpr int PASSES = SROWS * C4 / 256;
-  const bool vec_ok = (p.Cout & 3) == 0;
-  const bool has_cb = MODE == MODE_CONV && p.coord_bias != nullptr;
-  float *pdst = full ? nullptr : p.partial + (size_t)slot * (BM * BN);   // K-range of a split tile: raw accumulators, row-major [BM][BN]
-  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(full ? p.partial : pdst), 0, BM * BN * 4, 0x00020000);   // this K-range's slab
-  v4f keep[MT][PASSES];
-  float lsum = 0.f, lcnt = 0.f;
-  // one 16-byte piece (tile row LROW_, channels 4*C4_..+4) of the finished tile: CoordNet table, store, statistics
-#define MSI_EMIT(V_, I_, K_, LROW_, C4_)                                                                      \
-  {                                                                                                           \
-    v4f v = (V_);                                                                                             \
-    const int m = tile_m * BM + (LROW_);                                                                      \
-    const int n = tile_n * BN + (C4_) * 4;                                                                    \
-    if (interior || (m < mtot && n < p.Cout)) {                                                               \
-      size_t opix;                                                                                            \
-      if (MODE == MODE_CONVT) {                                                                               \
-        const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);                                 \
-        const int mw = m - mh * p.Mw;                                                                         \
-        opix = ((size_t)b * p.Hout + (2 * mh + ph)) * p.Wout + (2 * mw + pw);                                 \
-      } else {                                                                                                \
-        opix = (size_t)b * mtot + m;                                                                          \
-        if (has_cb) {                                                                                         \
-          const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);                               \
-          const int mw = m - mh * p.Mw;                                                                       \
-          const v4f cb = *reinterpret_cast<const v4f *>(                                                      \
-              p.coord_bias + (size_t)(mh * COORD_CLASSES + coord_class(mw, p.Mw)) * p.cb_stride + n);         \
-          v.x += cb.x; v.y += cb.y; v.z += cb.z; v.w += cb.w;                                                 \
-        }                                                                                                     \
-      }                                                                                                       \
-      float *dst = p.y + opix * p.Cout + n;                                                                   \
-      if (vec_ok) {                                                                                           \
-        *reinterpret_cast<v4f *>(dst) = v;                                                                    \
-      } else {                                                                                                \
-        dst[0] = v.x;                                                                                         \
-        if (n + 1 < p.Cout) dst[1] = v.y;                                                                     \
-        if (n + 2 < p.Cout) dst[2] = v.z;                                                                     \
-        if (n + 3 < p.Cout) dst[3] = v.w;                                                                     \
-      }                                                                                                       \
-      if (want_stats) {                                                                                       \
-        if (interior || n + 3 < p.Cout) {                                                                     \
-          lcnt += 4.f;                                                                                        \
-        } else { /* channel tail inside the last float4 */                                                    \
-          if (n + 1 >= p.Cout) v.y = 0.f;                                                                     \
-          if (n + 2 >= p.Cout) v.z = 0.f;                                                                     \
-          if (n + 3 >= p.Cout) v.w = 0.f;                                                                     \
-          lcnt += (float)(p.Cout - n);                                                                        \
-        }                                                                                                     \
-        lsum += (v.x + v.y) + (v.z + v.w);                                                                    \
-        keep[I_][K_] = v;                                                                                     \
-      }                                                                                                       \
-    }                                                                                                         \
-  }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    if (i > 0) __syncthreads();                    // the previous pass has been read out
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        ct[(wm * 32 + (r & 3) + 8 * (r >> 2) + rowq) * LDW + wn * (NT * 32) + j * 32 + col] = acc[i][j][r];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-      const int idx = tid + 256 * k;
-      const int srow = idx / C4, c4 = idx - srow * C4;
-      const int lrow = (srow >> 5) * (MT * 32) + i * 32 + (srow & 31);   // staged row -> tile row
-      const v4f sv = *reinterpret_cast<const v4f *>(ct + srow * LDW + c4 * 4);
-      keep[i][k] = v4f{0.f, 0.f, 0.f, 0.f};
-      if (!full) {
-        if (p.tile_cnt != nullptr)   // write-through (sc1): visible to the reducer on any XCD without a release fence
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, sv), rsrc_p, (unsigned)((lrow * BN + c4 * 4) * 4), 0, 16);
-        else
-          *reinterpret_cast<v4f *>(pdst + lrow * BN + c4 * 4) = sv;
-        continue;
-      }
-      MSI_EMIT(sv, i, k, lrow, c4)
-    }
-  }
+  // ---- epilogue ------------------------------------------------------------------------------
   if (!full) {
-    // ---- K-range of a split tile: the LAST of the tile's workgroups to arrive sums the partial accumulators in k
-    // order (deterministic whoever is last) and emits the tile.  Hand-off per cdna_hip_programming.md (in-launch
-    // split-K, write-through form): sc1 slab stores -> vmcnt(0) -> workgroup barrier -> one lane takes a relaxed
-    // agent-scope ticket; the last arriver reads the slabs with sc1 loads.  (MSI_CONV_FIXUP=kernel: separate launch.)
+    // K-range of a split tile: the raw accumulators go to this range's slab; the LAST of the tile's workgroups to
+    // arrive sums the slabs in k order (deterministic whoever is last) and emits the tile.  Hand-off per
+    // cdna_hip_programming.md (in-launch split-K, write-through form): sc1 slab stores -> vmcnt(0) -> workgroup
+    // barrier -> one lane takes a relaxed agent-scope ticket; the last arriver reads the slabs with sc1 loads.
+    // (Plan option MSI_NET_OPT_FIXUP_KERNEL: plain stores here, conv_fixup_kernel as a separate launch.)
+    constexpr int SLAB = BM * BN * 4;
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.partial + (size_t)slot * (BM * BN)), 0, SLAB, 0x00020000);
     if (p.tile_cnt == nullptr) {
+      dump_acc<MT, NT, 0>(acc, rsrc_p, tid);
 #ifdef MSI_CONV_TIMING
       stamp();
 #endif
       return;
     }
-    if constexpr (MT == 1) {
-      const int nsp = t < p.n_main ? p.split0 : p.split;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have left (sc1: written through)
-      __syncthreads();
-      if (tid == 0) {
-        const int old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-        reinterpret_cast<int *>(wpart)[15] = old;
-      }
-      __syncthreads();
-      const int old = reinterpret_cast<int *>(wpart)[15];
-      if (old != nsp - 1) {
-#ifdef MSI_CONV_TIMING
-        stamp();
-#endif
-        return;
-      }
-      // the last arriver reads every slab with sc1 loads (coherent with the sc1 stores: no acquire fence)
-      const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)(p.partial + (size_t)(slot - ks) * (BM * BN)), 0, nsp * BM * BN * 4, 0x00020000);
-      v4f sumv[PASSES];
-#pragma unroll
-      for (int k = 0; k < PASSES; ++k)
-        sumv[k] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_t, (unsigned)((tid + 256 * k) * 16), 0, 16));
-      for (int s2 = 1; s2 < nsp; ++s2) {
-        v4f tv[PASSES];
-#pragma unroll
-        for (int k = 0; k < PASSES; ++k)
-          tv[k] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_t, (unsigned)((tid + 256 * k) * 16), s2 * BM * BN * 4, 16));
-#pragma unroll
-        for (int k = 0; k < PASSES; ++k) { sumv[k].x += tv[k].x; sumv[k].y += tv[k].y; sumv[k].z += tv[k].z; sumv[k].w += tv[k].w; }
-      }
-#pragma unroll
-      for (int k = 0; k < PASSES; ++k) {
-        const int idx = tid + 256 * k;
-        const int lrow = idx / C4, c4 = idx - lrow * C4;
-        if (MODE == MODE_HEAD) {
-          const int n = tile_n * BN + c4 * 4;
-          sumv[k].x = tanhf(sumv[k].x + p.bias[min(n, p.Cout - 1)]);
-          sumv[k].y = tanhf(sumv[k].y + p.bias[min(n + 1, p.Cout - 1)]);
-          sumv[k].z = tanhf(sumv[k].z + p.bias[min(n + 2, p.Cout - 1)]);
-          sumv[k].w = tanhf(sumv[k].w + p.bias[min(n + 3, p.Cout - 1)]);
-        }
-        MSI_EMIT(sumv[k], 0, k, lrow, c4)
-      }
-    } else {
-      return;   // (big tiles are never split)
-    }
-  }
-#undef MSI_EMIT
-  if (want_stats) {
-    auto wave_sum = [&](float x) __attribute__((always_inline)) -> float {   // butterfly: every lane gets the total
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-      return x;
-    };
-    const float wcnt = interior ? (float)(MT * PASSES * 4 * 64) : wave_sum(lcnt);
-    const float wmean = wcnt > 0.f ? wave_sum(lsum) / wcnt : 0.f;
-    float lm2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int k = 0; k < PASSES; ++k) {
-        const v4f v = keep[i][k];
-        const float dx = v.x - wmean, dy = v.y - wmean, dz = v.z - wmean, dw = v.w - wmean;
-        if (interior) {
-          lm2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        } else {   // re-derive which of the four values exist (skipped pieces were kept as zeros and must not count)
-          const int idx = tid + 256 * k;
-          const int srow = idx / C4, c4 = idx - srow * C4;
-          const int m = tile_m * BM + (srow >> 5) * (MT * 32) + i * 32 + (srow & 31);
-          const int n = tile_n * BN + c4 * 4;
-          if (m < mtot) {
-            if (n < p.Cout) lm2 += dx * dx;
-            if (n + 1 < p.Cout) lm2 += dy * dy;
-            if (n + 2 < p.Cout) lm2 += dz * dz;
-            if (n + 3 < p.Cout) lm2 += dw * dw;
-          }
-        }
-      }
-    const float wm2 = wave_sum(lm2);
-    if (lane == 0) {
-      wpart[wave * 4 + 0] = wcnt;
-      wpart[wave * 4 + 1] = wmean;
-      wpart[wave * 4 + 2] = wm2;
+    dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
+    const int nsp = t < p.n_main ? p.split0 : p.split;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have left (sc1: written through)
+    __syncthreads();
+    int *s_old = reinterpret_cast<int *>(smem);        // (all LDS reads of the main loop are behind its last barrier)
+    if (tid == 0) {
+      *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (tid == 0) {
-      // Chan's merge of the four wave partials in a fixed order: (0,1), (2,3), then the pair
-      auto merge = [](float &na, float &ma, float &sa, float nb, float mb, float sb) __attribute__((always_inline)) {
-        const float nt = na + nb;
-        if (nb > 0.f) {
-          const float dl = mb - ma, f = nb / nt;
-          ma += dl * f;
-          sa += sb + dl * dl * (na * f);
-          na = nt;
-        }
-      };
-      float n0 = wpart[0], m0 = wpart[1], s0 = wpart[2];
-      float n2 = wpart[8], m2 = wpart[9], s2 = wpart[10];
-      merge(n0, m0, s0, wpart[4], wpart[5], wpart[6]);
-      merge(n2, m2, s2, wpart[12], wpart[13], wpart[14]);
-      merge(n0, m0, s0, n2, m2, s2);
-      const int nparts = p.tiles_m * p.tiles_n * p.nclass;
-      const int part = (cls * p.tiles_n + tile_n) * p.tiles_m + tile_m;
-      float *o = p.stats + ((size_t)b * nparts + part) * 4;
-      o[0] = n0;
-      o[1] = m0;
-      o[2] = s0;
-      o[3] = 0.f;
+    if (*s_old != nsp - 1) {
+#ifdef MSI_CONV_TIMING
+      stamp();
+#endif
+      return;
     }
+    // the last arriver reads every slab with sc1 loads (coherent with the sc1 stores: no acquire fence)
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.partial + (size_t)(slot - ks) * (BM * BN)), 0, nsp * SLAB, 0x00020000);
+    sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
   }
+  emit_tile<BM, BN, MODE>(p, acc, tile_m, tile_n, cls, b, tid);
 #ifdef MSI_CONV_TIMING
   stamp();
 #endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-// Fix-up of the split tiles: sums the `split` partial accumulators of a tile in k order
-// (deterministic) and performs the epilogue no single workgroup could (bias + tanh for the head,
-// store, LayerNorm partial).  One workgroup per split tile.
+// Fix-up of the split tiles as a separate launch (plan option MSI_NET_OPT_FIXUP_KERNEL; the default is the in-launch
+// hand-off above): sums the K-range slabs of a tile in k order and runs the same epilogue.  One workgroup per split tile.
 template <int BM, int BN, int MODE>
 __global__ void __launch_bounds__(256)
 conv_fixup_kernel(const ConvParams p) {
-  __shared__ float red[4];
-  constexpr int C4 = BN / 4;
-  constexpr int PASSES = BM * C4 / 256;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int MT = BM / 64, NT = BN / 64;
+  const int tid = threadIdx.x;
   // split tiles: [0, ntiles) when the first group is split too, else [n_main, ntiles); their partial
   // slots are consecutive in workgroup order of conv_igemm_kernel
   const int t = (p.split0 == 1 ? p.n_main : 0) + blockIdx.x;
@@ -782,175 +828,32 @@ conv_fixup_kernel(const ConvParams p) {
     cls = r - q3 * p.nclass;
     b = q3;
   }
-  const int ph = cls >> 1, pw = cls & 1;
-  const int mtot = p.Mh * p.Mw;
-  // All `split` partial tiles are requested before the first one is used: one memory round trip
-  // instead of `split` dependent ones (the loop over a run-time count waited per K-range).  Ranges
-  // beyond `split` re-read the last one and are masked out of the sum, which stays in k order.
-  // The CoordNet contribution of each piece (see the conv epilogue) is requested in the same round trip.
-  v4f cbv[PASSES];
-#pragma unroll
-  for (int k = 0; k < PASSES; ++k) {
-    cbv[k] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (MODE == MODE_CONV && p.coord_bias != nullptr) {
-      const int idx = tid + 256 * k;
-      const int m = tile_m * BM + idx / C4, n = tile_n * BN + (idx % C4) * 4;
-      if (m < mtot && n < p.Cout) {   // cb_stride is Cout rounded up to 4: the whole float4 is in range
-        const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);
-        const int mw = m - mh * p.Mw;
-        cbv[k] = *reinterpret_cast<const v4f *>(p.coord_bias + (size_t)(mh * COORD_CLASSES + coord_class(mw, p.Mw)) * p.cb_stride + n);
-      }
-    }
-  }
-  v4f a[MAX_SPLIT][PASSES];
-#pragma unroll
-  for (int ks = 0; ks < MAX_SPLIT; ++ks) {
-    const float *src = p.partial + (size_t)(slot0 + min(ks, nsp - 1)) * (BM * BN);
-#pragma unroll
-    for (int k = 0; k < PASSES; ++k) a[ks][k] = *reinterpret_cast<const v4f *>(src + (size_t)(tid + 256 * k) * 4);
-  }
-  v4f v[PASSES];
-#pragma unroll
-  for (int k = 0; k < PASSES; ++k) v[k] = a[0][k];
-#pragma unroll
-  for (int ks = 1; ks < MAX_SPLIT; ++ks) {
-    const bool on = ks < nsp;
-#pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-      v[k].x += on ? a[ks][k].x : 0.f; v[k].y += on ? a[ks][k].y : 0.f;
-      v[k].z += on ? a[ks][k].z : 0.f; v[k].w += on ? a[ks][k].w : 0.f;
-    }
-  }
-  const bool vec_ok = (p.Cout & 3) == 0;
-  float lsum = 0.f;
-#pragma unroll
-  for (int k = 0; k < PASSES; ++k) {
-    const int idx = tid + 256 * k;
-    const int lrow = idx / C4, c4 = idx - lrow * C4;
-    const int m = tile_m * BM + lrow;
-    const int n = tile_n * BN + c4 * 4;
-    float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-    e[0] += cbv[k].x; e[1] += cbv[k].y; e[2] += cbv[k].z; e[3] += cbv[k].w;
-    if (MODE == MODE_HEAD) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) e[q] = tanhf(e[q] + p.bias[min(n + q, p.Cout - 1)]);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      e[q] = (m < mtot && n + q < p.Cout) ? e[q] : 0.f;
-      lsum += e[q];
-    }
-    v[k] = v4f{e[0], e[1], e[2], e[3]};
-    if (m >= mtot || n >= p.Cout) continue;
-    size_t opix;
-    if (MODE == MODE_CONVT) {
-      const int mh = m / p.Mw, mw = m - mh * p.Mw;
-      opix = ((size_t)b * p.Hout + (2 * mh + ph)) * p.Wout + (2 * mw + pw);
-    } else {
-      opix = (size_t)b * mtot + m;
-    }
-    float *dst = p.y + opix * p.Cout + n;
-    if (vec_ok) {
-      *reinterpret_cast<v4f *>(dst) = v[k];
-    } else {
-      dst[0] = e[0];
-      if (n + 1 < p.Cout) dst[1] = e[1];
-      if (n + 2 < p.Cout) dst[2] = e[2];
-      if (n + 3 < p.Cout) dst[3] = e[3];
-    }
-  }
-  if (MODE == MODE_HEAD || p.stats == nullptr) return;
-  auto block_sum = [&](float x) __attribute__((always_inline)) -> float {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    __syncthreads();
-    if (lane == 0) red[wave] = x;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-  };
-  const float bsum = block_sum(lsum);
-  const float bcnt = (float)(min(BM, mtot - tile_m * BM) * min(BN, p.Cout - tile_n * BN));
-  const float bmean = bcnt > 0.f ? bsum / bcnt : 0.f;
-  float lm2 = 0.f;
-#pragma unroll
-  for (int k = 0; k < PASSES; ++k) {
-    const int idx = tid + 256 * k;
-    const int lrow = idx / C4, c4 = idx - lrow * C4;
-    const int m = tile_m * BM + lrow;
-    const int n = tile_n * BN + c4 * 4;
-    const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (m < mtot && n + q < p.Cout) {
-        const float dlt = e[q] - bmean;
-        lm2 += dlt * dlt;
-      }
-  }
-  const float bm2 = block_sum(lm2);
-  if (tid == 0) {
-    const int nparts = p.tiles_m * p.tiles_n * p.nclass;
-    const int part = (cls * p.tiles_n + tile_n) * p.tiles_m + tile_m;
-    float *o = p.stats + ((size_t)b * nparts + part) * 4;
-    o[0] = bcnt;
-    o[1] = bmean;
-    o[2] = bm2;
-    o[3] = 0.f;
-  }
+  constexpr int SLAB = BM * BN * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(p.partial + (size_t)slot0 * (BM * BN)), 0, nsp * SLAB, 0x00020000);
+  f32x16 acc[MT][NT];
+  sum_slabs<MT, NT, 0>(acc, rsrc_t, nsp, SLAB, tid);
+  emit_tile<BM, BN, MODE>(p, acc, tile_m, tile_n, cls, b, tid);
+#endif
 }
 
-// LayerNorm finish + apply in ONE launch.  Every workgroup first merges the per-workgroup (count,
-// mean, M2) partials of its sample in fp64 (two parallel passes in a fixed order => identical in
-// every workgroup and deterministic) into the affine of slim.layer_norm,
+// LayerNorm apply (+ ReLU), one launch per layer.  Every workgroup derives the affine of slim.layer_norm,
 //   scale = gamma * rsqrt(var + eps), shift = beta - mean * scale,
-// keeps it in LDS, and then applies x = max(x*scale[c] + shift[c], 0) IN PLACE to its grid-stride
-// slice (nets.py:401,485 arg_scope: normalizer, then the default ReLU).  Merging redundantly
-// (<= 3200 partials = 51 KB from L2 per workgroup) is cheaper than a separate single-block launch
-// plus a kernel boundary per layer.  Workgroup 0 also publishes the affine (debug / tests).
+// from the sample's 64 x 4 fixed-point sums (ln_mean_inv), keeps it in LDS, and applies
+// x = max(x*scale[c] + shift[c], 0) to its grid-stride slice (nets.py:401,485 arg_scope: normalizer, then the
+// default ReLU).  Workgroup 0 also publishes the affine (tests).
 // BF16OUT = 1: the normalised activation is written as bf16 to `yb` (the operand buffer of the bf16 path)
-// and the fp32 raw output is left alone; 0: x is normalised in place; 2: finish only -- the affine is
-// published to `aff` and x stays raw (the consumer applies it: the head's fused path).
+// and the fp32 raw output is left alone; 0: x is normalised in place.
 template <int BF16OUT>
 __global__ void __launch_bounds__(256)
-ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int nparts,
+ln_apply_kernel(float *__restrict__ x, const long long *__restrict__ sums, double inv_n,
                 const float *__restrict__ gamma, const float *__restrict__ beta, size_t per_sample, int C,
                 float *__restrict__ aff, unsigned short *__restrict__ yb) {
   extern __shared__ __attribute__((aligned(16))) float s_aff[];  // scale[C] shift[C]
-  __shared__ double s_red[2][4];
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float *st = stats + (size_t)b * nparts * 4;
-  // fixed-order block sum of two doubles: wave shuffle tree, then the four wave sums
-  auto block_sum2 = [&](double &x, double &y) __attribute__((always_inline)) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      x += __shfl_down(x, off, 64);
-      y += __shfl_down(y, off, 64);
-    }
-    __syncthreads();
-    if (lane == 0) { s_red[0][wave] = x; s_red[1][wave] = y; }
-    __syncthreads();
-    x = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
-    y = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
-  };
-  // One pass over the partials, three fp64 sums: N = sum n_i, S = sum n_i mean_i, Q = sum (M2_i + n_i mean_i^2);
-  // mean = S / N, M2 = Q - N mean^2 (in fp64 the cancellation costs ~1e-16 (1 + mean^2/var): nothing at fp32
-  // outputs).  No division and no dependent second pass on the critical path between two conv launches; the
-  // loads of a thread's partials are independent (unrolled), so their latencies overlap.
-  double sn = 0.0, sm = 0.0, s2 = 0.0;
-#pragma unroll 4
-  for (int i = tid; i < nparts; i += 256) {
-    const v4f pr = *reinterpret_cast<const v4f *>(st + (size_t)i * 4);
-    const double n_i = (double)pr.x, m_i = (double)pr.y;
-    sn += n_i;
-    sm += n_i * m_i;
-    s2 += (double)pr.z + n_i * m_i * m_i;
-  }
-  block_sum2(sn, sm);
-  double dummy = 0.0;
-  block_sum2(s2, dummy);
-  const double mu = sm / sn;
-  s2 -= sn * mu * mu;
-  const double var = s2 / sn;
-  const double inv = 1.0 / sqrt(var + LN_EPS);
+  __shared__ double s_stat[2];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  ln_mean_inv(sums + (size_t)b * LN_SHARDS * 4, inv_n, s_stat, tid);
+  const double mu = s_stat[0], inv = s_stat[1];
   for (int c = tid; c < C; c += 256) {
     const double sc = inv * (double)gamma[c];
     const float fs = (float)sc, ft = (float)((double)beta[c] - mu * sc);
@@ -962,7 +865,6 @@ ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int npar
     }
   }
   __syncthreads();
-  if (BF16OUT == 2) return;
 
   v4f *xv = reinterpret_cast<v4f *>(x + (size_t)b * per_sample);
   const size_t nvec = per_sample / 4;
@@ -1000,7 +902,7 @@ ln_apply_kernel(float *__restrict__ x, const float *__restrict__ stats, int npar
 }
 
 // ============================================================================================
-// host: layer table, parameter packing, forward
+// host: layer table, parameter packing, plan, forward
 // ============================================================================================
 struct Layer {
   char name[16];
@@ -1010,23 +912,28 @@ struct Layer {
   int src0, src1;  // producer layer indices (-1 = net_input; src1 = -1: none)
   int c0, c1;
   int ntaps, cpt0, cpt1, ksteps, nclass, npad;
+  int wrapt;       // conv-transpose of msi_train_net: GEMM rows cover the uncropped VALID output (see tap_delta)
+  int mh, mw;      // GEMM row grid per sample and class
+  double ln_count; // elements per sample the LayerNorm statistics run over
   size_t param_off, param_floats;  // floats
   size_t packed_off;               // floats: weights, then gamma, beta (or bias), then the CoordNet bias table
   size_t packed_w_floats;
   size_t gamma_off, beta_off, coord_off;  // floats inside the packed blob
   size_t raw_off, aff_off;                // bytes inside the workspace
   size_t act_off;                         // bf16 path: normalised bf16 activation (the next layer's operand)
+  size_t sums_off;                        // LayerNorm sums [B][LN_SHARDS][4] int64
 };
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Net {
   std::vector<Layer> layers;
-  size_t param_floats = 0, packed_floats = 0, ws_bytes = 0, stats_off = 0, stats_bytes = 0, partial_off = 0;
-  size_t cnt_off = 0;   // arrival tickets of the in-launch fix-up: [layer][CNT_PER_LAYER] ints, zeroed per forward
+  size_t param_floats = 0, packed_floats = 0, ws_bytes = 0, partial_off = 0, partial_bytes = 0;
+  size_t zero_off = 0, zero_bytes = 0;   // [tickets of the in-launch fix-up | LayerNorm sums]: one memset per forward
+  size_t cnt_off = 0;   // arrival tickets: [layer][2 * num_cus] ints
 };
 
-int build_net(const msi_net_desc *d, Net &net) {
+int build_net(const msi_net_desc *d, int num_cus, Net &net) {
   if (!d) return msi::fail(MSI_E_BADARG, "net: null descriptor");
   if (d->batch < 0 || d->height <= 0 || d->width <= 0 || d->in_channels <= 0 || d->num_outputs <= 0 ||
       d->ngf <= 0)
@@ -1042,7 +949,7 @@ int build_net(const msi_net_desc *d, Net &net) {
   const int esz = bf16 ? 2 : 4, bke = ROW_BYTES / esz;   // operand bytes, channels per k-step
   if (bf16 && (d->in_channels % 8 || d->ngf % 8))
     return msi::fail(MSI_E_UNSUPPORTED, "net: bf16 needs in_channels and ngf in multiples of 8 (16-byte channel chunks)");
-  if ((long)d->height * d->width >= (1L << 24))
+  if ((long)(d->height + 16) * (d->width + 16) >= (1L << 24))
     return msi::fail(MSI_E_UNSUPPORTED, "net: more than 2^24 pixels per sample (24-bit pixel index in the conv kernel)");
   const int ngf = d->ngf, ex = d->coord_net ? 1 : 0;
   struct Spec { const char *name; int kind, src0, src1, cout, stride, rate; };
@@ -1059,7 +966,6 @@ int build_net(const msi_net_desc *d, Net &net) {
   };
   net.layers.resize(MSI_NET_NUM_LAYERS);
   size_t poff = 0, koff = 0, woff = 0;
-  size_t max_parts = 1;
   for (int i = 0; i < MSI_NET_NUM_LAYERS; ++i) {
     Layer &L = net.layers[i];
     const Spec &s = specs[i];
@@ -1086,16 +992,27 @@ int build_net(const msi_net_desc *d, Net &net) {
       L.out_w = (sw + s.stride - 1) / s.stride;
       L.ntaps = 9;
       L.nclass = 1;
+      L.mh = L.out_h; L.mw = L.out_w;
+      L.ln_count = (double)L.out_h * L.out_w * L.cout;
     } else if (s.kind == MODE_CONVT) {
       L.out_h = sh * 2;
       L.out_w = sw * 2;
       L.ntaps = 4;
       L.nclass = 4;
+      L.wrapt = d->coord_net ? 0 : 1;
+      if (L.wrapt) {   // nets.py:423-435: LayerNorm over the uncropped (2H+10) x (2W+10) VALID output
+        L.mh = sh + 1; L.mw = sw + 5;
+        L.ln_count = (double)(2 * sh + 10) * (2 * sw + 10) * L.cout;
+      } else {
+        L.mh = sh; L.mw = sw;
+        L.ln_count = (double)L.out_h * L.out_w * L.cout;
+      }
     } else {
       L.out_h = sh;
       L.out_w = sw;
       L.ntaps = 1;
       L.nclass = 1;
+      L.mh = sh; L.mw = sw;
     }
     if ((size_t)sh * sw * (size_t)(L.c0 > L.c1 ? L.c0 : L.c1) * esz >= ((size_t)1 << 31))
       return msi::fail(MSI_E_UNSUPPORTED, "net: %s input exceeds 2 GiB per sample", s.name);
@@ -1132,58 +1049,87 @@ int build_net(const msi_net_desc *d, Net &net) {
       L.raw_off = (size_t)-1;
       L.aff_off = (size_t)-1;
     }
-    // the smallest tile (64x64) bounds the number of LayerNorm partials
-    const size_t mgrid = (s.kind == MODE_CONVT) ? (size_t)sh * sw : (size_t)L.out_h * L.out_w;
-    const size_t parts = ((mgrid + 63) / 64) * ((L.cout + 63) / 64) * L.nclass;
-    if (parts > max_parts) max_parts = parts;
   }
   net.param_floats = poff;
   net.packed_floats = koff;
-  net.stats_off = woff;
-  net.stats_bytes = round_up((size_t)d->batch * max_parts * 4 * sizeof(float), 256);
-  net.partial_off = woff + net.stats_bytes;
-  net.cnt_off = net.partial_off + PARTIAL_BYTES;
-  net.ws_bytes = net.cnt_off + round_up((size_t)MSI_NET_NUM_LAYERS * CNT_PER_LAYER * sizeof(int), 256);
+  net.partial_off = woff;
+  // split tiles per launch: < num_cus remainder tiles, or < 2 num_cus when the first group is split too;
+  // at most MAX_SPLIT K-ranges each, 64x64 fp32 accumulators per range
+  net.partial_bytes = (size_t)2 * num_cus * MAX_SPLIT * 64 * 64 * sizeof(float);
+  net.zero_off = net.partial_off + net.partial_bytes;
+  net.cnt_off = net.zero_off;
+  size_t zoff = net.cnt_off + round_up((size_t)MSI_NET_NUM_LAYERS * 2 * num_cus * sizeof(int), 256);
+  for (int i = 0; i < MSI_NET_NUM_LAYERS; ++i) {
+    net.layers[i].sums_off = zoff;
+    if (net.layers[i].kind != MODE_HEAD) zoff += (size_t)d->batch * LN_SHARDS * 4 * sizeof(long long);
+  }
+  net.zero_bytes = zoff - net.zero_off;
+  net.ws_bytes = round_up(zoff, 256);
   return MSI_OK;
 }
 
-template <int BM, int BN, int MODE, int BF16>
-int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
+int device_cu_count() {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) {
+    (void)hipGetLastError();   // no device (build container): sizes for the default part
+    return DEFAULT_CUS;
+  }
+  return prop.multiProcessorCount;
+}
+
+enum { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x64 = 2 };
+
+// One layer's launch, everything but the pointers resolved at plan time.
+struct LayerLaunch {
+  ConvParams p;     // pointer members are filled per forward
+  int tile;         // TILE_*
+  int nblocks, nfix;
+  int inlaunch;     // the split tiles are summed inside the conv launch (tickets) rather than by conv_fixup_kernel
+  int fuse_ln;      // head: applies its source's LayerNorm while loading (the source is not normalised in memory)
+  int skip_apply;   // this layer's output is consumed raw by the head: no ln_apply launch
+  unsigned ln_blocks;
+};
+
+}  // namespace
+
+struct msi_net_plan {
+  msi_net_desc desc;
+  int num_cus;
+  int opt[MSI_NET_OPT_COUNT];
+  Net net;
+  LayerLaunch launch[MSI_NET_NUM_LAYERS];
+};
+
+namespace {
+
+// Work decomposition of one layer ("tail split", see the kernel) for a BM x BN tile.
+void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tailsplit, int *nblocks, int *nfix) {
   const int mtot = p.Mh * p.Mw;
   p.tiles_m = (mtot + BM - 1) / BM;
   p.tiles_n = (p.Cout + BN - 1) / BN;
   p.ntiles = p.tiles_m * p.tiles_n * p.nclass * batch;
-  *nparts = p.tiles_m * p.tiles_n * p.nclass;
-  // tail split (see the kernel): whole tiles in multiples of the CU count, the remainder cut into
-  // `split` K-ranges so that (remainder x split) is again close to a multiple of the CU count
+  // whole tiles in multiples of the CU count, the remainder cut into `split` K-ranges so that
+  // (remainder x split) is again close to a multiple of the CU count
   p.n_main = p.ntiles;
   p.split0 = 1;
   p.split = 1;
-  static const char *ts = getenv("MSI_CONV_TAILSPLIT");   // debug: 0 disables
-  const int rem = p.ntiles % NUM_CUS;
-  if (BM * BN == 64 * 64 &&   // (the fix-up kernel is written for the 64x64 tile; big tiles are only chosen for big grids)
-      rem != 0 && p.ntiles > NUM_CUS / 2 && p.ksteps >= 2 * MAX_SPLIT && !(ts && atoi(ts) == 0)) {
+  const int rem = p.ntiles % num_cus;
+  if (BM * BN == 64 * 64 &&   // (big tiles are only chosen for big grids)
+      rem != 0 && p.ntiles > num_cus / 2 && p.ksteps >= 2 * MAX_SPLIT && tailsplit) {
     int best = 1;
     double best_cost = 1.0;   // time of the tail in tile-times: ceil(rem*s/CUs)/s
     for (int sp = 2; sp <= MAX_SPLIT; ++sp) {
-      const double cost = (double)((rem * sp + NUM_CUS - 1) / NUM_CUS) / sp;
+      const double cost = (double)((rem * sp + num_cus - 1) / num_cus) / sp;
       if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
     }
     if (best > 1) { p.split = best; p.n_main = p.ntiles - rem; }
     // One whole tile per CU next to four short K-ranges ends with that tile running alone (one wave per
-    // SIMD, nothing to hide its barriers behind): such layers (256 <= tiles < 512: the 40x80 ones) also cut
-    // the first group in two.  Measured: 2.750 -> 2.72 ms per frame, flat over 2..4 x 5..8
-    // (debug override MSI_CONV_SPLIT01="s0xs1").
-    if (p.n_main == NUM_CUS && p.split > 1 && p.ksteps >= 4 * MAX_SPLIT) {
+    // SIMD, nothing to hide its barriers behind): such layers (CUs <= tiles < 2 CUs: the 40x80 ones) also cut
+    // the first group in two.  Measured (r01): 2.750 -> 2.72 ms per frame, flat over 2..4 x 5..8.
+    if (p.n_main == num_cus && p.split > 1 && p.ksteps >= 4 * MAX_SPLIT) {
       p.split0 = 2;
       p.split = p.split > 6 ? 6 : p.split;   // remainder ranges not much shorter than the halves
-    }
-    static const char *s01 = getenv("MSI_CONV_SPLIT01");
-    int a0 = 0, a1 = 0;
-    if (s01 && p.n_main == NUM_CUS && sscanf(s01, "%dx%d", &a0, &a1) == 2 && a0 >= 1 && a0 <= MAX_SPLIT && a1 >= 2 &&
-        a1 <= MAX_SPLIT && p.ksteps >= 2 * a0 && p.ksteps >= 2 * a1) {
-      p.split0 = a0;
-      p.split = a1;
     }
   }
   p.nb_main = p.n_main * p.split0;
@@ -1191,11 +1137,84 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
   p.mg_mw = magic(p.Mw); p.mg_tm = magic(p.tiles_m); p.mg_tn = magic(p.tiles_n); p.mg_nc = magic(p.nclass);
   p.mg_sp0 = magic(p.split0);
   p.mg_sp = magic(p.split);
-  const int nblocks = p.nb_main + (p.ntiles - p.n_main) * p.split;
-  const int nfix = (p.split0 > 1 ? p.n_main : 0) + (p.split > 1 ? p.ntiles - p.n_main : 0);
-  if (nfix > CNT_PER_LAYER) p.tile_cnt = nullptr;   // (cannot happen with the split rules above; falls back to the fix-up launch)
-  if ((size_t)(nblocks - (p.split0 == 1 ? p.nb_main : 0)) * BM * BN * sizeof(float) > PARTIAL_BYTES)
-    return msi::fail(MSI_E_WORKSPACE, "conv: %d partial accumulators exceed the workspace", nblocks);
+  *nblocks = p.nb_main + (p.ntiles - p.n_main) * p.split;
+  *nfix = (p.split0 > 1 ? p.n_main : 0) + (p.split > 1 ? p.ntiles - p.n_main : 0);
+}
+
+int plan_layers(msi_net_plan *pl) {
+  const msi_net_desc *desc = &pl->desc;
+  int rc = build_net(desc, pl->num_cus, pl->net);
+  if (rc) return rc;
+  const Net &net = pl->net;
+  const int bf16 = desc->dtype == MSI_DTYPE_BF16;
+  const int head_src = net.layers[MSI_NET_NUM_LAYERS - 1].src0;
+  // The head (1x1, two k-steps, HBM-bound) applies its producer's LayerNorm + ReLU itself: one HBM round trip of
+  // that activation less (fp32 only; option MSI_NET_OPT_HEAD_FUSE_LN = 0 restores the separate pass)
+  const bool fuse_head_ln = !bf16 && pl->opt[MSI_NET_OPT_HEAD_FUSE_LN] && net.layers[head_src].cout <= HEAD_MAX_C;
+  for (int li = 0; li < MSI_NET_NUM_LAYERS; ++li) {
+    const Layer &L = net.layers[li];
+    LayerLaunch &Q = pl->launch[li];
+    memset(&Q, 0, sizeof(Q));
+    ConvParams &p = Q.p;
+    p.C0 = L.c0;
+    p.C1 = L.src1 >= 0 ? L.c1 : 0;
+    p.cb_stride = (int)round_up(L.cout, 4);
+    p.Hin = L.in_h; p.Win = L.in_w; p.Hout = L.out_h; p.Wout = L.out_w;
+    p.Cout = L.cout; p.npad = L.npad;
+    p.ntaps = L.ntaps; p.cpt0 = L.cpt0; p.cpt1 = L.cpt1; p.ksteps = L.ksteps;
+    p.mode = L.kind; p.nclass = L.nclass;
+    p.wrap = desc->coord_net ? 0 : 1;
+    p.rate = L.rate;
+    p.Mh = L.mh; p.Mw = L.mw;
+    p.stride = 1;
+    if (L.kind == MODE_CONV) {
+      p.stride = L.stride;
+      if (desc->coord_net) {
+        // TF SAME: total = max((out-1)*s + k_eff - in, 0), floor(total/2) before
+        const int keff = 2 * L.rate + 1;
+        const int th = (L.out_h - 1) * L.stride + keff - L.in_h, tw = (L.out_w - 1) * L.stride + keff - L.in_w;
+        p.pad_t = (th > 0 ? th : 0) / 2;
+        p.pad_l = (tw > 0 ? tw : 0) / 2;
+      } else {
+        p.pad_t = L.rate;  // wrap_pad(x, rate, rate) + VALID (nets.py:403-421)
+        p.pad_l = L.rate;
+      }
+    } else if (L.kind == MODE_CONVT && L.wrapt) {
+      p.pad_t = 0;   // tap v reads input row mh - v and padded column mw - v = image column mw - v - 2 (tap_delta)
+      p.pad_l = 2;
+    }
+    if (L.kind == MODE_HEAD && fuse_head_ln) {
+      Q.fuse_ln = 1;
+      p.ln_inv_n = 1.0 / net.layers[L.src0].ln_count;
+    }
+    Q.skip_apply = fuse_head_ln && li == head_src;
+    // bf16: at 4 MFMAs per k-step the 64x64 tile is bound by its LDS traffic; where the grid stays large
+    // (>= 4 tiles per CU) and Cout allows, the 128x128 tile (64x64 per wave) halves that traffic per flop
+    const long tiles_big = (long)((p.Mh * p.Mw + 127) / 128) * ((L.cout + 127) / 128) * L.nclass * desc->batch;
+    const int bigmode = pl->opt[MSI_NET_OPT_BIGTILE];   // 0 = never, 1 = auto, 2 = whenever Cout allows (tests)
+    int BM = 64, BN = 64;
+    Q.tile = TILE_64x64;
+    if (bf16 && L.cout % 128 == 0 && bigmode != 0 && (tiles_big >= 4L * pl->num_cus || bigmode == 2)) {
+      Q.tile = TILE_128x128; BM = 128; BN = 128;
+    } else if (bf16 && L.cout % 64 == 0 && bigmode != 0 && ((tiles_big >= 4L * pl->num_cus && L.cin <= 128) || bigmode == 2)) {
+      Q.tile = TILE_128x64; BM = 128; BN = 64;   // Cout = 64, short K (conv8_2: 495 vs 599 us; conv1_1 / conv8_1 are faster at 64x64)
+    }
+    plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], &Q.nblocks, &Q.nfix);
+    Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= 2 * pl->num_cus;
+    if ((size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * BM * BN * sizeof(float) > net.partial_bytes)
+      return msi::fail(MSI_E_WORKSPACE, "conv %s: %d partial accumulators exceed the workspace", L.name, Q.nblocks);
+    if (L.kind != MODE_HEAD) {
+      const size_t per_sample = (size_t)L.out_h * L.out_w * L.cout;
+      size_t blocks = (per_sample / 4 + 255) / 256;
+      if (blocks > 1024) blocks = 1024;  // grid-stride
+      Q.ln_blocks = (unsigned)blocks;
+    }
+  }
+  return MSI_OK;
+}
+
+template <int BM, int BN, int MODE, int BF16>
+int launch_conv_mode(const LayerLaunch &Q, const ConvParams &p, hipStream_t stream) {
   const size_t lds = (size_t)NSTAGE * (BM + BN) * ROW_BYTES;
   if (lds > 64 * 1024) {
     static thread_local bool done = false;
@@ -1206,37 +1225,36 @@ int launch_conv_mode(ConvParams p, int batch, hipStream_t stream, int *nparts) {
       done = true;
     }
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, BF16>), dim3(nblocks), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, BF16>), dim3(Q.nblocks), dim3(256), lds, stream, p);
   int rc = msi::check_launch("conv_igemm");
-  if (rc || nfix == 0 || p.tile_cnt != nullptr) return rc;
-  hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, MODE>), dim3(nfix), dim3(256), 0, stream, p);
-  return msi::check_launch("conv_fixup");
+  if (rc || Q.nfix == 0 || p.tile_cnt != nullptr) return rc;
+  if constexpr (BM * BN == 64 * 64) {   // (big tiles are never split)
+    hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, MODE>), dim3(Q.nfix), dim3(256), 0, stream, p);
+    return msi::check_launch("conv_fixup");
+  } else {
+    return msi::fail(MSI_E_UNSUPPORTED, "conv: split big tile");
+  }
 }
 
 template <int BM, int BN>
-int launch_conv(const ConvParams &p, int bf16, int batch, hipStream_t stream, int *nparts) {
+int launch_conv(const LayerLaunch &Q, const ConvParams &p, int bf16, hipStream_t stream) {
   if (bf16) {
     switch (p.mode) {
-      case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 1>(p, batch, stream, nparts);
-      case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 1>(p, batch, stream, nparts);
-      default: return launch_conv_mode<BM, BN, MODE_HEAD, 1>(p, batch, stream, nparts);
+      case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 1>(Q, p, stream);
+      case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 1>(Q, p, stream);
+      default: return launch_conv_mode<BM, BN, MODE_HEAD, 1>(Q, p, stream);
     }
   }
   if constexpr (BM * BN == 64 * 64) {
     switch (p.mode) {
-      case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 0>(p, batch, stream, nparts);
-      case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 0>(p, batch, stream, nparts);
-      default: return launch_conv_mode<BM, BN, MODE_HEAD, 0>(p, batch, stream, nparts);
+      case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 0>(Q, p, stream);
+      case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 0>(Q, p, stream);
+      default: return launch_conv_mode<BM, BN, MODE_HEAD, 0>(Q, p, stream);
     }
   } else {
     return msi::fail(MSI_E_UNSUPPORTED, "conv: the fp32 path is built for the 64x64 tile");
   }
 }
-
-// Tile: 64x64 on every layer.  Its 32 KB of LDS lets five workgroups share a CU, and occupancy
-// hides the per-k-step barrier better than a larger tile's arithmetic intensity helps (measured on
-// the BASELINE network, profiles/r01_*: 128x64 +4 %, 128x128 +20 % time).
-constexpr int TILE_M = 64, TILE_N = 64;
 
 }  // namespace
 
@@ -1246,7 +1264,7 @@ static unsigned long long *g_timing_buf = nullptr;
 static int g_timing_layer = -1;
 extern "C" int msi_debug_conv_occupancy(int lds_bytes) {
   int n = -1;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<TILE_M, TILE_N, MODE_CONV, 0>, 256, (size_t)lds_bytes);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<64, 64, MODE_CONV, 0>, 256, (size_t)lds_bytes);
   return n;
 }
 extern "C" void msi_debug_conv_timing(void *device_buffer, int layer) {
@@ -1259,7 +1277,7 @@ extern "C" {
 
 int msi_net_layer_info(const msi_net_desc *desc, int32_t layer, msi_layer_info *out) {
   Net net;
-  int rc = build_net(desc, net);
+  int rc = build_net(desc, DEFAULT_CUS, net);
   if (rc) return rc;
   MSI_REQUIRE(out && layer >= 0 && layer < MSI_NET_NUM_LAYERS, "net_layer_info: bad layer %d", layer);
   const Layer &L = net.layers[layer];
@@ -1275,22 +1293,17 @@ int msi_net_layer_info(const msi_net_desc *desc, int32_t layer, msi_layer_info *
 
 size_t msi_net_param_floats(const msi_net_desc *desc) {
   Net net;
-  return build_net(desc, net) ? 0 : net.param_floats;
+  return build_net(desc, DEFAULT_CUS, net) ? 0 : net.param_floats;
 }
 
 size_t msi_net_packed_floats(const msi_net_desc *desc) {
   Net net;
-  return build_net(desc, net) ? 0 : net.packed_floats;
-}
-
-size_t msi_net_workspace_bytes(const msi_net_desc *desc) {
-  Net net;
-  return build_net(desc, net) ? 0 : net.ws_bytes;
+  return build_net(desc, DEFAULT_CUS, net) ? 0 : net.packed_floats;
 }
 
 int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, float *packed) {
   Net net;
-  int rc = build_net(desc, net);
+  int rc = build_net(desc, DEFAULT_CUS, net);
   if (rc) return rc;
   MSI_REQUIRE(params && packed, "net_pack_weights: null pointer");
   memset(packed, 0, net.packed_floats * sizeof(float));
@@ -1332,8 +1345,9 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
               v = w[((size_t)tap * cin_w + c) * L.cout + n];
             } else if (L.kind == MODE_CONVT) {    // [4,4,cout,cin]
               const int th = tap >> 1, tw = tap & 1;
-              const int kh = ph == 0 ? 1 + 2 * th : 2 - 2 * th;
-              const int kw = pw == 0 ? 1 + 2 * tw : 2 - 2 * tw;
+              // SAME: y[2i+k-1] += x[i] w[k] (see tap_delta); VALID over the wrap-padded input: k = parity + 2 v
+              const int kh = L.wrapt ? ph + 2 * th : (ph == 0 ? 1 + 2 * th : 2 - 2 * th);
+              const int kw = L.wrapt ? pw + 2 * tw : (pw == 0 ? 1 + 2 * tw : 2 - 2 * tw);
               v = w[(((size_t)kh * 4 + kw) * L.cout + n) * L.cin + c];
             } else {                              // [1,1,cin,cout]
               v = w[(size_t)c * L.cout + n];
@@ -1404,11 +1418,53 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
   return MSI_OK;
 }
 
-static int net_forward(const msi_net_desc *desc, const float *packed, const void *net_input,
-                       float *pred, void *workspace, size_t workspace_bytes, msi_stream_t stream_) {
-  Net net;
-  int rc = build_net(desc, net);
-  if (rc) return rc;
+// ---- plan ---------------------------------------------------------------------------------------
+int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
+  MSI_REQUIRE(desc && out, "net_plan_create: null pointer");
+  *out = nullptr;
+  msi_net_plan *pl = new (std::nothrow) msi_net_plan();
+  if (!pl) return msi::fail(MSI_E_WORKSPACE, "net_plan_create: out of host memory");
+  pl->desc = *desc;
+  pl->num_cus = device_cu_count();
+  pl->opt[MSI_NET_OPT_FIXUP_KERNEL] = 0;
+  pl->opt[MSI_NET_OPT_TAILSPLIT] = 1;
+  pl->opt[MSI_NET_OPT_BIGTILE] = 1;
+  pl->opt[MSI_NET_OPT_HEAD_FUSE_LN] = 1;
+  pl->opt[MSI_NET_OPT_NUM_CUS] = pl->num_cus;
+  int rc = plan_layers(pl);
+  if (rc) { delete pl; return rc; }
+  *out = pl;
+  return MSI_OK;
+}
+
+void msi_net_plan_destroy(msi_net_plan *plan) { delete plan; }
+
+int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value) {
+  MSI_REQUIRE(plan, "net_plan_set_option: null plan");
+  MSI_REQUIRE(option >= 0 && option < MSI_NET_OPT_COUNT, "net_plan_set_option: unknown option %d", option);
+  if (option == MSI_NET_OPT_NUM_CUS) {
+    MSI_REQUIRE(value >= 8 && value <= 4096, "net_plan_set_option: num_cus %d out of range", value);
+    plan->num_cus = value;
+  }
+  if (option == MSI_NET_OPT_BIGTILE) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: bigtile %d", value);
+  const int old = plan->opt[option];
+  plan->opt[option] = value;
+  int rc = plan_layers(plan);
+  if (rc) {   // keep the plan usable
+    plan->opt[option] = old;
+    if (option == MSI_NET_OPT_NUM_CUS) plan->num_cus = old;
+    plan_layers(plan);
+  }
+  return rc;
+}
+
+size_t msi_net_plan_workspace_bytes(const msi_net_plan *plan) { return plan ? plan->net.ws_bytes : 0; }
+
+int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
+                         void *workspace, size_t workspace_bytes, msi_stream_t stream_) {
+  MSI_REQUIRE(plan, "net_forward: null plan");
+  const msi_net_desc *desc = &plan->desc;
+  const Net &net = plan->net;
   const int bf16 = desc->dtype == MSI_DTYPE_BF16;
   MSI_REQUIRE(packed && net_input && pred && workspace, "net_forward: null pointer");
   if (workspace_bytes < net.ws_bytes)
@@ -1417,25 +1473,14 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
   if (desc->batch == 0) return MSI_OK;
   hipStream_t stream = msi::as_stream(stream_);
   char *ws = static_cast<char *>(workspace);
-  float *stats = reinterpret_cast<float *>(ws + net.stats_off);
-
-  // The head (1x1, two k-steps, HBM-bound) applies its producer's LayerNorm + ReLU itself: one HBM round trip of
-  // that activation less (MSI_HEAD_FUSE_LN=0 restores the separate pass; the bf16 path keeps it).
-  const char *fenv = getenv("MSI_HEAD_FUSE_LN");
-  const bool fuse_head_ln = !bf16 && !(fenv && atoi(fenv) == 0);
-  const int head_src = net.layers[MSI_NET_NUM_LAYERS - 1].src0;
-  // in-launch fix-up of the split tiles (default) or the separate conv_fixup_kernel launch (MSI_CONV_FIXUP=kernel)
-  const char *fxenv = getenv("MSI_CONV_FIXUP");
-  const bool inlaunch_fixup = !(fxenv && strcmp(fxenv, "kernel") == 0);
+  // tickets of the in-launch fix-ups and the LayerNorm sums start from zero
+  hipError_t e = hipMemsetAsync(ws + net.zero_off, 0, net.zero_bytes, stream);
+  if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_forward: %s", hipGetErrorString(e));
   int *cnt = reinterpret_cast<int *>(ws + net.cnt_off);
-  if (inlaunch_fixup) {
-    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)MSI_NET_NUM_LAYERS * CNT_PER_LAYER * sizeof(int), stream);
-    if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_forward: %s", hipGetErrorString(e));
-  }
   for (int li = 0; li < MSI_NET_NUM_LAYERS; ++li) {
     const Layer &L = net.layers[li];
-    ConvParams p;
-    memset(&p, 0, sizeof(p));
+    const LayerLaunch &Q = plan->launch[li];
+    ConvParams p = Q.p;
     // sources: the network input, or the normalised output of the producer -- in place in its raw
     // buffer (fp32) or the bf16 copy ln_apply wrote next to it
     auto src_ptr = [&](int s) -> const char * {
@@ -1443,84 +1488,44 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
       return ws + (bf16 ? net.layers[s].act_off : net.layers[s].raw_off);
     };
     p.x0 = src_ptr(L.src0);
-    p.C0 = L.c0;
-    p.x1 = p.x0;  // unused second source: alias the first (cpt1 = 0 keeps it unselected)
-    p.C1 = 0;
-    if (L.src1 >= 0) {
-      p.x1 = src_ptr(L.src1);
-      p.C1 = L.c1;
-    }
+    p.x1 = L.src1 >= 0 ? src_ptr(L.src1) : p.x0;  // unused second source: alias the first (cpt1 = 0 keeps it unselected)
     p.wpk = reinterpret_cast<const char *>(packed + L.packed_off);
     p.coord_bias = L.has_coord ? packed + L.coord_off : nullptr;
-    p.cb_stride = (int)round_up(L.cout, 4);
     p.bias = L.kind == MODE_HEAD ? packed + L.gamma_off : nullptr;
-    // fp32 head: its producer's LayerNorm + ReLU is applied while loading (the producer's buffer holds the raw output)
-    p.ln_aff = (L.kind == MODE_HEAD && fuse_head_ln) ? reinterpret_cast<const float *>(ws + net.layers[L.src0].aff_off) : nullptr;
+    if (Q.fuse_ln) {   // fp32 head: its producer's LayerNorm + ReLU is applied while loading (the producer's buffer holds the raw output)
+      const Layer &S = net.layers[L.src0];
+      p.ln_sums = reinterpret_cast<const long long *>(ws + S.sums_off);
+      p.ln_gamma = packed + S.gamma_off;
+      p.ln_beta = packed + S.beta_off;
+    }
     p.y = L.kind == MODE_HEAD ? pred : reinterpret_cast<float *>(ws + L.raw_off);
-    p.stats = L.kind == MODE_HEAD ? nullptr : stats;
+    p.sums = L.kind == MODE_HEAD ? nullptr : reinterpret_cast<long long *>(ws + L.sums_off);
     p.partial = reinterpret_cast<float *>(ws + net.partial_off);
-    p.tile_cnt = inlaunch_fixup ? cnt + (size_t)li * CNT_PER_LAYER : nullptr;
-    p.Hin = L.in_h; p.Win = L.in_w; p.Hout = L.out_h; p.Wout = L.out_w;
-    p.Cout = L.cout; p.npad = L.npad;
-    p.ntaps = L.ntaps; p.cpt0 = L.cpt0; p.cpt1 = L.cpt1; p.ksteps = L.ksteps;
-    p.mode = L.kind; p.nclass = L.nclass;
-    p.wrap = desc->coord_net ? 0 : 1;
-    p.rate = L.rate;
-    if (L.kind == MODE_CONV) {
-      p.Mh = L.out_h; p.Mw = L.out_w; p.stride = L.stride;
-      if (desc->coord_net) {
-        // TF SAME: total = max((out-1)*s + k_eff - in, 0), floor(total/2) before
-        const int keff = 2 * L.rate + 1;
-        const int th = (L.out_h - 1) * L.stride + keff - L.in_h, tw = (L.out_w - 1) * L.stride + keff - L.in_w;
-        p.pad_t = (th > 0 ? th : 0) / 2;
-        p.pad_l = (tw > 0 ? tw : 0) / 2;
-      } else {
-        p.pad_t = L.rate;  // wrap_pad(x, rate, rate) + VALID (nets.py:403-421)
-        p.pad_l = L.rate;
-      }
-    } else if (L.kind == MODE_CONVT) {
-      p.Mh = L.in_h; p.Mw = L.in_w; p.stride = 1;
-    } else {
-      p.Mh = L.out_h; p.Mw = L.out_w; p.stride = 1;
-    }
-    int nparts = 0;
-    {  // debug knob, read once
-      static const char *abl = getenv("MSI_CONV_ABLATE");
-      p.ablate = abl ? atoi(abl) : 0;
-    }
+    p.tile_cnt = Q.inlaunch ? cnt + (size_t)li * 2 * plan->num_cus : nullptr;
 #ifdef MSI_CONV_TIMING
     p.dbg = (li == g_timing_layer) ? g_timing_buf : nullptr;
 #endif
-    // bf16: at 4 MFMAs per k-step the 64x64 tile is bound by its LDS traffic; where the grid stays large
-    // (>= 4 tiles per CU) and Cout allows, the 128x128 tile (64x64 per wave) halves that traffic per flop
-    const long tiles_big = (long)((p.Mh * p.Mw + 127) / 128) * ((L.cout + 127) / 128) * L.nclass * desc->batch;
-    const char *bigenv = getenv("MSI_CONV_BIGTILE");   // debug / tests: 0 = never, 2 = whenever Cout allows (read per call)
-    const int bigmode = bigenv ? atoi(bigenv) : 1;
-    if (bf16 && L.cout % 128 == 0 && bigmode != 0 && (tiles_big >= 4 * NUM_CUS || bigmode == 2))
-      rc = launch_conv<128, 128>(p, bf16, desc->batch, stream, &nparts);
-    else if (bf16 && L.cout % 64 == 0 && bigmode != 0 && ((tiles_big >= 4 * NUM_CUS && L.cin <= 128) || bigmode == 2))
-      rc = launch_conv<128, 64>(p, bf16, desc->batch, stream, &nparts);   // Cout = 64, short K (conv8_2: 495 vs 599 us;
-                                                                           // conv1_1 / conv8_1 are faster at 64x64)
-    else
-      rc = launch_conv<TILE_M, TILE_N>(p, bf16, desc->batch, stream, &nparts);
+    int rc;
+    switch (Q.tile) {
+      case TILE_128x128: rc = launch_conv<128, 128>(Q, p, bf16, stream); break;
+      case TILE_128x64: rc = launch_conv<128, 64>(Q, p, bf16, stream); break;
+      default: rc = launch_conv<64, 64>(Q, p, bf16, stream); break;
+    }
     if (rc) return rc;
-    if (L.kind != MODE_HEAD) {
+    if (L.kind != MODE_HEAD && !Q.skip_apply) {
       const size_t per_sample = (size_t)L.out_h * L.out_w * L.cout;
-      size_t blocks = (per_sample / 4 + 255) / 256;
-      if (blocks > 512) blocks = 512;  // grid-stride: keeps the redundant partial merge cheap
       float *raw = reinterpret_cast<float *>(ws + L.raw_off), *aff = reinterpret_cast<float *>(ws + L.aff_off);
-      const dim3 grid((unsigned)blocks, desc->batch);
+      const dim3 grid(Q.ln_blocks, desc->batch);
       const size_t lds = (size_t)2 * L.cout * sizeof(float);
+      const long long *sums = reinterpret_cast<const long long *>(ws + L.sums_off);
       if (bf16)
-        hipLaunchKernelGGL(ln_apply_kernel<1>, grid, dim3(256), lds, stream, raw, stats, nparts, packed + L.gamma_off,
-                           packed + L.beta_off, per_sample, L.cout, aff, reinterpret_cast<unsigned short *>(ws + L.act_off));
-      else if (fuse_head_ln && li == head_src)   // finish only: the head applies the affine
-        hipLaunchKernelGGL(ln_apply_kernel<2>, dim3(1, desc->batch), dim3(256), lds, stream, raw, stats, nparts,
+        hipLaunchKernelGGL(ln_apply_kernel<1>, grid, dim3(256), lds, stream, raw, sums, 1.0 / L.ln_count,
+                           packed + L.gamma_off, packed + L.beta_off, per_sample, L.cout, aff,
+                           reinterpret_cast<unsigned short *>(ws + L.act_off));
+      else
+        hipLaunchKernelGGL(ln_apply_kernel<0>, grid, dim3(256), lds, stream, raw, sums, 1.0 / L.ln_count,
                            packed + L.gamma_off, packed + L.beta_off, per_sample, L.cout, aff,
                            static_cast<unsigned short *>(nullptr));
-      else
-        hipLaunchKernelGGL(ln_apply_kernel<0>, grid, dim3(256), lds, stream, raw, stats, nparts, packed + L.gamma_off,
-                           packed + L.beta_off, per_sample, L.cout, aff, static_cast<unsigned short *>(nullptr));
       rc = msi::check_launch("ln_apply");
       if (rc) return rc;
     }
@@ -1528,16 +1533,35 @@ static int net_forward(const msi_net_desc *desc, const float *packed, const void
   return MSI_OK;
 }
 
+// ---- descriptor-level convenience (a transient plan per call; the frame loop uses a plan) -----------
+size_t msi_net_workspace_bytes(const msi_net_desc *desc) {
+  msi_net_plan *pl = nullptr;
+  if (msi_net_plan_create(desc, &pl)) return 0;
+  const size_t n = pl->net.ws_bytes;
+  msi_net_plan_destroy(pl);
+  return n;
+}
+
+static int forward_once(const msi_net_desc *desc, const float *packed, const void *net_input, float *pred,
+                        void *workspace, size_t workspace_bytes, msi_stream_t stream) {
+  msi_net_plan *pl = nullptr;
+  int rc = msi_net_plan_create(desc, &pl);
+  if (rc) return rc;
+  rc = msi_net_plan_forward(pl, packed, net_input, pred, workspace, workspace_bytes, stream);
+  msi_net_plan_destroy(pl);
+  return rc;
+}
+
 int msi_net_forward_f32(const msi_net_desc *desc, const float *packed, const float *net_input,
                         float *pred, void *workspace, size_t workspace_bytes, msi_stream_t stream) {
   MSI_REQUIRE(desc && desc->dtype == MSI_DTYPE_F32, "net_forward_f32: desc->dtype must be MSI_DTYPE_F32");
-  return net_forward(desc, packed, net_input, pred, workspace, workspace_bytes, stream);
+  return forward_once(desc, packed, net_input, pred, workspace, workspace_bytes, stream);
 }
 
 int msi_net_forward_bf16(const msi_net_desc *desc, const float *packed, const void *net_input_bf16,
                          float *pred, void *workspace, size_t workspace_bytes, msi_stream_t stream) {
   MSI_REQUIRE(desc && desc->dtype == MSI_DTYPE_BF16, "net_forward_bf16: desc->dtype must be MSI_DTYPE_BF16");
-  return net_forward(desc, packed, net_input_bf16, pred, workspace, workspace_bytes, stream);
+  return forward_once(desc, packed, net_input_bf16, pred, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -240,14 +240,25 @@ ods_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose
 constexpr int K3_TP = 32;
 
 // PSV_BF16: the PSV is the bf16 network input (converted to fp32 on its way into LDS).
-template <int PSV_BF16>
+// COLOR: which_color_pred of infer_msi (msi.py:119-275):
+//   0 blend_psv    pred = [w | alpha]              rgb = w fg + (1-w) bg_psv                       (msi.py:130-147)
+//   1 blend_bg     pred = [w | alpha | bg(3)]      rgb = w fg + (1-w) bg      (bg: raw tanh output, msi.py:177-188)
+//   2 blend_bg_psv pred = [w | alpha | bw | bg(3)] rgb = bw (w fg + (1-w) bg_psv) + (1-bw) bg      (msi.py:223-242)
+//   3 alpha_only   pred = [alpha]                  rgb = fg                                        (msi.py:258-268)
+// with w, alpha, bw = (x + 1) / 2.  The channel counts of 1 and 2 are odd, so those modes place pred element
+// by element (the 32-pixel tile is still one contiguous, 16-byte aligned run) and write the optional
+// [B,H,W,D] outputs from phase 2.
+enum { COLOR_BLEND_PSV = 0, COLOR_BLEND_BG = 1, COLOR_BLEND_BG_PSV = 2, COLOR_ALPHA_ONLY = 3 };
+
+template <int PSV_BF16, int COLOR>
 __global__ void __launch_bounds__(256)
 assemble_kernel(const void *__restrict__ psv_, const float *__restrict__ pred,
                 float4 *__restrict__ rgba, float *__restrict__ bw_out,
-                float *__restrict__ al_out, long npix_total, int hw, int nd, int pred_scaled) {
+                float *__restrict__ al_out, float *__restrict__ bgw_out, long npix_total, int hw, int nd, int pred_scaled) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int c_psv = 6 * nd, c_pred = 2 * nd;
-  const int s_psv = c_psv + 1, s_pred = c_pred + 1;  // odd row strides
+  const int c_psv = 6 * nd;
+  const int c_pred = COLOR == COLOR_BLEND_PSV ? 2 * nd : (COLOR == COLOR_BLEND_BG ? 2 * nd + 3 : (COLOR == COLOR_BLEND_BG_PSV ? 3 * nd + 3 : nd));
+  const int s_psv = c_psv + 1, s_pred = c_pred | 1;  // odd row strides
   float *l_psv = smem;
   float *l_pred = smem + K3_TP * s_psv;
 
@@ -281,7 +292,7 @@ assemble_kernel(const void *__restrict__ psv_, const float *__restrict__ pred,
       dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
     }
   }
-  {
+  if (COLOR == COLOR_BLEND_PSV) {
     const float4 *g = reinterpret_cast<const float4 *>(pred + p0 * c_pred);
     const int nv = npx * c_pred / 4;
     for (int v = tid; v < nv; v += 256) {
@@ -301,6 +312,16 @@ assemble_kernel(const void *__restrict__ psv_, const float *__restrict__ pred,
         if (al_out) *reinterpret_cast<float4 *>(al_out + (p0 + row) * nd + (col - nd)) = q;
       }
     }
+  } else {
+    const float *g = pred + p0 * c_pred;
+    const int n = npx * c_pred;
+    const int nscaled = c_pred - ((COLOR == COLOR_BLEND_BG || COLOR == COLOR_BLEND_BG_PSV) ? 3 : 0);  // bg stays in [-1, 1]
+    for (int e = tid; e < n; e += 256) {
+      const int row = e / c_pred, col = e - row * c_pred;
+      float x = g[e];
+      if (col < nscaled) x = (x + 1.0f) / 2.0f;
+      l_pred[row * s_pred + col] = x;
+    }
   }
   __syncthreads();
 
@@ -312,16 +333,42 @@ assemble_kernel(const void *__restrict__ psv_, const float *__restrict__ pred,
   const float *rp = l_psv + px * s_psv;
   const float *rq = l_pred + px * s_pred;
   for (int d = tid / K3_TP; d < nd; d += 256 / K3_TP) {
-    const float w = rq[d];
-    const float al = rq[nd + d];
-    const float omw = 1.0f - w;
     const float *fg = rp + d * 3;
     const float *bg = rp + (nd + d) * 3;
     float4 o;
-    o.x = w * fg[0] + omw * bg[0];
-    o.y = w * fg[1] + omw * bg[1];
-    o.z = w * fg[2] + omw * bg[2];
-    o.w = al;
+    if (COLOR == COLOR_BLEND_PSV) {
+      const float w = rq[d];
+      const float omw = 1.0f - w;
+      o.x = w * fg[0] + omw * bg[0];
+      o.y = w * fg[1] + omw * bg[1];
+      o.z = w * fg[2] + omw * bg[2];
+      o.w = rq[nd + d];
+    } else if (COLOR == COLOR_BLEND_BG) {
+      const float w = rq[d];
+      const float omw = 1.0f - w;
+      const float *pb = rq + 2 * nd;
+      o.x = w * fg[0] + omw * pb[0];
+      o.y = w * fg[1] + omw * pb[1];
+      o.z = w * fg[2] + omw * pb[2];
+      o.w = rq[nd + d];
+      if (bw_out) bw_out[p * nd + d] = w;
+      if (al_out) al_out[p * nd + d] = o.w;
+    } else if (COLOR == COLOR_BLEND_BG_PSV) {
+      const float w = rq[d], bw = rq[2 * nd + d];
+      const float omw = 1.0f - w, ombw = 1.0f - bw;
+      const float *pb = rq + 3 * nd;
+      o.x = bw * (w * fg[0] + omw * bg[0]) + ombw * pb[0];
+      o.y = bw * (w * fg[1] + omw * bg[1]) + ombw * pb[1];
+      o.z = bw * (w * fg[2] + omw * bg[2]) + ombw * pb[2];
+      o.w = rq[nd + d];
+      if (bw_out) bw_out[p * nd + d] = w;
+      if (al_out) al_out[p * nd + d] = o.w;
+      if (bgw_out) bgw_out[p * nd + d] = bw;
+    } else {
+      o.x = fg[0]; o.y = fg[1]; o.z = fg[2];
+      o.w = rq[d];
+      if (al_out) al_out[p * nd + d] = o.w;
+    }
     rgba[(b * nd + d) * hw + off] = o;
   }
 }
@@ -755,10 +802,8 @@ static int sweep_common(const float *image, const float *pose, const float *intr
   if (batch == 0) return MSI_OK;
   MSI_REQUIRE((long)width * num_depths < 2147483647L && height <= 65535 && batch <= 65535,
               "ods_sphere_sweep: problem too large");
-  // NS depths per thread (bit-identical results for every NS; MSI_SWEEP_NS=1/2/4 overrides the default)
-  const char *nsenv = getenv("MSI_SWEEP_NS");
-  int ns = nsenv ? atoi(nsenv) : MSI_SWEEP_NS_DEFAULT;
-  if (ns != 1 && ns != 2 && ns != 4) ns = MSI_SWEEP_NS_DEFAULT;
+  // NS depths per thread (bit-identical results for every NS; -DMSI_SWEEP_NS_DEFAULT=1/2/4 at build time)
+  int ns = MSI_SWEEP_NS_DEFAULT;
   while (num_depths % ns != 0) ns >>= 1;
   const dim3 grid((unsigned)(((long)width * (num_depths / ns) + 255) / 256), height, batch);
 #define MSI_LAUNCH_SWEEP(T, NS_)                                                                         \
@@ -791,56 +836,65 @@ int msi_ods_sphere_sweep_bf16(const float *image, const float *pose, const float
                       psv_channels, channel_offset, stream);
 }
 
-static int assemble_common(const void *psv, int psv_bf16, const float *pred, float *rgba_native,
-                           float *blend_weights, float *alphas, int32_t batch, int32_t height,
+static int assemble_common(const void *psv, int psv_bf16, const float *pred, int color, float *rgba_native,
+                           float *blend_weights, float *alphas, float *bg_blend_weights, int32_t batch, int32_t height,
                            int32_t width, int32_t num_planes, int pred_scaled, msi_stream_t stream) {
   MSI_REQUIRE(psv && pred && rgba_native, "assemble_rgba: null pointer");
   MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_planes > 0, "assemble_rgba: bad dims");
+  MSI_REQUIRE(color >= COLOR_BLEND_PSV && color <= COLOR_ALPHA_ONLY, "assemble_rgba: which_color_pred %d", color);
   if (num_planes % 4 != 0)
     return msi::fail(MSI_E_UNSUPPORTED, "assemble_rgba: num_planes=%d must be a multiple of 4",
                      num_planes);
-  const size_t lds = (size_t)K3_TP * (8 * num_planes + 2) * sizeof(float);
+  const int c_pred = color == COLOR_BLEND_PSV ? 2 * num_planes : (color == COLOR_BLEND_BG ? 2 * num_planes + 3
+                     : (color == COLOR_BLEND_BG_PSV ? 3 * num_planes + 3 : num_planes));
+  const size_t lds = (size_t)K3_TP * ((6 * num_planes + 1) + (c_pred | 1)) * sizeof(float);
   if (lds > 160 * 1024)
     return msi::fail(MSI_E_UNSUPPORTED, "assemble_rgba: num_planes=%d needs %zu B of LDS", num_planes,
                      lds);
   const long npix = (long)batch * height * width;
   if (npix == 0) return MSI_OK;
   const long blocks = (npix + K3_TP - 1) / K3_TP;
+  typedef void (*kern_t)(const void *, const float *, float4 *, float *, float *, float *, long, int, int, int);
+  static const kern_t table[2][4] = {
+      {assemble_kernel<0, 0>, assemble_kernel<0, 1>, assemble_kernel<0, 2>, assemble_kernel<0, 3>},
+      {assemble_kernel<1, 0>, assemble_kernel<1, 1>, assemble_kernel<1, 2>, assemble_kernel<1, 3>}};
+  const kern_t kern = table[psv_bf16 ? 1 : 0][color];
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(
-        psv_bf16 ? reinterpret_cast<const void *>(assemble_kernel<1>) : reinterpret_cast<const void *>(assemble_kernel<0>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "assemble_rgba: %s", hipGetErrorString(e));
   }
-  if (psv_bf16)
-    hipLaunchKernelGGL(assemble_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, msi::as_stream(stream),
-                       psv, pred, reinterpret_cast<float4 *>(rgba_native), blend_weights, alphas, npix,
-                       height * width, num_planes, pred_scaled);
-  else
-    hipLaunchKernelGGL(assemble_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, msi::as_stream(stream),
-                       psv, pred, reinterpret_cast<float4 *>(rgba_native), blend_weights, alphas, npix,
-                       height * width, num_planes, pred_scaled);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, msi::as_stream(stream), psv, pred,
+                     reinterpret_cast<float4 *>(rgba_native), blend_weights, alphas, bg_blend_weights, npix,
+                     height * width, num_planes, pred_scaled);
   return msi::check_launch("assemble_rgba");
 }
 
 int msi_assemble_rgba_f32(const float *psv, const float *pred, float *rgba_native,
                           float *blend_weights, float *alphas, int32_t batch, int32_t height,
                           int32_t width, int32_t num_planes, msi_stream_t stream) {
-  return assemble_common(psv, 0, pred, rgba_native, blend_weights, alphas, batch, height, width, num_planes, 0, stream);
+  return assemble_common(psv, 0, pred, COLOR_BLEND_PSV, rgba_native, blend_weights, alphas, nullptr, batch, height, width,
+                         num_planes, 0, stream);
 }
 
 int msi_assemble_rgba_bf16psv_f32(const void *psv_bf16, const float *pred, float *rgba_native,
                                   float *blend_weights, float *alphas, int32_t batch, int32_t height,
                                   int32_t width, int32_t num_planes, msi_stream_t stream) {
-  return assemble_common(psv_bf16, 1, pred, rgba_native, blend_weights, alphas, batch, height, width, num_planes, 0,
-                         stream);
+  return assemble_common(psv_bf16, 1, pred, COLOR_BLEND_PSV, rgba_native, blend_weights, alphas, nullptr, batch, height,
+                         width, num_planes, 0, stream);
+}
+
+int msi_assemble_rgba_color_f32(const void *psv, int32_t psv_is_bf16, const float *pred, int32_t which_color_pred,
+                                float *rgba_native, float *blend_weights, float *alphas, float *bg_blend_weights,
+                                int32_t batch, int32_t height, int32_t width, int32_t num_planes, msi_stream_t stream) {
+  return assemble_common(psv, psv_is_bf16 != 0, pred, which_color_pred, rgba_native, blend_weights, alphas,
+                         bg_blend_weights, batch, height, width, num_planes, 0, stream);
 }
 
 int msi_assemble_rgba_scaled_f32(const float *psv, const float *weights_alphas, float *rgba_native,
                                  int32_t batch, int32_t height, int32_t width, int32_t num_planes,
                                  msi_stream_t stream) {
-  return assemble_common(psv, 0, weights_alphas, rgba_native, nullptr, nullptr, batch, height, width, num_planes, 1,
-                         stream);
+  return assemble_common(psv, 0, weights_alphas, COLOR_BLEND_PSV, rgba_native, nullptr, nullptr, nullptr, batch, height,
+                         width, num_planes, 1, stream);
 }
 
 int msi_resize_bilinear_f32(const float *in, float *out, int32_t batch, int32_t in_h, int32_t in_w,

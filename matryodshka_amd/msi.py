@@ -47,7 +47,8 @@ class MSI(object):
         self._weights = None
         self._blob_cache = {}     # (in_channels, num_outputs, ngf) -> np blob
         self._packed_cache = {}   # desc key -> device tensor
-        self._ws_cache = {}       # desc key -> device workspace
+        self._ws_cache = {}       # desc key -> (native plan, device workspace)
+        self.net_options = {}     # msi_net_plan_set_option key -> value, applied to plans created from now on (tests)
         self._trig_cache = {}     # (H, W) -> device tensor
         self._planes_cache = {}   # tuple(planes) -> device tensor
         if weights is not None:
@@ -103,14 +104,20 @@ class MSI(object):
                 self._blob_cache[bkey] = blob
             packed = torch.from_numpy(nets.pack_params(desc, blob)).to(self.device)
             self._packed_cache[pkey] = packed
-        ws = self._ws_cache.get(key)
-        if ws is None:
-            nbytes = N.lib.msi_net_workspace_bytes(desc)
-            if nbytes == 0:
-                raise N.MsiError("unsupported network configuration: " + N.last_error())
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self._ws_cache[key] = ws
-        return desc, packed, ws
+        key = key + tuple(sorted(self.net_options.items()))
+        pw = self._ws_cache.get(key)
+        if pw is None:
+            plan = N.NetPlan(desc, self.net_options)      # layer table, tiling and work split resolved once
+            ws = torch.empty(plan.workspace_bytes(), dtype=torch.uint8, device=self.device)
+            pw = (plan, ws)
+            self._ws_cache[key] = pw
+        return desc, packed, pw[1]
+
+    def _plan(self, batch, height, width, in_channels, num_outputs, ngf):
+        self._net(batch, height, width, in_channels, num_outputs, ngf)
+        key = (batch, height, width, in_channels, num_outputs, ngf, self.coord_net, self.dtype) \
+            + tuple(sorted(self.net_options.items()))
+        return self._ws_cache[key][0]
 
     # ------------------------------------------------------------------ msi.py:1196-1217
     def inv_depths(self, start_depth, end_depth, num_depths):
@@ -234,9 +241,9 @@ class MSI(object):
         if net_input.dtype != want or not net_input.is_contiguous():
             net_input = net_input.to(want).contiguous()
         pred = torch.empty((b, h, w, num_outputs), dtype=torch.float32, device=self.device)
-        fwd = N.lib.msi_net_forward_bf16 if self.dtype == 'bf16' else N.lib.msi_net_forward_f32
-        N.check(fwd(desc, packed.data_ptr(), net_input.data_ptr(), pred.data_ptr(),
-                    ws.data_ptr(), ws.numel(), self._stream()), "msi_net_forward")
+        plan = self._plan(b, h, w, cin, num_outputs, ngf)
+        N.check(N.lib.msi_net_plan_forward(plan.handle, packed.data_ptr(), net_input.data_ptr(), pred.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), self._stream()), "msi_net_plan_forward")
         return pred
 
     def assemble_layers(self, net_input, msi_pred, num_msi_planes, extra_outputs=''):

@@ -103,7 +103,7 @@ def add_sph_coords(x):
     return torch.cat([x, c], dim=1)
 
 
-def layer_norm_relu(x, gamma, beta):
+def layer_norm_relu(x, gamma, beta, affine_out=None):
     """slim.layer_norm over (H,W,C) per sample + ReLU (nets.py:401,485 arg_scope).
     Statistics in fp64 (the ideal two-pass value), normalisation in fp32."""
     xd = x.double()
@@ -114,6 +114,8 @@ def layer_norm_relu(x, gamma, beta):
     be = torch.from_numpy(beta).view(1, -1, 1, 1).double()
     scale = (inv * g).float()
     shift = (be - mean * inv * g).float()
+    if affine_out is not None:      # tests: the per-sample, per-channel affine [B, 2, C]
+        affine_out.append(torch.stack([scale.flatten(1), shift.flatten(1)], dim=1).numpy())
     return torch.relu(x * scale + shift)
 
 
@@ -149,6 +151,13 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
     rnd = bf16_round if bf16 else (lambda t: t)
     x = rnd(torch.from_numpy(np.ascontiguousarray(np.transpose(net_input, (0, 3, 1, 2)))).float())
     acts = {}
+    affines = {}
+
+    def ln(name, y):
+        out = []
+        y = layer_norm_relu(y, weights[name + "/LayerNorm/gamma"], weights[name + "/LayerNorm/beta"], affine_out=out)
+        affines[name] = out[0]
+        return y
 
     def conv(name, x, stride=1, rate=1):
         w = rnd(_conv_w(weights[name + "/weights"]))
@@ -162,7 +171,7 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
             x = wrap_pad(x, rate, rate)
         y = TF.conv2d(x, w, stride=stride, dilation=rate)
         acts[name + "/raw"] = y
-        y = rnd(layer_norm_relu(y, weights[name + "/LayerNorm/gamma"], weights[name + "/LayerNorm/beta"]))
+        y = rnd(ln(name, y))
         acts[name] = y
         return y
 
@@ -170,11 +179,17 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
         w = rnd(_convT_w(weights[name + "/weights"]))
         if coord_net:
             y = TF.conv_transpose2d(x, w, stride=2, padding=1)
+            acts[name + "/raw"] = y
+            y = rnd(ln(name, y))
         else:
+            # nets.py:423-435: slim.conv2d_transpose(wrap_pad(skip, 2, 2), padding='VALID') runs under the
+            # layer_norm arg_scope, so LayerNorm + ReLU cover the FULL (2H+10) x (2W+10) output -- zero rows and
+            # wrap columns of the border included -- and the [5:-5] crop happens afterwards, in the consumer's
+            # input expression (cnv6_1[:,5:-5,5:-5,:], nets.py:426)
             y = TF.conv_transpose2d(wrap_pad(x, 2, 2), w, stride=2, padding=0)
+            acts[name + "/raw"] = y[:, :, 5:-5, 5:-5]
+            y = rnd(ln(name, y))
             y = y[:, :, 5:-5, 5:-5]
-        acts[name + "/raw"] = y
-        y = rnd(layer_norm_relu(y, weights[name + "/LayerNorm/gamma"], weights[name + "/LayerNorm/beta"]))
         acts[name] = y
         return y
 
@@ -201,5 +216,7 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
         pred = torch.tanh(TF.conv2d(c82, w, bias=b))
     out = np.ascontiguousarray(pred.permute(0, 2, 3, 1).numpy())
     if return_activations:
-        return out, {k: np.ascontiguousarray(v.permute(0, 2, 3, 1).numpy()) for k, v in acts.items()}
+        res = {k: np.ascontiguousarray(v.permute(0, 2, 3, 1).numpy()) for k, v in acts.items()}
+        res.update({k + "/affine": v for k, v in affines.items()})     # [B, 2, C]: scale | shift
+        return out, res
     return out

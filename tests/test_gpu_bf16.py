@@ -48,17 +48,18 @@ def test_bf16_net_matches_bf16_oracle(env, coord, b, h, w, cin, nout, ngf):
     assert np.abs(pred - ref32).mean() <= 2e-2
 
 
-def test_bf16_big_tile_matches_small_tile(env, monkeypatch):
+def test_bf16_big_tile_matches_small_tile(env):
     """The 128x128 tile (chosen for large grids) forced on a small problem: same accumulators as the 64x64
     tile up to fp32 summation order, hence the same prediction up to isolated bf16 rounding flips."""
     torch, MSI, nets, onets, _ = env
     b, h, w, cin, nout, ngf = 2, 32, 64, 48, 16, 64
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=9, randomize_affine=True)
     x = torch.from_numpy(np.random.RandomState(1).uniform(-1, 1, (b, h, w, cin)).astype(np.float32)).cuda().bfloat16()
+    from matryodshka_amd import _native as N
     m = MSI(weights=weights, dtype='bf16')
-    monkeypatch.setenv("MSI_CONV_BIGTILE", "0")
+    m.net_options[N.NET_OPT_BIGTILE] = 0
     small = m.run_net(x, nout, ngf).cpu().numpy()
-    monkeypatch.setenv("MSI_CONV_BIGTILE", "2")
+    m.net_options[N.NET_OPT_BIGTILE] = 2
     big = m.run_net(x, nout, ngf).cpu().numpy()
     ref = onets.forward(weights, x.float().cpu().numpy(), coord_net=True, bf16=True)
     d = np.abs(big - small)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-_HEAD_FUSED = __import__("os").environ.get("MSI_HEAD_FUSE_LN") != "0"   # debug knob: separate LayerNorm pass before the head
+_HEAD_FUSED = True   # default plan: the fp32 head applies conv8_2's LayerNorm itself (conv8_2's buffer stays raw)
 
 
 @pytest.fixture(scope="module")
@@ -21,12 +21,13 @@ def env():
     return torch, MSI, nets, _native, onets
 
 
-def _run(env, b, h, w, cin, nout, ngf, coord, seed=0):
+def _run(env, b, h, w, cin, nout, ngf, coord, seed=0, options=None):
     torch, MSI, nets, N, onets = env
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=seed, randomize_affine=True)
     rng = np.random.RandomState(seed + 1)
     x = rng.uniform(-1, 1, size=(b, h, w, cin)).astype(np.float32)
     m = MSI(weights=weights, coord_net=coord)
+    m.net_options.update(options or {})
     pred = m.run_net(torch.from_numpy(x).cuda(), nout, ngf)
     torch.cuda.synchronize()
     ref, acts = onets.forward(weights, x, coord_net=coord, return_activations=True)
@@ -77,12 +78,73 @@ def test_workspace_too_small_is_an_error(env):
     assert rc == -4 and b"workspace" in N.lib.msi_last_error_string()
 
 
+def test_unfused_head_and_odd_output_counts(env):
+    """Plan option HEAD_FUSE_LN = 0 (separate LayerNorm pass before the head) and head widths that are not a
+    multiple of 4 (which_color_pred blend_bg: 2 D + 3, blend_bg_psv: 3 D + 3 -> scalar store / statistics tails)."""
+    torch, MSI, nets, N, onets = env
+    pred, ref, raws, acts = _run(env, 1, 16, 32, 24, 11, 16, True, seed=3, options={N.NET_OPT_HEAD_FUSE_LN: 0})
+    o = acts["conv8_2"]
+    assert np.abs(raws["conv8_2"] - o).max() / np.abs(o).max() < 2e-4
+    assert np.abs(pred - ref).max() <= 1e-3
+    pred, ref, _, _ = _run(env, 2, 16, 32, 24, 15, 16, False, seed=4)
+    assert np.abs(pred - ref).max() <= 1e-3
+
+
+def test_layernorm_affine_matches_fp64_statistics(env):
+    """The published per-channel affine (scale | shift) of every layer against fp64 two-pass statistics of the
+    oracle's raw activations -- including msi_train_net's conv-transposes, whose statistics run over the uncropped
+    (2H+10) x (2W+10) output (nets.py:423-435)."""
+    torch, MSI, nets, N, onets = env
+    for coord in (True, False):
+        b, h, w, cin, nout, ngf = 2, 16, 40, 24, 8, 16
+        weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=6, randomize_affine=True)
+        x = np.random.RandomState(2).uniform(-1, 1, size=(b, h, w, cin)).astype(np.float32)
+        m = MSI(weights=weights, coord_net=coord)
+        m.net_options[N.NET_OPT_HEAD_FUSE_LN] = 0
+        m.run_net(torch.from_numpy(x).cuda(), nout, ngf)
+        torch.cuda.synchronize()
+        _, acts = onets.forward(weights, x, coord_net=coord, return_activations=True)
+        desc, _, ws = m._net(b, h, w, cin, nout, ngf)
+        for info in nets.layer_infos(desc):
+            if info.kind == nets.KIND_HEAD:
+                continue
+            name = info.name.decode()
+            aff = ws[info.affine_offset:info.affine_offset + 4 * b * 2 * info.cout].view(torch.float32).reshape(b, 2, info.cout).cpu().numpy()
+            exp = acts[name + "/affine"]
+            tol = 2e-4 * np.abs(exp).max() + 1e-7
+            assert np.abs(aff - exp).max() <= tol, (name, np.abs(aff - exp).max(), tol)
+
+
 def test_forward_is_bitwise_deterministic(env):
-    """Fixed summation orders everywhere (k order in the fix-up, fixed-order LayerNorm merges, no atomics):
-    the same input gives the same bits, at the grid sizes where the tail split is active."""
+    """Fixed summation orders in the fix-up (ascending k whoever arrives last) and exact integer accumulation of the
+    LayerNorm sums: the same input gives the same bits, at the grid sizes where the tail split is active."""
     torch, MSI, nets, N, onets = env
     m = MSI(weights=nets.init_weights(96, 32, 64, True), coord_net=True)
     x = torch.rand((1, 160, 320, 96), device="cuda") * 2 - 1
     ref = m.run_net(x, 32, 64).clone()
     for _ in range(3):
         assert torch.equal(m.run_net(x, 32, 64), ref)
+
+
+@pytest.mark.parametrize("dtype,batch", [("f32", 1), ("f32", 2), ("bf16", 1)])
+def test_full_size_split_k_handoff_is_deterministic(env, dtype, batch):
+    """BASELINE configs[1] shapes (640x320, 192 -> 64 channels, ngf 64): >= 20 repeats are bitwise identical, and the
+    in-launch split-K hand-off (sc1 slabs + relaxed ticket, last arriver sums) equals the separate fix-up launch
+    (plan option FIXUP_KERNEL) bit for bit -- same slabs, same ascending-k order, same epilogue."""
+    torch, MSI, nets, N, onets = env
+    weights = nets.init_weights(192, 64, 64, True)
+    m = MSI(weights=weights, coord_net=True, dtype=dtype)
+    x = torch.rand((batch, 320, 640, 192), device="cuda") * 2 - 1
+    if dtype == "bf16":
+        x = x.bfloat16()
+    ref = m.run_net(x, 64, 64).clone()
+    assert bool(torch.isfinite(ref).all())
+    for _ in range(20):
+        assert torch.equal(m.run_net(x, 64, 64), ref)
+    alt = MSI(weights=weights, coord_net=True, dtype=dtype)
+    alt.net_options[N.NET_OPT_FIXUP_KERNEL] = 1
+    assert torch.equal(alt.run_net(x, 64, 64), ref)
+    nosplit = MSI(weights=weights, coord_net=True, dtype=dtype)
+    nosplit.net_options[N.NET_OPT_TAILSPLIT] = 0
+    tol = 2e-5 if dtype == "f32" else 4e-2      # unsplit tiles: another fp32 summation order only
+    assert float((nosplit.run_net(x, 64, 64) - ref).abs().max()) <= tol

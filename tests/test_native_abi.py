@@ -97,6 +97,7 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
     its contribution is the fp32 table [out_row][5 column classes][Cout] behind gamma / beta."""
     from matryodshka_amd import nets
     cin, nout, ngf = 24, 8, 16
+    same_pad = bool(coord)      # msi_coord_train_net pads SAME; msi_train_net wrap-pads and runs VALID
     bke = 64 if dtype == "bf16" else 32
     w = onets.init_weights(cin, nout, ngf, coord, seed=3, randomize_affine=True)
     desc = nets.make_desc(1, 16, 32, cin, nout, ngf, coord, dtype=dtype)
@@ -133,8 +134,11 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
                     elif info.kind == 1:
                         ph, pw = cls >> 1, cls & 1
                         th, tw = tap >> 1, tap & 1
-                        kh = 1 + 2 * th if ph == 0 else 2 - 2 * th
-                        kw = 1 + 2 * tw if pw == 0 else 2 - 2 * tw
+                        if same_pad:    # SAME: y[2i+k-1] += x[i] w[k]
+                            kh = 1 + 2 * th if ph == 0 else 2 - 2 * th
+                            kw = 1 + 2 * tw if pw == 0 else 2 - 2 * tw
+                        else:        # VALID over wrap_pad(x, 2, 2) (uncropped output): k = parity + 2 * tap
+                            kh, kw = ph + 2 * th, pw + 2 * tw
                         exp[kk] = wt[kh, kw, n, c]
                     else:
                         exp[kk] = wt[0, 0, c, n]

@@ -156,3 +156,37 @@ def test_layer_table_matches_reference_counts():
     assert w["conv1_1/weights"].shape == (3, 3, 193, 64)
     assert w["conv6_1/weights"].shape == (4, 4, 256, 1024)
     assert w["color_pred/weights"].shape == (1, 1, 64, 64) and w["color_pred/biases"].shape == (64,)
+
+
+def test_kat10_wrap_convT_layernorm_runs_before_the_crop():
+    """nets.py:423-435: msi_train_net's conv6_1 / conv7_1 / conv8_1 are slim.conv2d_transpose(wrap_pad(skip, 2, 2),
+    padding='VALID') under the layer_norm arg_scope, so LayerNorm + ReLU see the whole (2H+10) x (2W+10) output and
+    the [5:-5] crop follows.  Independent scatter-form restatement (y[2i+kh, 2j+kw] += x[i, j] . w[kh, kw]) on a tiny
+    network; also shows that normalising after the crop is a different function."""
+    rng = np.random.RandomState(7)
+    cin, nout, ngf, h, w = 8, 4, 4, 8, 16
+    weights = nets.init_weights(cin, nout, ngf=ngf, coord_net=False, seed=7, randomize_affine=True)
+    x = rng.uniform(-1, 1, size=(1, h, w, cin)).astype(F)
+    _, acts = nets.forward(weights, x, coord_net=False, return_activations=True)
+    skip = np.concatenate([acts["conv4_3"], acts["conv3_3"]], axis=3)[0].astype(np.float64)      # [H/8, W/8, 16 ngf]
+    hh, ww, _ = skip.shape
+    padded = np.zeros((hh + 4, ww + 4, skip.shape[2]))
+    padded[2:-2] = np.concatenate([skip[:, -2:], skip, skip[:, :2]], axis=1)                     # wrap W, zeros H
+    wt = weights["conv6_1/weights"].astype(np.float64)                                           # [4,4,Cout,Cin]
+    full = np.zeros((2 * hh + 10, 2 * ww + 10, wt.shape[2]))
+    for i in range(hh + 4):
+        for j in range(ww + 4):
+            for kh in range(4):
+                for kw in range(4):
+                    full[2 * i + kh, 2 * j + kw] += wt[kh, kw] @ padded[i, j]
+    g = weights["conv6_1/LayerNorm/gamma"].astype(np.float64)
+    be = weights["conv6_1/LayerNorm/beta"].astype(np.float64)
+
+    def ln_relu(t):
+        return np.maximum((t - t.mean()) / np.sqrt(t.var() + 1e-12) * g + be, 0.0)
+
+    expect = ln_relu(full)[5:-5, 5:-5]
+    assert np.abs(acts["conv6_1/raw"][0] - full[5:-5, 5:-5]).max() < 1e-5
+    assert np.abs(acts["conv6_1"][0] - expect).max() < 2e-5
+    assert np.abs(ln_relu(full[5:-5, 5:-5]) - expect).max() > 1e-3    # crop-then-normalise is NOT what the reference does
+    assert np.all(full[:4] == 0) and np.all(full[-4:] == 0) and np.any(full[4] != 0) and np.any(full[-5] != 0)
