@@ -1,20 +1,26 @@
 #!/usr/bin/env python
 """Benchmark of the MSI infer -> render hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): novel-view frames/sec, 640x320 ODS -> 32-sphere MSI infer +
-render.  One step = one frame per rank (weak scaling): preprocess the ODS pair ->
-2x sphere sweep -> CNN -> RGBA assemble -> equirect RGB + depth render -> deprocess,
-inputs already resident in HBM, outputs left in HBM (uint8).  Frames are independent,
-so ranks shard frames with no data-path collective; the only collective is the
-start-up weight broadcast (RCCL) and the timing barrier / max.
+Metric (BASELINE.json): novel-view frames/sec, 640x320 ODS -> 32-sphere MSI infer + render
+(--config 1, the default and the configuration the metric is quoted on).  One step = one frame per rank
+(weak scaling): preprocess the ODS pair -> 2x sphere sweep -> CNN -> RGBA assemble -> equirect RGB + depth
+render -> deprocess, inputs already resident in HBM, outputs left in HBM (uint8).  Frames are independent,
+so ranks shard frames with no data-path collective; the only collective is the start-up weight broadcast
+(RCCL) and the timing barrier / max.
 
-Rank 0 prints ONE JSON line with the metric, `roofline` (the CNN's conv kernels, the
-dominant cost, against the fp32 MFMA peak; per-stage detail under `stages`) and
-`cpu_baseline` (the CPU oracle timed on this box's host cores; N=1 only).
+The other BASELINE configurations are parity-test cases; `--config` times them with the same protocol:
+  2  640x320 ODS, 64 spheres + CoordNet, batch 16 per GPU, bf16 network                   (weak scaling)
+  3  1280x640 ODS, 32 spheres, batch 32 per step SHARDED over the ranks, fp32              (strong scaling)
+  4  input_type=PP, 256x256 cube faces, 32 planes, batch 64 faces per step sharded, fp32   (strong scaling)
+A rank's shard (dist.shard_frames) is run as one batch; `value` = frames of ALL ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line with the metric, `roofline` (the CNN's conv kernels, the dominant cost, against
+the MFMA peak of the compute type; per-stage detail under `stages`) and `cpu_baseline` (the CPU oracle timed on
+this box's host cores; config 1 at N=1 only).
 """
 import argparse
 import json
@@ -29,9 +35,21 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-H, W, D, NGF = 320, 640, 32, 64
+NGF = 64
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # HBM3E spec peak, same guide
+
+CONFIGS = {
+    1: dict(kind="ods", h=320, w=640, d=32, dtype="f32", per_rank=1, total=None, scaling="weak",
+            name="BASELINE configs[1]: 640x320 ODS pair, 32 spheres, batch=1 per GPU, fp32"),
+    2: dict(kind="ods", h=320, w=640, d=64, dtype="bf16", per_rank=16, total=None, scaling="weak",
+            name="BASELINE configs[2]: 640x320 ODS, 64 spheres + CoordNet, batch=16 per GPU, bf16 network"),
+    3: dict(kind="ods", h=640, w=1280, d=32, dtype="f32", per_rank=None, total=32, scaling="strong",
+            name="BASELINE configs[3]: 1280x640 high_res ODS, 32 spheres, batch=32 sharded over the GPUs, fp32"),
+    4: dict(kind="pp", h=256, w=256, d=32, dtype="f32", per_rank=None, total=64, scaling="strong",
+            name="BASELINE configs[4]: input_type=PP 256x256 cube faces, 32 planes, batch=64 faces sharded over the GPUs, fp32"),
+}
 
 
 def cnn_layer_flops(h, w, cin, nout, ngf, coord):
@@ -69,22 +87,27 @@ def cnn_flops(h, w, cin, nout, ngf, coord):
 
 
 def cnn_traffic():
-    """HBM bytes per frame of the conv kernels (18 launches) from the committed PMC passes
-    (profiles/r01_l_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH
-    doubled per the gfx950 note of MI355X_MICROARCH.md); None if the profile is not present."""
-    path = os.path.join(ROOT, "profiles", "r01_l_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            k = json.load(f)["kernels"]["conv_igemm_kernel"]
-        return int(k["hbm_bytes"])
-    except Exception:
-        return None
+    """HBM bytes per frame of the conv kernels (18 launches) from the newest committed PMC passes
+    (profiles/r*_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per
+    the gfx950 note of MI355X_MICROARCH.md, made by tools/hbm_traffic.py which stamps the git commit it measured);
+    (None, None) if no profile is present."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    for path in reversed(paths):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+            return int(j["kernels"]["conv_igemm_kernel"]["hbm_bytes"]), \
+                "%s (commit %s)" % (os.path.relpath(path, ROOT), j.get("git_commit", "not recorded: round-1 profile"))
+        except Exception:
+            continue
+    return None, None
 
 
-def geometry_bytes(h, w, d):
+def geometry_bytes(h, w, d, psv_bytes=4):
     """Algorithmic HBM bytes per frame of the HBM-bound stages."""
     img = h * w * 3 * 4
-    psv = h * w * 6 * d * 4
+    psv = h * w * 6 * d * psv_bytes
     pred = h * w * 2 * d * 4
     rgba = h * w * d * 4 * 4
     return {
@@ -94,18 +117,37 @@ def geometry_bytes(h, w, d):
     }
 
 
+def pp_inputs(seed, b, n):
+    """data_loader.py:205-226 (input_type PP): fx = cx = W/2, fy = cy = H/2; source shifted along -x by the input
+    offset, target by the target offset."""
+    from tests.util import smooth_noise
+    rng = np.random.RandomState(seed)
+    ref, src = smooth_noise(rng, b, n, n), smooth_noise(rng, b, n, n)
+    K = np.tile(np.array([[n / 2, 0, n / 2], [0, n / 2, n / 2], [0, 0, 1]], np.float32)[None], (b, 1, 1))
+    eye = np.tile(np.eye(4, dtype=np.float32)[None], (b, 1, 1))
+    src_pose = eye.copy(); src_pose[:, 0, 3] = -0.064
+    tgt_pose = eye.copy(); tgt_pose[:, 0, 3] = -0.03; tgt_pose[:, 1, 3] = 0.01
+    return ref, src, K, eye, src_pose, tgt_pose
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs[N]; 1 (default) is the configuration the metric is quoted on")
+    ap.add_argument("--repeats", type=int, default=4,
+                    help="extra timed regions of --steps steps after the contract one (reported under `repeats`; the "
+                         "headline `value` is always the first region right after the warm-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--no-coord-net", action="store_true", help="msi_train_net instead of msi_coord_train_net")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams consecutive frames are issued on (1 = strictly one frame at a time, the "
                          "default and the configuration BASELINE quotes; 2 = software-pipeline independent frames, "
-                         "each still batch 1, to fill the tile-quantisation tails of the small layers)")
+                         "each still batch 1, to fill the tile-quantisation tails of the small layers; config 1 only)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -116,8 +158,10 @@ def main():
         raise SystemExit("--gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
     local_rank = local_rank % torch.cuda.device_count()   # (ranks may share a GPU in the gloo functional test)
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)                      # one process per GPU: rank r drives device LOCAL_RANK
     dev = torch.device("cuda", local_rank)
+    if args.streams > 1 and args.config != 1:
+        raise SystemExit("--streams applies to --config 1")
 
     from matryodshka_amd import MSI, nets
     from matryodshka_amd import dist as mdist
@@ -125,139 +169,208 @@ def main():
     if world > 1:
         mdist.init_process_group()
 
+    H, W, D = cfg["h"], cfg["w"], cfg["d"]
     coord = not args.no_coord_net
     cin, nout = 6 * D, 2 * D
-    # weights: rank 0 initialises, everyone receives them over RCCL (xGMI)
+    # frames of this rank per step: its shard of the step's batch (strong scaling) or a fixed batch (weak scaling)
+    if cfg["total"] is not None:
+        lo, hi = mdist.shard_frames(cfg["total"], rank, world)
+        frames_total = cfg["total"]
+    else:
+        lo, hi = rank * cfg["per_rank"], (rank + 1) * cfg["per_rank"]
+        frames_total = cfg["per_rank"] * world
+    B = hi - lo
+
+    # weights: rank 0 initialises, everyone receives them over RCCL (xGMI); timed, outside the frame loop
     weights = nets.init_weights(cin, nout, NGF, coord, seed=8964) if rank == 0 else None
-    weights = mdist.broadcast_weights(weights, cin, nout, NGF, coord, dev, src=0) if world > 1 else weights
-    models = [MSI(weights=weights, coord_net=coord, device=dev) for _ in range(max(1, args.streams))]
+    broadcast_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        weights = mdist.broadcast_weights(weights, cin, nout, NGF, coord, dev, src=0)
+        torch.cuda.synchronize()
+        broadcast_ms = (time.perf_counter() - t0) * 1e3
+    models = [MSI(weights=weights, coord_net=coord, device=dev, dtype=cfg["dtype"],
+                  input_type="PP" if cfg["kind"] == "pp" else "ODS") for _ in range(max(1, args.streams))]
     model = models[0]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(args.streams - 1)]
     planes = model.inv_depths(1.0, 100.0, D)
 
-    # synthetic ODS pair, seeded per rank (each rank renders its own frames)
+    # synthetic inputs, seeded per global frame index (every rank renders its own frames), resident in HBM
     from tests.util import make_inputs
-    inp = make_inputs(8964 + rank, 1, H, W)
-    src_u8 = torch.from_numpy(np.ascontiguousarray(inp["src_image"])).to(dev).contiguous()   # resident, in the
-    ref_u8 = torch.from_numpy(np.ascontiguousarray(inp["ref_image"])).to(dev).contiguous()   # layout the API takes
-    ref_pose = torch.from_numpy(inp["ref_pose"]).to(dev)
-    src_pose = torch.from_numpy(inp["src_pose"]).to(dev)
-    ref_pose_inv = torch.linalg.inv(torch.from_numpy(inp["ref_pose"])).contiguous().to(dev)   # (LAPACK returns a transposed view)
-    intr = torch.from_numpy(inp["intrinsics"]).to(dev)
-    tgt_pose_rt = torch.from_numpy(inp["tgt_pose_rt"]).to(dev)
-    tgt_pos = torch.from_numpy(inp["tgt_pos"]).to(dev)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).contiguous()
+    inp = None
+    if B > 0 and cfg["kind"] == "ods":
+        parts = [make_inputs(8964 + f, 1, H, W) for f in range(lo, hi)]
+        inp = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+        src_u8, ref_u8 = g(inp["src_image"]), g(inp["ref_image"])   # in the layout the API takes
+        ref_pose, src_pose, intr = g(inp["ref_pose"]), g(inp["src_pose"]), g(inp["intrinsics"])
+        ref_pose_inv = g(np.linalg.inv(inp["ref_pose"].astype(np.float64)).astype(np.float32))
+        tgt_pose_rt, tgt_pos = g(inp["tgt_pose_rt"]), g(inp["tgt_pos"])
+    elif B > 0:
+        from matryodshka_amd import poses
+        parts = [pp_inputs(8964 + f, 1, H) for f in range(lo, hi)]
+        ref, src, K, eye, spose, tpose = (np.concatenate([p[i] for p in parts], axis=0) for i in range(6))
+        interp_inv = np.linalg.inv(poses.interpolate_pose(eye, spose).astype(np.float64)).astype(np.float32)   # train.py:118-121
+        rel = np.matmul(tpose, interp_inv).astype(np.float32)                                                  # msi.py:644-646
+        pp = dict(ref=g(ref), src=g(src), K=g(K), eye=g(eye), src_pose=g(spose), interp_inv=g(interp_inv), rel=g(rel),
+                  Kinv=g(np.linalg.inv(K.astype(np.float64)).astype(np.float32)))
 
     stage_names = ["preprocess", "sweep", "cnn", "assemble", "render", "deprocess"]
 
-    def frame(events=None, model=model):
+    def frame(events=None, model=model, cnn_events=None):
+        """One step of this rank: its B frames as one batch.  `events`: a HIP event at every stage boundary;
+        `cnn_events`: only around the network (the roofline kernel) -- what the timed region records."""
+        if B == 0:
+            return None
         def mark():
             if events is not None:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 events.append(e)
+        def mark_cnn():
+            if cnn_events is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                cnn_events.append(e)
         mark()
-        src = model.preprocess_image(src_u8)
-        ref = model.preprocess_image(ref_u8)
-        mark()
-        net_input = model.format_network_input(ref, src, ref_pose, src_pose, planes, intr, ref_pose_inv=ref_pose_inv)
-        mark()
+        if cfg["kind"] == "ods":
+            src = model.preprocess_image(src_u8)
+            ref = model.preprocess_image(ref_u8)
+            mark()
+            net_input = model.format_network_input(ref, src, ref_pose, src_pose, planes, intr, ref_pose_inv=ref_pose_inv)
+        else:
+            src = model.preprocess_image(pp["src"])
+            ref = model.preprocess_image(pp["ref"])
+            mark()
+            net_input = model.format_network_input(ref, src, pp["eye"], pp["src_pose"], planes, pp["K"], ref_pose_inv=pp["interp_inv"])
+        mark(); mark_cnn()
         pred = model.run_net(net_input, nout, NGF)
-        mark()
+        mark(); mark_cnn()
         out = model.assemble_layers(net_input, pred, D)
         mark()
-        rgb, dep = model.msi_render_equirect_view_and_depth(out["rgba_layers"], tgt_pose_rt, tgt_pos, planes, intr)
-        mark()
-        rgb8 = model.deprocess_image(rgb)
-        dep8 = model.deprocess_depth_image(dep)
+        if cfg["kind"] == "ods":
+            rgb, dep = model.msi_render_equirect_view_and_depth(out["rgba_layers"], tgt_pose_rt, tgt_pos, planes, intr)
+            mark()
+            rgb8 = model.deprocess_image(rgb)
+            dep8 = model.deprocess_depth_image(dep)
+        else:
+            rgb = model.mpi_render_view(out["rgba_layers"], pp["rel"], planes, pp["K"], intrinsics_inv=pp["Kinv"])
+            dep = None
+            mark()
+            rgb8, dep8 = model.deprocess_image(rgb), None
         mark()
         return rgb, dep, rgb8, dep8, out
 
-    def step(k, events=None):
+    def step(k, cnn_events=None):
         if args.streams == 1:
-            return frame(events)
+            return frame(None, cnn_events=cnn_events)
         with torch.cuda.stream(streams[k % args.streams]):      # frame k and k+1 overlap on the device
             return frame(None, models[k % args.streams])
 
+    def timed_region(nsteps):
+        """EXACTLY nsteps steps between barrier + synchronize on both sides; max over ranks."""
+        torch.cuda.synchronize()
+        if world > 1:
+            mdist.barrier()
+        torch.cuda.synchronize()
+        ev = []
+        t0 = time.perf_counter()
+        for k in range(nsteps):
+            result = step(k, ev if args.streams == 1 else None)
+        torch.cuda.synchronize()
+        if world > 1:
+            mdist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        elapsed = mdist.max_over_ranks(elapsed, dev) if world > 1 else elapsed
+        cnn_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(len(ev) // 2)]
+        return elapsed, cnn_ms, result
+
     for k in range(max(args.warmup, args.streams)):
         step(k)
-    torch.cuda.synchronize()
-    if world > 1:
-        mdist.barrier()
-    torch.cuda.synchronize()
-    all_events = []
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev = []
-        result = step(k, ev)
-        all_events.append(ev)
-    torch.cuda.synchronize()
-    if world > 1:
-        mdist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = mdist.max_over_ranks(elapsed, dev) if world > 1 else elapsed
+    elapsed, cnn_ms, result = timed_region(args.steps)             # the contract region: `value` comes from here
+    repeats = [timed_region(args.steps)[0] for _ in range(max(0, args.repeats))]
 
+    nccl_world = torch.distributed.get_world_size() if world > 1 else 1
+    backend = torch.distributed.get_backend() if world > 1 else None
     if rank != 0:
         return
 
-    if args.streams > 1:
-        # per-stage HIP events are only meaningful when frames do not overlap: time one frame alone
-        torch.cuda.synchronize()
-        all_events = []
-        for _ in range(5):
-            ev = []
-            frame(ev)
-            all_events.append(ev)
-        torch.cuda.synchronize()
+    # per-stage HIP events: a separate, untimed pass (one frame batch at a time on the launch stream)
+    torch.cuda.synchronize()
+    all_events = []
+    for _ in range(5):
+        ev = []
+        frame(ev)
+        all_events.append(ev)
+    torch.cuda.synchronize()
     stage_ms = {}
     for si, name in enumerate(stage_names):
-        stage_ms[name] = float(np.mean([ev[si].elapsed_time(ev[si + 1]) for ev in all_events]))
+        stage_ms[name] = float(np.mean([ev[si].elapsed_time(ev[si + 1]) for ev in all_events])) if B > 0 else 0.0
     ms_per_step = elapsed / args.steps * 1e3
-    fps = world * args.steps / elapsed
+    fps = frames_total * args.steps / elapsed
+    cnn_ms_timed = float(np.mean(cnn_ms)) if cnn_ms else stage_ms["cnn"]   # (streams > 1: from the separate pass)
 
-    flops = cnn_flops(H, W, cin, nout, NGF, coord)
-    gbytes = geometry_bytes(H, W, D)
-    cnn_tflops = flops / (stage_ms["cnn"] * 1e-3) / 1e12
+    bf16 = cfg["dtype"] == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    flops = cnn_flops(H, W, cin, nout, NGF, coord)                 # per frame
+    gbytes = geometry_bytes(H, W, D, 2 if bf16 else 4)
+    nb = max(B, 1)
+    cnn_tflops = flops * nb / (cnn_ms_timed * 1e-3) / 1e12
     stages = {k: {"ms": round(v, 4)} for k, v in stage_ms.items()}
     for k in ("sweep", "assemble", "render"):
-        gbs = gbytes[k] / (stage_ms[k] * 1e-3) / 1e9
-        stages[k].update({"bound": "hbm", "algorithmic_MB": round(gbytes[k] / 1e6, 1),
-                          "achieved_GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)})
-    stages["cnn"].update({"bound": "mfma", "algorithmic_GFLOP": round(flops / 1e9, 1),
-                          "achieved_TFLOPps": round(cnn_tflops, 2),
-                          "frac": round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4)})
+        if stage_ms[k] > 0:
+            gbs = gbytes[k] * nb / (stage_ms[k] * 1e-3) / 1e9
+            stages[k].update({"bound": "hbm", "algorithmic_MB": round(gbytes[k] * nb / 1e6, 1),
+                              "achieved_GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)})
+    stages["cnn"].update({"bound": "mfma", "algorithmic_GFLOP": round(flops * nb / 1e9, 1),
+                          "achieved_TFLOPps": round(flops * nb / (max(stage_ms["cnn"], 1e-9) * 1e-3) / 1e12, 2)})
+    traffic, traffic_src = cnn_traffic() if args.config == 1 else (None, None)
 
+    unit = "faces/s" if cfg["kind"] == "pp" else "frames/s"
+    metric = "novel-view frames/sec, 640x320 ODS->32-sphere MSI infer+render" if args.config == 1 else \
+        "novel-view %s, %dx%d %s->%d-%s infer+render" % (unit.replace("/s", "/sec"), W, H, "PP face" if cfg["kind"] == "pp" else "ODS",
+                                                        D, "plane MPI" if cfg["kind"] == "pp" else "sphere MSI")
     line = {
-        "metric": "novel-view frames/sec, 640x320 ODS->32-sphere MSI infer+render",
-        "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "metric": metric,
+        "value": round(fps, 3), "unit": unit, "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: 640x320 ODS pair, 32 spheres, batch=1 per GPU, fp32, "
-                               + ("CoordNet" if coord else "wrap-pad net") + ", infer + RGB&depth render",
-                   "height": H, "width": W, "num_spheres": D, "ngf": NGF, "frames_per_step_per_gpu": 1,
-                   "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world,
+        "scaling": cfg["scaling"], "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+        "config": {"workload": cfg["name"] + ", " + ("CoordNet" if coord else "wrap-pad net") + ", infer + "
+                               + ("MPI render" if cfg["kind"] == "pp" else "RGB&depth render"),
+                   "baseline_config_index": args.config, "height": H, "width": W,
+                   "num_spheres": D, "ngf": NGF, "frames_per_step": frames_total, "frames_per_step_rank0": B,
+                   "parallelism": "frames sharded over %d GPU(s) (dist.shard_frames), no data-path collective" % world,
                    "streams_per_gpu": args.streams},
-        "roofline": {"kernel": "conv_igemm_kernel (18 launches/frame, fp32 MFMA implicit GEMM; + 17 ln_finish)",
-                     "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": cnn_traffic(),
-                     "traffic_note": "HBM bytes per frame of the 18 conv launches, profiles/r01_l_hbm_traffic.json "
-                                     "(separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH correction)",
-                     "launches_per_frame": 18, "algorithmic_flops_per_frame": flops,
-                     "ms_per_frame": round(stage_ms["cnn"], 4),
-                     "timed": "HIP events around msi_net_forward_f32 on the launch stream inside the timed region "
-                              "(18 conv + 17 fix-up + 17 ln_apply launches: conservative for the conv kernel alone)"},
+        "distributed": {"world_size_env": world, "world_size_process_group": nccl_world, "backend": backend,
+                        "weight_broadcast_ms": None if broadcast_ms is None else round(broadcast_ms, 3),
+                        "devices_visible": torch.cuda.device_count(), "device_of_rank0": torch.cuda.get_device_name(dev)},
+        "repeats": {"ms_per_step": [round(r / args.steps * 1e3, 4) for r in [elapsed] + repeats],
+                    "median_ms_per_step": round(float(np.median([elapsed] + repeats)) / args.steps * 1e3, 4),
+                    "note": "region 0 is the contract region `value` / `ms_per_step` are computed from"},
+        "roofline": {"kernel": "conv_igemm_kernel (18 launches per forward, %s MFMA implicit GEMM)" % ("bf16" if bf16 else "fp32"),
+                     "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": peak,
+                     "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4), "traffic": traffic,
+                     "traffic_note": None if traffic is None else
+                     "HBM bytes per frame of the 18 conv launches, %s (separate --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                     "gfx950 FETCH correction)" % traffic_src,
+                     "launches_per_frame": 18, "algorithmic_flops_per_launch_set": flops * nb,
+                     "ms_per_forward": round(cnn_ms_timed, 4),
+                     "timed": "HIP events around msi_net_plan_forward on the launch stream INSIDE the timed region, mean of "
+                              "%d forwards (18 conv + 16 ln_apply launches: conservative for the conv kernel alone)" % max(len(cnn_ms), 1)},
         "stages": stages,
     }
 
-    if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"], parity = cpu_baseline(model, weights, inp, planes, coord, result)
+    if world == 1 and args.config == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"], parity = cpu_baseline(model, weights, inp, planes, coord, result, D)
         line["parity_max_abs_vs_oracle"] = parity
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line), flush=True)
 
 
-def cpu_baseline(model, weights, inp, planes, coord, gpu_result):
+def cpu_baseline(model, weights, inp, planes, coord, gpu_result, D):
     """The CPU oracle ("port": the reference itself needs Python 2 + TF 1.14 and cannot run here)
     on the same workload, timed on this box's host cores: a bounded sample of 2 frames (~10-30 s)
     after a small warm-up that creates the thread pool / conv primitives.  torch-CPU conv runs on

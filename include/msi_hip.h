@@ -53,6 +53,9 @@ typedef void *msi_stream_t; /* hipStream_t */
 
 const char *msi_version(void);
 const char *msi_last_error_string(void);
+/* CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 for a new message): the per-tensor checksum of
+ * the TensorFlow checkpoints test.py:191-202 restores (matryodshka_amd/tf_checkpoint.py verifies it on load). */
+uint32_t msi_crc32c_host(const void *data_host, size_t n, uint32_t crc);
 
 /* ---- geometry tables (host) -------------------------------------------------
  * spherical.lat_long_grid (spherical.py:42-44) is separable; the kernels take

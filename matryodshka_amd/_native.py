@@ -45,6 +45,7 @@ _I = c_int32
 SIGNATURES = {
     "msi_version": (c_char_p, []),
     "msi_last_error_string": (c_char_p, []),
+    "msi_crc32c_host": (ctypes.c_uint32, [_P, c_size_t, ctypes.c_uint32]),
     "msi_trig_table_floats": (c_size_t, [_I, _I]),
     "msi_build_trig_tables_host": (_I, [_I, _I, _P]),
     "msi_preprocess_u8_f32": (_I, [_P, _P, c_size_t, _P]),

@@ -455,7 +455,10 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
     const float radius = depths[d];
     const float qc = cc - radius * radius;
     const float disc = qb2 - fa * qc;
-    const float t = (-qb + sqrtf(disc)) / ta;
+    // disc >= 0 whenever the ray origin is inside the sphere (the documented domain; the host-side guard of the MSI class
+    // enforces it for host inputs).  Outside it the reference takes sqrt of a negative number and casts NaN to int
+    // (undefined); the clamp keeps device-side inputs finite and changes nothing inside the domain.
+    const float t = (-qb + sqrtf(fmaxf(disc, 0.0f))) / ta;
     const float x = cx + t * rx;
     const float y = cy + t * ry;
     const float z = cz + t * rz;

@@ -63,7 +63,8 @@ def parse_camera_files(pattern):
                 yield parts[0], tuple(parts[1:4]), float(parts[4]), [float(x) for x in parts[5:8]]
 
 
-def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_outputs, output_dir, dirname):
+def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_outputs, output_dir, dirname,
+               which_color_pred="blend_psv", jitter_pose=None):
     """One iteration of the loop at test.py:199-281.  images = (ref, src, tgt) float [H,W,3] in [0,1]
     (image order ref, src, tgt: data_loader.py:134-136)."""
     import torch
@@ -71,8 +72,13 @@ def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_o
     eye = np.eye(4, dtype=np.float32)[None]
     intr = np.array([[[baseline, 0, 0], [0, 1, 0], [0, 0, 1]]], dtype=np.float32)       # data_loader.py:160
     pos = np.asarray(tgt_pos, dtype=np.float32)[None]
-    outs, net_input = model.infer_msi(src, ref, None, None, eye, eye, intr, "blend_psv", num_planes, planes,
+    outs, net_input = model.infer_msi(src, ref, None, None, eye, eye, intr, which_color_pred, num_planes, planes,
                                       extra_outputs="blend_weights alphas psv", ngf=ngf)
+    jouts = None
+    if jitter_pose is not None:      # test.py:141-147: second inference with the sweep rotated by jitter_pose^-1
+        jinv = np.linalg.inv(np.asarray(jitter_pose, dtype=np.float64)).astype(np.float32)
+        jouts, _ = model.infer_msi(src, ref, None, None, eye, eye, intr, which_color_pred, num_planes, planes,
+                                   extra_outputs="blend_weights alphas psv", ngf=ngf, jitter_pose_inv=jinv)
     os.makedirs(output_dir, exist_ok=True)
     if "tgt_image" in test_outputs:
         rgb, dep = model.msi_render_equirect_view_and_depth(outs["rgba_layers"], eye, pos, planes, intr)
@@ -80,6 +86,14 @@ def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_o
         write_image(os.path.join(output_dir, "output_tgt_%s.png" % dirname), model.deprocess_image(rgb)[0].cpu().numpy())
         write_image(os.path.join(output_dir, "output_depth_%s.png" % dirname),
                     model.deprocess_depth_image(dep)[0].cpu().numpy())
+        if jouts is not None:        # test.py:160-165 renders through the jitter pose; :237-240 (the reference reads a
+            # 'jitter_output_depth' it never produces -- here the depth is rendered the same way)
+            jrgb, jdep = model.msi_render_equirect_view_and_depth(jouts["rgba_layers"], np.asarray(jitter_pose, np.float32),
+                                                                  pos, planes, intr)
+            write_image(os.path.join(output_dir, "jitter_output_tgt_%s.png" % dirname),
+                        model.deprocess_image(jrgb)[0].cpu().numpy())
+            write_image(os.path.join(output_dir, "jitter_output_depth_%s.png" % dirname),
+                        model.deprocess_depth_image(jdep)[0].cpu().numpy())
     if "src_image" in test_outputs:
         write_image(os.path.join(output_dir, "src_image_%s.png" % dirname), src[0].numpy() * 255.0)
     if "ref_image" in test_outputs:
@@ -99,7 +113,7 @@ def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_o
         psv = outs["psv"].cpu().numpy()
         for j in range(num_planes):
             write_image(os.path.join(output_dir, "psv_plane_%.3d.png" % j), (psv[0, :, :, j * 3:(j + 1) * 3] + 1.) / 2. * 255)
-    if "blend_weights" in test_outputs:
+    if "blend" in which_color_pred and "blend_weights" in test_outputs:      # test.py:262
         bw = outs["blend_weights"].cpu().numpy()
         np.save(os.path.join(output_dir, "blend_weights.npy"), bw)
         for i in range(num_planes):
@@ -111,6 +125,11 @@ def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_o
         for i in range(num_planes):
             write_image(os.path.join(output_dir, "msi_alpha_%.2d.png" % i), rgba[0, :, :, i, 3] * 255.0)
             write_image(os.path.join(output_dir, "msi_rgb_%.2d.png" % i), (rgba[0, :, :, i, :3] + 1.) / 2. * 255)
+        if jouts is not None:        # test.py:276-280
+            jr = jouts["rgba_layers"].cpu().numpy()
+            for i in range(num_planes):
+                write_image(os.path.join(output_dir, "jitter_msi_alpha_%.2d.png" % i), jr[0, :, :, i, 3] * 255.0)
+                write_image(os.path.join(output_dir, "jitter_msi_rgb_%.2d.png" % i), (jr[0, :, :, i, :3] + 1.) / 2. * 255)
     return outs
 
 
@@ -130,22 +149,40 @@ def main(argv=None):
     ap.add_argument("--min_depth", type=float, default=1.0)
     ap.add_argument("--max_depth", type=float, default=100.0)
     ap.add_argument("--ngf", type=int, default=64)
-    ap.add_argument("--no_coord_net", action="store_true")
+    ap.add_argument("--coord_net", action="store_true",
+                    help="msi_coord_train_net (FLAGS.coord_net, test.py:52, default False = msi_train_net); the released "
+                         "ODS models use it (scripts/test/ods-wotemp-elpips-coord-reg.sh).  With --checkpoint / --weights "
+                         "the network is inferred from conv1_1/weights' input channels when the flag is absent")
+    ap.add_argument("--which_color_pred", default="blend_psv",
+                    help="blend_psv | blend_bg | blend_bg_psv | alpha_only (test.py:55-56)")
+    ap.add_argument("--transform_inverse_reg", action="store_true",
+                    help="also infer with a jittered sweep pose and write jitter_output_* (test.py:141-147, 160-165)")
+    ap.add_argument("--rot_factor", type=float, default=0.0)
+    ap.add_argument("--tr_factor", type=float, default=0.0)
+    ap.add_argument("--random_seed", type=int, default=8964)
     ap.add_argument("--test_outputs", default="src_image_ref_image_tgt_image_psv_rgba_layers_blend_weights_alphas")
     ap.add_argument("--num_runs", type=int, default=-1)
     args = ap.parse_args(argv)
 
     from . import MSI, nets
     d = args.num_msi_planes
-    coord = not args.no_coord_net
+    coord = args.coord_net
+    nout = {"blend_psv": 2 * d, "blend_bg": 2 * d + 3, "blend_bg_psv": 3 * d + 3, "alpha_only": d}[args.which_color_pred]
     if args.checkpoint:
         from . import tf_checkpoint
         weights, args.step = tf_checkpoint.network_weights(args.checkpoint)
     elif args.weights:
         weights = dict(np.load(args.weights))
     else:
-        weights = nets.init_weights(6 * d, 2 * d, args.ngf, coord)
+        weights = nets.init_weights(6 * d, nout, args.ngf, coord)
+    if (args.checkpoint or args.weights) and not coord:
+        w0 = nets._lookup(weights, "conv1_1/weights")
+        coord = w0.shape[2] == 6 * d + 1          # nets.py:260-270: CoordNet appends one input channel
     model = MSI(weights=weights, coord_net=coord)
+    jitter = None
+    if args.transform_inverse_reg:
+        from . import poses
+        jitter = poses.random_rotation(args.rot_factor, args.tr_factor, np.random.RandomState(args.random_seed))
     planes = model.inv_depths(args.min_depth, args.max_depth, d)
     exp_dir = os.path.join(args.output_root, args.experiment_name)
     os.makedirs(exp_dir, exist_ok=True)
@@ -161,7 +198,8 @@ def main(argv=None):
         if n == 0:
             with open(os.path.join(exp_dir, "step.txt"), "w") as f:
                 f.write("%d" % args.step)
-        run_sample(model, images, baseline, tgt_pos, planes, d, args.ngf, args.test_outputs, out_dir, dirname)
+        run_sample(model, images, baseline, tgt_pos, planes, d, args.ngf, args.test_outputs, out_dir, dirname,
+                   which_color_pred=args.which_color_pred, jitter_pose=jitter)
         n += 1
     print("processed %d samples" % n)
     return n

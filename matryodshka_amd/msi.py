@@ -29,7 +29,11 @@ def _ptr(t):
 class MSI(object):
     """Class definition for the MSI inference module (reference: msi.py:33-38)."""
 
-    def __init__(self, weights=None, coord_net=True, device=None, input_type='ODS', dtype='f32'):
+    COLOR_SCHEMES = {'blend_psv': 0, 'blend_bg': 1, 'blend_bg_psv': 2, 'alpha_only': 3}   # MSI_COLOR_* of msi_hip.h
+
+    def __init__(self, weights=None, coord_net=False, device=None, input_type='ODS', dtype='f32'):
+        """coord_net: FLAGS.coord_net (test.py:52, default False = msi_train_net; the released ODS models are run with
+        --coord_net = msi_coord_train_net, scripts/test/ods-wotemp-elpips-coord-reg.sh)."""
         if not torch.cuda.is_available():
             raise RuntimeError("matryodshka_amd.MSI needs a HIP device (no CPU fallback)")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
@@ -121,16 +125,13 @@ class MSI(object):
 
     # ------------------------------------------------------------------ msi.py:1196-1217
     def inv_depths(self, start_depth, end_depth, num_depths):
-        """Sample reversed, sorted inverse depths between a near and far plane."""
-        inv_start_depth = 1.0 / start_depth
-        inv_end_depth = 1.0 / end_depth
-        depths = [start_depth, end_depth]
-        for i in range(1, num_depths - 1):
-            fraction = float(i) / float(num_depths - 1)
-            inv_depth = inv_start_depth + (inv_end_depth - inv_start_depth) * fraction
-            depths.append(1.0 / inv_depth)
-        depths = sorted(depths)
-        return depths[::-1]
+        """num_depths sphere radii uniform in inverse depth, both ends included exactly, far -> near
+        (python floats, fp64; tests assert equality with the oracle's restatement of msi.py:1196-1217)."""
+        near, far = float(start_depth), float(end_depth)
+        n = int(num_depths)
+        lo, hi = 1.0 / near, 1.0 / far
+        radii = [near, far] + [1.0 / (lo + (hi - lo) * (float(k) / float(n - 1))) for k in range(1, n - 1)]
+        return sorted(radii, reverse=True)
 
     # ------------------------------------------------------------------ msi.py:1163-1194
     def preprocess_image(self, image):
@@ -179,9 +180,11 @@ class MSI(object):
 
     # ------------------------------------------------------------------ msi.py:1094-1130
     def format_network_input(self, ref_image, src_image, ref_pose, src_pose, planes, intrinsics,
-                             ref_pose_inv=None):
+                             ref_pose_inv=None, jitter_pose_inv=None, dtype=None):
         """Format the network input into the double sphere-sweep volume.
-        Returns net_input [B,H,W,2*3*len(planes)]."""
+        Returns net_input [B,H,W,2*3*len(planes)].
+        jitter_pose_inv: the hidden graph input `jitter_pose_inv:0` of FLAGS.jitter (msi.py:1118-1120):
+        ref_pose_inv <- ref_pose_inv @ jitter_pose_inv.  dtype: 'f32' forces an fp32 volume on a bf16 model."""
         ref_image = self._f32(ref_image)
         src_image = self._f32(src_image)
         b, h, w, c = ref_image.shape
@@ -191,11 +194,13 @@ class MSI(object):
         if ref_pose_inv is None:
             ref_pose_inv = torch.linalg.inv(torch.as_tensor(ref_pose, dtype=torch.float32).cpu().double()).float()   # test.py:111
         ref_pose, src_pose, ref_pose_inv = self._f32(ref_pose), self._f32(src_pose), self._f32(ref_pose_inv)
+        if jitter_pose_inv is not None:
+            ref_pose_inv = self._compose(ref_pose_inv, jitter_pose_inv)          # msi.py:1120
         depths = self._planes(planes)
         nd = depths.numel()
         intr = self._f32(intrinsics)
         trig = self._trig(h, w)
-        bf16 = self.dtype == 'bf16'
+        bf16 = (dtype or self.dtype) == 'bf16'
         psv = torch.empty((b, h, w, 6 * nd), dtype=torch.bfloat16 if bf16 else torch.float32, device=self.device)
         # order = +1 for the reference image (i = 0), -1 for the source (i = 1), msi.py:1127
         for i, (img, pose) in enumerate(((ref_image, ref_pose), (src_image, src_pose))):
@@ -217,20 +222,23 @@ class MSI(object):
     # ------------------------------------------------------------------ msi.py:40-289
     def infer_msi(self, raw_src_image, raw_ref_image, raw_hres_src_image, raw_hres_ref_image,
                   ref_pose, src_pose, intrinsics, which_color_pred, num_msi_planes, psv_planes,
-                  extra_outputs='', ngf=64, ref_pose_inv=None):
+                  extra_outputs='', ngf=64, ref_pose_inv=None, jitter_pose_inv=None):
         """Construct and run the MSI inference path.  Returns (pred dict, net_input).
-        Note the reference's argument order: src before ref (msi.py:40-46)."""
-        if which_color_pred != 'blend_psv':
-            raise NotImplementedError("which_color_pred=%r (only blend_psv, the reference default)" % which_color_pred)
+        Note the reference's argument order: src before ref (msi.py:40-46).
+        which_color_pred: blend_psv (2D outputs) | blend_bg (2D+3) | blend_bg_psv (3D+3) | alpha_only (D), msi.py:119-275."""
+        if which_color_pred not in self.COLOR_SCHEMES:
+            raise ValueError("which_color_pred=%r (blend_psv, blend_bg, blend_bg_psv, alpha_only)" % which_color_pred)
         if len(psv_planes) != num_msi_planes:
             # msi.py:138 indexes the src PSV with num_msi_planes
             raise ValueError("infer_msi assumes len(psv_planes) == num_msi_planes (msi.py:138)")
         src_image = self.preprocess_image(raw_src_image)
         ref_image = self.preprocess_image(raw_ref_image)
         net_input = self.format_network_input(ref_image, src_image, ref_pose, src_pose, psv_planes,
-                                              intrinsics, ref_pose_inv=ref_pose_inv)
-        msi_pred = self.run_net(net_input, num_msi_planes * 2, ngf)
-        pred = self.assemble_layers(net_input, msi_pred, num_msi_planes, extra_outputs)
+                                              intrinsics, ref_pose_inv=ref_pose_inv, jitter_pose_inv=jitter_pose_inv)
+        d = num_msi_planes
+        num_outputs = {'blend_psv': 2 * d, 'blend_bg': 2 * d + 3, 'blend_bg_psv': 3 * d + 3, 'alpha_only': d}[which_color_pred]
+        msi_pred = self.run_net(net_input, num_outputs, ngf)
+        pred = self.assemble_layers(net_input, msi_pred, num_msi_planes, extra_outputs, which_color_pred)
         return pred, net_input
 
     def run_net(self, net_input, num_outputs, ngf=64):
@@ -246,20 +254,25 @@ class MSI(object):
                                            ws.data_ptr(), ws.numel(), self._stream()), "msi_net_plan_forward")
         return pred
 
-    def assemble_layers(self, net_input, msi_pred, num_msi_planes, extra_outputs=''):
-        """layer_prediction of infer_msi (msi.py:130-147, 276-289)."""
+    def assemble_layers(self, net_input, msi_pred, num_msi_planes, extra_outputs='', which_color_pred='blend_psv'):
+        """layer_prediction of infer_msi (msi.py:130-147, 177-188, 223-242, 258-268; outputs :276-289)."""
         b, h, w, _ = net_input.shape
         d = num_msi_planes
+        color = self.COLOR_SCHEMES[which_color_pred]
+        new = lambda: torch.empty((b, h, w, d), dtype=torch.float32, device=self.device)
         rgba = torch.empty((b, d, h, w, 4), dtype=torch.float32, device=self.device)
-        bw = torch.empty((b, h, w, d), dtype=torch.float32, device=self.device) if 'blend_weights' in extra_outputs else None
-        al = torch.empty((b, h, w, d), dtype=torch.float32, device=self.device) if 'alpha' in extra_outputs else None
-        asm = N.lib.msi_assemble_rgba_bf16psv_f32 if net_input.dtype == torch.bfloat16 else N.lib.msi_assemble_rgba_f32
-        N.check(asm(net_input.data_ptr(), msi_pred.data_ptr(), rgba.data_ptr(),
-                    _ptr(bw), _ptr(al), b, h, w, d, self._stream()),
-                "msi_assemble_rgba")
+        # msi.py:280-285: blend_weights only for the 'blend' schemes, bg_blend_weights where they exist (blend_bg_psv)
+        bw = new() if 'blend_weights' in extra_outputs and 'blend' in which_color_pred else None
+        bgw = new() if bw is not None and which_color_pred == 'blend_bg_psv' else None
+        al = new() if 'alpha' in extra_outputs else None
+        N.check(N.lib.msi_assemble_rgba_color_f32(
+            net_input.data_ptr(), 1 if net_input.dtype == torch.bfloat16 else 0, msi_pred.data_ptr(), color,
+            rgba.data_ptr(), _ptr(bw), _ptr(al), _ptr(bgw), b, h, w, d, self._stream()), "msi_assemble_rgba_color_f32")
         pred = {'rgba_layers': rgba.permute(0, 2, 3, 1, 4)}
         if bw is not None:
             pred['blend_weights'] = bw
+        if bgw is not None:
+            pred['bg_blend_weights'] = bgw
         if al is not None:
             pred['alphas'] = al
         if 'psv' in extra_outputs:
@@ -275,16 +288,32 @@ class MSI(object):
         native = rgba_layers.permute(0, 3, 1, 2, 4)   # [B,D,H,W,4]
         return native if native.is_contiguous() else native.contiguous()
 
+    @staticmethod
+    def _domain_guard(tgt_pos, pose, planes, swap_xz):
+        """Host-side only (never a device sync): the ray origin -- tgt_pos with its axes permuted as the ray model does
+        (spherical.py:286-288 / :390-392) and taken through the FULL 4x4 pose, translation included (spherical.py:303-310)
+        -- must lie inside the innermost sphere, or intersect_sphere takes the square root of a negative number
+        (spherical.py:316-318) and the int cast of the NaN pixel coordinate is undefined.  Skipped when either input
+        lives on the device (render_kernel clamps a negative discriminant to zero, so the result is finite, not reference-defined)."""
+        if any(torch.is_tensor(t) and t.is_cuda for t in (tgt_pos, pose, planes)):
+            return
+        tp = np.asarray(torch.as_tensor(tgt_pos), dtype=np.float64).reshape(-1, 3)
+        c = np.stack([tp[:, 2], tp[:, 1], tp[:, 0]] if swap_xz else [tp[:, 0], tp[:, 1], -tp[:, 2]], axis=1)
+        ps = np.asarray(torch.as_tensor(pose), dtype=np.float64).reshape(-1, 4, 4)
+        if ps.shape[0] == 1 and c.shape[0] > 1:
+            ps = np.repeat(ps, c.shape[0], axis=0)
+        if ps.shape[0] != c.shape[0]:
+            return      # the batch check that follows reports it
+        origin = np.einsum('bij,bj->bi', ps[:, :3, :3], c) + ps[:, :3, 3]
+        pl = np.asarray(planes.cpu() if torch.is_tensor(planes) else planes, dtype=np.float64)
+        if np.any(np.linalg.norm(origin, axis=1) >= np.abs(pl).min()):
+            raise ValueError("the target ray origin (pose @ tgt_pos) must lie inside the innermost sphere (radius %g)"
+                             % np.abs(pl).min())
+
     def _render_args(self, rgba_layers, tgt_pose_rt, tgt_pos, planes):
         native = self._native_layers(rgba_layers)
         b, d, h, w, _ = native.shape
-        if not torch.is_tensor(tgt_pos) or not tgt_pos.is_cuda:
-            # domain guard (host side only, never a device sync): a target centre outside
-            # the innermost sphere makes spherical.py:316-318 take sqrt of a negative number
-            tp = np.asarray(torch.as_tensor(tgt_pos).cpu(), dtype=np.float64).reshape(-1, 3)
-            pl = np.asarray(planes.cpu() if torch.is_tensor(planes) else planes, dtype=np.float64)
-            if np.any(np.linalg.norm(tp, axis=1) >= pl.min()):
-                raise ValueError("tgt_pos must lie inside the innermost sphere (radius %g)" % pl.min())
+        self._domain_guard(tgt_pos, tgt_pose_rt, planes, swap_xz=True)
         pose = self._f32(tgt_pose_rt).reshape(-1, 4, 4)
         # batch size is taken from tgt_pose_rt in the reference (msi.py:419); broadcast a single pose
         if pose.shape[0] == 1 and b > 1:
@@ -329,6 +358,11 @@ class MSI(object):
                                              out.data_ptr(), self._stream()), "msi_project_layers_f32")
         return out
 
+    def msi_render_equirect_depth_single(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics):
+        """msi.py:454-473: the same warped, un-composited layers as msi_render_equirect_view_single (the reference's
+        two functions have identical bodies; the caller composites the index channel, test.py:374-382)."""
+        return self.msi_render_equirect_view_single(rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics)
+
     # ------------------------------------------------------------------ msi.py:502-525
     def msi_render_ods_view(self, rgba_layers, order, jitter_pose, tgt_pos, planes, intrinsics):
         """Render the left (order=+1) / right (order=-1) ODS eye from an MSI -> [B,H,W,3].
@@ -368,7 +402,9 @@ class MSI(object):
         (projector.py:78-86)."""
         native = self._native_layers(rgba_layers)
         b, d, h, w, _ = native.shape
-        pose = self._f32(np.tile(self._crop_pose(viewing_window)[None], (b, 1, 1)))
+        crop = np.tile(self._crop_pose(viewing_window)[None], (b, 1, 1))
+        self._domain_guard(tgt_pos, crop, planes, swap_xz=False)
+        pose = self._f32(crop)
         pos = self._f32(tgt_pos).reshape(-1, 3)
         if pos.shape[0] != b:
             raise ValueError("tgt_pos batch must match rgba_layers")
@@ -397,8 +433,9 @@ class MSI(object):
         hres_ref = self.preprocess_image(raw_hres_ref_image)
         hres_src = self.preprocess_image(raw_hres_src_image)
         hh, hw = hres_ref.shape[1], hres_ref.shape[2]
+        # the high-res volume feeds the fp32 assembly (not the network): fp32 also on a bf16 model
         psv = self.format_network_input(hres_ref, hres_src, ref_pose, src_pose, planes, intrinsics,
-                                        ref_pose_inv=ref_pose_inv)
+                                        ref_pose_inv=ref_pose_inv, dtype='f32')
         low = torch.cat([bw, al], dim=-1).contiguous()
         up = torch.empty((b, hh, hw, 2 * d), dtype=torch.float32, device=self.device)
         N.check(N.lib.msi_resize_bilinear_f32(low.data_ptr(), up.data_ptr(), b, h, w, 2 * d, hh, hw, self._stream()),

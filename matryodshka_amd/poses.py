@@ -58,3 +58,26 @@ def interpolate_pose(ref_pose, src_pose):
         out[b, :3, 3] = 0.5 * ref[b, :3, 3] + 0.5 * src[b, :3, 3]
         out[b, 3, :] = ref[b, 3, :]
     return out.astype(np.float32)
+
+
+def rotation_from_euler(angles):
+    """tensorflow_graphics rotation_matrix_3d.from_euler [TF-knowledge, tfg 1.0.0]: angles (x, y, z) in radians,
+    R = Rz(z) @ Ry(y) @ Rx(x) (the x rotation is applied first).  float64 in, float64 out."""
+    ax, ay, az = (float(a) for a in angles)
+    cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return rz @ ry @ rx
+
+
+def random_rotation(rc, tc, rng, angle_range=(-0.03, 0.03), offset_range=(-0.01, 0.01)):
+    """geometry/spherical.py:21-40 tf_random_rotation: the jitter pose of the transform-inverse test path
+    (test.py:112): Euler angles uniform in angle_range * rc, translation uniform in offset_range * tc.
+    rng: numpy RandomState (the reference draws from the TF graph seed).  Returns [1,4,4] float32."""
+    ang = rng.uniform(angle_range[0] * rc, angle_range[1] * rc, size=3)
+    tr = rng.uniform(offset_range[0] * tc, offset_range[1] * tc, size=3)
+    m = np.eye(4)
+    m[:3, :3] = rotation_from_euler(ang)
+    m[:3, 3] = tr
+    return m[None].astype(np.float32)

@@ -8,9 +8,15 @@ A checkpoint `<prefix>` is `<prefix>.index` + `<prefix>.data-SSSSS-of-NNNNN`:
     variable name whose value is a BundleEntryProto {dtype=1, shape=2, shard_id=3, offset=4, size=5,
     crc32c=6};
   * the data shards hold the raw little-endian tensor bytes at [offset, offset+size).
+  * a PARTITIONED variable has one entry under its name (full shape, `slices` = field 7, no data) and one entry
+    per slice under the key EncodeTensorNameSlice(name, slice) (tensorflow/core/util/saved_tensor_slice_util:
+    OrderedCode 0, the name as an escaped string, the rank, and (start, length) per dimension), which sorts
+    before every plain name.
 Format knowledge, not code, is taken from TensorFlow's public sources [TF-knowledge]; there is no
-TensorFlow (and no checkpoint of the reference) in the build container, so the reader is tested
-against `write_checkpoint` below, which emits the same format.
+TensorFlow (and no checkpoint of the reference) in the build container, so the reader is tested against
+`write_checkpoint` below AND against a byte-level fixture assembled independently from the format
+description (tests/test_tf_checkpoint.py: two shards, a partitioned variable, Adam slots, multi-restart blocks).
+Every tensor restored is checked against its stored crc32c (verify_crc=True by default).
 
     weights = load_checkpoint("checkpoints/ods-wotemp-elpips-coord/model.ckpt-400000")
     model = MSI(weights=weights)        # names 'net/<layer>/weights', ... (nets.variable_shapes)
@@ -89,7 +95,7 @@ def _parse_shape(buf):
 
 
 def _parse_entry(buf):
-    e = {"dtype": 0, "shape": (), "shard_id": 0, "offset": 0, "size": 0, "crc32c": None, "sliced": False}
+    e = {"dtype": 0, "shape": (), "shard_id": 0, "offset": 0, "size": 0, "crc32c": None, "sliced": False, "slices": []}
     for field, _, v in _proto_fields(buf):
         if field == 1:
             e["dtype"] = v
@@ -103,9 +109,69 @@ def _parse_entry(buf):
             e["size"] = v
         elif field == 6:
             e["crc32c"] = struct.unpack("<I", v)[0]
-        elif field == 7:
+        elif field == 7:                                # repeated TensorSliceProto slices
             e["sliced"] = True
+            e["slices"].append(_parse_slice(v))
     return e
+
+
+def _parse_slice(buf):
+    """TensorSliceProto { repeated Extent extent = 1 { int64 start = 1; int64 length = 2 (absent = full) } }
+    -> [(start, length or -1)] per dimension."""
+    dims = []
+    for field, _, v in _proto_fields(buf):
+        if field == 1:
+            start, length = 0, -1
+            for f2, _, v2 in _proto_fields(v):
+                if f2 == 1:
+                    start = v2
+                elif f2 == 2:
+                    length = v2
+            dims.append((start, length))
+    return dims
+
+
+# ---- OrderedCode (tensorflow/core/lib/strings/ordered_code) as far as EncodeTensorNameSlice needs it
+def _oc_num_increasing(v):
+    """WriteNumIncreasing: one length byte, then the value big-endian without leading zero bytes."""
+    body = b"" if v == 0 else v.to_bytes((v.bit_length() + 7) // 8, "big")
+    return bytes([len(body)]) + body
+
+
+def _oc_string(b):
+    """WriteString: byte 0x00 -> 0x00 0xff, byte 0xff -> 0xff 0x00, terminated by 0x00 0x01."""
+    esc = {0: bytes([0, 255]), 255: bytes([255, 0])}
+    return b"".join(esc.get(c, bytes([c])) for c in b) + bytes([0, 1])
+
+
+def _oc_signed_increasing(val):
+    """WriteSignedNumIncreasing: sign-extended big-endian, the leading bits carry the length (len 1: 0x80 ^ val for
+    -64 <= val < 64; len n: n one-bits then a zero bit precede the payload, complemented for negatives)."""
+    x = ~val if val < 0 else val
+    if x < 64:
+        return bytes([(0x80 ^ val) & 0xff])
+    bits = x.bit_length() + 1                            # magnitude bits + sign
+    n = 2
+    while 7 * n < bits:                                  # n bytes carry 7 n payload bits (n <= 8), kBitsToLength
+        n += 1
+    if n > 8:
+        n = 9 if bits <= 63 + 1 else 10
+    raw = (val & ((1 << 80) - 1)).to_bytes(10, "big")    # two's complement, sign-extended to 10 bytes
+    out = bytearray(raw[10 - n:])
+    header = [(0x80, 0), (0xc0, 0), (0xe0, 0), (0xf0, 0), (0xf8, 0), (0xfc, 0), (0xfe, 0), (0xff, 0), (0xff, 0x80), (0xff, 0xc0)][n - 1]
+    out[0] ^= header[0]
+    if n >= 2:
+        out[1] ^= header[1]
+    return bytes(out)
+
+
+def encode_tensor_name_slice(name, extents):
+    """saved_tensor_slice_util EncodeTensorNameSlice: the table key of one slice of a partitioned variable.
+    extents: [(start, length)] per dimension; a full dimension is (0, -1) (TensorSlice::kFullExtent)."""
+    out = _oc_num_increasing(0) + _oc_string(name.encode()) + _oc_num_increasing(len(extents))
+    for start, length in extents:
+        out += _oc_signed_increasing(start) + _oc_signed_increasing(length)
+    return out
 
 
 # ---------------------------------------------------------------------------- table (.index)
@@ -152,6 +218,8 @@ def read_index(path):
                         header["num_shards"] = v
                     elif field == 2:
                         header["endianness"] = v
+            elif key[:1] == b"\x00":                  # slice of a partitioned variable (binary OrderedCode key)
+                entries[key] = _parse_entry(value)
             else:
                 entries[key.decode()] = _parse_entry(value)
     header.setdefault("num_shards", 1)
@@ -178,9 +246,10 @@ def latest_checkpoint(ckpt_dir):
     return best
 
 
-def load_checkpoint(prefix, names=None, verify_crc=False):
+def load_checkpoint(prefix, names=None, verify_crc=True):
     """{variable name: np.ndarray} of a checkpoint prefix (or of a directory's latest checkpoint).
-    `names`: optional predicate / collection restricting what is read (optimizer slots are large)."""
+    `names`: optional predicate / collection restricting what is read (optimizer slots are large).
+    Every tensor (and every slice of a partitioned one) is checked against its stored masked crc32c."""
     if os.path.isdir(prefix):
         prefix = latest_checkpoint(prefix)
         if prefix is None:
@@ -189,20 +258,43 @@ def load_checkpoint(prefix, names=None, verify_crc=False):
     nshards = header["num_shards"]
     shards = {}
     out = {}
-    for name, e in entries.items():
-        if names is not None and not (names(name) if callable(names) else name in names):
-            continue
-        if e["sliced"]:
-            raise ValueError("%s: partitioned variables are not supported" % name)
-        if e["dtype"] not in _DTYPES:
-            continue                                           # strings etc.: not network weights
+
+    def read(name, e):
         sid = e["shard_id"]
+        if sid >= nshards:
+            raise ValueError("%s: shard %d of a %d-shard checkpoint" % (name, sid, nshards))
         if sid not in shards:
             shards[sid] = np.memmap("%s.data-%05d-of-%05d" % (prefix, sid, nshards), dtype=np.uint8, mode="r")
-        raw = np.asarray(shards[sid][e["offset"]:e["offset"] + e["size"]])
-        if verify_crc and e["crc32c"] is not None and masked_crc32c(raw.tobytes()) != e["crc32c"]:
+        raw = np.ascontiguousarray(shards[sid][e["offset"]:e["offset"] + e["size"]])
+        if raw.size != e["size"]:
+            raise ValueError("%s: data shard %d is truncated" % (name, sid))
+        if verify_crc and e["crc32c"] is not None and masked_crc32c(raw) != e["crc32c"]:
             raise ValueError("%s: crc32c mismatch" % name)
-        out[name] = raw.view(_DTYPES[e["dtype"]]).reshape(e["shape"]).copy()
+        return raw.view(_DTYPES[e["dtype"]]).reshape(e["shape"])
+
+    for name, e in entries.items():
+        if isinstance(name, bytes):
+            continue                                           # slice entries are read through their variable
+        if names is not None and not (names(name) if callable(names) else name in names):
+            continue
+        if e["dtype"] not in _DTYPES:
+            continue                                           # strings etc.: not network weights
+        if not e["sliced"]:
+            out[name] = read(name, e).copy()
+            continue
+        full = np.empty(e["shape"], dtype=_DTYPES[e["dtype"]])
+        covered = 0
+        for ext in e["slices"]:
+            key = encode_tensor_name_slice(name, ext)
+            if key not in entries:
+                raise ValueError("%s: slice %r of the partitioned variable is missing from the index" % (name, ext))
+            idx = tuple(slice(None) if ln < 0 else slice(st, st + ln) for st, ln in ext)
+            part = read(name, entries[key])
+            full[idx] = part
+            covered += part.size
+        if covered != full.size:
+            raise ValueError("%s: slices cover %d of %d elements" % (name, covered, full.size))
+        out[name] = full
     return out
 
 
@@ -238,8 +330,19 @@ def crc32c(data):
     return c ^ 0xffffffff
 
 
+def _crc32c_fast(data):
+    """The native table-driven implementation when libmsi_hip.so is built (68 MB of weights in ~0.1 s; the pure
+    Python loop above takes minutes), else the Python one."""
+    try:
+        from . import _native
+    except Exception:       # library not built: the checkpoint reader stays usable
+        return crc32c(bytes(data))
+    a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data)
+    return int(_native.lib.msi_crc32c_host(a.ctypes.data, a.nbytes, 0))
+
+
 def masked_crc32c(data):
-    c = crc32c(data)
+    c = _crc32c_fast(data)
     return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xffffffff
 
 

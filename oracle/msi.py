@@ -3,7 +3,7 @@ CPU restatement of matryodshka/msi.py's infer -> render path with the
 reference's method names and argument order, on numpy arrays.
 
 Reference followed: matryodshka/msi.py
-  :40-52, 68-88, 119-147, 276-289   infer_msi (blend_psv)
+  :40-52, 68-88, 119-147, 276-289   infer_msi (blend_psv; :166-275 blend_bg, blend_bg_psv, alpha_only)
   :384-429                          msi_render_equirect_depth / _view
   :431-452                          msi_render_equirect_view_single
   :1094-1130, 1157-1161             format_network_input / sweep_src
@@ -22,7 +22,7 @@ F = np.float32
 
 
 class MSI(object):
-    def __init__(self, weights=None, coord_net=True, input_type='ODS', dtype='f32'):
+    def __init__(self, weights=None, coord_net=False, input_type='ODS', dtype='f32'):     # FLAGS.coord_net default, test.py:52
         self.weights = weights
         self.coord_net = coord_net
         # 'bf16': BASELINE configs[2] as the build defines it (the reference has no bf16 code): the sweep
@@ -69,13 +69,17 @@ class MSI(object):
 
     # -- msi.py:1094-1130 -----------------------------------------------------
     def format_network_input(self, ref_image, src_image, ref_pose, src_pose, planes,
-                             intrinsics, ref_pose_inv=None):
+                             intrinsics, ref_pose_inv=None, jitter_pose_inv=None):
         ref_image = np.asarray(ref_image, dtype=F)
         src_image = np.asarray(src_image, dtype=F)
         ref_pose = np.asarray(ref_pose, dtype=F)
         src_pose = np.asarray(src_pose, dtype=F)
         if ref_pose_inv is None:
             ref_pose_inv = np.linalg.inv(ref_pose.astype(np.float64)).astype(F)
+        if jitter_pose_inv is not None:     # FLAGS.jitter, msi.py:1118-1120
+            ref_pose_inv = np.matmul(np.asarray(ref_pose_inv, dtype=F),
+                                     np.broadcast_to(np.asarray(jitter_pose_inv, dtype=F).reshape(-1, 4, 4),
+                                                     np.asarray(ref_pose_inv).reshape(-1, 4, 4).shape)).astype(F)
         net_input = []
         # The reference concatenates [ref_pose, src_pose] on the batch axis and
         # so only works for B=1 (msi.py:1109-1110); here batch element b uses
@@ -93,32 +97,62 @@ class MSI(object):
     # -- msi.py:40-289 (blend_psv) -------------------------------------------
     def infer_msi(self, raw_src_image, raw_ref_image, raw_hres_src_image, raw_hres_ref_image,
                   ref_pose, src_pose, intrinsics, which_color_pred, num_msi_planes, psv_planes,
-                  extra_outputs='', ngf=64, ref_pose_inv=None):
-        assert which_color_pred == 'blend_psv'
+                  extra_outputs='', ngf=64, ref_pose_inv=None, jitter_pose_inv=None):
         src_image = self.preprocess_image(raw_src_image)
         ref_image = self.preprocess_image(raw_ref_image)
         net_input = self.format_network_input(ref_image, src_image, ref_pose, src_pose,
-                                              psv_planes, intrinsics, ref_pose_inv=ref_pose_inv)
+                                              psv_planes, intrinsics, ref_pose_inv=ref_pose_inv,
+                                              jitter_pose_inv=jitter_pose_inv)
         msi_pred = nets.forward(self.weights, net_input, coord_net=self.coord_net, bf16=self.dtype == 'bf16')
-        pred = self.assemble(net_input, msi_pred, num_msi_planes, extra_outputs)
+        pred = self.assemble(net_input, msi_pred, num_msi_planes, extra_outputs, which_color_pred)
         return pred, net_input
 
-    def assemble(self, net_input, msi_pred, num_msi_planes, extra_outputs=''):
-        """layer_prediction, msi.py:130-147."""
+    def assemble(self, net_input, msi_pred, num_msi_planes, extra_outputs='', which_color_pred='blend_psv'):
+        """layer_prediction: blend_psv msi.py:130-147, blend_bg :177-188, blend_bg_psv :223-242, alpha_only :258-268."""
         d = num_msi_planes
         b, h, w, _ = net_input.shape
-        blend_weights = (msi_pred[..., :d] + F(1.)) / F(2.)
-        alphas = (msi_pred[..., d:2 * d] + F(1.)) / F(2.)
+        net_input = np.asarray(net_input, dtype=F)
+        one = F(1)
+        blend_weights = bg_blend_weights = None
+        if which_color_pred == 'alpha_only':
+            assert msi_pred.shape[-1] == d
+            alphas = (msi_pred[..., :d] + F(1.)) / F(2.)
+        else:
+            blend_weights = (msi_pred[..., :d] + F(1.)) / F(2.)
+            alphas = (msi_pred[..., d:2 * d] + F(1.)) / F(2.)
+        if which_color_pred == 'blend_psv':
+            assert msi_pred.shape[-1] == 2 * d
+        elif which_color_pred == 'blend_bg':
+            assert msi_pred.shape[-1] == 2 * d + 3
+            pred_bg = msi_pred[..., -3:]                       # not rescaled (msi.py:177)
+        elif which_color_pred == 'blend_bg_psv':
+            assert msi_pred.shape[-1] == 3 * d + 3
+            bg_blend_weights = (msi_pred[..., 2 * d:3 * d] + F(1.)) / F(2.)
+            pred_bg = msi_pred[..., -3:]
+        elif which_color_pred != 'alpha_only':
+            raise ValueError(which_color_pred)
         rgba = np.empty((b, h, w, d, 4), dtype=F)
         for i in range(d):
             fg_rgb = net_input[..., i * 3:(1 + i) * 3]
             bg_rgb = net_input[..., (d + i) * 3:(d + 1 + i) * 3]
-            wgt = blend_weights[..., i:i + 1]
-            rgba[..., i, :3] = wgt * fg_rgb + (F(1) - wgt) * bg_rgb
+            if which_color_pred == 'alpha_only':
+                rgb = fg_rgb
+            else:
+                wgt = blend_weights[..., i:i + 1]
+                if which_color_pred == 'blend_bg':
+                    rgb = wgt * fg_rgb + (one - wgt) * pred_bg
+                else:
+                    rgb = wgt * fg_rgb + (one - wgt) * bg_rgb
+                    if which_color_pred == 'blend_bg_psv':
+                        bg_w = bg_blend_weights[..., i:i + 1]
+                        rgb = bg_w * rgb + (one - bg_w) * pred_bg
+            rgba[..., i, :3] = rgb
             rgba[..., i, 3] = alphas[..., i]
         pred = {'rgba_layers': rgba}
-        if 'blend_weights' in extra_outputs:
+        if 'blend_weights' in extra_outputs and 'blend' in which_color_pred:      # msi.py:280-284
             pred['blend_weights'] = blend_weights
+            if bg_blend_weights is not None:
+                pred['bg_blend_weights'] = bg_blend_weights
         if 'alpha' in extra_outputs:
             pred['alphas'] = alphas
         if 'psv' in extra_outputs:

@@ -56,7 +56,7 @@ def test_bf16_big_tile_matches_small_tile(env):
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=9, randomize_affine=True)
     x = torch.from_numpy(np.random.RandomState(1).uniform(-1, 1, (b, h, w, cin)).astype(np.float32)).cuda().bfloat16()
     from matryodshka_amd import _native as N
-    m = MSI(weights=weights, dtype='bf16')
+    m = MSI(weights=weights, coord_net=True, dtype='bf16')
     m.net_options[N.NET_OPT_BIGTILE] = 0
     small = m.run_net(x, nout, ngf).cpu().numpy()
     m.net_options[N.NET_OPT_BIGTILE] = 2
@@ -94,8 +94,8 @@ def test_bf16_pipeline_config3_shapes(env):
     b, h, w, d, ngf = 2, 32, 64, 64, 16
     inp = make_inputs(21, b, h, w)
     weights = onets.init_weights(6 * d, 2 * d, ngf=ngf, coord_net=True, seed=2, randomize_affine=True)
-    m = MSI(weights=weights, dtype='bf16')
-    o = OracleMSI(weights=weights, dtype='bf16')
+    m = MSI(weights=weights, coord_net=True, dtype='bf16')
+    o = OracleMSI(weights=weights, coord_net=True, dtype='bf16')
     planes = m.inv_depths(1.0, 100.0, d)
     out, net_input = m.infer_msi(torch.from_numpy(inp["src_image"]), torch.from_numpy(inp["ref_image"]), None, None,
                                  inp["ref_pose"], inp["src_pose"], inp["intrinsics"], 'blend_psv', d, planes, ngf=ngf)

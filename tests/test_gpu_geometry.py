@@ -244,3 +244,66 @@ def test_render_perspective_view_matches_oracle(gpu, vw):
                                         viewing_window=vw, psp_height=27, psp_width=48)
     assert tuple(got.shape) == ref.shape == (b, 27, 48, 3)
     assert np.abs(_np(got) - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("scheme", ["blend_psv", "blend_bg", "blend_bg_psv", "alpha_only"])
+@pytest.mark.parametrize("bf16_psv", [False, True])
+def test_assemble_colour_schemes_bit_exact(gpu, scheme, bf16_psv):
+    """which_color_pred (msi.py:119-275) through K3: same fp32 op order as the oracle -> bit-exact, including the odd
+    channel counts of blend_bg (2D+3) and blend_bg_psv (3D+3) and the optional [B,H,W,D] outputs (msi.py:276-289)."""
+    torch, m, o = gpu
+    from oracle import nets as onets
+    b, h, w, d = 2, 24, 40, 8
+    rng = np.random.RandomState(17)
+    psv = rng.uniform(-1, 1, size=(b, h, w, 6 * d)).astype(np.float32)
+    if bf16_psv:
+        psv = onets.bf16_round(psv)
+    nout = {"blend_psv": 2 * d, "blend_bg": 2 * d + 3, "blend_bg_psv": 3 * d + 3, "alpha_only": d}[scheme]
+    pred = np.tanh(rng.normal(size=(b, h, w, nout))).astype(np.float32)
+    t_psv = torch.from_numpy(psv).cuda()
+    out = m.assemble_layers(t_psv.bfloat16() if bf16_psv else t_psv, torch.from_numpy(pred).cuda(), d,
+                            extra_outputs="blend_weights_alphas", which_color_pred=scheme)
+    ref = o.assemble(psv, pred, d, "blend_weights_alphas", scheme)
+    assert set(out) == set(ref), (sorted(out), sorted(ref))
+    for k in ref:
+        assert np.array_equal(_np(out[k]), ref[k]), k
+
+
+def test_jitter_pose_enters_the_sweep(gpu):
+    """FLAGS.jitter (msi.py:1118-1120): ref_pose_inv <- ref_pose_inv @ jitter_pose_inv before the sweep."""
+    torch, m, o = gpu
+    from matryodshka_amd import poses
+    b, h, w, d = 1, 32, 64, 4
+    inp = make_inputs(9, b, h, w)
+    planes = m.inv_depths(1.0, 100.0, d)
+    jit = poses.random_rotation(1.0, 1.0, np.random.RandomState(4))
+    jinv = np.linalg.inv(jit.astype(np.float64)).astype(np.float32)
+    ref = m.preprocess_image(torch.from_numpy(inp["ref_image"]))
+    src = m.preprocess_image(torch.from_numpy(inp["src_image"]))
+    psv = m.format_network_input(ref, src, inp["ref_pose"], inp["src_pose"], planes, inp["intrinsics"], jitter_pose_inv=jinv)
+    psv0 = m.format_network_input(ref, src, inp["ref_pose"], inp["src_pose"], planes, inp["intrinsics"])
+    psv_o = o.format_network_input(o.preprocess_image(inp["ref_image"]), o.preprocess_image(inp["src_image"]),
+                                   inp["ref_pose"], inp["src_pose"], planes, inp["intrinsics"], jitter_pose_inv=jinv)
+    assert np.abs(_np(psv) - psv_o).max() <= TOL
+    assert np.abs(_np(psv) - _np(psv0)).max() > 1e-2          # the jitter really moved the samples
+
+
+def test_domain_guard_uses_the_full_pose(gpu):
+    """The ray origin is pose @ permuted(tgt_pos), translation included (spherical.py:286-310): a small tgt_pos with a
+    large pose translation is outside the innermost sphere and must be rejected on the host; device-side inputs skip
+    the guard and stay finite (clamped discriminant)."""
+    torch, m, o = gpu
+    b, h, w, d = 1, 16, 32, 4
+    rgba = torch.from_numpy(random_rgba(1, b, h, w, d)).cuda()
+    planes = m.inv_depths(1.0, 100.0, d)
+    pose = np.eye(4, dtype=np.float32)[None].copy()
+    pose[0, 0, 3] = 1.5
+    pos = np.zeros((1, 3), np.float32)
+    with pytest.raises(ValueError):
+        m.msi_render_equirect_view(rgba, pose, pos, planes, None)
+    with pytest.raises(ValueError):
+        m.msi_render_perspective_view(rgba, pose, np.array([[0.0, 0.0, 1.2]], np.float32), planes, None, psp_height=8, psp_width=8)
+    out = m.msi_render_equirect_view(rgba, torch.from_numpy(pose).cuda(), torch.from_numpy(pos).cuda(), planes, None)
+    assert bool(torch.isfinite(out).all())
+    same = m.msi_render_equirect_depth_single(rgba, np.eye(4, dtype=np.float32)[None], pos, planes, None)
+    assert torch.equal(same, m.msi_render_equirect_view_single(rgba, np.eye(4, dtype=np.float32)[None], pos, planes, None))

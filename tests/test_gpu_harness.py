@@ -75,3 +75,64 @@ def test_harness_restores_a_tf_checkpoint(tmp_path):
     assert np.array_equal(np.load(str(fa / "alphas.npy")), np.load(str(fb / "alphas.npy")))
     assert np.array_equal(np.asarray(Image.open(str(fa / "output_tgt_s_000001002.png"))),
                           np.asarray(Image.open(str(fb / "output_tgt_s_000001002.png"))))
+
+
+@pytest.mark.parametrize("coord,scheme", [(True, "blend_psv"), (False, "blend_psv"), (True, "blend_bg_psv")])
+def test_harness_outputs_equal_the_oracle(tmp_path, coord, scheme):
+    """SURVEY 8f-2 / test.py:231-281: the written PNGs / NPYs against the CPU oracle run on the same decoded and
+    area-resized images: uint8 outputs equal up to 1 LSB on < 0.1 % of the pixels (DESIGN.md tolerances); the network
+    variant is inferred from the weights (CoordNet has one more input channel)."""
+    from PIL import Image
+    from matryodshka_amd import harness
+    from oracle import nets as onets
+    from oracle.msi import MSI as OracleMSI
+    h, w, d, ngf = 32, 64, 8, 16
+    nout = {"blend_psv": 2 * d, "blend_bg_psv": 3 * d + 3}[scheme]
+    img_dir = tmp_path / "images"; img_dir.mkdir()
+    from tests.util import smooth_noise
+    rng = np.random.RandomState(5)
+    for name in ("000", "001", "002"):
+        arr = (smooth_noise(rng, 1, 2 * h, 2 * w)[0] * 255).astype(np.uint8)
+        Image.fromarray(arr).save(str(img_dir / ("apt_pos%s.jpeg" % name)), quality=95)
+    cam = tmp_path / "cams.txt"
+    cam.write_text("apt 000 001 002 0.032 0.02 -0.01 0.03\n")
+    weights = onets.init_weights(6 * d, nout, ngf=ngf, coord_net=coord, seed=13, randomize_affine=True)
+    np.savez(str(tmp_path / "w.npz"), **weights)
+    outputs = "src_image_ref_image_tgt_image_psv_rgba_layers_blend_weights_alphas_src_output_image_ref_output_image_psp"
+    assert harness.main(["--cameras_glob", str(cam), "--image_dir", str(img_dir), "--output_root", str(tmp_path / "o"),
+                         "--experiment_name", "e", "--height", str(h), "--width", str(w), "--num_msi_planes", str(d),
+                         "--ngf", str(ngf), "--weights", str(tmp_path / "w.npz"), "--which_color_pred", scheme,
+                         "--test_outputs", outputs]) == 1
+    sample = tmp_path / "o" / "e" / "apt_000001002"
+    ref, src = (harness.load_image(str(img_dir / ("apt_pos%s.jpeg" % n)), h, w)[None] for n in ("000", "001"))
+    o = OracleMSI(weights=weights, coord_net=coord)
+    planes = o.inv_depths(1.0, 100.0, d)
+    eye = np.eye(4, dtype=np.float32)[None]
+    intr = np.array([[[0.032, 0, 0], [0, 1, 0], [0, 0, 1]]], np.float32)
+    pos = np.array([[0.02, -0.01, 0.03]], np.float32)
+    pred, psv = o.infer_msi(src, ref, None, None, eye, eye, intr, scheme, d, planes, extra_outputs="blend_weights alphas", ngf=ngf)
+
+    def png(name):
+        return np.asarray(Image.open(str(sample / name))).astype(int)
+
+    def close(name, want_u8):
+        got = png(name)
+        diff = np.abs(got - want_u8.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (name, diff.max(), (diff > 0).mean())
+
+    tag = "apt_000001002"
+    close("output_tgt_%s.png" % tag, o.deprocess_image(o.msi_render_equirect_view(pred["rgba_layers"], eye, pos, planes, intr))[0])
+    close("output_depth_%s.png" % tag, o.deprocess_depth_image(o.msi_render_equirect_depth(pred["rgba_layers"], eye, pos, planes, intr))[0])
+    close("output_src_%s.png" % tag, o.deprocess_image(o.msi_render_ods_view(pred["rgba_layers"], -1, eye, pos, planes, intr))[0])
+    close("output_ref_%s.png" % tag, o.deprocess_image(o.msi_render_ods_view(pred["rgba_layers"], 1, eye, pos, planes, intr))[0])
+    for vw in range(4):
+        want = o.deprocess_image(o.msi_render_perspective_view(pred["rgba_layers"], eye, pos, planes, intr, viewing_window=vw))[0]
+        close("output_ptgt%d_%s.png" % (vw, tag), want)
+    u8 = lambda x: np.clip(x, 0, 255).astype("uint8")          # utils.write_image (utils.py:76-81)
+    for i in (0, d // 2, d - 1):
+        close("msi_alpha_%.2d.png" % i, u8(pred["rgba_layers"][0, :, :, i, 3] * 255.0))
+        close("msi_rgb_%.2d.png" % i, u8((pred["rgba_layers"][0, :, :, i, :3] + 1.) / 2. * 255))
+        close("psv_plane_%.3d.png" % i, u8((psv[0, :, :, i * 3:(i + 1) * 3] + 1.) / 2. * 255))
+        close("blend_weight_%.3d.png" % i, u8(pred["blend_weights"][0, :, :, i] * 255.0))
+    assert np.abs(np.load(str(sample / "blend_weights.npy")) - pred["blend_weights"]).max() <= 1e-3
+    assert np.abs(np.load(str(sample / "alphas.npy")) - pred["alphas"]).max() <= 1e-3

@@ -62,7 +62,7 @@ def test_batch_elements_are_independent():
     b, h, w, d, ngf = 3, 16, 32, 8, 16
     inp = make_inputs(77, b, h, w)
     weights = onets.init_weights(6 * d, 2 * d, ngf=ngf, coord_net=True, seed=5)
-    m = MSI(weights=weights)
+    m = MSI(weights=weights, coord_net=True)
     planes = m.inv_depths(1.0, 100.0, d)
 
     def run(sl):
@@ -89,7 +89,7 @@ def test_high_res_rerender_matches_plane_by_plane_oracle():
     inp = make_inputs(31, b, h, w)
     hres = make_inputs(32, b, hh, hw)
     weights = onets.init_weights(6 * d, 2 * d, ngf=ngf, coord_net=True, seed=31, randomize_affine=True)
-    m, o = MSI(weights=weights), OracleMSI(weights=weights)
+    m, o = MSI(weights=weights, coord_net=True), OracleMSI(weights=weights, coord_net=True)
     planes = m.inv_depths(1.0, 100.0, d)
     pred, _ = m.infer_msi(torch.from_numpy(inp["src_image"]), torch.from_numpy(inp["ref_image"]), None, None,
                           inp["ref_pose"], inp["src_pose"], inp["intrinsics"], "blend_psv", d, planes,
@@ -132,8 +132,8 @@ def test_pp_cube_face_path_matches_oracle():
     b, n, d, ngf = 2, 32, 8, 16
     ref, src, K, eye, src_pose, tgt_pose = _pp_inputs(5, b, n)
     weights = onets.init_weights(6 * d, 2 * d, ngf=ngf, coord_net=True, seed=3, randomize_affine=True)
-    m = MSI(weights=weights, input_type='PP')
-    o = OracleMSI(weights=weights, input_type='PP')
+    m = MSI(weights=weights, coord_net=True, input_type='PP')
+    o = OracleMSI(weights=weights, coord_net=True, input_type='PP')
     planes = m.inv_depths(1.0, 100.0, d)
     pred, net_input = m.infer_msi(torch.from_numpy(src), torch.from_numpy(ref), None, None, eye, src_pose, K,
                                   "blend_psv", d, planes, ngf=ngf)
@@ -173,3 +173,53 @@ def test_mpi_render_identity_and_zero_padding():
     assert np.abs(got - ref).max() < 1e-5
     zero_cols = [j for j in range(n) if not got[0, :, j].any()]
     assert len(zero_cols) == 4 and (zero_cols == [0, 1, 2, 3] or zero_cols == [n - 4, n - 3, n - 2, n - 1])
+
+
+def test_hres_rerender_on_a_bf16_model_uses_an_fp32_volume():
+    """msi_render_equirect_hres on a dtype='bf16' model used to hand a bf16 high-res volume to the
+    fp32 assembly.  The high-res volume is fp32 whatever the model's dtype: same result as on an fp32 model."""
+    import torch
+    from matryodshka_amd import MSI
+    b, h, w, d = 1, 16, 32, 8
+    hh, hw = 32, 64
+    inp = make_inputs(41, b, h, w)
+    hres = make_inputs(42, b, hh, hw)
+    rng = np.random.RandomState(0)
+    bw = torch.from_numpy(rng.uniform(0, 1, (b, h, w, d)).astype(np.float32)).cuda()
+    al = torch.from_numpy(rng.uniform(0, 1, (b, h, w, d)).astype(np.float32)).cuda()
+    outs = []
+    for dtype in ("f32", "bf16"):
+        m = MSI(coord_net=True, dtype=dtype)
+        planes = m.inv_depths(1.0, 100.0, d)
+        outs.append(m.msi_render_equirect_hres(bw, al, torch.from_numpy(hres["ref_image"]), torch.from_numpy(hres["src_image"]),
+                                               inp["ref_pose"], inp["src_pose"], inp["tgt_pose_rt"], inp["tgt_pos"], planes,
+                                               inp["intrinsics"]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert bool(torch.isfinite(outs[1][0]).all())
+
+
+@pytest.mark.parametrize("scheme,coord", [("blend_bg", True), ("blend_bg_psv", False), ("alpha_only", True)])
+def test_infer_msi_colour_schemes_match_oracle(scheme, coord):
+    """FLAGS.which_color_pred (test.py:55-56, msi.py:166-275) end to end: network with 2D+3 / 3D+3 / D outputs,
+    layer assembly, render."""
+    import torch
+    from matryodshka_amd import MSI
+    from oracle import nets as onets
+    from oracle.msi import MSI as OracleMSI
+    b, h, w, d, ngf = 2, 16, 40, 8, 16
+    nout = {"blend_bg": 2 * d + 3, "blend_bg_psv": 3 * d + 3, "alpha_only": d}[scheme]
+    inp = make_inputs(51, b, h, w)
+    weights = onets.init_weights(6 * d, nout, ngf=ngf, coord_net=coord, seed=9, randomize_affine=True)
+    m, o = MSI(weights=weights, coord_net=coord), OracleMSI(weights=weights, coord_net=coord)
+    planes = m.inv_depths(1.0, 100.0, d)
+    pred, _ = m.infer_msi(torch.from_numpy(inp["src_image"]), torch.from_numpy(inp["ref_image"]), None, None,
+                          inp["ref_pose"], inp["src_pose"], inp["intrinsics"], scheme, d, planes,
+                          extra_outputs="blend_weights alphas", ngf=ngf)
+    pred_o, _ = o.infer_msi(inp["src_image"], inp["ref_image"], None, None, inp["ref_pose"], inp["src_pose"],
+                            inp["intrinsics"], scheme, d, planes, extra_outputs="blend_weights alphas", ngf=ngf)
+    assert set(pred) == set(pred_o)
+    for k in pred_o:
+        assert np.abs(pred[k].cpu().numpy() - pred_o[k]).max() <= TOL, k
+    rgb = m.msi_render_equirect_view(pred["rgba_layers"], inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    rgb_o = o.msi_render_equirect_view(pred_o["rgba_layers"], inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+    assert np.abs(rgb.cpu().numpy() - rgb_o).max() <= TOL

@@ -38,3 +38,16 @@ def test_identity_large_angle_and_orthonormality():
         assert np.allclose(m @ m.T, np.eye(3), atol=1e-6) and abs(np.linalg.det(m) - 1) < 1e-6
         # half-way on the shortest arc: the relative rotations ref->mid and mid->src are equal
         assert np.allclose(r0.T @ m, m.T @ r1, atol=1e-5)
+
+
+def test_random_rotation_is_a_rigid_jitter_pose():
+    from matryodshka_amd import poses
+    m = poses.random_rotation(1.0, 1.0, np.random.RandomState(3))
+    assert m.shape == (1, 4, 4) and m.dtype == np.float32
+    r = m[0, :3, :3].astype(np.float64)
+    assert np.allclose(r @ r.T, np.eye(3), atol=1e-6) and abs(np.linalg.det(r) - 1.0) < 1e-6
+    assert np.all(np.abs(m[0, :3, 3]) <= 0.01) and np.array_equal(m[0, 3], [0, 0, 0, 1])
+    assert np.array_equal(poses.random_rotation(0.0, 0.0, np.random.RandomState(3))[0], np.eye(4, dtype=np.float32))
+    # y-only Euler angle = the crop rotation of projector.py:78-86 ([[c,0,s],[0,1,0],[-s,0,c]])
+    ry = poses.rotation_from_euler([0.0, 0.3, 0.0])
+    assert np.allclose(ry, [[np.cos(0.3), 0, np.sin(0.3)], [0, 1, 0], [-np.sin(0.3), 0, np.cos(0.3)]])
