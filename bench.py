@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=4,
                     help="extra timed regions of --steps steps after the contract one (reported under `repeats`; the "
                          "headline `value` is always the first region right after the warm-up)")
+    ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed steps before the --warmup steps")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--no-coord-net", action="store_true", help="msi_train_net instead of msi_coord_train_net")
     ap.add_argument("--streams", type=int, default=1,
@@ -173,12 +174,7 @@ def main():
     coord = not args.no_coord_net
     cin, nout = 6 * D, 2 * D
     # frames of this rank per step: its shard of the step's batch (strong scaling) or a fixed batch (weak scaling)
-    if cfg["total"] is not None:
-        lo, hi = mdist.shard_frames(cfg["total"], rank, world)
-        frames_total = cfg["total"]
-    else:
-        lo, hi = rank * cfg["per_rank"], (rank + 1) * cfg["per_rank"]
-        frames_total = cfg["per_rank"] * world
+    lo, hi, frames_total = mdist.step_frames(cfg["total"], cfg["per_rank"], rank, world)
     B = hi - lo
 
     # weights: rank 0 initialises, everyone receives them over RCCL (xGMI); timed, outside the frame loop
@@ -287,11 +283,19 @@ def main():
         cnn_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(len(ev) // 2)]
         return elapsed, cnn_ms, result
 
+    # clock / allocator pre-warm (untimed, disclosed as `prewarm_s`): an idle MI355X needs ~0.1 s under load to reach
+    # its sustained clocks -- a 20-step region is 60 ms -- and the first frames create the plan, workspaces and tables
+    t_pre, k = time.perf_counter(), 0
+    while time.perf_counter() - t_pre < args.prewarm:
+        step(k); k += 1
+        if k % 8 == 0:
+            torch.cuda.synchronize()
     for k in range(max(args.warmup, args.streams)):
         step(k)
     elapsed, cnn_ms, result = timed_region(args.steps)             # the contract region: `value` comes from here
     repeats = [timed_region(args.steps)[0] for _ in range(max(0, args.repeats))]
 
+    ranges = mdist.gather_ranges(lo, hi, dev) if world > 1 else [(lo, hi)]
     nccl_world = torch.distributed.get_world_size() if world > 1 else 1
     backend = torch.distributed.get_backend() if world > 1 else None
     if rank != 0:
@@ -335,7 +339,7 @@ def main():
     line = {
         "metric": metric,
         "value": round(fps, 3), "unit": unit, "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "warmup": args.warmup, "prewarm_s": args.prewarm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": cfg["scaling"], "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
         "config": {"workload": cfg["name"] + ", " + ("CoordNet" if coord else "wrap-pad net") + ", infer + "
                                + ("MPI render" if cfg["kind"] == "pp" else "RGB&depth render"),
@@ -344,6 +348,7 @@ def main():
                    "parallelism": "frames sharded over %d GPU(s) (dist.shard_frames), no data-path collective" % world,
                    "streams_per_gpu": args.streams},
         "distributed": {"world_size_env": world, "world_size_process_group": nccl_world, "backend": backend,
+                        "frame_ranges_per_rank": ranges,
                         "weight_broadcast_ms": None if broadcast_ms is None else round(broadcast_ms, 3),
                         "devices_visible": torch.cuda.device_count(), "device_of_rank0": torch.cuda.get_device_name(dev)},
         "repeats": {"ms_per_step": [round(r / args.steps * 1e3, 4) for r in [elapsed] + repeats],

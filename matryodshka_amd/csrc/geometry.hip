@@ -21,6 +21,7 @@ namespace {
 struct PixConsts {
   float pi, pi_over_w, u_den, wm1;          // u = ((theta + pi) - pi/W) / (2pi - 2pi/W) * (W-1)
   float half_pi, half_pi_over_h, v_den, hm1;  // v = ((phi + pi/2) - (pi/2)/H) / (pi - pi/H) * (H-1)
+  float u_scale, v_scale;                   // (W-1) / u_den, (H-1) / v_den, rounded once from fp64 (fast tail)
 };
 
 PixConsts make_consts(int height, int width) {
@@ -34,6 +35,8 @@ PixConsts make_consts(int height, int width) {
   k.half_pi_over_h = (float)(0.5 * PI / height);
   k.v_den = (float)(PI - PI / height);
   k.hm1 = (float)(height - 1);
+  k.u_scale = (float)((double)(width - 1) / (2 * PI - 2 * PI / width));
+  k.v_scale = (float)((double)(height - 1) / (PI - PI / height));
   return k;
 }
 
@@ -75,6 +78,61 @@ __device__ __forceinline__ Taps make_taps(float x, float y, int width, int heigh
 __device__ __forceinline__ float blend4(const Taps &t, float a, float b, float c, float d) {
   // tf.add_n([area_a*A, area_b*B, area_c*C, area_d*D]) summed in list order.
   return ((t.wa * a + t.wb * b) + t.wc * c) + t.wd * d;
+}
+
+// ---- the CONTINUOUS tail of the angle math ----------------------------------------------------------
+// Everything that feeds a branch of the reference (|z| > |x|, sign(pz), disc >= 0: the quadratic of project_ods up
+// to `disc`) is evaluated op for op in IEEE fp32 above / below.  What follows the branches -- the root, the direction,
+// the two angles and the pixel coordinates -- is a continuous function of its inputs, so 1-ulp primitives
+// (v_rcp_f32 + one Newton step, v_sqrt_f32, a degree-7 odd minimax atan, 1.3e-7 rad) move a sample by <= 2e-5 px,
+// i.e. the bilinear result by ~1e-5 of the image range (tolerance 1e-3), and cost a third of the IEEE sequences
+// (the sweep and the render are VALU-bound: ~470 / ~260 instructions per sample with libm atan2f and IEEE
+// divide / sqrt, profiles/r01_*).  -DMSI_FAST_TAIL=0 restores the IEEE / libm tail.
+#ifndef MSI_FAST_TAIL
+#define MSI_FAST_TAIL 1
+#endif
+
+__device__ __forceinline__ float t_sqrt(float x) {
+#if MSI_FAST_TAIL
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return sqrtf(x);
+#endif
+}
+
+__device__ __forceinline__ float t_div(float a, float b) {
+#if MSI_FAST_TAIL
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float q = a * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, b, a), r, q);   // one correction step: <= 1 ulp for normal operands
+#else
+  return a / b;
+#endif
+}
+
+__device__ __forceinline__ float t_atan2(float y, float x) {
+#if MSI_FAST_TAIL
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float a = mn * __builtin_amdgcn_rcpf(mx);
+  a = (mx == 0.0f) ? 0.0f : a;                                // atan2(+-0, +-0) = +-0 / +-pi like libm
+  const float s = a * a;
+  float p = -0.0040545277297496796f;
+  p = __builtin_fmaf(p, s, 0.021862812340259552f);
+  p = __builtin_fmaf(p, s, -0.05591211095452309f);
+  p = __builtin_fmaf(p, s, 0.09642180800437927f);
+  p = __builtin_fmaf(p, s, -0.13908623158931732f);
+  p = __builtin_fmaf(p, s, 0.19946564733982086f);
+  p = __builtin_fmaf(p, s, -0.33329859375953674f);
+  p = __builtin_fmaf(p, s, 0.9999993443489075f);
+  float r = p * a;
+  r = (ay > ax) ? 1.57079632679489662f - r : r;
+  r = (x < 0.0f || (x == 0.0f && __builtin_signbitf(x))) ? 3.14159265358979324f - r : r;
+  r = (mx != mx || mn != mn) ? __builtin_nanf("") : r;        // NaN in -> NaN out (the callers test for it)
+  return __builtin_copysignf(r, y);
+#else
+  return atan2f(y, x);
+#endif
 }
 
 // ------------------------------------------------------------------------ K5

@@ -33,6 +33,24 @@ def shard_frames(num_frames, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def step_frames(total, per_rank, rank, world_size):
+    """Global frame indices [lo, hi) this rank renders in ONE bench step and the step's total:
+    strong scaling (`total` frames per step sharded over the ranks, BASELINE configs[3]/[4]) or weak scaling
+    (`per_rank` frames on every rank, configs[1]/[2])."""
+    if total is not None:
+        lo, hi = shard_frames(total, rank, world_size)
+        return lo, hi, int(total)
+    return rank * per_rank, (rank + 1) * per_rank, per_rank * world_size
+
+
+def gather_ranges(lo, hi, device):
+    """[(lo, hi)] of every rank (one small all_gather; used by the tests and by bench.py's report)."""
+    t = torch.tensor([int(lo), int(hi)], dtype=torch.int64, device=_coll_device(device))
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [(int(o[0]), int(o[1])) for o in out]
+
+
 def _coll_device(device):
     """Collectives run on the GPU with nccl (RCCL) and on the host with gloo."""
     return torch.device("cpu") if dist.get_backend() == "gloo" else device

@@ -29,8 +29,14 @@ def _worker(rank, world, port, q):
     blob = nets.flatten_params(w, cin, nout, ngf, True)
     lo, hi = mdist.shard_frames(7, rank, world)
     t = mdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    # the sharded bench loop (bench.py --config 3 / 4: B = 32 / 64 frames per step over the ranks; --config 1 / 2: weak)
+    loops = {}
+    for name, total, per_rank in (("config3", 32, None), ("config4", 64, None), ("config1", None, 1), ("odd", 7, None)):
+        flo, fhi, ftotal = mdist.step_frames(total, per_rank, rank, world)
+        rendered = list(range(flo, fhi))                 # what frame() would be called with
+        loops[name] = (mdist.gather_ranges(flo, fhi, torch.device("cpu")), ftotal, rendered)
     mdist.barrier()
-    q.put((rank, float(blob.sum()), blob.size, (lo, hi), t))
+    q.put((rank, float(blob.sum()), blob.size, (lo, hi), t, loops))
     dist.destroy_process_group()
 
 
@@ -61,3 +67,10 @@ def test_two_rank_gloo_broadcast_and_reduce(native_lib):
     assert res[0][1] == res[1][1] == float(ref.sum()) and res[0][2] == ref.size   # both hold rank 0's weights
     assert res[0][3] == (0, 4) and res[1][3] == (4, 7)
     assert res[0][4] == res[1][4] == 2.0
+    # sharded loop: every rank sees the same partition; the union of the ranks' frames is exactly the step's batch
+    for name, total in (("config3", 32), ("config4", 64), ("config1", 2), ("odd", 7)):
+        ranges0, total0, frames0 = res[0][5][name]
+        ranges1, total1, frames1 = res[1][5][name]
+        assert ranges0 == ranges1 and total0 == total1 == total
+        assert sorted(frames0 + frames1) == list(range(total)) and not set(frames0) & set(frames1)
+        assert [tuple(r) for r in ranges0] == [(frames0[0], frames0[-1] + 1), (frames1[0], frames1[-1] + 1)]

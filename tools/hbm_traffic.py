@@ -4,7 +4,10 @@
 /opt/skills/guides/MI355X_MICROARCH.md prescribes: counters are in KB; FETCH_SIZE reports half of
 the bytes of wide coalesced reads on gfx950 and is doubled here).
 
-    python tools/hbm_traffic.py fetch_results.db write_results.db FRAMES > profiles/rNN_hbm_traffic.json
+    python tools/hbm_traffic.py fetch_results.db write_results.db FRAMES [GIT_COMMIT] > profiles/rNN_hbm_traffic.json
+
+GIT_COMMIT: the commit the measured library was built from (bench.py prints it next to `roofline.traffic`, so a
+stale profile is visible); the GPU box has no .git, pass `git rev-parse --short HEAD` from the build container.
 """
 import json
 import re
@@ -28,6 +31,7 @@ def per_kernel(db, counter):
 
 def main():
     fetch_db, write_db, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    commit = sys.argv[4] if len(sys.argv) > 4 else "unknown"
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
     kernels = {}
@@ -38,10 +42,10 @@ def main():
         kernels[k] = {"launches_per_frame": round(n / frames, 2), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
                       "hbm_bytes": int(rd + wr)}
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes with --kernel-trace only, over "
-                       "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline` (%d frames, 640x320, 32 spheres, B=1). "
+                       "`python bench.py --steps 3 --warmup 1 --repeats 0 --no-cpu-baseline` (%d frames, 640x320, 32 spheres, B=1). "
                        "Counters are KB; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md (calibration: "
                        "assemble_kernel reads 209.7 MB algorithmic, ln_apply_kernel 367 MB)." % frames,
-               "kernels": kernels}, sys.stdout, indent=1)
+               "git_commit": commit, "kernels": kernels}, sys.stdout, indent=1)
     print()
 
 
