@@ -85,7 +85,8 @@ int msi_compose_poses_f32(const float *lhs, const float *rhs, float *out, int32_
  * backproject_spherical (spherical.py:116-129), apply_pose (projector.py:275-291),
  * project_ods (spherical.py:170-233) and the wrap-around bilinear gather
  * sampling.resample (sampling.py:135-197), fused; nothing is materialised but
- * the output.  Writes channels [channel_offset, channel_offset+3*D) of psv.
+ * the output.  The part of project_ods that decides its branches (up to the discriminant) is IEEE fp32 op for op;
+ * the continuous remainder (root, angles, pixel coordinates) uses 1-ulp primitives (<= 2e-5 px).  Writes channels [channel_offset, channel_offset+3*D) of psv.
  *   pose [B,4,4] (curr_pose = src_pose @ ref_pose_inv, msi.py:1125),
  *   intrinsics [B,3,3] (ODS baseline in [b,0,0], data_loader.py:160),
  *   depths [D], order = +1 (ref) / -1 (src) (msi.py:1127). */
@@ -102,6 +103,19 @@ int msi_ods_sphere_sweep_bf16(const float *image, const float *pose, const float
                               int32_t height, int32_t width, int32_t num_depths, int32_t order,
                               void *psv_bf16, int32_t psv_channels, int32_t channel_offset,
                               msi_stream_t stream);
+
+/* The whole double volume of MSI.format_network_input (msi.py:1124-1129) in one launch: ref_image with order +1
+ * into channels [0,3D), src_image with order -1 into [3D,6D) of psv [B,H,W,6D] (fp32, or bf16 when psv_is_bf16 != 0).
+ * The poses are the two curr_pose = pose @ ref_pose_inv (msi_compose_pose_pair_f32).  When they are equal per
+ * sample (test path: identity poses) the branch-deciding quadratic of project_ods is evaluated once for both
+ * sources; results are identical to two msi_ods_sphere_sweep_* calls. */
+int msi_ods_sweep_volume(const float *ref_image, const float *src_image, const float *ref_curr_pose,
+                         const float *src_curr_pose, const float *intrinsics, const float *depths, const float *trig,
+                         int32_t batch, int32_t height, int32_t width, int32_t num_depths, void *psv, int32_t psv_is_bf16,
+                         msi_stream_t stream);
+/* out0[b] = lhs0[b] @ rhs[b], out1[b] = lhs1[b] @ rhs[b] (one launch for both curr_pose, msi.py:1125). */
+int msi_compose_pose_pair_f32(const float *lhs0, const float *lhs1, const float *rhs, float *out0, float *out1,
+                              int32_t batch, msi_stream_t stream);
 
 /* ---- K3: RGBA layer assembly ----------------------------------------------------
  * infer_msi "layer_prediction", which_color_pred = blend_psv (msi.py:130-147):

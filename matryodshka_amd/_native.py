@@ -54,6 +54,8 @@ SIGNATURES = {
     "msi_compose_poses_f32": (_I, [_P, _P, _P, _I, _P]),
     "msi_ods_sphere_sweep_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "msi_ods_sphere_sweep_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "msi_ods_sweep_volume": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "msi_compose_pose_pair_f32": (_I, [_P, _P, _P, _P, _P, _I, _P]),
     "msi_assemble_rgba_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msi_assemble_rgba_bf16psv_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msi_assemble_rgba_color_f32": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -181,6 +181,22 @@ compose_poses_kernel(const float *__restrict__ lhs, const float *__restrict__ rh
   out[i] = acc;
 }
 
+// out0 = lhs0 @ rhs, out1 = lhs1 @ rhs in one launch: the two curr_pose of format_network_input (msi.py:1124-1125)
+__global__ void __launch_bounds__(256)
+compose_pose_pair_kernel(const float *__restrict__ lhs0, const float *__restrict__ lhs1, const float *__restrict__ rhs,
+                         float *__restrict__ out0, float *__restrict__ out1, int batch) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= batch * 32) return;
+  const int which = t / (batch * 16), i = t - which * batch * 16;
+  const int b = i >> 4, r = (i >> 2) & 3, c = i & 3;
+  const float *A = (which ? lhs1 : lhs0) + b * 16 + r * 4, *Bm = rhs + b * 16 + c;
+  float acc = A[0] * Bm[0];
+  acc = acc + A[1] * Bm[4];
+  acc = acc + A[2] * Bm[8];
+  acc = acc + A[3] * Bm[12];
+  (which ? out1 : out0)[i] = acc;
+}
+
 // fp32 <-> bf16 (round to nearest even; the values stored here are finite)
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   const unsigned u = __builtin_bit_cast(unsigned, f);
@@ -193,17 +209,99 @@ __device__ __forceinline__ void store_elem(float *p, size_t i, float v) { p[i] =
 __device__ __forceinline__ void store_elem(unsigned short *p, size_t i, float v) { p[i] = f32_to_bf16(v); }
 
 // ------------------------------------------------------------------------ K1
-// One work item = (pixel, depth); depth is the fastest index so a wavefront's 64
-// lanes write 64 consecutive 12-byte texels of the NHWC volume (768 contiguous
-// bytes at D=32 per source).  The source image (2.4 MB) stays L2-resident.
+// project_ods (spherical.py:181-229) in two parts.
+// (1) ods_quad: everything up to the discriminant, op for op in IEEE fp32 (no contraction: this file is compiled with
+//     -ffp-contract=off) -- it decides the reference's three branches (|z| > |x|, sign(pz), disc >= 0), and `disc` is
+//     ill conditioned, so not one rounding may differ from the oracle here.
+// (2) ods_tail: root, ray direction, angles, pixel coordinates -- continuous in (a, bq, f, px, pz, disc), evaluated
+//     with the 1-ulp primitives above.  It is the only part that depends on `order`, so when both sources of the sweep
+//     volume have the same pose (the test path: identity poses, msi.py:1125) they share (1).
+struct OdsQuad {
+  float f, px, pz, a, bq, disc, y;
+  bool zlx;
+};
+
+__device__ __forceinline__ OdsQuad ods_quad(const float *__restrict__ P, float r, float depth, float csct, float st, float ssct) {
+  OdsQuad q;
+  // backproject_spherical (spherical.py:125-128)
+  float x = depth * csct;
+  float y = depth * st;
+  float z = depth * ssct;
+  // apply_pose (projector.py:275-291): pose @ [x,y,z,1], terms summed left to right
+  const float px_ = ((P[0] * x + P[1] * y) + P[2] * z) + P[3] * 1.0f;
+  const float py_ = ((P[4] * x + P[5] * y) + P[6] * z) + P[7] * 1.0f;
+  const float pz_ = ((P[8] * x + P[9] * y) + P[10] * z) + P[11] * 1.0f;
+  x = px_;
+  y = py_;
+  z = pz_;
+  // project_ods (spherical.py:181-192)
+  q.f = r * r - (x * x + z * z);
+  q.zlx = fabsf(z) > fabsf(x);
+  q.px = q.zlx ? x : z;
+  q.pz = q.zlx ? z : x;
+  const float pz2 = q.pz * q.pz;
+  q.a = 1.0f + (q.px * q.px) / pz2;
+  q.bq = ((-2.0f * q.f) * q.px) / pz2;
+  const float c = q.f + (q.f * q.f) / pz2;
+  q.disc = q.bq * q.bq - (4.0f * q.a) * c;
+  q.y = y;
+  return q;
+}
+
+// (spherical.py:195-229) -> pixel coordinates (u, v); (1, 1) where disc < 0 or NaN
+__device__ __forceinline__ void ods_tail(const OdsQuad &q, float order, const PixConsts &K, float &u, float &v) {
+  const float sgn = (q.pz > 0.0f) ? 1.0f : ((q.pz < 0.0f) ? -1.0f : q.pz);
+  float s = ((-order) * sgn) * t_sqrt(q.disc);
+  s = q.zlx ? s : -s;
+  float dx = t_div(-q.bq + s, 2.0f * q.a);
+  float dz = t_div(q.f - q.px * dx, q.pz);
+  const float dxf = q.zlx ? -dx : -dz;
+  const float dzf = q.zlx ? -dz : -dx;
+  dx = dxf;
+  dz = dzf;
+  const float theta = -t_atan2(dz, dx);
+  float phi = t_atan2(q.y, t_sqrt(dx * dx + dz * dz));
+  if (phi != phi) phi = 1.0f;
+  phi = (phi <= K.half_pi) ? phi : K.half_pi;
+  phi = (phi >= -K.half_pi) ? phi : -K.half_pi;
+#if MSI_FAST_TAIL
+  u = ((theta + K.pi) - K.pi_over_w) * K.u_scale;
+  v = ((phi + K.half_pi) - K.half_pi_over_h) * K.v_scale;
+#else
+  u = (((theta + K.pi) - K.pi_over_w) / K.u_den) * K.wm1;
+  v = (((phi + K.half_pi) - K.half_pi_over_h) / K.v_den) * K.hm1;
+#endif
+  if (!(q.disc >= 0.0f)) {
+    u = 1.0f;
+    v = 1.0f;
+  }
+}
+
+// resample (sampling.py:135-197) of one RGB texel
+__device__ __forceinline__ void gather3(const float *__restrict__ img, int width, int height, float u, float v, float *out) {
+  const Taps t = make_taps(u, v, width, height);
+  const float *pa = img + ((size_t)t.y0 * width + t.x0) * 3;
+  const float *pb = img + ((size_t)t.y0 * width + t.x1) * 3;
+  const float *pc = img + ((size_t)t.y1 * width + t.x0) * 3;
+  const float *pd = img + ((size_t)t.y1 * width + t.x1) * 3;
+  out[0] = blend4(t, pa[0], pb[0], pc[0], pd[0]);
+  out[1] = blend4(t, pa[1], pb[1], pc[1], pd[1]);
+  out[2] = blend4(t, pa[2], pb[2], pc[2], pd[2]);
+}
+
+// One work item = (pixel, NS consecutive depths); depth is the fastest index so a wavefront's 64
+// lanes write 64 x NS consecutive 12-byte texels of the NHWC volume.  The source image (2.4 MB) stays L2-resident.
 // OutT = float, or unsigned short = bf16 bits (the bf16 network input of BASELINE configs[2]).
 // NS = samples (consecutive depths of one pixel) per thread: with two, the per-pixel work (trigonometry,
 // index arithmetic) is shared and hipcc pairs the independent multiplies / adds of the two samples into
 // v_pk_mul_f32 / v_pk_add_f32 (IEEE, same roundings as the scalar forms) -- this kernel is VALU-bound.
-template <typename OutT, int NS>
+// NSRC = 1: one source (image0, pose0, order) -> channels [coff, coff + 3D).
+// NSRC = 2: the whole double volume of format_network_input (msi.py:1124-1129): source 0 with order +1 into
+// channels [0, 3D), source 1 with order -1 into [3D, 6D); the quadratic is shared when the two poses are equal.
+template <typename OutT, int NS, int NSRC>
 __global__ void __launch_bounds__(256)
-ods_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose,
-                 const float *__restrict__ intrinsics, const float *__restrict__ depths,
+ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ image1, const float *__restrict__ pose0,
+                 const float *__restrict__ pose1, const float *__restrict__ intrinsics, const float *__restrict__ depths,
                  const float *__restrict__ trig, int batch, int height, int width, int nd,
                  float order, OutT *__restrict__ psv, int channels, int coff, PixConsts K) {
   // grid = (ceil(W*(D/NS) / 256), H, B): 32-bit index math only (64-bit div/mod are emulated in ~100
@@ -217,75 +315,44 @@ ods_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose
 
   const float cs = trig[j], ss = trig[width + j];
   const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
-  const float *P = pose + (size_t)b * 16;
+  const float *P0 = pose0 + (size_t)b * 16;
+  const float *P1 = NSRC == 2 ? pose1 + (size_t)b * 16 : P0;
   const float r = intrinsics[(size_t)b * 9];
-  const float *img = image + (size_t)b * height * width * 3;
+  const float *img0 = image0 + (size_t)b * height * width * 3;
+  const float *img1 = NSRC == 2 ? image1 + (size_t)b * height * width * 3 : img0;
   const float csct = cs * ct, ssct = ss * ct;
-  float out[NS][3];
+  bool same = NSRC == 2;                         // wave-uniform (scalar loads)
+  if (NSRC == 2) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) same = same && (P0[k] == P1[k]);
+  }
+  float out[NSRC][NS][3];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     const float depth = depths[d0 + q];
-
-    // backproject_spherical (spherical.py:125-128)
-    float x = depth * csct;
-    float y = depth * st;
-    float z = depth * ssct;
-
-    // apply_pose (projector.py:275-291): pose @ [x,y,z,1], terms summed left to right
-    const float px_ = ((P[0] * x + P[1] * y) + P[2] * z) + P[3] * 1.0f;
-    const float py_ = ((P[4] * x + P[5] * y) + P[6] * z) + P[7] * 1.0f;
-    const float pz_ = ((P[8] * x + P[9] * y) + P[10] * z) + P[11] * 1.0f;
-    x = px_;
-    y = py_;
-    z = pz_;
-
-    // project_ods (spherical.py:181-229)
-    const float f = r * r - (x * x + z * z);
-    const bool zlx = fabsf(z) > fabsf(x);
-    const float px = zlx ? x : z;
-    const float pz = zlx ? z : x;
-    const float pz2 = pz * pz;
-    const float a = 1.0f + (px * px) / pz2;
-    const float bq = ((-2.0f * f) * px) / pz2;
-    const float c = f + (f * f) / pz2;
-    const float disc = bq * bq - (4.0f * a) * c;
-    const float sgn = (pz > 0.0f) ? 1.0f : ((pz < 0.0f) ? -1.0f : pz);
-    float s = ((-order) * sgn) * sqrtf(disc);
-    s = zlx ? s : -s;
-    float dx = (-bq + s) / (2.0f * a);
-    float dz = (f - px * dx) / pz;
-    const float dxf = zlx ? -dx : -dz;
-    const float dzf = zlx ? -dz : -dx;
-    dx = dxf;
-    dz = dzf;
-    const float theta = -atan2f(dz, dx);
-    float phi = atan2f(y, sqrtf(dx * dx + dz * dz));
-    if (phi != phi) phi = 1.0f;
-    phi = (phi <= K.half_pi) ? phi : K.half_pi;
-    phi = (phi >= -K.half_pi) ? phi : -K.half_pi;
-    float u = (((theta + K.pi) - K.pi_over_w) / K.u_den) * K.wm1;
-    float v = (((phi + K.half_pi) - K.half_pi_over_h) / K.v_den) * K.hm1;
-    if (!(disc >= 0.0f)) {
-      u = 1.0f;
-      v = 1.0f;
+    float u, v;
+    const OdsQuad q0 = ods_quad(P0, r, depth, csct, st, ssct);
+    ods_tail(q0, NSRC == 2 ? 1.0f : order, K, u, v);
+    gather3(img0, width, height, u, v, out[0][q]);
+    if (NSRC == 2) {
+      if (same) {
+        ods_tail(q0, -1.0f, K, u, v);
+      } else {
+        const OdsQuad q1 = ods_quad(P1, r, depth, csct, st, ssct);
+        ods_tail(q1, -1.0f, K, u, v);
+      }
+      gather3(img1, width, height, u, v, out[NSRC - 1][q]);
     }
-
-    // resample (sampling.py:135-197)
-    const Taps t = make_taps(u, v, width, height);
-    const float *pa = img + ((size_t)t.y0 * width + t.x0) * 3;
-    const float *pb = img + ((size_t)t.y0 * width + t.x1) * 3;
-    const float *pc = img + ((size_t)t.y1 * width + t.x0) * 3;
-    const float *pd = img + ((size_t)t.y1 * width + t.x1) * 3;
-    out[q][0] = blend4(t, pa[0], pb[0], pc[0], pd[0]);
-    out[q][1] = blend4(t, pa[1], pb[1], pc[1], pd[1]);
-    out[q][2] = blend4(t, pa[2], pb[2], pc[2], pd[2]);
   }
-  const size_t o = (size_t)p * channels + coff + d0 * 3;
 #pragma unroll
-  for (int q = 0; q < NS; ++q) {
-    store_elem(psv, o + q * 3 + 0, out[q][0]);
-    store_elem(psv, o + q * 3 + 1, out[q][1]);
-    store_elem(psv, o + q * 3 + 2, out[q][2]);
+  for (int sidx = 0; sidx < NSRC; ++sidx) {
+    const size_t o = (size_t)p * channels + (NSRC == 2 ? sidx * 3 * nd : coff) + d0 * 3;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      store_elem(psv, o + q * 3 + 0, out[sidx][q][0]);
+      store_elem(psv, o + q * 3 + 1, out[sidx][q][1]);
+      store_elem(psv, o + q * 3 + 2, out[sidx][q][2]);
+    }
   }
 }
 
@@ -516,15 +583,21 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
     // disc >= 0 whenever the ray origin is inside the sphere (the documented domain; the host-side guard of the MSI class
     // enforces it for host inputs).  Outside it the reference takes sqrt of a negative number and casts NaN to int
     // (undefined); the clamp keeps device-side inputs finite and changes nothing inside the domain.
-    const float t = (-qb + sqrtf(fmaxf(disc, 0.0f))) / ta;
+    // (no branch of the reference depends on these values: the whole chain is continuous -> 1-ulp primitives)
+    const float t = t_div(-qb + t_sqrt(fmaxf(disc, 0.0f)), ta);
     const float x = cx + t * rx;
     const float y = cy + t * ry;
     const float z = cz + t * rz;
     // project_spherical (spherical.py:243-246) + theta_phi_to_pixels (:54-68)
-    const float theta = -atan2f(z, x);
-    const float phi = atan2f(y, sqrtf(x * x + z * z));
+    const float theta = -t_atan2(z, x);
+    const float phi = t_atan2(y, t_sqrt(x * x + z * z));
+#if MSI_FAST_TAIL
+    const float u = ((theta + K.pi) - K.pi_over_w) * K.u_scale;
+    const float v = ((phi + K.half_pi) - K.half_pi_over_h) * K.v_scale;
+#else
     const float u = (((theta + K.pi) - K.pi_over_w) / K.u_den) * K.wm1;
     const float v = (((phi + K.half_pi) - K.half_pi_over_h) / K.v_den) * K.hm1;
+#endif
 
     const Taps tp4 = make_taps(u, v, width, height);
     const float4 *L = rgba + ((size_t)b * nd + d) * hw;
@@ -836,6 +909,16 @@ int msi_deprocess_f32_u8(const float *in, uint8_t *out, size_t n, int32_t is_dep
   return msi::check_launch("deprocess");
 }
 
+int msi_compose_pose_pair_f32(const float *lhs0, const float *lhs1, const float *rhs, float *out0, float *out1,
+                              int32_t batch, msi_stream_t stream) {
+  MSI_REQUIRE(lhs0 && lhs1 && rhs && out0 && out1, "compose_pose_pair: null pointer");
+  MSI_REQUIRE(batch >= 0, "compose_pose_pair: bad batch");
+  if (batch == 0) return MSI_OK;
+  hipLaunchKernelGGL(compose_pose_pair_kernel, dim3(grid_1d((size_t)batch * 32)), dim3(256), 0, msi::as_stream(stream),
+                     lhs0, lhs1, rhs, out0, out1, (int)batch);
+  return msi::check_launch("compose_pose_pair");
+}
+
 int msi_compose_poses_f32(const float *lhs, const float *rhs, float *out, int32_t batch,
                           msi_stream_t stream) {
   MSI_REQUIRE(lhs && rhs && out, "compose_poses: null pointer");
@@ -849,17 +932,19 @@ int msi_compose_poses_f32(const float *lhs, const float *rhs, float *out, int32_
 #ifndef MSI_SWEEP_NS_DEFAULT
 #define MSI_SWEEP_NS_DEFAULT 2
 #endif
-static int sweep_common(const float *image, const float *pose, const float *intrinsics,
+static int sweep_common(const float *image, const float *image1, const float *pose, const float *pose1,
+                        const float *intrinsics,
                         const float *depths, const float *trig, int32_t batch,
                         int32_t height, int32_t width, int32_t num_depths, int32_t order,
                         void *psv, int psv_bf16, int32_t psv_channels, int32_t channel_offset,
                         msi_stream_t stream) {
-  MSI_REQUIRE(image && pose && intrinsics && depths && trig && psv, "ods_sphere_sweep: null pointer");
+  const bool pair = image1 != nullptr;
+  MSI_REQUIRE(image && pose && intrinsics && depths && trig && psv && (!pair || pose1), "ods_sphere_sweep: null pointer");
   MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_depths > 0, "ods_sphere_sweep: bad dims");
   MSI_REQUIRE(order == 1 || order == -1, "ods_sphere_sweep: order must be +1 or -1");
-  MSI_REQUIRE(channel_offset >= 0 && channel_offset + 3 * num_depths <= psv_channels,
+  MSI_REQUIRE(channel_offset >= 0 && channel_offset + (pair ? 6 : 3) * num_depths <= psv_channels,
               "ods_sphere_sweep: channel window [%d,%d) outside %d channels", channel_offset,
-              channel_offset + 3 * num_depths, psv_channels);
+              channel_offset + (pair ? 6 : 3) * num_depths, psv_channels);
   if (batch == 0) return MSI_OK;
   MSI_REQUIRE((long)width * num_depths < 2147483647L && height <= 65535 && batch <= 65535,
               "ods_sphere_sweep: problem too large");
@@ -867,14 +952,16 @@ static int sweep_common(const float *image, const float *pose, const float *intr
   int ns = MSI_SWEEP_NS_DEFAULT;
   while (num_depths % ns != 0) ns >>= 1;
   const dim3 grid((unsigned)(((long)width * (num_depths / ns) + 255) / 256), height, batch);
-#define MSI_LAUNCH_SWEEP(T, NS_)                                                                         \
-  hipLaunchKernelGGL((ods_sweep_kernel<T, NS_>), grid, dim3(256), 0, msi::as_stream(stream), image, pose, \
-                     intrinsics, depths, trig, batch, height, width, num_depths, (float)order,           \
+#define MSI_LAUNCH_SWEEP(T, NS_, NSRC_)                                                                          \
+  hipLaunchKernelGGL((ods_sweep_kernel<T, NS_, NSRC_>), grid, dim3(256), 0, msi::as_stream(stream), image, image1, \
+                     pose, pose1, intrinsics, depths, trig, batch, height, width, num_depths, (float)order,      \
                      static_cast<T *>(psv), psv_channels, channel_offset, make_consts(height, width))
-#define MSI_LAUNCH_SWEEP_T(T)                                                            \
-  { if (ns == 4) MSI_LAUNCH_SWEEP(T, 4); else if (ns == 2) MSI_LAUNCH_SWEEP(T, 2); else MSI_LAUNCH_SWEEP(T, 1); }
+#define MSI_LAUNCH_SWEEP_N(T, NSRC_)                                                                     \
+  { if (ns == 4) MSI_LAUNCH_SWEEP(T, 4, NSRC_); else if (ns == 2) MSI_LAUNCH_SWEEP(T, 2, NSRC_); else MSI_LAUNCH_SWEEP(T, 1, NSRC_); }
+#define MSI_LAUNCH_SWEEP_T(T) { if (pair) MSI_LAUNCH_SWEEP_N(T, 2) else MSI_LAUNCH_SWEEP_N(T, 1) }
   if (psv_bf16) MSI_LAUNCH_SWEEP_T(unsigned short) else MSI_LAUNCH_SWEEP_T(float)
 #undef MSI_LAUNCH_SWEEP_T
+#undef MSI_LAUNCH_SWEEP_N
 #undef MSI_LAUNCH_SWEEP
   return msi::check_launch("ods_sphere_sweep");
 }
@@ -884,7 +971,7 @@ int msi_ods_sphere_sweep_f32(const float *image, const float *pose, const float 
                              int32_t height, int32_t width, int32_t num_depths, int32_t order,
                              float *psv, int32_t psv_channels, int32_t channel_offset,
                              msi_stream_t stream) {
-  return sweep_common(image, pose, intrinsics, depths, trig, batch, height, width, num_depths, order, psv, 0,
+  return sweep_common(image, nullptr, pose, nullptr, intrinsics, depths, trig, batch, height, width, num_depths, order, psv, 0,
                       psv_channels, channel_offset, stream);
 }
 
@@ -893,8 +980,17 @@ int msi_ods_sphere_sweep_bf16(const float *image, const float *pose, const float
                               int32_t height, int32_t width, int32_t num_depths, int32_t order,
                               void *psv_bf16, int32_t psv_channels, int32_t channel_offset,
                               msi_stream_t stream) {
-  return sweep_common(image, pose, intrinsics, depths, trig, batch, height, width, num_depths, order, psv_bf16, 1,
+  return sweep_common(image, nullptr, pose, nullptr, intrinsics, depths, trig, batch, height, width, num_depths, order, psv_bf16, 1,
                       psv_channels, channel_offset, stream);
+}
+
+int msi_ods_sweep_volume(const float *ref_image, const float *src_image, const float *ref_curr_pose,
+                         const float *src_curr_pose, const float *intrinsics, const float *depths, const float *trig,
+                         int32_t batch, int32_t height, int32_t width, int32_t num_depths, void *psv, int32_t psv_is_bf16,
+                         msi_stream_t stream) {
+  MSI_REQUIRE(src_image, "ods_sweep_volume: null pointer");
+  return sweep_common(ref_image, src_image, ref_curr_pose, src_curr_pose, intrinsics, depths, trig, batch, height, width,
+                      num_depths, 1, psv, psv_is_bf16 != 0, 6 * num_depths, 0, stream);
 }
 
 static int assemble_common(const void *psv, int psv_bf16, const float *pred, int color, float *rgba_native,

@@ -202,19 +202,22 @@ class MSI(object):
         trig = self._trig(h, w)
         bf16 = (dtype or self.dtype) == 'bf16'
         psv = torch.empty((b, h, w, 6 * nd), dtype=torch.bfloat16 if bf16 else torch.float32, device=self.device)
-        # order = +1 for the reference image (i = 0), -1 for the source (i = 1), msi.py:1127
-        for i, (img, pose) in enumerate(((ref_image, ref_pose), (src_image, src_pose))):
-            curr_pose = self._compose(pose, ref_pose_inv)                      # msi.py:1125
-            order = 1 if (i % 2) == 0 else -1
-            if self.input_type == 'ODS':
-                sweep = N.lib.msi_ods_sphere_sweep_bf16 if bf16 else N.lib.msi_ods_sphere_sweep_f32
-                N.check(sweep(
-                    img.data_ptr(), curr_pose.data_ptr(), intr.data_ptr(), depths.data_ptr(), trig.data_ptr(),
-                    b, h, w, nd, order, psv.data_ptr(), 6 * nd, i * 3 * nd, self._stream()),
-                    "msi_ods_sphere_sweep")
-            else:   # sweep_src for perspective inputs (msi.py:1157-1161); ref_pose_inv = interp_pose_inv (:1113)
+        # order = +1 for the reference image (i = 0), -1 for the source (i = 1), msi.py:1127;
+        # curr_pose = pose @ ref_pose_inv for both sources in one launch (msi.py:1125)
+        if ref_pose_inv.shape[0] != b:
+            ref_pose_inv = ref_pose_inv.reshape(-1, 4, 4).expand(b, 4, 4).contiguous()
+        cur = torch.empty((2, b, 4, 4), dtype=torch.float32, device=self.device)
+        N.check(N.lib.msi_compose_pose_pair_f32(ref_pose.data_ptr(), src_pose.data_ptr(), ref_pose_inv.data_ptr(),
+                                                cur[0].data_ptr(), cur[1].data_ptr(), b, self._stream()),
+                "msi_compose_pose_pair_f32")
+        if self.input_type == 'ODS':
+            N.check(N.lib.msi_ods_sweep_volume(ref_image.data_ptr(), src_image.data_ptr(), cur[0].data_ptr(), cur[1].data_ptr(),
+                                               intr.data_ptr(), depths.data_ptr(), trig.data_ptr(), b, h, w, nd,
+                                               psv.data_ptr(), 1 if bf16 else 0, self._stream()), "msi_ods_sweep_volume")
+        else:   # sweep_src for perspective inputs (msi.py:1157-1161); ref_pose_inv = interp_pose_inv (:1113)
+            for i, img in enumerate((ref_image, src_image)):
                 N.check(N.lib.msi_perspective_plane_sweep_f32(
-                    img.data_ptr(), curr_pose.data_ptr(), intr.data_ptr(), depths.data_ptr(),
+                    img.data_ptr(), cur[i].data_ptr(), intr.data_ptr(), depths.data_ptr(),
                     b, h, w, nd, psv.data_ptr(), 6 * nd, i * 3 * nd, self._stream()),
                     "msi_perspective_plane_sweep_f32")
         return psv

@@ -307,3 +307,39 @@ def test_domain_guard_uses_the_full_pose(gpu):
     assert bool(torch.isfinite(out).all())
     same = m.msi_render_equirect_depth_single(rgba, np.eye(4, dtype=np.float32)[None], pos, planes, None)
     assert torch.equal(same, m.msi_render_equirect_view_single(rgba, np.eye(4, dtype=np.float32)[None], pos, planes, None))
+
+
+@pytest.mark.parametrize("same_pose", [True, False])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_sweep_volume_equals_two_single_source_sweeps(gpu, same_pose, bf16):
+    """msi_ods_sweep_volume (both sources in one launch, the branch-deciding quadratic shared when the two poses are
+    equal) against two msi_ods_sphere_sweep_* calls through the C ABI: bit-identical either way."""
+    torch, m, o = gpu
+    from matryodshka_amd import _native as N
+    b, h, w, d = 2, 24, 48, 8
+    inp = make_inputs(23, b, h, w)
+    ref = m.preprocess_image(torch.from_numpy(inp["ref_image"]))
+    src = m.preprocess_image(torch.from_numpy(inp["src_image"]))
+    p0 = np.tile(np.eye(4, dtype=np.float32)[None], (b, 1, 1))
+    p1 = p0.copy()
+    if not same_pose:
+        p1[:, 0, 3] = 0.01; p1[1, 1, 3] = -0.02
+    t0, t1 = torch.from_numpy(p0).cuda(), torch.from_numpy(p1).cuda()
+    intr = torch.from_numpy(inp["intrinsics"]).cuda()
+    depths = torch.tensor(m.inv_depths(1.0, 100.0, d), dtype=torch.float32).cuda()
+    trig = m._trig(h, w)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    both = torch.zeros((b, h, w, 6 * d), dtype=dt, device="cuda")
+    two = torch.zeros_like(both)
+    N.check(N.lib.msi_ods_sweep_volume(ref.data_ptr(), src.data_ptr(), t0.data_ptr(), t1.data_ptr(), intr.data_ptr(),
+                                       depths.data_ptr(), trig.data_ptr(), b, h, w, d, both.data_ptr(), int(bf16), None), "volume")
+    single = N.lib.msi_ods_sphere_sweep_bf16 if bf16 else N.lib.msi_ods_sphere_sweep_f32
+    for i, (img, pose, order) in enumerate(((ref, t0, 1), (src, t1, -1))):
+        N.check(single(img.data_ptr(), pose.data_ptr(), intr.data_ptr(), depths.data_ptr(), trig.data_ptr(), b, h, w, d,
+                       order, two.data_ptr(), 6 * d, i * 3 * d, None), "single")
+    torch.cuda.synchronize()
+    assert torch.equal(both, two)
+    if not bf16:
+        want = np.concatenate([__import__("oracle.geometry", fromlist=["x"]).ods_sphere_sweep(o.preprocess_image(img), order, m.inv_depths(1.0, 100.0, d), pose, inp["intrinsics"])
+                               for img, pose, order in ((inp["ref_image"], p0, 1), (inp["src_image"], p1, -1))], axis=3)
+        assert np.abs(_np(both) - want).max() <= TOL
