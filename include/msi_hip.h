@@ -274,7 +274,12 @@ typedef struct msi_net_plan msi_net_plan;
 #define MSI_NET_OPT_BIGTILE 2      /* bf16 tile choice: 0 never 128x128 / 128x64, 1 (default) by grid size, 2 always */
 #define MSI_NET_OPT_HEAD_FUSE_LN 3 /* 1 (default): the fp32 head applies its source's LayerNorm while loading      */
 #define MSI_NET_OPT_NUM_CUS 4      /* CUs the work decomposition balances over (default: the device's count)      */
-#define MSI_NET_OPT_COUNT 5
+#define MSI_NET_OPT_F32_TILE 5     /* fp32 tile of the layers in F32_TILE_MASK: 0 = 64x64, 1 = 128x64, 2 = 64x128 (tuning)     */
+#define MSI_NET_OPT_F32_TILE_MASK 6 /* bit i = layer i (graph order) uses MSI_NET_OPT_F32_TILE                                 */
+#define MSI_NET_OPT_APPLY_AHEAD 7   /* 1: a layer's LayerNorm + ReLU is applied by the first workgroups of its consumer's launch,    */
+                                   /* overlapped with that layer's tiles (row counters); 0 (default): one ln_apply launch per layer */
+                                   /* -- bit-identical results; measured slower on MI355X (write-through hand-off), see DESIGN.md  */
+#define MSI_NET_OPT_COUNT 8
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
 int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);

@@ -78,6 +78,7 @@ constexpr double LN_EPS = 1e-12;  // slim.layer_norm variance epsilon [TF-knowle
 // value = hi * 2^-8 + lo * 2^-52 (hi carries the integer part and 8 fraction bits, lo the next 44)
 constexpr int LN_SHARDS = 64;
 constexpr double LN_HI_SCALE = 256.0, LN_LO_SCALE = 17592186044416.0 /* 2^44, applied to the residue of S * 2^8 */;
+constexpr int AP_FLAG_STRIDE = 16;  // ints between two row counters of the apply-ahead hand-off: one counter per 64-byte line
 constexpr int HEAD_MAX_C = 256;   // the head's fused LayerNorm keeps scale | shift of its source in LDS
 
 enum { MODE_CONV = 0, MODE_CONVT = 1, MODE_HEAD = 2 };
@@ -107,6 +108,18 @@ struct ConvParams {
   int ntaps, cpt0, cpt1, ksteps;  // taps, 32-channel chunks per tap of each source, total k-steps
   int stride, rate, pad_t, pad_l;
   int mode, wrap, nclass;
+  // "apply-ahead": the first n_apply workgroups of the launch normalise source 0 (LayerNorm + ReLU of the producer layer)
+  // while the tile workgroups behind them already compute; see apply_ahead() below.  n_apply = 0: source 0 is
+  // normalised already (separate ln_apply launch, or the network input).
+  float *ap_x;               // raw fp32 output of the producer, normalised in place (fp32 path) ...
+  unsigned short *ap_yb;     // ... or written as bf16 into the operand copy (bf16 path), else null
+  const long long *ap_sums;  // the producer's LayerNorm sums [B][LN_SHARDS][4]
+  const float *ap_gamma, *ap_beta;
+  float *ap_aff;             // published affine [B][scale | shift] (tests)
+  int *ap_flags;             // [B][Hin][AP_FLAG_STRIDE] completed units per input row (zeroed per forward)
+  int *ap_err;               // set to 1 if a tile workgroup gave up waiting (never in a healthy launch)
+  double ap_inv_n;
+  int n_apply, ap_units_per_row, ap_unit_vec, ap_row_vec;   // workgroups; units per row; float4 per unit / per row
 #ifdef MSI_CONV_TIMING
   unsigned long long *dbg;   // [block][6]: s_memtime at start, loop start, loop end, end; HW_ID; XCC_ID (tools/conv_timing.py)
 #endif
@@ -358,7 +371,7 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
     const float wcnt = INTERIOR ? (float)(MT * NT * 16 * 64) : wave_sum(cnt);
     if (lane == 0 && wcnt > 0.f) {
       const double P = (double)pivot, n = (double)wcnt, a = (double)s1;
-      long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * 4;
+      long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * 4;   // (any spread will do)
       ln_atomic_add(dst, n * P + a);
       ln_atomic_add(dst + 2, (double)s2 + 2.0 * P * a + n * P * P);
     }
@@ -374,6 +387,128 @@ __device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM 
   else emit_tile_impl<BM, BN, MODE, false>(p, acc, tile_m, tile_n, cls, b, tid);
 }
 
+
+// ---- apply-ahead: LayerNorm + ReLU of the producer inside the consumer's launch ------------------------------
+// The LayerNorm of layer N needs all of layer N (global statistics), so it cannot be folded into N's epilogue, and the
+// k-loop of layer N+1 has no VALU slot for it; as a launch of its own it is an HBM-bound pass (read + write every
+// activation: 0.15 ms of a 2.7 ms frame) during which the matrix pipes idle, plus a kernel boundary per layer.
+// Here the first n_apply workgroups of layer N+1's launch do that pass -- row by row, in place, publishing a counter per
+// input row -- and every tile workgroup waits only for the input rows its halo touches: the HBM-bound pass overlaps
+// the MFMA-bound one.  The unit sequence is dealt out like the tiles (XCD x sweeps the x-th eighth of the rows, in
+// order), so the rows a tile workgroup needs first are normalised first, by workgroups of its own XCD.
+// Hand-off (cdna_hip_programming.md, write-through form): the apply workgroups read the raw values with sc1 loads (the
+// raw lines never enter an L1) and write the normalised ones with sc1 stores (write-through), drain vmcnt, barrier,
+// one relaxed agent-scope atomic per unit; a tile workgroup polls the counters of its rows with relaxed agent-scope
+// loads and only then issues its first DMA -- no line of the activation is fetched by anyone before it is final, so
+// no cache holds a stale copy.  Dead-lock freedom: the apply workgroups have the lowest block indices, never wait,
+// and are all resident before any tile workgroup can occupy their slots; the wait is bounded anyway (ap_err).
+__device__ __forceinline__ void apply_ahead(const ConvParams &p, char *smem, int tid) {
+  float *s_aff = reinterpret_cast<float *>(smem);                 // scale[C0] | shift[C0]
+  double *s_stat = reinterpret_cast<double *>(smem + 2 * 512 * 4 + 64);
+  const int C = p.C0;
+  const int upr = p.ap_units_per_row;
+  const long units_per_sample = (long)p.Hin * upr;
+  // batch is not a kernel parameter: the grid covers ntiles = tiles per sample * batch
+  const int batch = p.ntiles / (p.tiles_m * p.tiles_n * p.nclass);
+  const long total = units_per_sample * batch;
+  const long per = (total + 7) / 8;                                // units of one XCD's range
+  const int x = blockIdx.x & 7;
+  const __amdgpu_buffer_rsrc_t rs_aff = __builtin_amdgcn_make_buffer_rsrc((void *)p.ap_aff, 0, 0x7fffffff, 0x00020000);
+  (void)rs_aff;
+  int cur_b = -1;
+  for (long l = blockIdx.x >> 3; l < per; l += p.n_apply >> 3) {
+    const long u = (long)x * per + l;
+    if (u >= total) break;
+    const int b = (int)(u / units_per_sample);
+    const long ur = u - (long)b * units_per_sample;
+    const int row = (int)(ur / upr), part = (int)(ur - (long)row * upr);
+    if (b != cur_b) {   // (the sweep is in order: the sample changes at most a few times per workgroup)
+      __syncthreads();
+      ln_mean_inv(p.ap_sums + (size_t)b * LN_SHARDS * 4, p.ap_inv_n, s_stat, tid);
+      const double mu = s_stat[0], inv = s_stat[1];
+      for (int c = tid; c < C; c += 256) {
+        const double sc = inv * (double)p.ap_gamma[c];
+        const float fs = (float)sc, ft = (float)((double)p.ap_beta[c] - mu * sc);
+        s_aff[c] = fs;
+        s_aff[C + c] = ft;
+        if (row == 0 && part == 0) {   // exactly one workgroup per sample starts at its first unit
+          p.ap_aff[(size_t)b * 2 * C + c] = fs;
+          p.ap_aff[(size_t)b * 2 * C + C + c] = ft;
+        }
+      }
+      __syncthreads();
+      cur_b = b;
+    }
+    const size_t row_elems = (size_t)p.ap_row_vec * 4;
+    const size_t base = ((size_t)b * p.Hin + row) * row_elems;    // element offset of the row
+    const int v0 = part * p.ap_unit_vec;
+    const int v1 = min(v0 + p.ap_unit_vec, p.ap_row_vec);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.ap_x + base), 0, (int)(row_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = p.ap_yb ? __builtin_amdgcn_make_buffer_rsrc((void *)(p.ap_yb + base), 0, (int)(row_elems * 2), 0x00020000) : rs;
+    auto bf16_bits = [](float f) __attribute__((always_inline)) -> unsigned {
+      const unsigned uu = __builtin_bit_cast(unsigned, f);
+      return (uu + 0x7fffu + ((uu >> 16) & 1u)) >> 16;
+    };
+    for (int v = v0 + tid; v < v1; v += 4 * 256) {
+      v4f xv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)   // out-of-range offsets read zeros and are not stored
+        xv[k] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((v + 256 * k) * 16), 0, 16));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int vv = v + 256 * k;
+        if (vv >= v1) break;
+        const int c = (vv * 4) % C;                               // C % 4 == 0: a float4 never straddles channels' wrap
+        const v4f s4 = *reinterpret_cast<const v4f *>(s_aff + c), t4 = *reinterpret_cast<const v4f *>(s_aff + C + c);
+        v4f y;
+        y.x = fmaxf(xv[k].x * s4.x + t4.x, 0.f); y.y = fmaxf(xv[k].y * s4.y + t4.y, 0.f);
+        y.z = fmaxf(xv[k].z * s4.z + t4.z, 0.f); y.w = fmaxf(xv[k].w * s4.w + t4.w, 0.f);
+        if (p.ap_yb) {
+          typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+          const v2u_t o = {bf16_bits(y.x) | (bf16_bits(y.y) << 16), bf16_bits(y.z) | (bf16_bits(y.w) << 16)};
+          __builtin_amdgcn_raw_buffer_store_b64(o, rd, (unsigned)(vv * 8), 0, 16);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, y), rs, (unsigned)(vv * 16), 0, 16);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have left
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(p.ap_flags + ((size_t)b * p.Hin + row) * AP_FLAG_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// A tile workgroup's side, in two steps so that the round trip of the counter loads hides behind the prologue:
+// rows_probe (right after the tile decode) -- lane l loads the counter of input row r0 + l once;
+// rows_wait (before the first DMA) -- all done: nothing more; else ONE lane polls the missing rows, last row first
+// (the sweep is in row order), one counter per 64-byte line: thousands of lanes polling a few shared lines starve the
+// apply workgroups' own counter updates (measured: +30 % on every layer).
+__device__ __forceinline__ int rows_probe(const ConvParams &p, int b, int r0, int r1, int tid) {
+  const int r = r0 + tid;
+  if (r > r1) return 0x7fffffff;
+  return __hip_atomic_load(p.ap_flags + ((size_t)b * p.Hin + r) * AP_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void rows_wait(const ConvParams &p, int b, int r0, int r1, int probed, int tid, int *s_flag) {
+  const bool ready = probed >= p.ap_units_per_row;
+  if (tid < 64) {   // rows of one tile fit one wave's lanes (host-checked: <= 64 input rows per tile)
+    const bool all = __builtin_amdgcn_ballot_w64(!ready) == 0;
+    if (tid == 0) *s_flag = all ? 1 : 0;
+  }
+  __syncthreads();
+  if (*s_flag) return;
+  if (tid == 0) {
+    int spins = 0;
+    for (int r = r1; r >= r0; --r) {
+      const int *f = p.ap_flags + ((size_t)b * p.Hin + r) * AP_FLAG_STRIDE;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.ap_units_per_row) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1 << 20)) { *p.ap_err = 1; r = r0; break; }   // ~1 s: something is badly wrong; do not hang the GPU
+      }
+    }
+  }
+  __syncthreads();
+}
 
 // amdgpu_waves_per_eu: with a dynamic LDS size hipcc cannot see that five 32 KB workgroups share a CU
 // and spends registers freely (116 for the 64x64 tile => four waves per SIMD); five need <= 96.
@@ -407,10 +542,14 @@ conv_igemm_kernel(const ConvParams p) {
   // XCD-aware order for the whole tiles: workgroup b runs on XCD b % 8 (observed, speed only) and
   // each XCD has a private L2; consecutive tiles share halo rows and weights, so every XCD gets a
   // CONTIGUOUS range of tiles instead of every eighth one (bijective remap).
+  if (p.n_apply > 0 && (int)blockIdx.x < p.n_apply) {   // apply-ahead workgroup (see apply_ahead)
+    apply_ahead(p, smem, tid);
+    return;
+  }
   const int S = p.ksteps;
   int t, k0 = 0, k1 = S, ks = 0, slot = 0;   // slot: index of this K-range's partial accumulator
   {
-    const int bid = blockIdx.x;
+    const int bid = (int)blockIdx.x - p.n_apply;   // (n_apply is a multiple of 8: the XCD of a tile workgroup is still bid % 8)
     if (bid < p.nb_main && p.split0 == 1) {
       const int q = p.n_main >> 3, r = p.n_main & 7, xcd = bid & 7, local = bid >> 3;
       t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
@@ -445,6 +584,19 @@ conv_igemm_kernel(const ConvParams p) {
   const int mtot = p.Mh * p.Mw;
   const int wrap_w = p.wrap ? p.Win : 0;
   const bool wrapt = MODE == MODE_CONVT && p.wrap != 0;
+  // apply-ahead: source 0 is being normalised by the first workgroups of this launch; the tile needs input rows
+  // [ap_r0, ap_r1] of it (source 1, the skip, was normalised by an earlier launch).  Probe their counters now.
+  int ap_r0 = 0, ap_r1 = -1, ap_probe = 0;
+  if (p.n_apply > 0) {
+    const int m_lo = tile_m * BM, m_hi = min(m_lo + BM, mtot) - 1;
+    const int mh_lo = (int)udiv_magic((unsigned)m_lo, (unsigned)p.Mw, p.mg_mw), mh_hi = (int)udiv_magic((unsigned)m_hi, (unsigned)p.Mw, p.mg_mw);
+    if (MODE == MODE_CONV) { ap_r0 = mh_lo * p.stride - p.pad_t; ap_r1 = mh_hi * p.stride - p.pad_t + 2 * p.rate; }
+    else if (MODE == MODE_CONVT) { ap_r0 = mh_lo - 1; ap_r1 = wrapt ? mh_hi : mh_hi + 1; }
+    else { ap_r0 = mh_lo; ap_r1 = mh_hi; }
+    ap_r0 = max(ap_r0, 0);
+    ap_r1 = min(ap_r1, p.Hin - 1);
+    ap_probe = rows_probe(p, b, ap_r0, ap_r1, tid);
+  }
 
   // ---- DMA lane mapping: instruction i of this wave fills LDS rows [wave*BM/4 + 8i, +8);
   // lane -> (row = lane>>3, 16-byte slot = lane&7); the slot holds data chunk slot ^ ((row>>1)&7).
@@ -601,6 +753,8 @@ _Pragma("unroll")                                                               
       }                                                                                                                          \
     }                                                                                                                            \
   }
+
+  if (p.n_apply > 0) rows_wait(p, b, ap_r0, ap_r1, ap_probe, tid, reinterpret_cast<int *>(smem));   // (LDS is still unused)
 
   // fp32 head: the affine of its source's LayerNorm (scale | shift per channel) from the source's sums -> LDS; the
   // k-step issue applies it (+ ReLU) while loading, so the source is read RAW and never normalised in memory
@@ -922,6 +1076,7 @@ struct Layer {
   size_t raw_off, aff_off;                // bytes inside the workspace
   size_t act_off;                         // bf16 path: normalised bf16 activation (the next layer's operand)
   size_t sums_off;                        // LayerNorm sums [B][LN_SHARDS][4] int64
+  size_t flags_off;                       // apply-ahead row counters of THIS layer's output [B][out_h] ints
 };
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -931,6 +1086,7 @@ struct Net {
   size_t param_floats = 0, packed_floats = 0, ws_bytes = 0, partial_off = 0, partial_bytes = 0;
   size_t zero_off = 0, zero_bytes = 0;   // [tickets of the in-launch fix-up | LayerNorm sums]: one memset per forward
   size_t cnt_off = 0;   // arrival tickets: [layer][2 * num_cus] ints
+  size_t err_off = 0;   // one int: a tile workgroup gave up waiting for apply-ahead rows (stays 0)
 };
 
 int build_net(const msi_net_desc *d, int num_cus, Net &net) {
@@ -1063,6 +1219,12 @@ int build_net(const msi_net_desc *d, int num_cus, Net &net) {
     net.layers[i].sums_off = zoff;
     if (net.layers[i].kind != MODE_HEAD) zoff += (size_t)d->batch * LN_SHARDS * 4 * sizeof(long long);
   }
+  for (int i = 0; i < MSI_NET_NUM_LAYERS; ++i) {
+    net.layers[i].flags_off = zoff;
+    if (net.layers[i].kind != MODE_HEAD) zoff += (size_t)d->batch * net.layers[i].out_h * AP_FLAG_STRIDE * sizeof(int);
+  }
+  net.err_off = zoff;
+  zoff += 64;
   net.zero_bytes = zoff - net.zero_off;
   net.ws_bytes = round_up(zoff, 256);
   return MSI_OK;
@@ -1078,7 +1240,7 @@ int device_cu_count() {
   return prop.multiProcessorCount;
 }
 
-enum { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x64 = 2 };
+enum { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x128 = 3 };
 
 // One layer's launch, everything but the pointers resolved at plan time.
 struct LayerLaunch {
@@ -1087,7 +1249,7 @@ struct LayerLaunch {
   int nblocks, nfix;
   int inlaunch;     // the split tiles are summed inside the conv launch (tickets) rather than by conv_fixup_kernel
   int fuse_ln;      // head: applies its source's LayerNorm while loading (the source is not normalised in memory)
-  int skip_apply;   // this layer's output is consumed raw by the head: no ln_apply launch
+  int skip_apply;   // this layer's output is consumed raw by the head, or normalised by its consumer's launch: no ln_apply launch
   unsigned ln_blocks;
 };
 
@@ -1199,7 +1361,27 @@ int plan_layers(msi_net_plan *pl) {
     } else if (bf16 && L.cout % 64 == 0 && bigmode != 0 && ((tiles_big >= 4L * pl->num_cus && L.cin <= 128) || bigmode == 2)) {
       Q.tile = TILE_128x64; BM = 128; BN = 64;   // Cout = 64, short K (conv8_2: 495 vs 599 us; conv1_1 / conv8_1 are faster at 64x64)
     }
+    // fp32 tile experiments (per-layer mask in MSI_NET_OPT_F32_TILE_MASK): 128x64 (MT = 2) or 64x128 (NT = 2) instead of
+    // 64x64 on the layers whose bit is set -- more MFMA work per prologue / epilogue and per DMA byte
+    if (!bf16 && ((pl->opt[MSI_NET_OPT_F32_TILE_MASK] >> li) & 1) && L.kind != MODE_HEAD) {
+      if (pl->opt[MSI_NET_OPT_F32_TILE] == 1) { Q.tile = TILE_128x64; BM = 128; BN = 64; }
+      else if (pl->opt[MSI_NET_OPT_F32_TILE] == 2 && L.cout % 128 == 0) { Q.tile = TILE_64x128; BM = 64; BN = 128; }
+    }
     plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], &Q.nblocks, &Q.nfix);
+    // apply-ahead (see apply_ahead): this launch also normalises its source 0
+    if (pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.src0 >= 0 && L.kind != MODE_HEAD && L.c0 <= 512 && L.c0 % 4 == 0 &&
+        ((long)L.in_w * L.c0) % 4 == 0) {
+      constexpr int UNIT_VEC = 2048;   // float4 per unit: 32 KB of fp32
+      p.ap_row_vec = L.in_w * L.c0 / 4;
+      p.ap_unit_vec = UNIT_VEC;
+      p.ap_units_per_row = (p.ap_row_vec + UNIT_VEC - 1) / UNIT_VEC;
+      p.ap_inv_n = 1.0 / net.layers[L.src0].ln_count;
+      const long units = (long)desc->batch * L.in_h * p.ap_units_per_row;
+      long n = 2L * pl->num_cus;                      // two apply workgroups per CU keep ~8 MB of loads in flight
+      if (n > units) n = units;
+      p.n_apply = (int)((n + 7) / 8 * 8);
+      pl->launch[L.src0].skip_apply = 1;              // (the producer precedes its consumer in graph order)
+    }
     Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= 2 * pl->num_cus;
     if ((size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * BM * BN * sizeof(float) > net.partial_bytes)
       return msi::fail(MSI_E_WORKSPACE, "conv %s: %d partial accumulators exceed the workspace", L.name, Q.nblocks);
@@ -1225,7 +1407,7 @@ int launch_conv_mode(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
       done = true;
     }
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, BF16>), dim3(Q.nblocks), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, BF16>), dim3(Q.nblocks + p.n_apply), dim3(256), lds, stream, p);
   int rc = msi::check_launch("conv_igemm");
   if (rc || Q.nfix == 0 || p.tile_cnt != nullptr) return rc;
   if constexpr (BM * BN == 64 * 64) {   // (big tiles are never split)
@@ -1238,7 +1420,9 @@ int launch_conv_mode(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
 
 template <int BM, int BN>
 int launch_conv(const LayerLaunch &Q, const ConvParams &p, int bf16, hipStream_t stream) {
-  if (bf16) {
+  if constexpr (BM == 64 && BN == 128) {
+    if (bf16) return msi::fail(MSI_E_UNSUPPORTED, "conv: 64x128 is an fp32 tile");
+  } else if (bf16) {
     switch (p.mode) {
       case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 1>(Q, p, stream);
       case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 1>(Q, p, stream);
@@ -1251,8 +1435,14 @@ int launch_conv(const LayerLaunch &Q, const ConvParams &p, int bf16, hipStream_t
       case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 0>(Q, p, stream);
       default: return launch_conv_mode<BM, BN, MODE_HEAD, 0>(Q, p, stream);
     }
+  } else if constexpr (BM * BN == 128 * 64) {
+    switch (p.mode) {
+      case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 0>(Q, p, stream);
+      case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 0>(Q, p, stream);
+      default: return msi::fail(MSI_E_UNSUPPORTED, "conv: fp32 head uses the 64x64 tile");
+    }
   } else {
-    return msi::fail(MSI_E_UNSUPPORTED, "conv: the fp32 path is built for the 64x64 tile");
+    return msi::fail(MSI_E_UNSUPPORTED, "conv: the fp32 path is built for the 64x64, 128x64 and 64x128 tiles");
   }
 }
 
@@ -1431,6 +1621,9 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_BIGTILE] = 1;
   pl->opt[MSI_NET_OPT_HEAD_FUSE_LN] = 1;
   pl->opt[MSI_NET_OPT_NUM_CUS] = pl->num_cus;
+  pl->opt[MSI_NET_OPT_APPLY_AHEAD] = 0;   // measured r02_h: correct and bit-identical, but 2.69 vs 2.56 ms per network
+  pl->opt[MSI_NET_OPT_F32_TILE] = 0;
+  pl->opt[MSI_NET_OPT_F32_TILE_MASK] = 0;
   int rc = plan_layers(pl);
   if (rc) { delete pl; return rc; }
   *out = pl;
@@ -1502,6 +1695,17 @@ int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const vo
     p.sums = L.kind == MODE_HEAD ? nullptr : reinterpret_cast<long long *>(ws + L.sums_off);
     p.partial = reinterpret_cast<float *>(ws + net.partial_off);
     p.tile_cnt = Q.inlaunch ? cnt + (size_t)li * 2 * plan->num_cus : nullptr;
+    if (p.n_apply > 0) {
+      const Layer &S = net.layers[L.src0];
+      p.ap_x = reinterpret_cast<float *>(ws + S.raw_off);
+      p.ap_yb = bf16 ? reinterpret_cast<unsigned short *>(ws + S.act_off) : nullptr;
+      p.ap_sums = reinterpret_cast<const long long *>(ws + S.sums_off);
+      p.ap_gamma = packed + S.gamma_off;
+      p.ap_beta = packed + S.beta_off;
+      p.ap_aff = reinterpret_cast<float *>(ws + S.aff_off);
+      p.ap_flags = reinterpret_cast<int *>(ws + S.flags_off);
+      p.ap_err = reinterpret_cast<int *>(ws + net.err_off);
+    }
 #ifdef MSI_CONV_TIMING
     p.dbg = (li == g_timing_layer) ? g_timing_buf : nullptr;
 #endif
@@ -1509,6 +1713,7 @@ int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const vo
     switch (Q.tile) {
       case TILE_128x128: rc = launch_conv<128, 128>(Q, p, bf16, stream); break;
       case TILE_128x64: rc = launch_conv<128, 64>(Q, p, bf16, stream); break;
+      case TILE_64x128: rc = bf16 ? msi::fail(MSI_E_UNSUPPORTED, "conv: 64x128 is an fp32 tile") : launch_conv<64, 128>(Q, p, 0, stream); break;
       default: rc = launch_conv<64, 64>(Q, p, bf16, stream); break;
     }
     if (rc) return rc;

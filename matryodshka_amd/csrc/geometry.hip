@@ -75,6 +75,41 @@ __device__ __forceinline__ Taps make_taps(float x, float y, int width, int heigh
   return t;
 }
 
+// make_taps for coordinates that lie in [-1, n] by construction -- the sweep and the render derive them from angles
+// (theta in [-pi, pi], phi clamped / in [-pi/2, pi/2]  =>  u in [-0.5, W-0.5], v in [-0.5, H-0.5]) -- so the floor-mod
+// is one unsigned min per corner, nothing branches, and the corner positions are 24-bit pixel offsets (row * W + col,
+// full-rate v_mul_u32_u24; the host checks H * W < 2^24) for 32-bit buffer addressing: the generic form above spent
+// a quarter of these VALU-bound kernels in 64-bit address multiplies and exec-masked division fall-backs.
+// Weights as above (unwrapped corners; (float)(int)floor(x) == floor(x) in this range); garbage inputs (NaN -> 0, inf)
+// are clamped into the image instead of taking the reference's undefined int cast.
+struct TapsR {
+  unsigned oa, ob, oc, od;   // pixel offsets of (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+  float wa, wb, wc, wd;
+};
+
+__device__ __forceinline__ TapsR make_taps_ranged(float x, float y, int width, int height) {
+  TapsR t;
+  const float fx0 = floorf(x), fy0 = floorf(y);
+  const float dx0 = x - fx0, dy0 = y - fy0;
+  const float dx1 = (fx0 + 1.0f) - x, dy1 = (fy0 + 1.0f) - y;
+  t.wa = dy1 * dx1;
+  t.wb = dy1 * dx0;
+  t.wc = dy0 * dx1;
+  t.wd = dy0 * dx0;
+  const int x0 = max(-1, min((int)fx0, width - 1)), y0 = max(-1, min((int)fy0, height - 1));
+  const unsigned ax = (unsigned)(x0 + width), ay = (unsigned)(y0 + height);
+  const unsigned x0w = min(ax, ax - (unsigned)width), y0w = min(ay, ay - (unsigned)height);   // -1 -> n-1
+  const unsigned bx = (unsigned)(x0 + 1), by = (unsigned)(y0 + 1);
+  const unsigned x1w = min(bx, bx - (unsigned)width), y1w = min(by, by - (unsigned)height);   // n -> 0
+  const unsigned r0 = __umul24(y0w, (unsigned)width), r1 = __umul24(y1w, (unsigned)width);
+  t.oa = r0 + x0w; t.ob = r0 + x1w; t.oc = r1 + x0w; t.od = r1 + x1w;
+  return t;
+}
+
+__device__ __forceinline__ float blend4(const TapsR &t, float a, float b, float c, float d) {
+  return ((t.wa * a + t.wb * b) + t.wc * c) + t.wd * d;
+}
+
 __device__ __forceinline__ float blend4(const Taps &t, float a, float b, float c, float d) {
   // tf.add_n([area_a*A, area_b*B, area_c*C, area_d*D]) summed in list order.
   return ((t.wa * a + t.wb * b) + t.wc * c) + t.wd * d;
@@ -277,16 +312,18 @@ __device__ __forceinline__ void ods_tail(const OdsQuad &q, float order, const Pi
   }
 }
 
-// resample (sampling.py:135-197) of one RGB texel
-__device__ __forceinline__ void gather3(const float *__restrict__ img, int width, int height, float u, float v, float *out) {
-  const Taps t = make_taps(u, v, width, height);
-  const float *pa = img + ((size_t)t.y0 * width + t.x0) * 3;
-  const float *pb = img + ((size_t)t.y0 * width + t.x1) * 3;
-  const float *pc = img + ((size_t)t.y1 * width + t.x0) * 3;
-  const float *pd = img + ((size_t)t.y1 * width + t.x1) * 3;
-  out[0] = blend4(t, pa[0], pb[0], pc[0], pd[0]);
-  out[1] = blend4(t, pa[1], pb[1], pc[1], pd[1]);
-  out[2] = blend4(t, pa[2], pb[2], pc[2], pd[2]);
+// resample (sampling.py:135-197) of one RGB texel; `img` = buffer descriptor of one sample's [H,W,3] image
+typedef unsigned u32x3_g __attribute__((ext_vector_type(3)));
+typedef float f32x3_g __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void gather3(__amdgpu_buffer_rsrc_t img, int width, int height, float u, float v, float *out) {
+  const TapsR t = make_taps_ranged(u, v, width, height);
+  const f32x3_g a = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, __umul24(t.oa, 12u), 0, 0));
+  const f32x3_g b = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, __umul24(t.ob, 12u), 0, 0));
+  const f32x3_g c = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, __umul24(t.oc, 12u), 0, 0));
+  const f32x3_g d = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, __umul24(t.od, 12u), 0, 0));
+  out[0] = blend4(t, a.x, b.x, c.x, d.x);
+  out[1] = blend4(t, a.y, b.y, c.y, d.y);
+  out[2] = blend4(t, a.z, b.z, c.z, d.z);
 }
 
 // One work item = (pixel, NS consecutive depths); depth is the fastest index so a wavefront's 64
@@ -303,13 +340,15 @@ __global__ void __launch_bounds__(256)
 ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ image1, const float *__restrict__ pose0,
                  const float *__restrict__ pose1, const float *__restrict__ intrinsics, const float *__restrict__ depths,
                  const float *__restrict__ trig, int batch, int height, int width, int nd,
-                 float order, OutT *__restrict__ psv, int channels, int coff, PixConsts K) {
+                 float order, OutT *__restrict__ psv, int channels, int coff, PixConsts K, unsigned ng_magic, int coalesce) {
   // grid = (ceil(W*(D/NS) / 256), H, B): 32-bit index math only (64-bit div/mod are emulated in ~100
   // VALU instructions each and used to dominate this kernel)
   const int ng = nd / NS;                       // depth groups per pixel (nd % NS == 0, checked on the host)
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= width * ng) return;
-  const int j = idx / ng, d0 = (idx - j * ng) * NS;
+  unsigned jq = __umulhi((unsigned)idx, ng_magic);   // idx / ng by multiply-high (+ one correction), see cnn.hip udiv_magic
+  if ((unsigned)idx - jq * (unsigned)ng >= (unsigned)ng) ++jq;
+  const int j = (int)jq, d0 = (idx - j * ng) * NS;
   const int i = blockIdx.y, b = blockIdx.z;
   const long p = ((long)b * height + i) * width + j;
 
@@ -318,8 +357,9 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
   const float *P0 = pose0 + (size_t)b * 16;
   const float *P1 = NSRC == 2 ? pose1 + (size_t)b * 16 : P0;
   const float r = intrinsics[(size_t)b * 9];
-  const float *img0 = image0 + (size_t)b * height * width * 3;
-  const float *img1 = NSRC == 2 ? image1 + (size_t)b * height * width * 3 : img0;
+  const int img_bytes = height * width * 12;
+  const __amdgpu_buffer_rsrc_t img0 = __builtin_amdgcn_make_buffer_rsrc((void *)(image0 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t img1 = NSRC == 2 ? __builtin_amdgcn_make_buffer_rsrc((void *)(image1 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000) : img0;
   const float csct = cs * ct, ssct = ss * ct;
   bool same = NSRC == 2;                         // wave-uniform (scalar loads)
   if (NSRC == 2) {
@@ -343,6 +383,32 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
       }
       gather3(img1, width, height, u, v, out[NSRC - 1][q]);
     }
+  }
+  if (NSRC == 2 && coalesce) {
+    // Whole-pixel stores: with both sources in one thread a wavefront owns 64 / ng complete pixels = 384 NS
+    // CONTIGUOUS elements of the NHWC volume.  They are exchanged through a wave-private LDS strip and leave as
+    // 16-byte-per-lane stores (3 fully coalesced instructions per wave instead of 12 strided dword stores per lane,
+    // which kept the store path -- not the VALU -- the limiter of this kernel).  No block barrier: LDS operations of
+    // one wave are performed in order.
+    constexpr int WAVE_ELEMS = 384 * NS;
+    __shared__ __attribute__((aligned(16))) OutT s_out[4][WAVE_ELEMS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane / ng, dg = lane - pl * ng;
+    OutT *w = s_out[wave];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) store_elem(w, (size_t)(pl * 6 * nd + sidx * 3 * nd + (dg * NS + q) * 3 + c), out[sidx][q][c]);
+    __builtin_amdgcn_wave_barrier();
+    const size_t first = (size_t)(p - pl) * channels;      // element offset of the wave's first pixel (lane 0's pixel)
+    const uint4 *src = reinterpret_cast<const uint4 *>(w);
+    uint4 *dst = reinterpret_cast<uint4 *>(psv + first);
+    constexpr int NV = WAVE_ELEMS * (int)sizeof(OutT) / 16;
+#pragma unroll
+    for (int k = lane; k < NV; k += 64) dst[k] = src[k];
+    return;
   }
 #pragma unroll
   for (int sidx = 0; sidx < NSRC; ++sidx) {
@@ -506,6 +572,7 @@ assemble_kernel(const void *__restrict__ psv_, const float *__restrict__ pred,
 // remain; the running composite lives in registers and every texel of the
 // D x H x W x 4 stack is fetched from HBM once.
 enum RenderMode { RENDER_RGB = 1, RENDER_DEPTH = 2, RENDER_LAYERS = 4 };
+constexpr int RENDER_SEGS = 4;   // layer segments per pixel (threads in y)
 // ray model of the TARGET view: equirect (spherical.intersect_sphere, spherical.py:268-326),
 // ODS eye (intersect_ods, :328-365) or the hard-coded perspective crop (intersect_perspective, :367-401)
 enum RayModel { RAY_EQUIRECT = 0, RAY_ODS = 1, RAY_PERSPECTIVE = 2 };
@@ -523,10 +590,19 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
               const float *__restrict__ depths, const float *__restrict__ trig, int batch, int height,
               int width, int nd, float *__restrict__ out_rgb, float *__restrict__ out_depth,
               float4 *__restrict__ out_layers, PixConsts K, RayParams R) {
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  const int i = blockIdx.y * 4 + threadIdx.y;
+  // block = 64 pixels of one target row x RENDER_SEGS layer segments: a pixel's D layers are split over RENDER_SEGS
+  // threads (same lane, different waves), each compositing its contiguous range of layers from transparent black,
+  //   C <- rgb a + C (1-a),   T <- T (1-a),
+  // and the segments are combined back to front, out = C_3 + T_3 (C_2 + T_2 (C_1 + T_1 C_0)) (the over operator is
+  // associative; rounding differs from the strictly sequential form by ~1e-7).  One thread per pixel left the chip with
+  // 3 200 wavefronts for 8 192 wave slots and a 32-deep chain of dependent-latency gathers per thread.
+  const int j_raw = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y;
   const int b = blockIdx.z;
-  if (j >= R.out_w || i >= R.out_h) return;
+  const int seg = threadIdx.y;
+  const bool valid = j_raw < R.out_w;
+  const int j = valid ? j_raw : R.out_w - 1;      // (lanes past the row end compute a duplicate and store nothing: no early return before the barrier)
+  __shared__ float s_part[RENDER_SEGS][64][5];
 
   float rx, ry, rz, cx, cy, cz;
   if (RAY == RAY_PERSPECTIVE) {
@@ -571,12 +647,14 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
   const float fa = 4.0f * qa, ta = 2.0f * qa;
 
   const size_t hw = (size_t)height * width;             // source layer size
+  const int layer_bytes = (int)(hw * 16);                // (H * W < 2^24, checked on the host)
   const size_t ohw = (size_t)R.out_h * R.out_w;          // target size
   const size_t pix = (size_t)i * R.out_w + j;
-  float o0 = 0.f, o1 = 0.f, o2 = 0.f, od = 0.f;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, od = 0.f, tr = 1.f;
+  const int d_lo = (seg * nd) / RENDER_SEGS, d_hi = ((seg + 1) * nd) / RENDER_SEGS;
 
 #pragma unroll 4
-  for (int d = 0; d < nd; ++d) {
+  for (int d = d_lo; d < d_hi; ++d) {
     const float radius = depths[d];
     const float qc = cc - radius * radius;
     const float disc = qb2 - fa * qc;
@@ -599,12 +677,14 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
     const float v = (((phi + K.half_pi) - K.half_pi_over_h) / K.v_den) * K.hm1;
 #endif
 
-    const Taps tp4 = make_taps(u, v, width, height);
-    const float4 *L = rgba + ((size_t)b * nd + d) * hw;
-    const float4 A = L[(size_t)tp4.y0 * width + tp4.x0];
-    const float4 Bv = L[(size_t)tp4.y0 * width + tp4.x1];
-    const float4 C = L[(size_t)tp4.y1 * width + tp4.x0];
-    const float4 Dv = L[(size_t)tp4.y1 * width + tp4.x1];
+    const TapsR tp4 = make_taps_ranged(u, v, width, height);
+    // one descriptor per layer (scalar work): 32-bit texel offsets also for stacks beyond 2 GiB
+    const __amdgpu_buffer_rsrc_t L = __builtin_amdgcn_make_buffer_rsrc((void *)(rgba + ((size_t)b * nd + d) * hw), 0, layer_bytes, 0x00020000);
+    typedef unsigned u32x4_g __attribute__((ext_vector_type(4)));
+    const float4 A = __builtin_bit_cast(float4, (u32x4_g)__builtin_amdgcn_raw_buffer_load_b128(L, tp4.oa << 4, 0, 0));
+    const float4 Bv = __builtin_bit_cast(float4, (u32x4_g)__builtin_amdgcn_raw_buffer_load_b128(L, tp4.ob << 4, 0, 0));
+    const float4 C = __builtin_bit_cast(float4, (u32x4_g)__builtin_amdgcn_raw_buffer_load_b128(L, tp4.oc << 4, 0, 0));
+    const float4 Dv = __builtin_bit_cast(float4, (u32x4_g)__builtin_amdgcn_raw_buffer_load_b128(L, tp4.od << 4, 0, 0));
     const float al = blend4(tp4, A.w, Bv.w, C.w, Dv.w);
     if (MODE & RENDER_LAYERS) {
       float4 o;
@@ -612,7 +692,7 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
       o.y = blend4(tp4, A.y, Bv.y, C.y, Dv.y);
       o.z = blend4(tp4, A.z, Bv.z, C.z, Dv.z);
       o.w = al;
-      out_layers[((size_t)d * batch + b) * ohw + pix] = o;
+      if (valid) out_layers[((size_t)d * batch + b) * ohw + pix] = o;
     }
     if (MODE & RENDER_RGB) {
       const float r = blend4(tp4, A.x, Bv.x, C.x, Dv.x);
@@ -635,6 +715,18 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
         od = frac * al + od * (1.0f - al);
       }
     }
+    tr = tr * (1.0f - al);
+  }
+  if (MODE & RENDER_LAYERS) return;            // (nothing to combine)
+  s_part[seg][threadIdx.x][0] = o0; s_part[seg][threadIdx.x][1] = o1; s_part[seg][threadIdx.x][2] = o2;
+  s_part[seg][threadIdx.x][3] = od; s_part[seg][threadIdx.x][4] = tr;
+  __syncthreads();
+  if (seg != 0 || !valid) return;
+#pragma unroll
+  for (int sg = 1; sg < RENDER_SEGS; ++sg) {    // back to front: segment 0 holds the farthest layers
+    const float *q = s_part[sg][threadIdx.x];
+    o0 = q[0] + q[4] * o0; o1 = q[1] + q[4] * o1; o2 = q[2] + q[4] * o2;
+    od = q[3] + q[4] * od;
   }
   if (MODE & RENDER_RGB) {
     float *o = out_rgb + ((size_t)b * ohw + pix) * 3;
@@ -946,8 +1038,8 @@ static int sweep_common(const float *image, const float *image1, const float *po
               "ods_sphere_sweep: channel window [%d,%d) outside %d channels", channel_offset,
               channel_offset + (pair ? 6 : 3) * num_depths, psv_channels);
   if (batch == 0) return MSI_OK;
-  MSI_REQUIRE((long)width * num_depths < 2147483647L && height <= 65535 && batch <= 65535,
-              "ods_sphere_sweep: problem too large");
+  MSI_REQUIRE((long)width * num_depths < 2147483647L && height <= 65535 && batch <= 65535 && (long)height * width < (1L << 24),
+              "ods_sphere_sweep: problem too large (24-bit pixel offsets: H * W < 2^24)");
   // NS depths per thread (bit-identical results for every NS; -DMSI_SWEEP_NS_DEFAULT=1/2/4 at build time)
   int ns = MSI_SWEEP_NS_DEFAULT;
   while (num_depths % ns != 0) ns >>= 1;
@@ -955,7 +1047,9 @@ static int sweep_common(const float *image, const float *image1, const float *po
 #define MSI_LAUNCH_SWEEP(T, NS_, NSRC_)                                                                          \
   hipLaunchKernelGGL((ods_sweep_kernel<T, NS_, NSRC_>), grid, dim3(256), 0, msi::as_stream(stream), image, image1, \
                      pose, pose1, intrinsics, depths, trig, batch, height, width, num_depths, (float)order,      \
-                     static_cast<T *>(psv), psv_channels, channel_offset, make_consts(height, width))
+                     static_cast<T *>(psv), psv_channels, channel_offset, make_consts(height, width),           \
+                     (num_depths / NS_) == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)(num_depths / NS_)),  \
+                     (pair && 64 % (num_depths / NS_) == 0 && ((long)width * (num_depths / NS_)) % 64 == 0) ? 1 : 0)
 #define MSI_LAUNCH_SWEEP_N(T, NSRC_)                                                                     \
   { if (ns == 4) MSI_LAUNCH_SWEEP(T, 4, NSRC_); else if (ns == 2) MSI_LAUNCH_SWEEP(T, 2, NSRC_); else MSI_LAUNCH_SWEEP(T, 1, NSRC_); }
 #define MSI_LAUNCH_SWEEP_T(T) { if (pair) MSI_LAUNCH_SWEEP_N(T, 2) else MSI_LAUNCH_SWEEP_N(T, 1) }
@@ -1077,8 +1171,10 @@ static int render_common(int mode, int ray, const float *rgba_native, const floa
   MSI_REQUIRE(rgba_native && pose && depths, "render: null pointer");
   MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_planes > 0 && R.out_h > 0 && R.out_w > 0,
               "render: bad dims");
+  MSI_REQUIRE((long)height * width < (1L << 24), "render: layers of more than 2^24 texels (24-bit texel offsets)");
   if (batch == 0) return MSI_OK;
-  const dim3 grid((R.out_w + 63) / 64, (R.out_h + 3) / 4, batch), block(64, 4);
+  MSI_REQUIRE(R.out_h <= 65535 && batch <= 65535, "render: target too tall / batch too large for the launch grid");
+  const dim3 grid((R.out_w + 63) / 64, R.out_h, batch), block(64, RENDER_SEGS);
   const PixConsts K = make_consts(height, width);
   const float4 *src = reinterpret_cast<const float4 *>(rgba_native);
   float4 *lay = reinterpret_cast<float4 *>(out_layers);

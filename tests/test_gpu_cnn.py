@@ -148,3 +148,37 @@ def test_full_size_split_k_handoff_is_deterministic(env, dtype, batch):
     nosplit.net_options[N.NET_OPT_TAILSPLIT] = 0
     tol = 2e-5 if dtype == "f32" else 4e-2      # unsplit tiles: another fp32 summation order only
     assert float((nosplit.run_net(x, 64, 64) - ref).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("coord,b,h,w,cin,nout,ngf", [(True, 1, 160, 320, 96, 32, 64), (False, 2, 32, 64, 24, 8, 16),
+                                                     (True, 3, 16, 40, 24, 8, 16)])
+def test_apply_ahead_equals_separate_layernorm_launches(env, dtype, coord, b, h, w, cin, nout, ngf):
+    """Plan option APPLY_AHEAD (default off: measured slower): a layer's LayerNorm + ReLU applied by the first workgroups of its consumer's
+    launch, behind per-row counters, against one ln_apply launch per layer -- the same arithmetic on the same sums, so the
+    prediction and every activation are bit-identical; the wait never times out (error word stays 0)."""
+    torch, MSI, nets, N, onets = env
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=21, randomize_affine=True)
+    x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
+    if dtype == "bf16":
+        x = x.bfloat16()
+    outs = []
+    for ahead in (1, 0):
+        m = MSI(weights=weights, coord_net=coord, dtype=dtype)
+        m.net_options[N.NET_OPT_APPLY_AHEAD] = ahead
+        pred = m.run_net(x, nout, ngf)
+        for _ in range(5):
+            assert torch.equal(m.run_net(x, nout, ngf), pred)
+        torch.cuda.synchronize()
+        desc, _, ws = m._net(b, h, w, cin, nout, ngf)
+        acts = []
+        for info in nets.layer_infos(desc):
+            if info.kind != nets.KIND_HEAD:
+                n = b * info.out_h * info.out_w * info.cout
+                acts.append(ws[info.raw_offset:info.raw_offset + 4 * n].clone())
+        outs.append((pred.clone(), acts))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if dtype == "f32":      # (the bf16 path keeps the raw fp32 outputs and writes bf16 copies: compare the raw ones)
+        pass
+    for a, c in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, c)

@@ -21,12 +21,16 @@ ap.add_argument("--width", type=int, default=640)
 ap.add_argument("--planes", type=int, default=32)
 ap.add_argument("--no-coord-net", action="store_true")
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+ap.add_argument("--opt", action="append", default=[], help="plan option KEY=VALUE (msi_net_plan_set_option), repeatable")
 a = ap.parse_args()
 
 from matryodshka_amd import MSI, nets
 coord = not a.no_coord_net
 cin, nout = 6 * a.planes, 2 * a.planes
 m = MSI(weights=nets.init_weights(cin, nout, 64, coord), coord_net=coord, dtype=a.dtype)
+for kv in a.opt:
+    k, v = kv.split("=")
+    m.net_options[int(k)] = int(v, 0)
 x = torch.rand((a.batch, a.height, a.width, cin), device="cuda") * 2 - 1
 if a.dtype == "bf16":
     x = x.bfloat16()
