@@ -212,7 +212,8 @@ def main():
         pp = dict(ref=g(ref), src=g(src), K=g(K), eye=g(eye), src_pose=g(spose), interp_inv=g(interp_inv), rel=g(rel),
                   Kinv=g(np.linalg.inv(K.astype(np.float64)).astype(np.float32)))
 
-    stage_names = ["preprocess", "sweep", "cnn", "assemble", "render", "deprocess"]
+    stage_names = ["preprocess", "sweep", "cnn", "assemble", "render", "deprocess"]   # cnn = the convolutions (+ ln_apply);
+    # assemble = head + layer assembly (one fused kernel on the fp32 blend_psv path, head launch + K3 otherwise)
 
     def frame(events=None, model=model, cnn_events=None):
         """One step of this rank: its B frames as one batch.  `events`: a HIP event at every stage boundary;
@@ -231,8 +232,7 @@ def main():
                 cnn_events.append(e)
         mark()
         if cfg["kind"] == "ods":
-            src = model.preprocess_image(src_u8)
-            ref = model.preprocess_image(ref_u8)
+            src, ref = model.preprocess_image_pair(src_u8, ref_u8)
             mark()
             net_input = model.format_network_input(ref, src, ref_pose, src_pose, planes, intr, ref_pose_inv=ref_pose_inv)
         else:
@@ -241,15 +241,20 @@ def main():
             mark()
             net_input = model.format_network_input(ref, src, pp["eye"], pp["src_pose"], planes, pp["K"], ref_pose_inv=pp["interp_inv"])
         mark(); mark_cnn()
-        pred = model.run_net(net_input, nout, NGF)
-        mark(); mark_cnn()
-        out = model.assemble_layers(net_input, pred, D)
+        # network + layer assembly: on the fp32 blend_psv path the head and the assembly are ONE fused HBM-bound kernel; the
+        # event between the 17 convolutions and that tail keeps the MFMA roofline of the conv kernel clean
+        mid = torch.cuda.Event(enable_timing=True)
+        mid.record()                                            # (creates the handle; re-recorded by the library)
+        out = model.infer_layers(net_input, D, NGF, event_after_convs=mid)
+        if events is not None:
+            events.append(mid)
+        if cnn_events is not None:
+            cnn_events.append(mid)
         mark()
         if cfg["kind"] == "ods":
             rgb, dep = model.msi_render_equirect_view_and_depth(out["rgba_layers"], tgt_pose_rt, tgt_pos, planes, intr)
             mark()
-            rgb8 = model.deprocess_image(rgb)
-            dep8 = model.deprocess_depth_image(dep)
+            rgb8, dep8 = model.deprocess_image_and_depth(rgb, dep)
         else:
             rgb = model.mpi_render_view(out["rgba_layers"], pp["rel"], planes, pp["K"], intrinsics_inv=pp["Kinv"])
             dep = None

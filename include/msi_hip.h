@@ -68,11 +68,17 @@ int msi_build_trig_tables_host(int32_t height, int32_t width, float *out_host);
  * MSI.preprocess_image (msi.py:1163-1171): uint8 -> x*(1/255), then x*2-1. */
 int msi_preprocess_u8_f32(const uint8_t *in, float *out, size_t n, msi_stream_t stream);
 int msi_preprocess_f32(const float *in, float *out, size_t n, msi_stream_t stream);
+/* both images of a frame (raw_src_image, raw_ref_image of infer_msi, msi.py:73-75) in one launch */
+int msi_preprocess_pair_u8_f32(const uint8_t *in0, const uint8_t *in1, float *out0, float *out1, size_t n,
+                               msi_stream_t stream);
 /* MSI.deprocess_image (msi.py:1173-1181): trunc(((x+1)/2)*255.5) -> uint8;
  * is_depth != 0: MSI.deprocess_depth_image (msi.py:1186-1194): trunc(x*255.5).
  * Values are clamped to [0,255] before the cast. */
 int msi_deprocess_f32_u8(const float *in, uint8_t *out, size_t n, int32_t is_depth,
                          msi_stream_t stream);
+/* deprocess_image(rgb) and deprocess_depth_image(depth) of test.py:149-159 in one launch (n elements each) */
+int msi_deprocess_pair_f32_u8(const float *rgb, const float *depth, uint8_t *out_rgb, uint8_t *out_depth, size_t n,
+                              msi_stream_t stream);
 
 /* out[b] = lhs[b] @ rhs[b] for [B,4,4] row-major poses, terms summed k = 0..3 without fma:
  * curr_pose = psv_src_pose @ ref_pose_inv (msi.py:1125), tgt_pose @ interp_pose_inv (msi.py:644-646).
@@ -287,6 +293,18 @@ size_t msi_net_plan_workspace_bytes(const msi_net_plan *plan);
 /* net_input [B,H,W,in_channels] (fp32, or bf16 when desc.dtype = MSI_DTYPE_BF16) -> pred [B,H,W,num_outputs] fp32. */
 int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
                          void *workspace, size_t workspace_bytes, msi_stream_t stream);
+
+/* The network followed by infer_msi's layer_prediction for which_color_pred = blend_psv (msi.py:130-147) with the
+ * 1x1 head, its source's LayerNorm and the RGBA assembly fused into ONE kernel: `pred` never exists in HBM.
+ * net_input [B,H,W,6D] fp32 is both the network input and the sweep volume the layers are blended from;
+ * rgba_native [B,D,H,W,4]; blend_weights / alphas [B,H,W,D] and pred [B,H,W,2D] (the tanh output) are optional (NULL).
+ * Results are bit-identical to msi_net_plan_forward + msi_assemble_rgba_f32.  event_after_convs: optional
+ * hipEvent_t recorded on `stream` between the last convolution and the fused tail (bench.py times the MFMA-bound and
+ * the HBM-bound part separately).  MSI_E_UNSUPPORTED for bf16 plans / other colour schemes / ngf > 64 / D > 64 /
+ * HEAD_FUSE_LN = 0: use msi_net_plan_forward + msi_assemble_rgba_color_f32 there. */
+int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, const float *net_input, float *rgba_native,
+                              float *blend_weights, float *alphas, float *pred, void *workspace, size_t workspace_bytes,
+                              msi_stream_t stream, void *event_after_convs);
 
 /* Descriptor-level convenience: the two calls below build a transient plan per call (set-up time, tests); the
  * frame loop uses msi_net_plan_forward.

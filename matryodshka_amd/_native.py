@@ -50,6 +50,8 @@ SIGNATURES = {
     "msi_trig_table_floats": (c_size_t, [_I, _I]),
     "msi_build_trig_tables_host": (_I, [_I, _I, _P]),
     "msi_preprocess_u8_f32": (_I, [_P, _P, c_size_t, _P]),
+    "msi_preprocess_pair_u8_f32": (_I, [_P, _P, _P, _P, c_size_t, _P]),
+    "msi_deprocess_pair_f32_u8": (_I, [_P, _P, _P, _P, c_size_t, _P]),
     "msi_preprocess_f32": (_I, [_P, _P, c_size_t, _P]),
     "msi_deprocess_f32_u8": (_I, [_P, _P, c_size_t, _I, _P]),
     "msi_compose_poses_f32": (_I, [_P, _P, _P, _I, _P]),
@@ -78,6 +80,7 @@ SIGNATURES = {
     "msi_net_plan_set_option": (_I, [_P, _I, _I]),
     "msi_net_plan_workspace_bytes": (c_size_t, [_P]),
     "msi_net_plan_forward": (_I, [_P, _P, _P, _P, _P, c_size_t, _P]),
+    "msi_net_plan_forward_rgba": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "msi_net_forward_f32": (_I, [POINTER(NetDesc), _P, _P, _P, _P, c_size_t, _P]),
     "msi_net_forward_bf16": (_I, [POINTER(NetDesc), _P, _P, _P, _P, c_size_t, _P]),
 }

@@ -991,6 +991,205 @@ conv_fixup_kernel(const ConvParams p) {
 #endif
 }
 
+// ---- fused tail: 1x1 head (+ the producer's LayerNorm) + RGBA layer assembly ------------------------------------
+// color_pred (nets.py:509-515) followed by infer_msi's layer_prediction for blend_psv (msi.py:130-147) in ONE kernel:
+// `pred` (52 MB at the BASELINE size) is never written to or re-read from HBM and one launch disappears.  A workgroup
+// owns 32 consecutive pixels: the sweep-volume tile (32 x 6D floats, contiguous) is requested first and stays in
+// flight while the 32 x C0 activations (conv8_2 raw, normalised + ReLU'd on the way like the stand-alone head does)
+// and the 2D x C0 weights go to LDS and 2 D / 32 waves run the k-steps on the fp32 MFMA -- the SAME instruction
+// sequence as the stand-alone head (k ascending, transposed accumulators), so the prediction is bit-identical --
+// then bias + tanh + (x+1)/2 land in an LDS tile and the assembly of K3 (geometry.hip, same expressions, no
+// contraction) writes float4 texels of the D-major stack.  HBM-bound: reads C0 + 6D floats, writes 4D per pixel.
+constexpr int HA_TP = 32;   // pixels per workgroup
+
+struct HeadAsmParams {
+  const float *x;            // conv8_2 raw [B,H,W,C0]
+  const float *wpk;          // packed head weights [ksteps][npad][32 floats] (slots swizzled by output row)
+  const float *bias;
+  const float *aff;          // affine of the source layer's LayerNorm [B][scale[C0] | shift[C0]] (ln_finish_kernel)
+  const float *psv;          // [B,H,W,6D]
+  float4 *rgba;              // [B,D,H,W] float4
+  float *bw_out, *al_out;    // optional [B,H,W,D]
+  float *pred_out;           // optional [B,H,W,2D] (tanh output)
+  int C0, ksteps, npad, nd, hw;
+  long npix_total;
+};
+
+template <int NT>   // 64 * NT >= 2 D output channels: NT = 1 (D <= 32) or 2 (D <= 64)
+__global__ void __launch_bounds__(256)
+head_assemble_kernel(const HeadAsmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BN = 64 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nd = p.nd, c_psv = 6 * nd, c_pred = 2 * nd;
+  const int s_psv = c_psv + 1, s_pred = c_pred + 1;             // odd row strides (see assemble_kernel)
+  // LDS: [affine 2 C0 | stat | R | pred tile]; R holds A (ksteps x 32 rows) | B (ksteps x BN rows) during the GEMM and
+  // the sweep-volume tile afterwards (33.6 KB per workgroup at D = 32: four workgroups per CU, like assemble_kernel)
+  float *s_aff = reinterpret_cast<float *>(smem);
+  double *s_stat = reinterpret_cast<double *>(smem + 2 * 64 * 4);
+  char *sR = smem + 2 * 64 * 4 + 64;
+  char *sA = sR;
+  char *sB = sA + p.ksteps * HA_TP * ROW_BYTES;
+  const size_t r_bytes = max((size_t)p.ksteps * (HA_TP + BN) * ROW_BYTES, (size_t)HA_TP * s_psv * sizeof(float));
+  float *l_psv = reinterpret_cast<float *>(sR);
+  float *l_pred = reinterpret_cast<float *>(sR + ((r_bytes + 15) & ~(size_t)15));
+
+  const long p0 = (long)blockIdx.x * HA_TP;
+  const int b = (int)(p0 / p.hw);                               // (H * W is a multiple of 32: a tile never straddles samples)
+  // 1. every global load of the workgroup goes out first and is parked in registers: the sweep-volume tile, the raw
+  //    activations (C0 <= 64: at most two float4 per thread), the weight rows -- ONE memory round trip per workgroup
+  constexpr int PSV_PER_THREAD = 6 * NT;                        // 32 x 6 D floats / 4 / 256 threads, D <= 32 NT
+  constexpr int B_PER_THREAD = 4 * NT;                          // ksteps (<= 2) x BN rows x 8 float4 / 256
+  const int nv_psv = HA_TP * c_psv / 4;
+  float4 q[PSV_PER_THREAD];
+  {
+    const float4 *g = reinterpret_cast<const float4 *>(p.psv + p0 * c_psv);
+#pragma unroll
+    for (int k = 0; k < PSV_PER_THREAD; ++k) {
+      const int v = tid + 256 * k;
+      if (v < nv_psv) q[k] = g[v];
+    }
+  }
+  const int nchunk = p.ksteps * 8;                              // 16-byte chunks per pixel (zero beyond C0)
+  v4f araw[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + 256 * k;
+    const int r = e / nchunk, c = (e - r * nchunk) * 4;
+    araw[k] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (e < HA_TP * nchunk && c < p.C0) araw[k] = *reinterpret_cast<const v4f *>(p.x + (size_t)(p0 + r) * p.C0 + c);
+  }
+  const int nb = p.ksteps * BN * 8;
+  v4f braw[B_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < B_PER_THREAD; ++k) {
+    const int e = tid + 256 * k;
+    const int row = e >> 3, j = e & 7;
+    const int ks = row / BN, n = row - ks * BN;
+    if (e < nb) braw[k] = *reinterpret_cast<const v4f *>(p.wpk + ((size_t)ks * p.npad + n) * (ROW_BYTES / 4) + j * 4);
+  }
+  // 2. affine of the source's LayerNorm (precomputed once per forward by ln_finish_kernel: 6 400 workgroups deriving it
+  //    from the sums themselves put two more dependent round trips on every workgroup's critical path)
+  (void)s_stat;
+  if (tid < 2 * p.C0) s_aff[tid] = p.aff[(size_t)b * 2 * p.C0 + tid];
+  __syncthreads();
+  // 3. A: 32 pixels x (ksteps * 32) channels, LayerNorm + ReLU applied (the stand-alone head's expression), zero beyond
+  //    C0; the 16-byte slot s of row r holds data chunk s ^ ((r >> 1) & 7) (the conv kernel's LDS image).  B: rows
+  //    [0, BN) of every k-step of the packed blob as they are (pre-swizzled; rows >= Cout are zero)
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + 256 * k;
+    if (e < HA_TP * nchunk) {
+      const int r = e / nchunk, ch = e - r * nchunk;
+      const int c = ch * 4;
+      v4f y = {0.f, 0.f, 0.f, 0.f};
+      if (c < p.C0) {                                           // C0 % 4 == 0
+        const v4f s4 = *reinterpret_cast<const v4f *>(s_aff + c), t4 = *reinterpret_cast<const v4f *>(s_aff + p.C0 + c);
+        y.x = fmaxf(araw[k].x * s4.x + t4.x, 0.f); y.y = fmaxf(araw[k].y * s4.y + t4.y, 0.f);
+        y.z = fmaxf(araw[k].z * s4.z + t4.z, 0.f); y.w = fmaxf(araw[k].w * s4.w + t4.w, 0.f);
+      }
+      const int ks = ch >> 3, chunk = ch & 7;
+      *reinterpret_cast<v4f *>(sA + (ks * HA_TP + r) * ROW_BYTES + ((chunk ^ ((r >> 1) & 7)) << 4)) = y;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < B_PER_THREAD; ++k) {
+    const int e = tid + 256 * k;
+    if (e < nb) *reinterpret_cast<v4f *>(sB + (e >> 3) * ROW_BYTES + ((e & 7) << 4)) = braw[k];
+  }
+  __syncthreads();
+  // 4. the GEMM: wave w owns output channels [32 w, 32 w + 32) of the 32 pixels; 5. bias + tanh (-> optional pred),
+  //    (x + 1) / 2 (msi.py:132-133) -> LDS tile (+ the optional [B,H,W,D] outputs)
+  if (wave < 2 * NT) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+    for (int ks = 0; ks < p.ksteps; ++ks) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int slot = ((fh * 4 + qq) ^ fswz) << 4;
+        const v4f a = *reinterpret_cast<const v4f *>(sA + (ks * HA_TP + frow) * ROW_BYTES + slot);
+        const v4f w = *reinterpret_cast<const v4f *>(sB + (ks * BN + wave * 32 + frow) * ROW_BYTES + slot);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, a.w, acc, 0, 0, 0);
+      }
+    }
+    const int px = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = wave * 32 + 8 * g + 4 * half;
+      if (n < c_pred) {                                         // 2 D is a multiple of 8: whole float4 in range
+        const v4f bs = *reinterpret_cast<const v4f *>(p.bias + n);
+        v4f t = {tanhf(acc[4 * g] + bs.x), tanhf(acc[4 * g + 1] + bs.y), tanhf(acc[4 * g + 2] + bs.z), tanhf(acc[4 * g + 3] + bs.w)};
+        if (p.pred_out) *reinterpret_cast<v4f *>(p.pred_out + (p0 + px) * c_pred + n) = t;
+        t.x = (t.x + 1.0f) / 2.0f; t.y = (t.y + 1.0f) / 2.0f; t.z = (t.z + 1.0f) / 2.0f; t.w = (t.w + 1.0f) / 2.0f;
+        float *dst = l_pred + px * s_pred + n;
+        dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+        if (n < nd) {
+          if (p.bw_out) *reinterpret_cast<v4f *>(p.bw_out + (p0 + px) * nd + n) = t;
+        } else {
+          if (p.al_out) *reinterpret_cast<v4f *>(p.al_out + (p0 + px) * nd + (n - nd)) = t;
+        }
+      }
+    }
+  }
+  __syncthreads();                                              // A | B have been read: the sweep-volume tile replaces them
+  // 6. the parked sweep-volume tile -> LDS, rows padded to an odd stride
+#pragma unroll
+  for (int k = 0; k < PSV_PER_THREAD; ++k) {
+    const int v = tid + 256 * k;
+    if (v < nv_psv) {
+      const int e = v * 4;
+      const int row = e / c_psv, col = e - row * c_psv;         // c_psv % 4 == 0: no row straddle
+      float *dst = l_psv + row * s_psv + col;
+      dst[0] = q[k].x; dst[1] = q[k].y; dst[2] = q[k].z; dst[3] = q[k].w;
+    }
+  }
+  __syncthreads();
+  // 7. assembly (assemble_kernel, COLOR_BLEND_PSV; no contraction, like geometry.hip): thread -> (pixel, every 8th layer)
+  {
+#pragma clang fp contract(off)
+    const int px = tid & (HA_TP - 1);
+    const long pp = p0 + px;
+    const long off = pp - (long)b * p.hw;
+    const float *rp = l_psv + px * s_psv;
+    const float *rq = l_pred + px * s_pred;
+    for (int d = tid / HA_TP; d < nd; d += 256 / HA_TP) {
+      const float *fg = rp + d * 3;
+      const float *bg = rp + (nd + d) * 3;
+      const float w = rq[d];
+      const float omw = 1.0f - w;
+      float4 o;
+      o.x = w * fg[0] + omw * bg[0];
+      o.y = w * fg[1] + omw * bg[1];
+      o.z = w * fg[2] + omw * bg[2];
+      o.w = rq[nd + d];
+      p.rgba[((long)b * nd + d) * p.hw + off] = o;
+    }
+  }
+#endif
+}
+
+// The affine of one layer's LayerNorm, scale | shift per channel, for consumers that apply it themselves while loading
+// (head_assemble_kernel): one workgroup per sample.
+__global__ void __launch_bounds__(256)
+ln_finish_kernel(const long long *__restrict__ sums, double inv_n, const float *__restrict__ gamma,
+                 const float *__restrict__ beta, int C, float *__restrict__ aff) {
+  __shared__ double s_stat[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  ln_mean_inv(sums + (size_t)b * LN_SHARDS * 4, inv_n, s_stat, tid);
+  const double mu = s_stat[0], inv = s_stat[1];
+  for (int c = tid; c < C; c += 256) {
+    const double sc = inv * (double)gamma[c];
+    aff[(size_t)b * 2 * C + c] = (float)sc;
+    aff[(size_t)b * 2 * C + C + c] = (float)((double)beta[c] - mu * sc);
+  }
+}
+
 // LayerNorm apply (+ ReLU), one launch per layer.  Every workgroup derives the affine of slim.layer_norm,
 //   scale = gamma * rsqrt(var + eps), shift = beta - mean * scale,
 // from the sample's 64 x 4 fixed-point sums (ln_mean_inv), keeps it in LDS, and applies
@@ -1653,13 +1852,83 @@ int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value) {
 
 size_t msi_net_plan_workspace_bytes(const msi_net_plan *plan) { return plan ? plan->net.ws_bytes : 0; }
 
+static int run_layers(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
+                      void *workspace, size_t workspace_bytes, msi_stream_t stream_, int nlayers);
+
 int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
                          void *workspace, size_t workspace_bytes, msi_stream_t stream_) {
+  MSI_REQUIRE(pred, "net_forward: null pointer");
+  return run_layers(plan, packed, net_input, pred, workspace, workspace_bytes, stream_, MSI_NET_NUM_LAYERS);
+}
+
+int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, const float *net_input, float *rgba_native,
+                              float *blend_weights, float *alphas, float *pred, void *workspace, size_t workspace_bytes,
+                              msi_stream_t stream_, void *event_after_convs) {
+  MSI_REQUIRE(plan, "net_forward_rgba: null plan");
+  const msi_net_desc *desc = &plan->desc;
+  const Net &net = plan->net;
+  const Layer &H = net.layers[MSI_NET_NUM_LAYERS - 1];
+  const int nd = desc->num_outputs / 2;
+  if (desc->dtype != MSI_DTYPE_F32 || !plan->launch[MSI_NET_NUM_LAYERS - 1].fuse_ln || H.c0 > 64 || H.c0 % 4 != 0 ||
+      desc->num_outputs != 2 * nd || nd % 4 != 0 || nd > 64 || desc->in_channels != 6 * nd ||
+      ((long)desc->height * desc->width) % HA_TP != 0)
+    return msi::fail(MSI_E_UNSUPPORTED, "net_forward_rgba: fused tail needs an fp32 blend_psv network (in = 6 D, out = 2 D, "
+                     "D %% 4 == 0, D <= 64, ngf <= 64, head LayerNorm fused)");
+  MSI_REQUIRE(rgba_native, "net_forward_rgba: null pointer");
+  int rc = run_layers(plan, packed, net_input, nullptr, workspace, workspace_bytes, stream_, MSI_NET_NUM_LAYERS - 1);
+  if (rc || desc->batch == 0) return rc;
+  hipStream_t stream = msi::as_stream(stream_);
+  if (event_after_convs) {
+    hipError_t e = hipEventRecord(static_cast<hipEvent_t>(event_after_convs), stream);
+    if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_forward_rgba: %s", hipGetErrorString(e));
+  }
+  char *ws = static_cast<char *>(workspace);
+  const Layer &S = net.layers[H.src0];
+  HeadAsmParams q;
+  q.x = reinterpret_cast<const float *>(ws + S.raw_off);
+  q.wpk = packed + H.packed_off;
+  q.bias = packed + H.gamma_off;
+  float *aff = reinterpret_cast<float *>(ws + S.aff_off);
+  hipLaunchKernelGGL(ln_finish_kernel, dim3(desc->batch), dim3(256), 0, stream,
+                     reinterpret_cast<const long long *>(ws + S.sums_off), 1.0 / S.ln_count, packed + S.gamma_off,
+                     packed + S.beta_off, S.cout, aff);
+  rc = msi::check_launch("ln_finish");
+  if (rc) return rc;
+  q.aff = aff;
+  q.psv = net_input;
+  q.rgba = reinterpret_cast<float4 *>(rgba_native);
+  q.bw_out = blend_weights;
+  q.al_out = alphas;
+  q.pred_out = pred;
+  q.C0 = H.c0; q.ksteps = H.ksteps; q.npad = H.npad; q.nd = nd; q.hw = desc->height * desc->width;
+  q.npix_total = (long)desc->batch * q.hw;
+  const int NT = nd > 32 ? 2 : 1, BN = 64 * NT;
+  size_t r_bytes = (size_t)H.ksteps * (HA_TP + BN) * ROW_BYTES;
+  if (r_bytes < (size_t)HA_TP * (6 * nd + 1) * sizeof(float)) r_bytes = (size_t)HA_TP * (6 * nd + 1) * sizeof(float);
+  const size_t lds = 2 * 64 * 4 + 64 + ((r_bytes + 15) & ~(size_t)15) + (size_t)HA_TP * (2 * nd + 1) * sizeof(float);
+  const dim3 grid((unsigned)(q.npix_total / HA_TP));
+  if (NT == 1) {
+    hipLaunchKernelGGL(head_assemble_kernel<1>, grid, dim3(256), lds, stream, q);
+  } else {
+    static thread_local bool done = false;
+    if (!done && lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(head_assemble_kernel<2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_forward_rgba: %s", hipGetErrorString(e));
+      done = true;
+    }
+    hipLaunchKernelGGL(head_assemble_kernel<2>, grid, dim3(256), lds, stream, q);
+  }
+  return msi::check_launch("head_assemble");
+}
+
+static int run_layers(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
+                      void *workspace, size_t workspace_bytes, msi_stream_t stream_, int nlayers) {
   MSI_REQUIRE(plan, "net_forward: null plan");
   const msi_net_desc *desc = &plan->desc;
   const Net &net = plan->net;
   const int bf16 = desc->dtype == MSI_DTYPE_BF16;
-  MSI_REQUIRE(packed && net_input && pred && workspace, "net_forward: null pointer");
+  MSI_REQUIRE(packed && net_input && workspace, "net_forward: null pointer");
   if (workspace_bytes < net.ws_bytes)
     return msi::fail(MSI_E_WORKSPACE, "net_forward: workspace %zu B < required %zu B", workspace_bytes,
                      net.ws_bytes);
@@ -1670,7 +1939,7 @@ int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const vo
   hipError_t e = hipMemsetAsync(ws + net.zero_off, 0, net.zero_bytes, stream);
   if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_forward: %s", hipGetErrorString(e));
   int *cnt = reinterpret_cast<int *>(ws + net.cnt_off);
-  for (int li = 0; li < MSI_NET_NUM_LAYERS; ++li) {
+  for (int li = 0; li < nlayers; ++li) {
     const Layer &L = net.layers[li];
     const LayerLaunch &Q = plan->launch[li];
     ConvParams p = Q.p;

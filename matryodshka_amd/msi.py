@@ -149,6 +149,27 @@ class MSI(object):
                     "msi_preprocess_f32")
         return out
 
+    def preprocess_image_pair(self, image0, image1):
+        """preprocess_image of two uint8 images of one shape in a single launch (raw_src_image / raw_ref_image)."""
+        if not (torch.is_tensor(image0) and torch.is_tensor(image1) and image0.dtype == torch.uint8 and
+                image1.dtype == torch.uint8 and image0.shape == image1.shape):
+            return self.preprocess_image(image0), self.preprocess_image(image1)
+        image0, image1 = image0.to(self.device).contiguous(), image1.to(self.device).contiguous()
+        out = torch.empty((2,) + tuple(image0.shape), dtype=torch.float32, device=self.device)
+        N.check(N.lib.msi_preprocess_pair_u8_f32(image0.data_ptr(), image1.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                                 image0.numel(), self._stream()), "msi_preprocess_pair_u8_f32")
+        return out[0], out[1]
+
+    def deprocess_image_and_depth(self, rgb, depth):
+        """deprocess_image(rgb), deprocess_depth_image(depth) (test.py:149-159) in a single launch."""
+        rgb, depth = self._f32(rgb), self._f32(depth)
+        if rgb.shape != depth.shape:
+            return self.deprocess_image(rgb), self.deprocess_depth_image(depth)
+        out = torch.empty((2,) + tuple(rgb.shape), dtype=torch.uint8, device=self.device)
+        N.check(N.lib.msi_deprocess_pair_f32_u8(rgb.data_ptr(), depth.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                                rgb.numel(), self._stream()), "msi_deprocess_pair_f32_u8")
+        return out[0], out[1]
+
     def _deprocess(self, image, is_depth):
         image = self._f32(image)
         out = torch.empty(image.shape, dtype=torch.uint8, device=self.device)
@@ -234,14 +255,10 @@ class MSI(object):
         if len(psv_planes) != num_msi_planes:
             # msi.py:138 indexes the src PSV with num_msi_planes
             raise ValueError("infer_msi assumes len(psv_planes) == num_msi_planes (msi.py:138)")
-        src_image = self.preprocess_image(raw_src_image)
-        ref_image = self.preprocess_image(raw_ref_image)
+        src_image, ref_image = self.preprocess_image_pair(raw_src_image, raw_ref_image)
         net_input = self.format_network_input(ref_image, src_image, ref_pose, src_pose, psv_planes,
                                               intrinsics, ref_pose_inv=ref_pose_inv, jitter_pose_inv=jitter_pose_inv)
-        d = num_msi_planes
-        num_outputs = {'blend_psv': 2 * d, 'blend_bg': 2 * d + 3, 'blend_bg_psv': 3 * d + 3, 'alpha_only': d}[which_color_pred]
-        msi_pred = self.run_net(net_input, num_outputs, ngf)
-        pred = self.assemble_layers(net_input, msi_pred, num_msi_planes, extra_outputs, which_color_pred)
+        pred = self.infer_layers(net_input, num_msi_planes, ngf, extra_outputs, which_color_pred)
         return pred, net_input
 
     def run_net(self, net_input, num_outputs, ngf=64):
@@ -255,6 +272,43 @@ class MSI(object):
         plan = self._plan(b, h, w, cin, num_outputs, ngf)
         N.check(N.lib.msi_net_plan_forward(plan.handle, packed.data_ptr(), net_input.data_ptr(), pred.data_ptr(),
                                            ws.data_ptr(), ws.numel(), self._stream()), "msi_net_plan_forward")
+        return pred
+
+    def infer_layers(self, net_input, num_msi_planes, ngf=64, extra_outputs='', which_color_pred='blend_psv',
+                     event_after_convs=None):
+        """msi_net + layer_prediction of infer_msi (msi.py:95-147): net_input -> pred dict.  For the reference's default
+        colour scheme on an fp32 model the 1x1 head, conv8_2's LayerNorm and the RGBA assembly run as ONE fused kernel
+        (msi_net_plan_forward_rgba: the tanh prediction never goes to HBM; bit-identical to the two-step path);
+        everything else takes run_net + assemble_layers.  event_after_convs: torch.cuda.Event (already recorded once, so
+        that its handle exists) recorded between the convolutions and the fused tail."""
+        b, h, w, cin = net_input.shape
+        d = num_msi_planes
+        fused = (which_color_pred == 'blend_psv' and self.dtype == 'f32' and net_input.dtype == torch.float32 and
+                 cin == 6 * d and d % 4 == 0 and d <= 64 and ngf <= 64 and
+                 self.net_options.get(N.NET_OPT_HEAD_FUSE_LN, 1) and net_input.is_contiguous())
+        if not fused:
+            num_outputs = {'blend_psv': 2 * d, 'blend_bg': 2 * d + 3, 'blend_bg_psv': 3 * d + 3, 'alpha_only': d}[which_color_pred]
+            msi_pred = self.run_net(net_input, num_outputs, ngf)
+            if event_after_convs is not None:
+                event_after_convs.record()
+            return self.assemble_layers(net_input, msi_pred, d, extra_outputs, which_color_pred)
+        desc, packed, ws = self._net(b, h, w, cin, 2 * d, ngf)
+        plan = self._plan(b, h, w, cin, 2 * d, ngf)
+        new = lambda: torch.empty((b, h, w, d), dtype=torch.float32, device=self.device)
+        rgba = torch.empty((b, d, h, w, 4), dtype=torch.float32, device=self.device)
+        bw = new() if 'blend_weights' in extra_outputs else None
+        al = new() if 'alpha' in extra_outputs else None
+        ev = 0 if event_after_convs is None else event_after_convs.cuda_event
+        N.check(N.lib.msi_net_plan_forward_rgba(plan.handle, packed.data_ptr(), net_input.data_ptr(), rgba.data_ptr(),
+                                                _ptr(bw), _ptr(al), 0, ws.data_ptr(), ws.numel(), self._stream(), ev),
+                "msi_net_plan_forward_rgba")
+        pred = {'rgba_layers': rgba.permute(0, 2, 3, 1, 4)}
+        if bw is not None:
+            pred['blend_weights'] = bw
+        if al is not None:
+            pred['alphas'] = al
+        if 'psv' in extra_outputs:
+            pred['psv'] = net_input
         return pred
 
     def assemble_layers(self, net_input, msi_pred, num_msi_planes, extra_outputs='', which_color_pred='blend_psv'):

@@ -182,3 +182,31 @@ def test_apply_ahead_equals_separate_layernorm_launches(env, dtype, coord, b, h,
         pass
     for a, c in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("coord,b,h,w,d,ngf", [(True, 1, 32, 64, 32, 64), (False, 2, 16, 40, 8, 16), (True, 1, 16, 32, 64, 16),
+                                               (True, 3, 16, 24, 4, 12)])
+def test_fused_head_assembly_is_bit_identical(env, coord, b, h, w, d, ngf):
+    """msi_net_plan_forward_rgba (1x1 head + conv8_2's LayerNorm + RGBA assembly in one kernel; `pred` never in HBM)
+    against msi_net_plan_forward + msi_assemble_rgba_f32: same MFMA sequence, same fp32 expressions -> same bits for the
+    layer stack, the optional blend weights / alphas, and (through the oracle) within 1e-3 of the reference path."""
+    torch, MSI, nets, N, onets = env
+    from oracle.msi import MSI as OracleMSI
+    weights = onets.init_weights(6 * d, 2 * d, ngf=ngf, coord_net=coord, seed=33, randomize_affine=True)
+    m = MSI(weights=weights, coord_net=coord)
+    x = torch.rand((b, h, w, 6 * d), device="cuda") * 2 - 1
+    fused = m.infer_layers(x, d, ngf, extra_outputs="blend_weights alphas")
+    pred = m.run_net(x, 2 * d, ngf)
+    two = m.assemble_layers(x, pred, d, extra_outputs="blend_weights alphas")
+    for k in ("rgba_layers", "blend_weights", "alphas"):
+        assert torch.equal(fused[k], two[k]), k
+    ref = OracleMSI(weights=weights, coord_net=coord).assemble(x.cpu().numpy(), onets.forward(weights, x.cpu().numpy(), coord_net=coord), d)
+    assert np.abs(fused["rgba_layers"].cpu().numpy() - ref["rgba_layers"]).max() <= 1e-3
+    # the optional tanh output of the fused kernel == the stand-alone head
+    desc, packed, ws = m._net(b, h, w, 6 * d, 2 * d, ngf)
+    plan = m._plan(b, h, w, 6 * d, 2 * d, ngf)
+    rgba = torch.empty((b, d, h, w, 4), device="cuda")
+    p2 = torch.empty((b, h, w, 2 * d), device="cuda")
+    N.check(N.lib.msi_net_plan_forward_rgba(plan.handle, packed.data_ptr(), x.data_ptr(), rgba.data_ptr(), 0, 0, p2.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), None, None), "forward_rgba")
+    assert torch.equal(p2, pred)

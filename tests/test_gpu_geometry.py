@@ -343,3 +343,16 @@ def test_sweep_volume_equals_two_single_source_sweeps(gpu, same_pose, bf16):
         want = np.concatenate([__import__("oracle.geometry", fromlist=["x"]).ods_sphere_sweep(o.preprocess_image(img), order, m.inv_depths(1.0, 100.0, d), pose, inp["intrinsics"])
                                for img, pose, order in ((inp["ref_image"], p0, 1), (inp["src_image"], p1, -1))], axis=3)
         assert np.abs(_np(both) - want).max() <= TOL
+
+
+def test_pair_launches_equal_single_ones(gpu):
+    """preprocess / deprocess of the two images of a frame in one launch: same bits as the single-image entry points."""
+    torch, m, o = gpu
+    inp = make_inputs(4, 2, 16, 32)
+    a, b = torch.from_numpy(inp["ref_image"]).cuda(), torch.from_numpy(inp["src_image"]).cuda()
+    pa, pb = m.preprocess_image_pair(a, b)
+    assert torch.equal(pa, m.preprocess_image(a)) and torch.equal(pb, m.preprocess_image(b))
+    x = torch.rand((2, 16, 32, 3), device="cuda") * 2.4 - 1.2
+    y = torch.rand((2, 16, 32, 3), device="cuda") * 1.2 - 0.1
+    r8, d8 = m.deprocess_image_and_depth(x, y)
+    assert torch.equal(r8, m.deprocess_image(x)) and torch.equal(d8, m.deprocess_depth_image(y))
