@@ -276,7 +276,8 @@ size_t msi_net_workspace_bytes(const msi_net_desc *desc);
 typedef struct msi_net_plan msi_net_plan;
 #define MSI_NET_OPT_FIXUP_KERNEL 0 /* 0 (default): split tiles are summed inside the conv launch (last arriver);  */
                                    /* 1: by a separate conv_fixup_kernel launch (bitwise-identical results)       */
-#define MSI_NET_OPT_TAILSPLIT 1    /* 1 (default): cut the tiles of the partial last wave over the CUs along K    */
+#define MSI_NET_OPT_TAILSPLIT 1    /* cut the tiles of the partial last round along K: 1 (default) whole tiles in multiples of   */
+                                   /* the CU count, 2 in multiples of a full residency (5 workgroups x CUs; measured slower), 0 never */
 #define MSI_NET_OPT_BIGTILE 2      /* bf16 tile choice: 0 never 128x128 / 128x64, 1 (default) by grid size, 2 always */
 #define MSI_NET_OPT_HEAD_FUSE_LN 3 /* 1 (default): the fp32 head applies its source's LayerNorm while loading      */
 #define MSI_NET_OPT_NUM_CUS 4      /* CUs the work decomposition balances over (default: the device's count)      */

@@ -73,6 +73,7 @@ constexpr int COORD_CLASSES = 5;    // column border classes of the CoordNet tab
 [[maybe_unused]] constexpr unsigned OOB = 0x80000000u;  // per-lane offset that is out of range of every descriptor (device code)
 constexpr int DEFAULT_CUS = 256;  // MI355X; the plan queries hipDeviceProp.multiProcessorCount (option MSI_NET_OPT_NUM_CUS overrides)
 constexpr int MAX_SPLIT = 8;
+constexpr int CONV_SLOTS_PER_CU = 5;   // 64x64 workgroups (32 KB of LDS each) resident per CU
 constexpr double LN_EPS = 1e-12;  // slim.layer_norm variance epsilon [TF-knowledge]
 // LayerNorm sums: [sample][LN_SHARDS][4] signed 64-bit fixed point {S1 hi, S1 lo, S2 hi, S2 lo},
 // value = hi * 2^-8 + lo * 2^-52 (hi carries the integer part and 8 fraction bits, lo the next 44)
@@ -1284,7 +1285,7 @@ struct Net {
   std::vector<Layer> layers;
   size_t param_floats = 0, packed_floats = 0, ws_bytes = 0, partial_off = 0, partial_bytes = 0;
   size_t zero_off = 0, zero_bytes = 0;   // [tickets of the in-launch fix-up | LayerNorm sums]: one memset per forward
-  size_t cnt_off = 0;   // arrival tickets: [layer][2 * num_cus] ints
+  size_t cnt_off = 0;   // arrival tickets: [layer][5 * num_cus] ints
   size_t err_off = 0;   // one int: a tile workgroup gave up waiting for apply-ahead rows (stays 0)
 };
 
@@ -1413,7 +1414,7 @@ int build_net(const msi_net_desc *d, int num_cus, Net &net) {
   net.partial_bytes = (size_t)2 * num_cus * MAX_SPLIT * 64 * 64 * sizeof(float);
   net.zero_off = net.partial_off + net.partial_bytes;
   net.cnt_off = net.zero_off;
-  size_t zoff = net.cnt_off + round_up((size_t)MSI_NET_NUM_LAYERS * 2 * num_cus * sizeof(int), 256);
+  size_t zoff = net.cnt_off + round_up((size_t)MSI_NET_NUM_LAYERS * CONV_SLOTS_PER_CU * num_cus * sizeof(int), 256);
   for (int i = 0; i < MSI_NET_NUM_LAYERS; ++i) {
     net.layers[i].sums_off = zoff;
     if (net.layers[i].kind != MODE_HEAD) zoff += (size_t)d->batch * LN_SHARDS * 4 * sizeof(long long);
@@ -1475,9 +1476,30 @@ void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tails
   p.n_main = p.ntiles;
   p.split0 = 1;
   p.split = 1;
+  // Residency-aware form (tailsplit = 2; NOT the default -- measured slower, see below), for grids of at least one full
+  // residency Q = 5 workgroups x CUs:
+  // per-workgroup phase stamps (tools/conv_timing.py, r02_l) show the matrix pipes saturated while five workgroups
+  // share a CU and starved when the last whole tile of a CU runs beside one short K-range -- e.g. 1 600 tiles = 6 whole
+  // per CU + a quarter: the sixth tile ran with 2 waves per SIMD for a whole tile time (14 % of the launch).  So whole
+  // tiles are issued in multiples of Q only, and the remaining < Q tiles are cut into K-ranges that fill one more
+  // residency (1 600 -> 1 280 whole + 320 x 4 ranges; 3 200 -> 2 560 + 640 x 2): long blocks first, short ones last.
+  // Measured (profiles/r02_m): conv2_1 115 -> 124 us, conv7_1 189 -> 205, conv1_1 325 -> 335: the extra K-range blocks
+  // (prologue + epilogue + slab traffic each) cost more than the straggler they remove.
+  const int Q = CONV_SLOTS_PER_CU * num_cus;
+  if (BM * BN == 64 * 64 && tailsplit == 2 && p.ntiles >= Q && p.ntiles % Q != 0 && p.ksteps >= 2 * MAX_SPLIT) {
+    const int remq = p.ntiles % Q;
+    int best = 1;
+    double best_cost = 1.0;   // time of the tail in tile-times: ceil(rem*s/Q)/s
+    for (int sp = 2; sp <= MAX_SPLIT; ++sp) {
+      if ((long)remq * sp > 2L * num_cus * MAX_SPLIT) break;     // slab capacity of the workspace
+      const double cost = (double)((remq * sp + Q - 1) / Q) / sp;
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+    }
+    if (best > 1) { p.split = best; p.n_main = p.ntiles - remq; }
+  }
   const int rem = p.ntiles % num_cus;
-  if (BM * BN == 64 * 64 &&   // (big tiles are only chosen for big grids)
-      rem != 0 && p.ntiles > num_cus / 2 && p.ksteps >= 2 * MAX_SPLIT && tailsplit) {
+  if (BM * BN == 64 * 64 && p.split == 1 &&   // (big tiles are only chosen for big grids)
+      rem != 0 && p.ntiles > num_cus / 2 && p.ksteps >= 2 * MAX_SPLIT && tailsplit && !(tailsplit == 2 && p.ntiles >= Q)) {
     int best = 1;
     double best_cost = 1.0;   // time of the tail in tile-times: ceil(rem*s/CUs)/s
     for (int sp = 2; sp <= MAX_SPLIT; ++sp) {
@@ -1581,7 +1603,7 @@ int plan_layers(msi_net_plan *pl) {
       p.n_apply = (int)((n + 7) / 8 * 8);
       pl->launch[L.src0].skip_apply = 1;              // (the producer precedes its consumer in graph order)
     }
-    Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= 2 * pl->num_cus;
+    Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
     if ((size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * BM * BN * sizeof(float) > net.partial_bytes)
       return msi::fail(MSI_E_WORKSPACE, "conv %s: %d partial accumulators exceed the workspace", L.name, Q.nblocks);
     if (L.kind != MODE_HEAD) {
@@ -1816,7 +1838,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->desc = *desc;
   pl->num_cus = device_cu_count();
   pl->opt[MSI_NET_OPT_FIXUP_KERNEL] = 0;
-  pl->opt[MSI_NET_OPT_TAILSPLIT] = 1;
+  pl->opt[MSI_NET_OPT_TAILSPLIT] = 1;   // (2, the residency-aware form, measured 6-10 % slower on every layer it changes: r02_m)
   pl->opt[MSI_NET_OPT_BIGTILE] = 1;
   pl->opt[MSI_NET_OPT_HEAD_FUSE_LN] = 1;
   pl->opt[MSI_NET_OPT_NUM_CUS] = pl->num_cus;
@@ -1963,7 +1985,7 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
     p.y = L.kind == MODE_HEAD ? pred : reinterpret_cast<float *>(ws + L.raw_off);
     p.sums = L.kind == MODE_HEAD ? nullptr : reinterpret_cast<long long *>(ws + L.sums_off);
     p.partial = reinterpret_cast<float *>(ws + net.partial_off);
-    p.tile_cnt = Q.inlaunch ? cnt + (size_t)li * 2 * plan->num_cus : nullptr;
+    p.tile_cnt = Q.inlaunch ? cnt + (size_t)li * CONV_SLOTS_PER_CU * plan->num_cus : nullptr;
     if (p.n_apply > 0) {
       const Layer &S = net.layers[L.src0];
       p.ap_x = reinterpret_cast<float *>(ws + S.raw_off);
