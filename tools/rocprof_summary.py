@@ -30,7 +30,7 @@ def main():
     conv = c.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, lds_size, vgpr_count, accum_vgpr_count "
                      "from kernels where name like '%conv_igemm%' order by start").fetchall()
     if len(conv) >= 18:
-        print("\n# conv_igemm launches of the last frame (18 layers, graph order)")
+        print("\n# conv_igemm launches of the last frame (graph order)")
         names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2",
                  "conv4_3", "conv6_1", "conv6_2", "conv6_3", "conv7_1", "conv7_2", "conv8_1", "conv8_2", "color_pred"]
         import os
@@ -39,7 +39,12 @@ def main():
         flops = bench.cnn_layer_flops(320, 640, 192, 64, 64, True)      # BASELINE config
         fix = c.execute("select start, end from kernels where name like '%conv_fixup%' order by start").fetchall()
         tot_us = 0.0
-        for nm, r, fl in zip(names, conv[-18:], flops):
+        # the 1x1 head is a conv_igemm launch (template MODE 2) only on the unfused path; on the fp32 blend_psv path it is
+        # part of head_assemble_kernel and a frame has 17 conv launches
+        fused_tail = "Li2E" not in conv[-1][0] and ", 2, " not in conv[-1][0]
+        nl = 17 if fused_tail else 18
+        ha = c.execute("select start, end from kernels where name like '%head_assemble%' order by start").fetchall()
+        for nm, r, fl in zip(names[:nl], conv[-nl:], flops[:nl]):
             tmpl = r[0].split("<")[1].split(">")[0] if "<" in r[0] else "?"
             us = (r[2] - r[1]) / 1e3
             # a fix-up launch (tail split) directly follows its conv launch
@@ -51,7 +56,9 @@ def main():
             print("%-10s tile<%s> blocks=%d lds=%d vgpr=%d agpr=%d  %8.1f us + fixup %5.1f us  %6.1f TFLOP/s (%4.1f%%, BASELINE shapes)" % (
                 nm, tmpl, (r[3] // r[6]) * r[4] * r[5], r[7], r[8], r[9], us, fus, fl / (us + fus) / 1e6,
                 100 * fl / (us + fus) / 1e6 / bench.PEAK_FP32_MFMA_TFLOPS))
-        print("sum %.1f us -> %.1f TFLOP/s" % (tot_us, sum(flops) / tot_us / 1e6))
+        if fused_tail and ha:
+            print("color_pred fused with the RGBA assembly: head_assemble_kernel %8.1f us (HBM-bound; not a conv_igemm launch)" % ((ha[-1][1] - ha[-1][0]) / 1e3))
+        print("sum %.1f us -> %.1f TFLOP/s (conv_igemm launches listed above)" % (tot_us, sum(flops[:nl]) / tot_us / 1e6))
 
 
 if __name__ == "__main__":
