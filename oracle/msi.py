@@ -21,6 +21,20 @@ from . import nets
 F = np.float32
 
 
+def matmul4(a, b):
+    """tf.matmul of [B,4,4] fp32 poses (msi.py:1120, :1125) with the four products summed k = 0..3 in fp32, one
+    rounding per operation (the order Eigen uses is not observable from the reference [TF-knowledge]; a BLAS call's
+    is not even fixed).  Identity operands -- the ODS test path -- are exact in any order."""
+    a = np.asarray(a, dtype=F).reshape(-1, 4, 4)
+    b = np.asarray(b, dtype=F).reshape(-1, 4, 4)
+    n = max(a.shape[0], b.shape[0])
+    a, b = np.broadcast_to(a, (n, 4, 4)), np.broadcast_to(b, (n, 4, 4))
+    out = (a[:, :, 0:1] * b[:, 0:1, :]).astype(F)
+    for k in range(1, 4):
+        out = (out + (a[:, :, k:k + 1] * b[:, k:k + 1, :]).astype(F)).astype(F)
+    return out
+
+
 class MSI(object):
     def __init__(self, weights=None, coord_net=False, input_type='ODS', dtype='f32'):     # FLAGS.coord_net default, test.py:52
         self.weights = weights
@@ -77,15 +91,13 @@ class MSI(object):
         if ref_pose_inv is None:
             ref_pose_inv = np.linalg.inv(ref_pose.astype(np.float64)).astype(F)
         if jitter_pose_inv is not None:     # FLAGS.jitter, msi.py:1118-1120
-            ref_pose_inv = np.matmul(np.asarray(ref_pose_inv, dtype=F),
-                                     np.broadcast_to(np.asarray(jitter_pose_inv, dtype=F).reshape(-1, 4, 4),
-                                                     np.asarray(ref_pose_inv).reshape(-1, 4, 4).shape)).astype(F)
+            ref_pose_inv = matmul4(ref_pose_inv, jitter_pose_inv)
         net_input = []
         # The reference concatenates [ref_pose, src_pose] on the batch axis and
         # so only works for B=1 (msi.py:1109-1110); here batch element b uses
         # (ref_pose[b], src_pose[b]) -- "B independent B=1 evaluations".
         for i, (img, pose) in enumerate(((ref_image, ref_pose), (src_image, src_pose))):
-            curr_pose = np.matmul(pose.astype(F), ref_pose_inv.astype(F)).astype(F)
+            curr_pose = matmul4(pose, ref_pose_inv)
             order = 1 if (i % 2) == 0 else -1
             if self.input_type == 'ODS':
                 net_input.append(G.ods_sphere_sweep(img, order, planes, curr_pose, intrinsics))

@@ -63,26 +63,9 @@ def test_sweep_float_input_and_nonidentity_pose(gpu):
     psv_o = o.format_network_input(o.preprocess_image(inp["ref_image"]), o.preprocess_image(inp["src_image"]),
                                    inp["ref_pose"], pose, planes, inp["intrinsics"])
     err = np.abs(_np(psv) - psv_o)
-    # a rotated pose is not exact in either implementation; allow isolated branch flips
-    assert np.percentile(err, 99.9) < 1e-3
-
-
-def test_sweep_depths_per_thread_variants_are_bit_identical(gpu, monkeypatch):
-    """K1 processes NS consecutive depths per thread (default 2): the per-sample arithmetic is untouched, so
-    NS = 1 / 2 / 4 must give the same bits (also with a depth count that only allows NS = 2)."""
-    torch, m, o = gpu
-    for b, h, w, d in ((1, 32, 64, 8), (2, 24, 40, 6)):
-        inp = make_inputs(3, b, h, w)
-        planes = m.inv_depths(1.0, 100.0, d)
-        pose = inp["src_pose"].copy()
-        pose[:, 0, 3] = 0.013
-        ref = m.preprocess_image(torch.from_numpy(inp["ref_image"]))
-        src = m.preprocess_image(torch.from_numpy(inp["src_image"]))
-        outs = []
-        for ns in ("1", "2", "4"):
-            monkeypatch.setenv("MSI_SWEEP_NS", ns)
-            outs.append(m.format_network_input(ref, src, inp["ref_pose"], pose, planes, inp["intrinsics"]).clone())
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # pose composition (k = 0..3, no fma), apply_pose and the quadratic up to the discriminant follow one op order on
+    # both sides: no branch flips, so the bound is on the MAXIMUM (8a-7 was only percentile-tested)
+    assert err.max() <= TOL, (err.max(), float((err > TOL).mean()))
 
 
 def test_compose_poses_matches_matmul(gpu):
@@ -309,14 +292,15 @@ def test_domain_guard_uses_the_full_pose(gpu):
     assert torch.equal(same, m.msi_render_equirect_view_single(rgba, np.eye(4, dtype=np.float32)[None], pos, planes, None))
 
 
+@pytest.mark.parametrize("d", [8, 6])          # 8: whole-pixel coalesced stores; 6 (3 depth groups per pixel): strided path
 @pytest.mark.parametrize("same_pose", [True, False])
 @pytest.mark.parametrize("bf16", [False, True])
-def test_sweep_volume_equals_two_single_source_sweeps(gpu, same_pose, bf16):
+def test_sweep_volume_equals_two_single_source_sweeps(gpu, same_pose, bf16, d):
     """msi_ods_sweep_volume (both sources in one launch, the branch-deciding quadratic shared when the two poses are
     equal) against two msi_ods_sphere_sweep_* calls through the C ABI: bit-identical either way."""
     torch, m, o = gpu
     from matryodshka_amd import _native as N
-    b, h, w, d = 2, 24, 48, 8
+    b, h, w = 2, 24, 48
     inp = make_inputs(23, b, h, w)
     ref = m.preprocess_image(torch.from_numpy(inp["ref_image"]))
     src = m.preprocess_image(torch.from_numpy(inp["src_image"]))
