@@ -87,7 +87,7 @@ def cnn_flops(h, w, cin, nout, ngf, coord):
 
 
 def cnn_traffic():
-    """HBM bytes per frame of the conv kernels (18 launches) from the newest committed PMC passes
+    """HBM bytes per frame of the conv kernels (conv_halo_kernel + conv_igemm_kernel launches) from the newest committed PMC passes
     (profiles/r*_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per
     the gfx950 note of MI355X_MICROARCH.md, made by tools/hbm_traffic.py which stamps the git commit it measured);
     (None, None) if no profile is present."""
@@ -97,7 +97,8 @@ def cnn_traffic():
         try:
             with open(path) as f:
                 j = json.load(f)
-            return int(j["kernels"]["conv_igemm_kernel"]["hbm_bytes"]), \
+            conv = [v["hbm_bytes"] for k, v in j["kernels"].items() if k in ("conv_igemm_kernel", "conv_halo_kernel", "conv_fixup_kernel")]
+            return int(sum(conv)), \
                 "%s (commit %s)" % (os.path.relpath(path, ROOT), j.get("git_commit", "not recorded: round-1 profile"))
         except Exception:
             continue
@@ -359,16 +360,16 @@ def main():
         "repeats": {"ms_per_step": [round(r / args.steps * 1e3, 4) for r in [elapsed] + repeats],
                     "median_ms_per_step": round(float(np.median([elapsed] + repeats)) / args.steps * 1e3, 4),
                     "note": "region 0 is the contract region `value` / `ms_per_step` are computed from"},
-        "roofline": {"kernel": "conv_igemm_kernel (18 launches per forward, %s MFMA implicit GEMM)" % ("bf16" if bf16 else "fp32"),
+        "roofline": {"kernel": "conv_halo_kernel + conv_igemm_kernel (the 3x3 / 4x4 conv launches of one forward, %s MFMA implicit GEMM)" % ("bf16" if bf16 else "fp32"),
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4), "traffic": traffic,
                      "traffic_note": None if traffic is None else
-                     "HBM bytes per frame of the 18 conv launches, %s (separate --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                     "HBM bytes per frame of the conv launches, %s (separate --pmc FETCH_SIZE / WRITE_SIZE passes, "
                      "gfx950 FETCH correction)" % traffic_src,
                      "launches_per_frame": 18, "algorithmic_flops_per_launch_set": flops * nb,
                      "ms_per_forward": round(cnn_ms_timed, 4),
                      "timed": "HIP events around msi_net_plan_forward on the launch stream INSIDE the timed region, mean of "
-                              "%d forwards (18 conv + 16 ln_apply launches: conservative for the conv kernel alone)" % max(len(cnn_ms), 1)},
+                              "%d forwards (conv launches + the remaining ln_apply launches: conservative for the conv kernels alone)" % max(len(cnn_ms), 1)},
         "stages": stages,
     }
 

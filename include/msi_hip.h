@@ -286,11 +286,17 @@ typedef struct msi_net_plan msi_net_plan;
 #define MSI_NET_OPT_APPLY_AHEAD 7   /* 1: a layer's LayerNorm + ReLU is applied by the first workgroups of its consumer's launch,    */
                                    /* overlapped with that layer's tiles (row counters); 0 (default): one ln_apply launch per layer */
                                    /* -- bit-identical results; measured slower on MI355X (write-through hand-off), see DESIGN.md  */
-#define MSI_NET_OPT_COUNT 8
+#define MSI_NET_OPT_HALO 8          /* 1 (default): stride-1 3x3 fp32 layers run conv_halo_kernel (one LDS-stationary halo patch per */
+                                   /* workgroup and input chunk; the producer's LayerNorm applied while staging it); 0: tap-DMA kernel */
+#define MSI_NET_OPT_COUNT 9
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
 int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);
 size_t msi_net_plan_workspace_bytes(const msi_net_plan *plan);
+/* After a forward, does workspace[raw_offset of `layer`] hold the layer's LayerNorm + ReLU'd activation (1) or its raw
+ * convolution output (0: every consumer applies the LayerNorm itself while loading -- the head, halo-patch layers)?
+ * -1: bad arguments.  (Tests / debugging; the frame loop does not need it.) */
+int32_t msi_net_plan_layer_is_normalized(const msi_net_plan *plan, int32_t layer);
 /* net_input [B,H,W,in_channels] (fp32, or bf16 when desc.dtype = MSI_DTYPE_BF16) -> pred [B,H,W,num_outputs] fp32. */
 int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
                          void *workspace, size_t workspace_bytes, msi_stream_t stream);

@@ -28,7 +28,7 @@ class NetDesc(Structure):
 MSI_DTYPE_F32, MSI_DTYPE_BF16 = 0, 1
 # msi_net_plan_set_option keys (include/msi_hip.h)
 NET_OPT_FIXUP_KERNEL, NET_OPT_TAILSPLIT, NET_OPT_BIGTILE, NET_OPT_HEAD_FUSE_LN, NET_OPT_NUM_CUS = 0, 1, 2, 3, 4
-NET_OPT_F32_TILE, NET_OPT_F32_TILE_MASK, NET_OPT_APPLY_AHEAD = 5, 6, 7
+NET_OPT_F32_TILE, NET_OPT_F32_TILE_MASK, NET_OPT_APPLY_AHEAD, NET_OPT_HALO = 5, 6, 7, 8
 
 
 class LayerInfo(Structure):
@@ -79,6 +79,7 @@ SIGNATURES = {
     "msi_net_plan_destroy": (None, [_P]),
     "msi_net_plan_set_option": (_I, [_P, _I, _I]),
     "msi_net_plan_workspace_bytes": (c_size_t, [_P]),
+    "msi_net_plan_layer_is_normalized": (_I, [_P, _I]),
     "msi_net_plan_forward": (_I, [_P, _P, _P, _P, _P, c_size_t, _P]),
     "msi_net_plan_forward_rgba": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "msi_net_forward_f32": (_I, [POINTER(NetDesc), _P, _P, _P, _P, c_size_t, _P]),

@@ -109,6 +109,8 @@ struct ConvParams {
   int ntaps, cpt0, cpt1, ksteps;  // taps, 32-channel chunks per tap of each source, total k-steps
   int stride, rate, pad_t, pad_l;
   int mode, wrap, nclass;
+  int halo_tx;               // halo-patch layers (conv_halo_kernel): spatial 4 x 16 tiles, halo_tx = W / 16 tiles per row;
+  unsigned mg_htx;           // 0 = the M tiles are 64 consecutive pixels (conv_igemm_kernel)
   // "apply-ahead": the first n_apply workgroups of the launch normalise source 0 (LayerNorm + ReLU of the producer layer)
   // while the tile workgroups behind them already compute; see apply_ahead() below.  n_apply = 0: source 0 is
   // normalised already (separate ln_apply launch, or the network input).
@@ -301,7 +303,12 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
   float s1 = 0.f, s2 = 0.f, cnt = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = tile_m * BM + wm * (MT * 32) + i * 32 + (lane & 31);
+    int m = tile_m * BM + wm * (MT * 32) + i * 32 + (lane & 31);
+    if (MODE == MODE_CONV && p.halo_tx) {   // 4 x 16 spatial tile: local pixel = 16 * row + column
+      const int local = wm * 32 + (lane & 31);
+      const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
+      m = (tyi * 4 + (local >> 4)) * p.Mw + (tile_m - tyi * p.halo_tx) * 16 + (local & 15);
+    }
     const bool mok = INTERIOR || m < mtot;
     int mh = 0, mw = 0;
     if (MODE == MODE_CONVT || has_cb) {
@@ -958,6 +965,249 @@ _Pragma("unroll")                                                               
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// ---- halo-patch convolution (stride-1 3x3 layers, fp32) -------------------------------------------------------------
+// The tap-DMA kernel above fetches every input pixel nine times (once per tap) from L2 and needs its input normalised in
+// memory (the k-loop has no VALU slot for the producer's LayerNorm).  Here a workgroup owns a 4 x 16-pixel SPATIAL tile
+// and, per 32-channel chunk of the input, stages the (4 + 2r) x (16 + 2r) halo patch in LDS ONCE: through registers, so
+// that the producer's LayerNorm + ReLU is applied on the way -- 2 VALU per element against its 9 taps x 64 output
+// channels = 576 MACs (0.4 % of the MFMA time) -- and the nine taps are nine `ds_read` IMMEDIATE offsets into that patch
+// (one base address VGPR; pixel stride 144 bytes = 128 + 16 of padding: 16 consecutive pixels of a row cover all 64
+// banks exactly once, no swizzle).  The weights stream per tap through a 3-stage DMA ring as before.  A layer whose
+// every consumer is a halo layer is never normalised in memory: its ln_apply launch (an HBM round trip of the whole
+// activation) disappears.  k order: chunk-major, tap-minor (the packed blob stays tap-major: only the DMA's scalar
+// offset changes).  K-ranges of split tiles are cut at chunk boundaries.
+template <int RATE>
+struct HaloGeom {
+  static constexpr int PW = 16 + 2 * RATE, PH = 4 + 2 * RATE, NPX = PW * PH;
+  static constexpr int PIX_BYTES = 144;
+  static constexpr int A_BYTES = (NPX * PIX_BYTES + 127) / 128 * 128;
+  static constexpr int B_STAGE = 64 * ROW_BYTES;          // one k-step of weights: 64 output rows x 128 B
+  static constexpr int NSTG = 3;                          // 9 taps per chunk = 3 x 3 stages: the stage of a tap is a literal
+  static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
+  static constexpr int NLOAD = (NPX * 8 + 255) / 256;     // float4 patch elements per thread and chunk
+};
+
+template <int RATE, int APPLY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RATE == 1 ? 4 : 3)))
+conv_halo_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef HaloGeom<RATE> G;
+  constexpr int R = RATE, PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
+  constexpr int MT = 1, NT = 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // ---- work decomposition: as conv_igemm_kernel (tail split), K-ranges in whole chunks ----
+  const int CH = p.cpt0;                                  // 32-channel chunks of the input
+  int t, c0 = 0, c1 = CH, ks = 0, slot = 0;
+  {
+    const int bid = blockIdx.x;
+    if (bid < p.nb_main && p.split0 == 1) {
+      const int q = p.n_main >> 3, r = p.n_main & 7, xcd = bid & 7, local = bid >> 3;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    } else {
+      int sp, r, tbase;
+      unsigned mg;
+      if (bid < p.nb_main) { sp = p.split0; mg = p.mg_sp0; r = bid; tbase = 0; }
+      else { sp = p.split; mg = p.mg_sp; r = bid - p.nb_main; tbase = p.n_main; }
+      const int tl = (int)udiv_magic((unsigned)r, (unsigned)sp, mg);
+      ks = r - tl * sp;
+      t = tbase + tl;
+      c0 = (int)udiv_magic((unsigned)(ks * CH), (unsigned)sp, mg);
+      c1 = (int)udiv_magic((unsigned)((ks + 1) * CH), (unsigned)sp, mg);
+      slot = bid - (p.split0 == 1 ? p.nb_main : 0);
+    }
+  }
+  const bool full = (c0 == 0) & (c1 == CH);
+  int tile_m, tile_n, b;
+  {
+    int r = t;
+    const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
+    tile_m = r - q1 * p.tiles_m; r = q1;
+    const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
+    tile_n = r - q2 * p.tiles_n;
+    b = q2;                                               // (nclass = 1)
+  }
+  const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
+  const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
+  const int H = p.Hin, W = p.Win, C = p.C0;
+
+  // ---- per-lane patch elements: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 (= tid % 8) ----
+  unsigned voff[NLOAD], lds_a[NLOAD];
+  bool pok[NLOAD];
+  const int cslot = tid & 7;
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const int pp = (tid + 256 * k) >> 3;
+    const int py = pp / PW, px = pp - py * PW;
+    const int ih = oh0 - R + py;
+    int iw = ow0 - R + px;
+    if (p.wrap) iw = iw < 0 ? iw + W : (iw >= W ? iw - W : iw);   // msi_train_net: wrap along W, zeros along H
+    pok[k] = pp < NPX && ih >= 0 && ih < H && iw >= 0 && iw < W;
+    voff[k] = pok[k] ? __umul24((unsigned)(ih * W + iw), (unsigned)(C * 4)) + (unsigned)(cslot * 16) : OOB;
+    lds_a[k] = pp < NPX ? (unsigned)(pp * G::PIX_BYTES + cslot * 16) : 0xffffffffu;
+  }
+  const size_t in_bytes = (size_t)H * W * C * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in_bytes), 0, (int)in_bytes, 0x00020000);
+  const int S = p.ksteps;                                 // 9 CH
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)S * p.npad * ROW_BYTES), 0x00020000);
+  const int drow = lane >> 3, dslot = lane & 7;
+  const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + drow) * ROW_BYTES + dslot * 16);
+
+  // producer's LayerNorm: mean / inv once per workgroup; the per-channel affine per chunk (the lane's four channels)
+  float inv_f = 1.f, mu_hi = 0.f, mu_lo = 0.f;
+  bool has_pad = false;                                   // wave-uniform: any of the wave's patch pixels is padding
+  if (APPLY) {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) bad |= (lds_a[k] != 0xffffffffu) && !pok[k];
+    has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
+  }
+  v4f araw[NLOAD], g4, be4;
+  // patch of chunk c -> registers (+ gamma / beta of the lane's channels)
+#define MSI_PATCH_LOAD(c)                                                                                              \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], (c) * ROW_BYTES, 0)); \
+    if (APPLY) {                                                                                                       \
+      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 32 + cslot * 4);                                          \
+      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 32 + cslot * 4);                                          \
+    }                                                                                                                  \
+  }
+  // registers -> LDS patch, the producer's affine + ReLU applied (ln_apply_kernel's expressions: same bits)
+#define MSI_PATCH_STORE()                                                                                              \
+  {                                                                                                                    \
+    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};                                                          \
+    if (APPLY) {   /* scale = inv * gamma; shift = beta - mean * scale with the mean as hi + lo floats: fp32 ops only */ \
+      s4 = inv_f * g4;                                                                                                 \
+      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};                          \
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
+      v4f y = araw[k_];                                                                                                \
+      if (APPLY) {                                                                                                     \
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
+        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */          \
+      }                                                                                                                \
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = y;                                    \
+    }                                                                                                                  \
+  }
+  // weights of k-step (chunk c, tap) -> ring stage st; the packed blob is tap-major: row block tap * CH + c
+#define MSI_B_ISSUE(c, tap, st)                                                                                        \
+  {                                                                                                                    \
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * ROW_BYTES;                                         \
+    const int soff_ = ((tap) * CH + (c)) * p.npad * ROW_BYTES;                                                         \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
+  }
+
+  // ---- MFMA side ----
+  const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
+  const unsigned a_base = lds_base + (unsigned)(((2 * wm + (frow >> 4)) * PW + (frow & 15)) * G::PIX_BYTES + fh * 64);
+  unsigned b_q[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    b_q[q] = lds_base + G::A_BYTES + (wn * 32 + frow) * ROW_BYTES + (((fh * 4 + q) ^ fswz) << 4);
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+
+  // one k-step = tap TAP of the current chunk, weights in ring stage TAP % 3; the DMA of the k-step two ahead is issued
+  // after the first MFMA quarter; before the closing barrier the NEXT k-step's weights must have landed: every VMEM
+  // operation issued before them (the next chunk's patch loads, issued in tap 0) completes first (in-order return)
+#define MSI_HTAP(TAP)                                                                                                  \
+  {                                                                                                                    \
+    constexpr int KH_ = (TAP) / 3, KW_ = (TAP) % 3, ST_ = (TAP) % 3;                                                   \
+    constexpr int AOFF_ = ((KH_ * R) * PW + KW_ * R) * G::PIX_BYTES;                                                   \
+    v4f a_[4], b_[4];                                                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
+      a_[q_] = q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 16>(a_base)                        \
+             : q_ == 2 ? lds_read128<AOFF_ + 32>(a_base) : lds_read128<AOFF_ + 48>(a_base);                            \
+      b_[q_] = lds_read128<ST_ * G::B_STAGE>(b_q[q_]);                                                                 \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
+      if (q_ == 0) wait_lgkm<6>(a_[0], b_[0]);                                                                         \
+      if (q_ == 1) wait_lgkm<4>(a_[1], b_[1]);                                                                         \
+      if (q_ == 2) wait_lgkm<2>(a_[2], b_[2]);                                                                         \
+      if (q_ == 3) wait_lgkm<0>(a_[3], b_[3]);                                                                         \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[0][0], 0, 0, 0);                        \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[0][0], 0, 0, 0);                        \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[0][0], 0, 0, 0);                        \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[0][0], 0, 0, 0);                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if (q_ == 0) {                                                                                                   \
+        if ((TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                            \
+        /* k-step two ahead: (c, TAP + 2) or (c + 1, TAP - 7) */                                                       \
+        if ((TAP) + 2 < 9) { MSI_B_ISSUE(c, (TAP) + 2, ((TAP) + 2) % 3) }                                              \
+        else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) - 7, ((TAP) + 2) % 3) }                                        \
+      }                                                                                                                \
+    }                                                                                                                  \
+    {                                                                                                                  \
+      const bool issued_ = ((TAP) + 2 < 9) || (c + 1 < c1);                                                            \
+      if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<2 + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight */ \
+      else if (issued_) wait_vmcnt<2>();                                                                               \
+      else wait_vmcnt<0>();                                                                                            \
+    }                                                                                                                  \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+  }
+
+  // ---- prologue: first patch, first two weight k-steps ----
+  int c = c0;
+  MSI_PATCH_LOAD(c0)
+  MSI_B_ISSUE(c0, 0, 0)
+  MSI_B_ISSUE(c0, 1, 1)
+  if (APPLY) {   // the sums' round trip rides on the patch's (s_stat sits in the A region: read back before the patch lands)
+    double *s_stat = reinterpret_cast<double *>(smem);
+    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * 4, p.ln_inv_n, s_stat, tid);
+    const double mu = s_stat[0];
+    inv_f = (float)s_stat[1];
+    mu_hi = (float)mu;
+    mu_lo = (float)(mu - (double)mu_hi);
+    __syncthreads();
+  }
+  wait_vmcnt<0>();
+  MSI_PATCH_STORE()
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; c < c1; ++c) {
+    MSI_HTAP(0) MSI_HTAP(1) MSI_HTAP(2) MSI_HTAP(3) MSI_HTAP(4) MSI_HTAP(5) MSI_HTAP(6) MSI_HTAP(7) MSI_HTAP(8)
+    if (c + 1 < c1) {   // every wave has read the last tap of this chunk (closing barrier of tap 8): swap the patch
+      MSI_PATCH_STORE()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+#undef MSI_HTAP
+#undef MSI_B_ISSUE
+#undef MSI_PATCH_STORE
+#undef MSI_PATCH_LOAD
+
+  // ---- epilogue: as conv_igemm_kernel ----
+  if (!full) {
+    constexpr int SLAB = 64 * 64 * 4;
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)slot * (64 * 64)), 0, SLAB, 0x00020000);
+    if (p.tile_cnt == nullptr) {
+      dump_acc<MT, NT, 0>(acc, rsrc_p, tid);
+      return;
+    }
+    dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
+    const int nsp = t < p.n_main ? p.split0 : p.split;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *s_old = reinterpret_cast<int *>(smem);
+    if (tid == 0)
+      *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_old != nsp - 1) return;
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
+    sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+  }
+  emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid);
+#endif
+}
+
 // Fix-up of the split tiles as a separate launch (plan option MSI_NET_OPT_FIXUP_KERNEL; the default is the in-launch
 // hand-off above): sums the K-range slabs of a tile in k order and runs the same epilogue.  One workgroup per split tile.
 template <int BM, int BN, int MODE>
@@ -1450,6 +1700,8 @@ struct LayerLaunch {
   int inlaunch;     // the split tiles are summed inside the conv launch (tickets) rather than by conv_fixup_kernel
   int fuse_ln;      // head: applies its source's LayerNorm while loading (the source is not normalised in memory)
   int skip_apply;   // this layer's output is consumed raw by the head, or normalised by its consumer's launch: no ln_apply launch
+  int halo;         // conv_halo_kernel instead of conv_igemm_kernel
+  int halo_apply;   // ... applying the producer's LayerNorm while staging the patch (the producer's buffer stays raw)
   unsigned ln_blocks;
 };
 
@@ -1466,7 +1718,7 @@ struct msi_net_plan {
 namespace {
 
 // Work decomposition of one layer ("tail split", see the kernel) for a BM x BN tile.
-void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tailsplit, int *nblocks, int *nfix) {
+void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tailsplit, int max_split, int *nblocks, int *nfix) {
   const int mtot = p.Mh * p.Mw;
   p.tiles_m = (mtot + BM - 1) / BM;
   p.tiles_n = (p.Cout + BN - 1) / BN;
@@ -1490,7 +1742,7 @@ void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tails
     const int remq = p.ntiles % Q;
     int best = 1;
     double best_cost = 1.0;   // time of the tail in tile-times: ceil(rem*s/Q)/s
-    for (int sp = 2; sp <= MAX_SPLIT; ++sp) {
+    for (int sp = 2; sp <= max_split; ++sp) {
       if ((long)remq * sp > 2L * num_cus * MAX_SPLIT) break;     // slab capacity of the workspace
       const double cost = (double)((remq * sp + Q - 1) / Q) / sp;
       if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
@@ -1502,7 +1754,7 @@ void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tails
       rem != 0 && p.ntiles > num_cus / 2 && p.ksteps >= 2 * MAX_SPLIT && tailsplit && !(tailsplit == 2 && p.ntiles >= Q)) {
     int best = 1;
     double best_cost = 1.0;   // time of the tail in tile-times: ceil(rem*s/CUs)/s
-    for (int sp = 2; sp <= MAX_SPLIT; ++sp) {
+    for (int sp = 2; sp <= max_split; ++sp) {
       const double cost = (double)((rem * sp + num_cus - 1) / num_cus) / sp;
       if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
     }
@@ -1510,7 +1762,7 @@ void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tails
     // One whole tile per CU next to four short K-ranges ends with that tile running alone (one wave per
     // SIMD, nothing to hide its barriers behind): such layers (CUs <= tiles < 2 CUs: the 40x80 ones) also cut
     // the first group in two.  Measured (r01): 2.750 -> 2.72 ms per frame, flat over 2..4 x 5..8.
-    if (p.n_main == num_cus && p.split > 1 && p.ksteps >= 4 * MAX_SPLIT) {
+    if (p.n_main == num_cus && p.split > 1 && p.ksteps >= 4 * MAX_SPLIT && max_split >= 2) {
       p.split0 = 2;
       p.split = p.split > 6 ? 6 : p.split;   // remainder ranges not much shorter than the halves
     }
@@ -1588,7 +1840,17 @@ int plan_layers(msi_net_plan *pl) {
       if (pl->opt[MSI_NET_OPT_F32_TILE] == 1) { Q.tile = TILE_128x64; BM = 128; BN = 64; }
       else if (pl->opt[MSI_NET_OPT_F32_TILE] == 2 && L.cout % 128 == 0) { Q.tile = TILE_64x128; BM = 64; BN = 128; }
     }
-    plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], &Q.nblocks, &Q.nfix);
+    // halo-patch kernel (conv_halo_kernel): stride-1 3x3 layers with one source, fp32, whole 4 x 16 tiles and 32-channel chunks
+    Q.halo = pl->opt[MSI_NET_OPT_HALO] && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && Q.tile == TILE_64x64 &&
+             L.kind == MODE_CONV && L.stride == 1 && L.src1 < 0 && L.in_h % 4 == 0 && L.in_w % 16 == 0 && L.c0 % 32 == 0 &&
+             (L.rate == 1 || L.rate == 2);
+    int max_split = MAX_SPLIT;
+    if (Q.halo) {
+      p.halo_tx = L.in_w / 16;
+      p.mg_htx = p.halo_tx == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)p.halo_tx);
+      if (L.cpt0 < max_split) max_split = L.cpt0;      // K-ranges are whole chunks
+    }
+    plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], max_split, &Q.nblocks, &Q.nfix);
     // apply-ahead (see apply_ahead): this launch also normalises its source 0
     if (pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.src0 >= 0 && L.kind != MODE_HEAD && L.c0 <= 512 && L.c0 % 4 == 0 &&
         ((long)L.in_w * L.c0) % 4 == 0) {
@@ -1611,6 +1873,26 @@ int plan_layers(msi_net_plan *pl) {
       size_t blocks = (per_sample / 4 + 255) / 256;
       if (blocks > 1024) blocks = 1024;  // grid-stride
       Q.ln_blocks = (unsigned)blocks;
+    }
+  }
+  // A layer whose EVERY consumer is a halo layer is never normalised in memory: its consumers apply its LayerNorm while
+  // staging their patches (a halo layer has one source, so its flag follows from that source alone)
+  for (int s = 0; s < MSI_NET_NUM_LAYERS - 1; ++s) {
+    int consumers = 0, halo_consumers = 0;
+    for (int li = s + 1; li < MSI_NET_NUM_LAYERS; ++li) {
+      const Layer &L = net.layers[li];
+      if (L.src0 == s || L.src1 == s) {
+        ++consumers;
+        if (pl->launch[li].halo) ++halo_consumers;
+      }
+    }
+    if (consumers > 0 && consumers == halo_consumers) {
+      pl->launch[s].skip_apply = 1;
+      for (int li = s + 1; li < MSI_NET_NUM_LAYERS; ++li)
+        if (net.layers[li].src0 == s) {
+          pl->launch[li].halo_apply = 1;
+          pl->launch[li].p.ln_inv_n = 1.0 / net.layers[s].ln_count;
+        }
     }
   }
   return MSI_OK;
@@ -1843,6 +2125,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_HEAD_FUSE_LN] = 1;
   pl->opt[MSI_NET_OPT_NUM_CUS] = pl->num_cus;
   pl->opt[MSI_NET_OPT_APPLY_AHEAD] = 0;   // measured r02_h: correct and bit-identical, but 2.69 vs 2.56 ms per network
+  pl->opt[MSI_NET_OPT_HALO] = 1;
   pl->opt[MSI_NET_OPT_F32_TILE] = 0;
   pl->opt[MSI_NET_OPT_F32_TILE_MASK] = 0;
   int rc = plan_layers(pl);
@@ -1873,6 +2156,11 @@ int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value) {
 }
 
 size_t msi_net_plan_workspace_bytes(const msi_net_plan *plan) { return plan ? plan->net.ws_bytes : 0; }
+
+int32_t msi_net_plan_layer_is_normalized(const msi_net_plan *plan, int32_t layer) {
+  if (!plan || layer < 0 || layer >= MSI_NET_NUM_LAYERS - 1) return -1;
+  return plan->launch[layer].skip_apply ? 0 : 1;
+}
 
 static int run_layers(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
                       void *workspace, size_t workspace_bytes, msi_stream_t stream_, int nlayers);
@@ -2001,6 +2289,27 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
     p.dbg = (li == g_timing_layer) ? g_timing_buf : nullptr;
 #endif
     int rc;
+    if (Q.halo) {
+      if (Q.halo_apply) {
+        const Layer &S = net.layers[L.src0];
+        p.ln_sums = reinterpret_cast<const long long *>(ws + S.sums_off);
+        p.ln_gamma = packed + S.gamma_off;
+        p.ln_beta = packed + S.beta_off;
+      }
+      const dim3 grid(Q.nblocks), block(256);
+      if (L.rate == 1) {
+        if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_kernel<1, 1>), grid, block, HaloGeom<1>::LDS_BYTES, stream, p);
+        else hipLaunchKernelGGL((conv_halo_kernel<1, 0>), grid, block, HaloGeom<1>::LDS_BYTES, stream, p);
+      } else {
+        if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_kernel<2, 1>), grid, block, HaloGeom<2>::LDS_BYTES, stream, p);
+        else hipLaunchKernelGGL((conv_halo_kernel<2, 0>), grid, block, HaloGeom<2>::LDS_BYTES, stream, p);
+      }
+      rc = msi::check_launch("conv_halo");
+      if (!rc && Q.nfix > 0 && p.tile_cnt == nullptr) {
+        hipLaunchKernelGGL((conv_fixup_kernel<64, 64, MODE_CONV>), dim3(Q.nfix), dim3(256), 0, stream, p);
+        rc = msi::check_launch("conv_fixup");
+      }
+    } else
     switch (Q.tile) {
       case TILE_128x128: rc = launch_conv<128, 128>(Q, p, bf16, stream); break;
       case TILE_128x64: rc = launch_conv<128, 64>(Q, p, bf16, stream); break;

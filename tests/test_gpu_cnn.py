@@ -32,13 +32,18 @@ def _run(env, b, h, w, cin, nout, ngf, coord, seed=0, options=None):
     torch.cuda.synchronize()
     ref, acts = onets.forward(weights, x, coord_net=coord, return_activations=True)
     desc, _, ws = m._net(b, h, w, cin, nout, ngf)
+    plan = m._plan(b, h, w, cin, nout, ngf)
     raws = {}
-    for info in nets.layer_infos(desc):
+    for li, info in enumerate(nets.layer_infos(desc)):
         if info.kind == nets.KIND_HEAD:
             continue
         n = b * info.out_h * info.out_w * info.cout
         raw = ws[info.raw_offset:info.raw_offset + 4 * n].view(torch.float32).reshape(b, info.out_h, info.out_w, info.cout)
-        raws[info.name.decode()] = raw.cpu().numpy()
+        name = info.name.decode()
+        raws[name] = raw.cpu().numpy()
+        # a layer whose every consumer applies its LayerNorm while loading (the head, halo-patch layers) stays RAW in memory
+        if N.lib.msi_net_plan_layer_is_normalized(plan.handle, li) == 0:
+            acts[name] = acts[name + "/raw"]
     return pred.cpu().numpy(), ref, raws, acts
 
 
@@ -47,7 +52,7 @@ def _run(env, b, h, w, cin, nout, ngf, coord, seed=0, options=None):
 def test_net_matches_oracle(env, coord, b, h, w, cin, nout, ngf):
     pred, ref, raws, acts = _run(env, b, h, w, cin, nout, ngf, coord)
     for name, raw in raws.items():
-        o = acts[name + "/raw"] if name == "conv8_2" and _HEAD_FUSED else acts[name]   # the head applies conv8_2's LayerNorm itself
+        o = acts[name]          # (acts[name] is the raw output where the plan leaves the buffer raw, see _run)
         assert raw.shape == o.shape, name
         scale = np.abs(o).max() + 1e-12
         err = np.abs(raw - o).max() / scale
@@ -61,7 +66,7 @@ def test_net_reference_width_channels(env):
     the two-source skip concat at 1024/512/256 channels and Cout=512 layers."""
     pred, ref, raws, acts = _run(env, 1, 16, 32, 48, 16, 64, True, seed=5)
     for name, raw in raws.items():
-        o = acts[name + "/raw"] if name == "conv8_2" and _HEAD_FUSED else acts[name]
+        o = acts[name]
         err = np.abs(raw - o).max() / (np.abs(o).max() + 1e-12)
         assert err < 2e-4, "%s: relative max err %g" % (name, err)
     assert np.abs(pred - ref).max() <= 1e-3
@@ -101,6 +106,7 @@ def test_layernorm_affine_matches_fp64_statistics(env):
         x = np.random.RandomState(2).uniform(-1, 1, size=(b, h, w, cin)).astype(np.float32)
         m = MSI(weights=weights, coord_net=coord)
         m.net_options[N.NET_OPT_HEAD_FUSE_LN] = 0
+        m.net_options[N.NET_OPT_HALO] = 0           # (every layer normalised by its own ln_apply launch, which publishes the affine)
         m.run_net(torch.from_numpy(x).cuda(), nout, ngf)
         torch.cuda.synchronize()
         _, acts = onets.forward(weights, x, coord_net=coord, return_activations=True)
@@ -166,6 +172,7 @@ def test_apply_ahead_equals_separate_layernorm_launches(env, dtype, coord, b, h,
     for ahead in (1, 0):
         m = MSI(weights=weights, coord_net=coord, dtype=dtype)
         m.net_options[N.NET_OPT_APPLY_AHEAD] = ahead
+        m.net_options[N.NET_OPT_HALO] = 0           # (same buffers raw / normalised on both sides)
         pred = m.run_net(x, nout, ngf)
         for _ in range(5):
             assert torch.equal(m.run_net(x, nout, ngf), pred)
@@ -210,3 +217,32 @@ def test_fused_head_assembly_is_bit_identical(env, coord, b, h, w, d, ngf):
     N.check(N.lib.msi_net_plan_forward_rgba(plan.handle, packed.data_ptr(), x.data_ptr(), rgba.data_ptr(), 0, 0, p2.data_ptr(),
                                             ws.data_ptr(), ws.numel(), None, None), "forward_rgba")
     assert torch.equal(p2, pred)
+
+
+@pytest.mark.parametrize("coord,b,h,w,cin,nout,ngf", [(True, 1, 160, 320, 96, 32, 64), (False, 2, 32, 64, 32, 8, 32),
+                                                     (True, 2, 16, 48, 64, 16, 32), (True, 1, 320, 640, 192, 64, 64)])
+def test_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, w, cin, nout, ngf):
+    """conv_halo_kernel (plan option HALO, default on: stride-1 3x3 fp32 layers stage one LDS-stationary halo patch per
+    input chunk and apply the producer's LayerNorm on the way) against the tap-DMA kernel: same products, chunk-major
+    instead of tap-major summation order -> equal to fp32 round-off; bitwise deterministic; K-ranges at chunk boundaries
+    (the first and last shapes split tiles); SAME-zero and wrap padding; rate-2 layers."""
+    torch, MSI, nets, N, onets = env
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=29, randomize_affine=True)
+    x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
+    halo = MSI(weights=weights, coord_net=coord)
+    tap = MSI(weights=weights, coord_net=coord)
+    tap.net_options[N.NET_OPT_HALO] = 0
+    p1, p0 = halo.run_net(x, nout, ngf), tap.run_net(x, nout, ngf)
+    plan = halo._plan(b, h, w, cin, nout, ngf)
+    raw_layers = [i for i in range(17) if N.lib.msi_net_plan_layer_is_normalized(plan.handle, i) == 0]
+    if h % 32 == 0 and w % 128 == 0:                 # every level tiles into 4 x 16 patches:
+        assert len(raw_layers) >= 8, raw_layers      # conv3_1, conv4_1/2, conv6_1/2, conv7_1, conv8_1 (+ conv8_2: head)
+    assert float((p1 - p0).abs().max()) <= 2e-5
+    for _ in range(5):
+        assert torch.equal(halo.run_net(x, nout, ngf), p1)
+    fix = MSI(weights=weights, coord_net=coord)
+    fix.net_options[N.NET_OPT_FIXUP_KERNEL] = 1
+    assert torch.equal(fix.run_net(x, nout, ngf), p1)
+    if h * w <= 160 * 320:
+        ref = onets.forward(weights, x.cpu().numpy(), coord_net=coord)
+        assert np.abs(p1.cpu().numpy() - ref).max() <= 1e-3
