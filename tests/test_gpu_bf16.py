@@ -174,3 +174,33 @@ def test_bf16_every_layer_tracks_the_bf16_oracle(env):
         assert mx <= gmx and mn <= gmn, (name, mx, mn, gmx, gmn)
     e = np.abs(pred - ref)
     assert e.max() <= 4e-2 and e.mean() <= 2e-3, (e.max(), e.mean())
+
+
+@pytest.mark.parametrize("coord,b,h,w,cin,nout,ngf", [(True, 1, 160, 320, 192, 64, 64), (False, 2, 64, 128, 64, 16, 64),
+                                                     (True, 2, 32, 64, 128, 32, 32)])
+def test_bf16_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, w, cin, nout, ngf):
+    """conv_halo_bf16_kernel (plan option HALO, default on: the stride-1 3x3 layers with 64-channel chunks stage one
+    LDS-stationary halo patch per chunk -- from the bf16 operand copy, or from the producer's raw fp32 output with its
+    LayerNorm + ReLU + bf16 rounding applied on the way) against the tap-DMA bf16 kernel: identical bf16 operands up to
+    isolated rounding flips of an activation, fp32 accumulation in a different order; bitwise deterministic."""
+    torch, MSI, nets, onets, _ = env
+    from matryodshka_amd import _native as N
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=41, randomize_affine=True)
+    x = onets.bf16_round(np.random.RandomState(6).uniform(-1, 1, size=(b, h, w, cin)).astype(np.float32))
+    xg = torch.from_numpy(x).cuda().bfloat16()
+    halo = MSI(weights=weights, coord_net=coord, dtype="bf16")
+    tap = MSI(weights=weights, coord_net=coord, dtype="bf16")
+    tap.net_options[N.NET_OPT_HALO] = 0
+    p1, p0 = halo.run_net(xg, nout, ngf), tap.run_net(xg, nout, ngf)
+    plan = halo._plan(b, h, w, cin, nout, ngf)
+    raw_layers = [i for i in range(17) if N.lib.msi_net_plan_layer_is_normalized(plan.handle, i) == 0]
+    if ngf == 64 and h % 64 == 0:
+        assert len(raw_layers) >= 4, raw_layers       # producers whose every consumer is a 128x128 halo layer
+    d = (p1 - p0).abs()
+    assert float(d.max()) <= 4e-2 and float(d.mean()) <= 3e-3, (float(d.max()), float(d.mean()))   # (as big tile vs small tile)
+    for _ in range(3):
+        assert torch.equal(halo.run_net(xg, nout, ngf), p1)
+    if h * w <= 64 * 128:
+        ref = onets.forward(weights, x, coord_net=coord, bf16=True)
+        e = np.abs(p1.cpu().numpy() - ref)
+        assert e.max() <= 4e-2 and e.mean() <= 3e-3, (e.max(), e.mean())
