@@ -6,6 +6,8 @@ the bytes of wide coalesced reads on gfx950 and is doubled here).
 
     python tools/hbm_traffic.py fetch_results.db write_results.db FRAMES [GIT_COMMIT] > profiles/rNN_hbm_traffic.json
 
+FRAMES = 0: counted from the render_kernel launches (one per frame).
+
 GIT_COMMIT: the commit the measured library was built from (bench.py prints it next to `roofline.traffic`, so a
 stale profile is visible); the GPU box has no .git, pass `git rev-parse --short HEAD` from the build container.
 """
@@ -34,6 +36,9 @@ def main():
     commit = sys.argv[4] if len(sys.argv) > 4 else "unknown"
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
+    if frames == 0:   # one render_kernel launch per frame (rgb + depth in one pass)
+        frames = f["render_kernel"][0]
+        assert frames == w["render_kernel"][0], "the two passes ran different frame counts"
     kernels = {}
     for k in sorted(set(f) | set(w)):
         n = f.get(k, w.get(k))[0]
@@ -42,7 +47,7 @@ def main():
         kernels[k] = {"launches_per_frame": round(n / frames, 2), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
                       "hbm_bytes": int(rd + wr)}
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes with --kernel-trace only, over "
-                       "`python bench.py --steps 3 --warmup 1 --repeats 0 --no-cpu-baseline` (%d frames, 640x320, 32 spheres, B=1). "
+                       "`python bench.py --steps 3 --warmup 1 --repeats 0 --prewarm 0 --no-cpu-baseline` (%d frames, 640x320, 32 spheres, B=1). "
                        "Counters are KB; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md (calibration: "
                        "assemble_kernel reads 209.7 MB algorithmic, ln_apply_kernel 367 MB)." % frames,
                "git_commit": commit, "kernels": kernels}, sys.stdout, indent=1)
