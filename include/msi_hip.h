@@ -303,13 +303,16 @@ int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const vo
 
 /* The network followed by infer_msi's layer_prediction for which_color_pred = blend_psv (msi.py:130-147) with the
  * 1x1 head, its source's LayerNorm and the RGBA assembly fused into ONE kernel: `pred` never exists in HBM.
- * net_input [B,H,W,6D] fp32 is both the network input and the sweep volume the layers are blended from;
- * rgba_native [B,D,H,W,4]; blend_weights / alphas [B,H,W,D] and pred [B,H,W,2D] (the tanh output) are optional (NULL).
- * Results are bit-identical to msi_net_plan_forward + msi_assemble_rgba_f32.  event_after_convs: optional
- * hipEvent_t recorded on `stream` between the last convolution and the fused tail (bench.py times the MFMA-bound and
- * the HBM-bound part separately).  MSI_E_UNSUPPORTED for bf16 plans / other colour schemes / ngf > 64 / D > 64 /
- * HEAD_FUSE_LN = 0: use msi_net_plan_forward + msi_assemble_rgba_color_f32 there. */
-int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, const float *net_input, float *rgba_native,
+ * net_input [B,H,W,6D] (fp32, or bf16 for a bf16 plan) is both the network input and the sweep volume the layers are
+ * blended from; rgba_native [B,D,H,W,4] fp32; blend_weights / alphas [B,H,W,D] and pred [B,H,W,2D] (the tanh output)
+ * are optional (NULL).  fp32 plans: bit-identical to msi_net_plan_forward + msi_assemble_rgba_f32.  bf16 plans: the
+ * head runs on the fp32 MFMA over the same bf16-rounded operands (activation rounded where ln_apply rounds it, weights
+ * rounded at pack time), so it equals the two-step bf16 path up to the fp32 summation order; conv8_2 then has no
+ * ln_apply launch and no bf16 copy.  event_after_convs: optional hipEvent_t recorded on `stream` between the last
+ * convolution and the fused tail (bench.py times the MFMA-bound and the HBM-bound part separately).
+ * MSI_E_UNSUPPORTED for other colour schemes / ngf > 64 / D > 64 / HEAD_FUSE_LN = 0: use msi_net_plan_forward +
+ * msi_assemble_rgba_color_f32 there. */
+int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, const void *net_input, float *rgba_native,
                               float *blend_weights, float *alphas, float *pred, void *workspace, size_t workspace_bytes,
                               msi_stream_t stream, void *event_after_convs);
 

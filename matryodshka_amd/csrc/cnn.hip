@@ -1545,54 +1545,83 @@ conv_fixup_kernel(const ConvParams p) {
 // then bias + tanh + (x+1)/2 land in an LDS tile and the assembly of K3 (geometry.hip, same expressions, no
 // contraction) writes float4 texels of the D-major stack.  HBM-bound: reads C0 + 6D floats, writes 4D per pixel.
 constexpr int HA_TP = 32;   // pixels per workgroup
+constexpr int HA_LG = 32;   // at most this many layers per workgroup: D = 64 runs as two layer groups (grid.y)
 
 struct HeadAsmParams {
   const float *x;            // conv8_2 raw [B,H,W,C0]
   const float *wpk;          // packed head weights [ksteps][npad][32 floats] (slots swizzled by output row)
   const float *bias;
   const float *aff;          // affine of the source layer's LayerNorm [B][scale[C0] | shift[C0]] (ln_finish_kernel)
-  const float *psv;          // [B,H,W,6D]
+  const void *psv;           // [B,H,W,6D] fp32, or bf16 (BF16IN)
   float4 *rgba;              // [B,D,H,W] float4
   float *bw_out, *al_out;    // optional [B,H,W,D]
   float *pred_out;           // optional [B,H,W,2D] (tanh output)
   int C0, ksteps, npad, nd, hw;
+  int lg;                    // layers per workgroup: D / gridDim.y (a multiple of 4, <= HA_LG)
   long npix_total;
 };
 
-template <int NT>   // 64 * NT >= 2 D output channels: NT = 1 (D <= 32) or 2 (D <= 64)
+// A workgroup owns 32 pixels x lg layers (layer group g = blockIdx.y: blend weights g lg .. + lg, the alphas behind
+// them, and the foreground / background colours of those layers: two runs of 3 lg channels of the sweep volume).
+// Locally everything is a D = lg problem: output column n < lg is blend weight g lg + n, column lg + n its alpha.
+// D <= 32: one group (the whole row is one run).  D = 64: two groups; the 32 x C0 activations are read by both
+// (8 KB of 65 KB per workgroup), each keeps the 34 KB LDS footprint = four workgroups per CU (one 64-layer workgroup
+// needed 66 KB: two per CU, 1.6 TB/s).
+// BF16IN (bf16 plans): the sweep volume is bf16 (widened exactly on the way into LDS) and the normalised activation is
+// rounded to bf16 (round to nearest even, where ln_apply_kernel<1> rounds it) before it enters the fp32 MFMA with the
+// bf16-rounded weights: the operands of the bf16 head, exact products, fp32 accumulation.
+template <int BF16IN>
 __global__ void __launch_bounds__(256)
 head_assemble_kernel(const HeadAsmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BN = 64 * NT;
+  constexpr int BN = 64;                                        // >= 2 lg local output columns
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nd = p.nd, c_psv = 6 * nd, c_pred = 2 * nd;
-  const int s_psv = c_psv + 1, s_pred = c_pred + 1;             // odd row strides (see assemble_kernel)
+  const int nd = p.nd, lg = p.lg, g = blockIdx.y;
+  const int c_psv = 6 * nd, c_pred = 2 * nd;                    // global row lengths
+  const int l_cpsv = 6 * lg, l_cpred = 2 * lg;                  // local ones
+  const int s_psv = l_cpsv + 1, s_pred = l_cpred + 1;           // odd row strides (see assemble_kernel)
   // LDS: [affine 2 C0 | stat | R | pred tile]; R holds A (ksteps x 32 rows) | B (ksteps x BN rows) during the GEMM and
-  // the sweep-volume tile afterwards (33.6 KB per workgroup at D = 32: four workgroups per CU, like assemble_kernel)
+  // the sweep-volume tile afterwards (33.6 KB per workgroup at lg = 32: four workgroups per CU, like assemble_kernel)
   float *s_aff = reinterpret_cast<float *>(smem);
-  double *s_stat = reinterpret_cast<double *>(smem + 2 * 64 * 4);
   char *sR = smem + 2 * 64 * 4 + 64;
   char *sA = sR;
   char *sB = sA + p.ksteps * HA_TP * ROW_BYTES;
   const size_t r_bytes = max((size_t)p.ksteps * (HA_TP + BN) * ROW_BYTES, (size_t)HA_TP * s_psv * sizeof(float));
   float *l_psv = reinterpret_cast<float *>(sR);
   float *l_pred = reinterpret_cast<float *>(sR + ((r_bytes + 15) & ~(size_t)15));
+  // local output column -> global one (in float4 groups: lg % 4 == 0)
+  auto gcol = [&](int n) __attribute__((always_inline)) -> int { return n < lg ? g * lg + n : nd + g * lg + (n - lg); };
 
   const long p0 = (long)blockIdx.x * HA_TP;
   const int b = (int)(p0 / p.hw);                               // (H * W is a multiple of 32: a tile never straddles samples)
   // 1. every global load of the workgroup goes out first and is parked in registers: the sweep-volume tile, the raw
   //    activations (C0 <= 64: at most two float4 per thread), the weight rows -- ONE memory round trip per workgroup
-  constexpr int PSV_PER_THREAD = 6 * NT;                        // 32 x 6 D floats / 4 / 256 threads, D <= 32 NT
-  constexpr int B_PER_THREAD = 4 * NT;                          // ksteps (<= 2) x BN rows x 8 float4 / 256
-  const int nv_psv = HA_TP * c_psv / 4;
+  constexpr int PSV_PER_THREAD = BF16IN ? 3 : 6;                // 32 x 6 lg elements in 16-byte vectors / 256 threads, lg <= 32
+  constexpr int B_PER_THREAD = 4;                               // ksteps (<= 2) x BN rows x 8 float4 / 256
+  constexpr int PSV_VEC = BF16IN ? 8 : 4;                       // elements per 16-byte vector
+  constexpr int ESZ = BF16IN ? 2 : 4;
+  // runs of the global row this group needs: the whole row (one group), or its foreground and background colours
+  const int nrun = gridDim.y == 1 ? 1 : 2;
+  const int run_len = gridDim.y == 1 ? c_psv : 3 * lg;          // elements; a multiple of PSV_VEC (host-checked)
+  const int vpr = run_len / PSV_VEC, vpp = nrun * vpr;          // vectors per run / per pixel
+  const int nv_psv = HA_TP * vpp;
   float4 q[PSV_PER_THREAD];
   {
-    const float4 *g = reinterpret_cast<const float4 *>(p.psv + p0 * c_psv);
+    const char *gp = static_cast<const char *>(p.psv) + (size_t)p0 * c_psv * ESZ;
 #pragma unroll
     for (int k = 0; k < PSV_PER_THREAD; ++k) {
       const int v = tid + 256 * k;
-      if (v < nv_psv) q[k] = g[v];
+      if (v < nv_psv) {
+        if (gridDim.y == 1) {   // the whole tile is contiguous: no index arithmetic in front of the loads
+          q[k] = reinterpret_cast<const float4 *>(gp)[v];
+        } else {
+          const int px = v / vpp, w = v - px * vpp;
+          const int r = w >= vpr ? 1 : 0, idx = w - r * vpr;
+          const int start = r == 0 ? 3 * g * lg : 3 * (nd + g * lg);
+          q[k] = *reinterpret_cast<const float4 *>(gp + ((size_t)px * c_psv + start + idx * PSV_VEC) * ESZ);
+        }
+      }
     }
   }
   const int nchunk = p.ksteps * 8;                              // 16-byte chunks per pixel (zero beyond C0)
@@ -1611,16 +1640,17 @@ head_assemble_kernel(const HeadAsmParams p) {
     const int e = tid + 256 * k;
     const int row = e >> 3, j = e & 7;
     const int ks = row / BN, n = row - ks * BN;
-    if (e < nb) braw[k] = *reinterpret_cast<const v4f *>(p.wpk + ((size_t)ks * p.npad + n) * (ROW_BYTES / 4) + j * 4);
+    braw[k] = v4f{0.f, 0.f, 0.f, 0.f};                          // local rows >= 2 lg: zero
+    if (e < nb && n < l_cpred)   // (the slot swizzle of a packed row depends on (row >> 1) & 7: lg % 16 == 0 or one group -- host-checked)
+      braw[k] = *reinterpret_cast<const v4f *>(p.wpk + ((size_t)ks * p.npad + gcol(n)) * (ROW_BYTES / 4) + j * 4);
   }
   // 2. affine of the source's LayerNorm (precomputed once per forward by ln_finish_kernel: 6 400 workgroups deriving it
   //    from the sums themselves put two more dependent round trips on every workgroup's critical path)
-  (void)s_stat;
   if (tid < 2 * p.C0) s_aff[tid] = p.aff[(size_t)b * 2 * p.C0 + tid];
   __syncthreads();
   // 3. A: 32 pixels x (ksteps * 32) channels, LayerNorm + ReLU applied (the stand-alone head's expression), zero beyond
-  //    C0; the 16-byte slot s of row r holds data chunk s ^ ((r >> 1) & 7) (the conv kernel's LDS image).  B: rows
-  //    [0, BN) of every k-step of the packed blob as they are (pre-swizzled; rows >= Cout are zero)
+  //    C0; the 16-byte slot s of row r holds data chunk s ^ ((r >> 1) & 7) (the conv kernel's LDS image).  B: the group's
+  //    rows of every k-step of the packed blob as they are (pre-swizzled by their GLOBAL row)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int e = tid + 256 * k;
@@ -1632,6 +1662,13 @@ head_assemble_kernel(const HeadAsmParams p) {
         const v4f s4 = *reinterpret_cast<const v4f *>(s_aff + c), t4 = *reinterpret_cast<const v4f *>(s_aff + p.C0 + c);
         y.x = fmaxf(araw[k].x * s4.x + t4.x, 0.f); y.y = fmaxf(araw[k].y * s4.y + t4.y, 0.f);
         y.z = fmaxf(araw[k].z * s4.z + t4.z, 0.f); y.w = fmaxf(araw[k].w * s4.w + t4.w, 0.f);
+        if (BF16IN) {
+          auto rne = [](float f) __attribute__((always_inline)) -> float {
+            const unsigned u = __builtin_bit_cast(unsigned, f);
+            return __builtin_bit_cast(float, (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+          };
+          y.x = rne(y.x); y.y = rne(y.y); y.z = rne(y.z); y.w = rne(y.w);
+        }
       }
       const int ks = ch >> 3, chunk = ch & 7;
       *reinterpret_cast<v4f *>(sA + (ks * HA_TP + r) * ROW_BYTES + ((chunk ^ ((r >> 1) & 7)) << 4)) = y;
@@ -1643,19 +1680,20 @@ head_assemble_kernel(const HeadAsmParams p) {
     if (e < nb) *reinterpret_cast<v4f *>(sB + (e >> 3) * ROW_BYTES + ((e & 7) << 4)) = braw[k];
   }
   __syncthreads();
-  // 4. the GEMM: wave w owns output channels [32 w, 32 w + 32) of the 32 pixels; 5. bias + tanh (-> optional pred),
+  // 4. the GEMM: wave w owns local output columns [32 w, 32 w + 32) of the 32 pixels; 5. bias + tanh (-> optional pred),
   //    (x + 1) / 2 (msi.py:132-133) -> LDS tile (+ the optional [B,H,W,D] outputs)
-  if (wave < 2 * NT) {
+  if (wave < 2) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int fswz_a = (frow >> 1) & 7;
+    const int fswz_b = (gcol(wave * 32 + frow < l_cpred ? wave * 32 + frow : 0) >> 1) & 7;   // B rows keep the swizzle of their global row
     for (int ks = 0; ks < p.ksteps; ++ks) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        const int slot = ((fh * 4 + qq) ^ fswz) << 4;
-        const v4f a = *reinterpret_cast<const v4f *>(sA + (ks * HA_TP + frow) * ROW_BYTES + slot);
-        const v4f w = *reinterpret_cast<const v4f *>(sB + (ks * BN + wave * 32 + frow) * ROW_BYTES + slot);
+        const v4f a = *reinterpret_cast<const v4f *>(sA + (ks * HA_TP + frow) * ROW_BYTES + (((fh * 4 + qq) ^ fswz_a) << 4));
+        const v4f w = *reinterpret_cast<const v4f *>(sB + (ks * BN + wave * 32 + frow) * ROW_BYTES + (((fh * 4 + qq) ^ fswz_b) << 4));
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a.z, acc, 0, 0, 0);
@@ -1664,33 +1702,42 @@ head_assemble_kernel(const HeadAsmParams p) {
     }
     const int px = lane & 31, half = lane >> 5;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = wave * 32 + 8 * g + 4 * half;
-      if (n < c_pred) {                                         // 2 D is a multiple of 8: whole float4 in range
-        const v4f bs = *reinterpret_cast<const v4f *>(p.bias + n);
-        v4f t = {tanhf(acc[4 * g] + bs.x), tanhf(acc[4 * g + 1] + bs.y), tanhf(acc[4 * g + 2] + bs.z), tanhf(acc[4 * g + 3] + bs.w)};
-        if (p.pred_out) *reinterpret_cast<v4f *>(p.pred_out + (p0 + px) * c_pred + n) = t;
+    for (int gg = 0; gg < 4; ++gg) {
+      const int n = wave * 32 + 8 * gg + 4 * half;             // local column
+      if (n < l_cpred) {                                        // 2 lg is a multiple of 8: whole float4 in range
+        const int gn = gcol(n);
+        const v4f bs = *reinterpret_cast<const v4f *>(p.bias + gn);
+        v4f t = {tanhf(acc[4 * gg] + bs.x), tanhf(acc[4 * gg + 1] + bs.y), tanhf(acc[4 * gg + 2] + bs.z), tanhf(acc[4 * gg + 3] + bs.w)};
+        if (p.pred_out) *reinterpret_cast<v4f *>(p.pred_out + (p0 + px) * c_pred + gn) = t;
         t.x = (t.x + 1.0f) / 2.0f; t.y = (t.y + 1.0f) / 2.0f; t.z = (t.z + 1.0f) / 2.0f; t.w = (t.w + 1.0f) / 2.0f;
         float *dst = l_pred + px * s_pred + n;
         dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
-        if (n < nd) {
-          if (p.bw_out) *reinterpret_cast<v4f *>(p.bw_out + (p0 + px) * nd + n) = t;
+        if (n < lg) {
+          if (p.bw_out) *reinterpret_cast<v4f *>(p.bw_out + (p0 + px) * nd + gn) = t;
         } else {
-          if (p.al_out) *reinterpret_cast<v4f *>(p.al_out + (p0 + px) * nd + (n - nd)) = t;
+          if (p.al_out) *reinterpret_cast<v4f *>(p.al_out + (p0 + px) * nd + (gn - nd)) = t;
         }
       }
     }
   }
   __syncthreads();                                              // A | B have been read: the sweep-volume tile replaces them
-  // 6. the parked sweep-volume tile -> LDS, rows padded to an odd stride
+  // 6. the parked sweep-volume tile -> LDS: local row = [foreground run | background run], padded to an odd stride
 #pragma unroll
   for (int k = 0; k < PSV_PER_THREAD; ++k) {
     const int v = tid + 256 * k;
     if (v < nv_psv) {
-      const int e = v * 4;
-      const int row = e / c_psv, col = e - row * c_psv;         // c_psv % 4 == 0: no row straddle
-      float *dst = l_psv + row * s_psv + col;
-      dst[0] = q[k].x; dst[1] = q[k].y; dst[2] = q[k].z; dst[3] = q[k].w;
+      const int px = v / vpp, w = v - px * vpp;                 // (run r of the pixel starts at local column r * run_len)
+      float *dst = l_psv + px * s_psv + w * PSV_VEC;
+      if (BF16IN) {
+        const unsigned w0 = __builtin_bit_cast(unsigned, q[k].x), w1 = __builtin_bit_cast(unsigned, q[k].y);
+        const unsigned w2 = __builtin_bit_cast(unsigned, q[k].z), w3 = __builtin_bit_cast(unsigned, q[k].w);
+        dst[0] = __builtin_bit_cast(float, w0 << 16); dst[1] = __builtin_bit_cast(float, w0 & 0xffff0000u);
+        dst[2] = __builtin_bit_cast(float, w1 << 16); dst[3] = __builtin_bit_cast(float, w1 & 0xffff0000u);
+        dst[4] = __builtin_bit_cast(float, w2 << 16); dst[5] = __builtin_bit_cast(float, w2 & 0xffff0000u);
+        dst[6] = __builtin_bit_cast(float, w3 << 16); dst[7] = __builtin_bit_cast(float, w3 & 0xffff0000u);
+      } else {
+        dst[0] = q[k].x; dst[1] = q[k].y; dst[2] = q[k].z; dst[3] = q[k].w;
+      }
     }
   }
   __syncthreads();
@@ -1702,17 +1749,17 @@ head_assemble_kernel(const HeadAsmParams p) {
     const long off = pp - (long)b * p.hw;
     const float *rp = l_psv + px * s_psv;
     const float *rq = l_pred + px * s_pred;
-    for (int d = tid / HA_TP; d < nd; d += 256 / HA_TP) {
+    for (int d = tid / HA_TP; d < lg; d += 256 / HA_TP) {
       const float *fg = rp + d * 3;
-      const float *bg = rp + (nd + d) * 3;
+      const float *bg = rp + (lg + d) * 3;
       const float w = rq[d];
       const float omw = 1.0f - w;
       float4 o;
       o.x = w * fg[0] + omw * bg[0];
       o.y = w * fg[1] + omw * bg[1];
       o.z = w * fg[2] + omw * bg[2];
-      o.w = rq[nd + d];
-      p.rgba[((long)b * nd + d) * p.hw + off] = o;
+      o.w = rq[lg + d];
+      p.rgba[((long)b * nd + g * lg + d) * p.hw + off] = o;
     }
   }
 #endif
@@ -1830,6 +1877,10 @@ struct Net {
   size_t zero_off = 0, zero_bytes = 0;   // [tickets of the in-launch fix-up | LayerNorm sums]: one memset per forward
   size_t cnt_off = 0;   // arrival tickets: [layer][5 * num_cus] ints
   size_t err_off = 0;   // one int: a tile workgroup gave up waiting for apply-ahead rows (stays 0)
+  // bf16 plans: the head's weights (rounded to bf16) once more as fp32 rows, for the fused tail (head_assemble_kernel
+  // runs the 1x1 head on the fp32 MFMA: exact products of bf16 values, fp32 accumulate -- the bf16 head's arithmetic)
+  size_t head_f32_off = 0;
+  int head_f32_ksteps = 0, head_f32_npad = 0;
 };
 
 int build_net(const msi_net_desc *d, int num_cus, Net &net) {
@@ -1948,6 +1999,13 @@ int build_net(const msi_net_desc *d, int num_cus, Net &net) {
       L.raw_off = (size_t)-1;
       L.aff_off = (size_t)-1;
     }
+  }
+  if (bf16) {
+    const Layer &H = net.layers.back();
+    net.head_f32_ksteps = (H.c0 + 31) / 32;
+    net.head_f32_npad = (int)round_up(H.cout, 64);
+    net.head_f32_off = koff;
+    koff = round_up(koff + (size_t)net.head_f32_ksteps * net.head_f32_npad * (ROW_BYTES / 4), 64);
   }
   net.param_floats = poff;
   net.packed_floats = koff;
@@ -2426,6 +2484,24 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
         }
     }
   }
+  if (bf16) {   // fp32 rows of the bf16-rounded head weights (the fp32 kernels' LDS image: 32 channels per 128-byte row)
+    const Layer &H = net.layers.back();
+    const float *w = params + H.param_off;
+    for (int ks = 0; ks < net.head_f32_ksteps; ++ks)
+      for (int n = 0; n < H.cout; ++n) {
+        char *row = reinterpret_cast<char *>(packed + net.head_f32_off) + ((size_t)ks * net.head_f32_npad + n) * ROW_BYTES;
+        const int swz = (n >> 1) & 7;
+        for (int kk = 0; kk < 32; ++kk) {
+          const int c = ks * 32 + kk;
+          if (c >= H.c0) continue;
+          float v = w[(size_t)c * H.cout + n];
+          uint32_t u;
+          memcpy(&u, &v, 4);
+          u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+          memcpy(row + (((kk >> 2) ^ swz) << 4) + (kk & 3) * 4, &u, 4);
+        }
+      }
+  }
   return MSI_OK;
 }
 
@@ -2489,7 +2565,7 @@ int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const vo
   return run_layers(plan, packed, net_input, pred, workspace, workspace_bytes, stream_, MSI_NET_NUM_LAYERS);
 }
 
-int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, const float *net_input, float *rgba_native,
+int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, const void *net_input, float *rgba_native,
                               float *blend_weights, float *alphas, float *pred, void *workspace, size_t workspace_bytes,
                               msi_stream_t stream_, void *event_after_convs) {
   MSI_REQUIRE(plan, "net_forward_rgba: null plan");
@@ -2497,12 +2573,17 @@ int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, con
   const Net &net = plan->net;
   const Layer &H = net.layers[MSI_NET_NUM_LAYERS - 1];
   const int nd = desc->num_outputs / 2;
-  if (desc->dtype != MSI_DTYPE_F32 || !plan->launch[MSI_NET_NUM_LAYERS - 1].fuse_ln || H.c0 > 64 || H.c0 % 4 != 0 ||
-      desc->num_outputs != 2 * nd || nd % 4 != 0 || nd > 64 || desc->in_channels != 6 * nd ||
+  const int bf16 = desc->dtype == MSI_DTYPE_BF16;
+  if ((!bf16 && !plan->launch[MSI_NET_NUM_LAYERS - 1].fuse_ln) || (bf16 && !plan->opt[MSI_NET_OPT_HEAD_FUSE_LN]) ||
+      H.c0 > 64 || H.c0 % 4 != 0 || desc->num_outputs != 2 * nd || nd % 4 != 0 || nd > 64 || desc->in_channels != 6 * nd ||
       ((long)desc->height * desc->width) % HA_TP != 0)
-    return msi::fail(MSI_E_UNSUPPORTED, "net_forward_rgba: fused tail needs an fp32 blend_psv network (in = 6 D, out = 2 D, "
-                     "D %% 4 == 0, D <= 64, ngf <= 64, head LayerNorm fused)");
+    return msi::fail(MSI_E_UNSUPPORTED, "net_forward_rgba: fused tail needs a blend_psv network (in = 6 D, out = 2 D, "
+                     "D %% 4 == 0, D <= 64, ngf <= 64, HEAD_FUSE_LN on)");
   MSI_REQUIRE(rgba_native, "net_forward_rgba: null pointer");
+  const int ng = (nd + HA_LG - 1) / HA_LG;   // layer groups (grid.y of the fused tail): D = 64 -> 2 x 32 layers
+  if (nd % ng != 0 || (nd / ng) % 4 != 0 || (ng > 1 && bf16 && (nd / ng) % 8 != 0))
+    return msi::fail(MSI_E_UNSUPPORTED, "net_forward_rgba: D = %d does not split into layer groups of a multiple of %d", nd, bf16 ? 8 : 4);
+  // (bf16: the head's source stays raw fp32 -- no ln_apply launch, no bf16 copy: this kernel normalises and rounds it)
   int rc = run_layers(plan, packed, net_input, nullptr, workspace, workspace_bytes, stream_, MSI_NET_NUM_LAYERS - 1);
   if (rc || desc->batch == 0) return rc;
   hipStream_t stream = msi::as_stream(stream_);
@@ -2514,7 +2595,7 @@ int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, con
   const Layer &S = net.layers[H.src0];
   HeadAsmParams q;
   q.x = reinterpret_cast<const float *>(ws + S.raw_off);
-  q.wpk = packed + H.packed_off;
+  q.wpk = packed + (bf16 ? net.head_f32_off : H.packed_off);
   q.bias = packed + H.gamma_off;
   float *aff = reinterpret_cast<float *>(ws + S.aff_off);
   hipLaunchKernelGGL(ln_finish_kernel, dim3(desc->batch), dim3(256), 0, stream,
@@ -2528,25 +2609,17 @@ int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, con
   q.bw_out = blend_weights;
   q.al_out = alphas;
   q.pred_out = pred;
-  q.C0 = H.c0; q.ksteps = H.ksteps; q.npad = H.npad; q.nd = nd; q.hw = desc->height * desc->width;
+  q.C0 = H.c0; q.ksteps = bf16 ? net.head_f32_ksteps : H.ksteps; q.npad = bf16 ? net.head_f32_npad : H.npad;
+  q.nd = nd; q.hw = desc->height * desc->width;
   q.npix_total = (long)desc->batch * q.hw;
-  const int NT = nd > 32 ? 2 : 1, BN = 64 * NT;
-  size_t r_bytes = (size_t)H.ksteps * (HA_TP + BN) * ROW_BYTES;
-  if (r_bytes < (size_t)HA_TP * (6 * nd + 1) * sizeof(float)) r_bytes = (size_t)HA_TP * (6 * nd + 1) * sizeof(float);
-  const size_t lds = 2 * 64 * 4 + 64 + ((r_bytes + 15) & ~(size_t)15) + (size_t)HA_TP * (2 * nd + 1) * sizeof(float);
-  const dim3 grid((unsigned)(q.npix_total / HA_TP));
-  if (NT == 1) {
-    hipLaunchKernelGGL(head_assemble_kernel<1>, grid, dim3(256), lds, stream, q);
-  } else {
-    static thread_local bool done = false;
-    if (!done && lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(head_assemble_kernel<2>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_forward_rgba: %s", hipGetErrorString(e));
-      done = true;
-    }
-    hipLaunchKernelGGL(head_assemble_kernel<2>, grid, dim3(256), lds, stream, q);
-  }
+  q.lg = nd / ng;
+  constexpr int BN = 64;
+  size_t r_bytes = (size_t)q.ksteps * (HA_TP + BN) * ROW_BYTES;
+  if (r_bytes < (size_t)HA_TP * (6 * q.lg + 1) * sizeof(float)) r_bytes = (size_t)HA_TP * (6 * q.lg + 1) * sizeof(float);
+  const size_t lds = 2 * 64 * 4 + 64 + ((r_bytes + 15) & ~(size_t)15) + (size_t)HA_TP * (2 * q.lg + 1) * sizeof(float);
+  const dim3 grid((unsigned)(q.npix_total / HA_TP), (unsigned)ng);
+  if (bf16) hipLaunchKernelGGL(head_assemble_kernel<1>, grid, dim3(256), lds, stream, q);
+  else hipLaunchKernelGGL(head_assemble_kernel<0>, grid, dim3(256), lds, stream, q);
   return msi::check_launch("head_assemble");
 }
 
@@ -2650,7 +2723,9 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       default: rc = launch_conv<64, 64>(Q, p, bf16, stream); break;
     }
     if (rc) return rc;
-    if (L.kind != MODE_HEAD && !Q.skip_apply) {
+    // (bf16 fused tail: head_assemble_kernel normalises + rounds the head's source itself)
+    const bool tail_src = bf16 && nlayers == MSI_NET_NUM_LAYERS - 1 && li == net.layers[MSI_NET_NUM_LAYERS - 1].src0;
+    if (L.kind != MODE_HEAD && !Q.skip_apply && !tail_src) {
       const size_t per_sample = (size_t)L.out_h * L.out_w * L.cout;
       float *raw = reinterpret_cast<float *>(ws + L.raw_off), *aff = reinterpret_cast<float *>(ws + L.aff_off);
       const dim3 grid(Q.ln_blocks, desc->batch);

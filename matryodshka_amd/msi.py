@@ -277,14 +277,17 @@ class MSI(object):
     def infer_layers(self, net_input, num_msi_planes, ngf=64, extra_outputs='', which_color_pred='blend_psv',
                      event_after_convs=None):
         """msi_net + layer_prediction of infer_msi (msi.py:95-147): net_input -> pred dict.  For the reference's default
-        colour scheme on an fp32 model the 1x1 head, conv8_2's LayerNorm and the RGBA assembly run as ONE fused kernel
-        (msi_net_plan_forward_rgba: the tanh prediction never goes to HBM; bit-identical to the two-step path);
+        colour scheme the 1x1 head, conv8_2's LayerNorm and the RGBA assembly run as ONE fused kernel
+        (msi_net_plan_forward_rgba: the tanh prediction never goes to HBM; fp32: bit-identical to the two-step path,
+        bf16: the same bf16 operands, fp32 summation order of the head differs);
         everything else takes run_net + assemble_layers.  event_after_convs: torch.cuda.Event (already recorded once, so
         that its handle exists) recorded between the convolutions and the fused tail."""
         b, h, w, cin = net_input.shape
         d = num_msi_planes
-        fused = (which_color_pred == 'blend_psv' and self.dtype == 'f32' and net_input.dtype == torch.float32 and
+        fused = (which_color_pred == 'blend_psv' and
+                 net_input.dtype == (torch.float32 if self.dtype == 'f32' else torch.bfloat16) and
                  cin == 6 * d and d % 4 == 0 and d <= 64 and ngf <= 64 and
+                 (d <= 32 or d % (8 if self.dtype == 'f32' else 16) == 0) and    # D > 32: two layer groups of whole vectors
                  self.net_options.get(N.NET_OPT_HEAD_FUSE_LN, 1) and net_input.is_contiguous())
         if not fused:
             num_outputs = {'blend_psv': 2 * d, 'blend_bg': 2 * d + 3, 'blend_bg_psv': 3 * d + 3, 'alpha_only': d}[which_color_pred]

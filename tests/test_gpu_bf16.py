@@ -204,3 +204,26 @@ def test_bf16_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, 
         ref = onets.forward(weights, x, coord_net=coord, bf16=True)
         e = np.abs(p1.cpu().numpy() - ref)
         assert e.max() <= 4e-2 and e.mean() <= 3e-3, (e.max(), e.mean())
+
+
+@pytest.mark.parametrize("b,h,w,d,ngf", [(2, 32, 64, 8, 16), (1, 64, 128, 64, 64), (1, 32, 64, 32, 32), (1, 16, 32, 48, 16)])
+def test_bf16_fused_tail_matches_two_step_path(env, b, h, w, d, ngf):
+    """msi_net_plan_forward_rgba on a bf16 plan (1x1 head on the fp32 MFMA over the bf16-rounded operands + conv8_2's
+    LayerNorm + the RGBA assembly from the bf16 sweep volume in one kernel) against run_net + assemble_layers: the same
+    operands, only the head's fp32 summation order differs."""
+    torch, MSI, nets, onets, _ = env
+    from matryodshka_amd import _native as N
+    cin = 6 * d
+    weights = onets.init_weights(cin, 2 * d, ngf=ngf, coord_net=True, seed=77, randomize_affine=True)
+    x = torch.from_numpy(onets.bf16_round(np.random.RandomState(2).uniform(-1, 1, size=(b, h, w, cin)).astype(np.float32))).cuda().bfloat16()
+    fused = MSI(weights=weights, coord_net=True, dtype="bf16")
+    two = MSI(weights=weights, coord_net=True, dtype="bf16")
+    two.net_options[N.NET_OPT_HEAD_FUSE_LN] = 0
+    extra = "blend_weights alpha"
+    pf = fused.infer_layers(x, d, ngf, extra_outputs=extra)
+    pt = two.infer_layers(x, d, ngf, extra_outputs=extra)
+    plan = fused._plan(b, h, w, cin, 2 * d, ngf)
+    for k in ("rgba_layers", "blend_weights", "alphas"):
+        e = float((pf[k] - pt[k]).abs().max())
+        assert e <= 2e-6, (k, e)
+    assert torch.equal(fused.infer_layers(x, d, ngf)["rgba_layers"], pf["rgba_layers"])
