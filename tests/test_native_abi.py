@@ -173,4 +173,19 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
                     assert np.allclose(tab[mh, cc, :info.cout], exp, rtol=1e-6, atol=1e-7), (name, mh, cc)
             off += tab.size
         off = -(-off // 64) * 64
+    if dtype == "bf16":
+        # bf16 plans end with the head's bf16-ROUNDED weights once more as fp32 rows (32 channels per 128-byte row, rows
+        # padded to 64, slots swizzled like every fp32 row): the fused tail runs the 1x1 head on the fp32 MFMA
+        head = infos[-1]
+        wt = w[head.name.decode() + "/weights"]
+        ks32, npad32 = -(-head.cin // 32), -(-head.cout // 64) * 64
+        hp = packed[off:off + ks32 * npad32 * 32].reshape(ks32, npad32, 32)
+        for ks in range(ks32):
+            for n in range(head.cout):
+                exp = np.zeros(32, np.float32)
+                m = min(32, head.cin - ks * 32)
+                exp[:m] = onets.bf16_round(wt[0, 0, ks * 32:ks * 32 + m, n])
+                assert np.array_equal(_unswizzle_row(hp[ks, n], n, "f32"), exp), (ks, n)
+        assert not hp[:, head.cout:, :].any()
+        off = -(-(off + hp.size) // 64) * 64
     assert off == packed.size
