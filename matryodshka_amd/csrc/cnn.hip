@@ -94,6 +94,10 @@ struct ConvParams {
                              // loading (the source buffer then holds the RAW conv output); null = source already normalised
   const float *ln_gamma, *ln_beta;   // ... with the source layer's gamma / beta
   double ln_inv_n;           // ... and 1 / (elements per sample)
+  const long long *ln_sums1; // convt_halo_kernel: the same for source 1 (the skip half of the concat)
+  const float *ln_gamma1, *ln_beta1;
+  double ln_inv_n1;
+  int halo_apply;            // convt_halo_kernel: bit s = source s is RAW, apply its LayerNorm + ReLU while staging the patch
   const float *bias;         // head only
   float *y;                  // raw output NHWC [B,Hout,Wout,Cout]
   long long *sums;           // LayerNorm sums of THIS layer [B][LN_SHARDS][4] (zeroed per forward), or null
@@ -319,7 +323,7 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     int m = tile_m * BM + wm * (MT * 32) + i * 32 + (lane & 31);
-    if (MODE == MODE_CONV && p.halo_tx) {   // (BM / 16) x 16 spatial tile: local pixel = 16 * row + column
+    if ((MODE == MODE_CONV || MODE == MODE_CONVT) && p.halo_tx) {   // (BM / 16) x 16 spatial tile: local pixel = 16 * row + column
       const int local = wm * (MT * 32) + i * 32 + (lane & 31);
       const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
       m = (tyi * (BM / 16) + (local >> 4)) * p.Mw + (tile_m - tyi * p.halo_tx) * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor));
@@ -1230,6 +1234,293 @@ conv_halo_kernel(const ConvParams p) {
 #endif
 }
 
+// ---- halo-patch kernel for the conv-transpose layers (4x4, stride 2, SAME; fp32) ----------------------------------
+// Output (2 mh + ph, 2 mw + pw) of parity class (ph, pw) reads input rows mh + {0, ph ? +1 : -1} and columns
+// mw + {0, pw ? +1 : -1} (tap_delta): over the four classes a 4 x 16 tile of the INPUT grid needs exactly the
+// 6 x 18 halo patch of the 3x3 kernel.  One workgroup therefore stages that patch once per 32-channel chunk and runs
+// 4 classes x 4 taps = 16 k-steps on it, each class into its own accumulator tile: the 8 x 32 output pixels of the
+// tile x 64 channels.  Compared with the tap kernel (one class per workgroup, four tap fetches per input element and
+// class) every input element is fetched once (+ halo) instead of 16 times, the chunk switch comes every 16 k-steps,
+// and both sources of the skip concat may be RAW (p.halo_apply bit per source): their LayerNorm + ReLU is applied
+// while staging, so neither the decoder input nor the skip tensor needs an ln_apply launch for this consumer.
+// Weights: 4-stage DMA ring (49 KB of LDS: three workgroups per CU, which is also what 64 accumulator registers
+// allow), run-time stage index; k order per class: chunk-major, tap-minor.  K-ranges of split tiles: whole chunks;
+// a partial tile dumps four slabs (class-minor) and the last arriver sums each class in ascending k.
+// MEASURED (profiles/r02_E_convt_halo_kernel_stats.txt): correct (every parity / determinism test passes with it on) and
+// SLOWER than the tap kernel, which is why it sits behind plan option HALO bit 1 (default off): conv8_1 218 vs 200 us
+// (three workgroups per CU instead of five), conv6_1 266 vs 199 us -- 200 four-class tiles on 256 CUs must be cut into
+// five K-ranges each, and the partial-accumulator traffic is four slabs per range (64 MB written + read for a 13 MB
+// output), conv7_1's ranges do not even fit the workspace.  The tap kernel's one-class tiles are four times lighter and
+// balance better; at fp32 its sixteen-fold tap fetch is not what limits it.  Dropping the four ln_apply launches of
+// these layers' sources (32 us) does not pay for that.
+struct ConvtHaloGeom : HaloGeom<1> {
+  static constexpr int NSTG = 4;
+  static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+convt_halo_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef ConvtHaloGeom G;
+  constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, NSTG = G::NSTG, PD = NSTG - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int CH = p.cpt0 + p.cpt1;                         // 32-channel chunks of both sources
+  int t, c0 = 0, c1 = CH, ks = 0, slot = 0;
+  {
+    const int bid = blockIdx.x;
+    if (bid < p.nb_main && p.split0 == 1) {
+      const int q = p.n_main >> 3, r = p.n_main & 7, xcd = bid & 7, local = bid >> 3;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    } else {
+      int sp, r, tbase;
+      unsigned mg;
+      if (bid < p.nb_main) { sp = p.split0; mg = p.mg_sp0; r = bid; tbase = 0; }
+      else { sp = p.split; mg = p.mg_sp; r = bid - p.nb_main; tbase = p.n_main; }
+      const int tl = (int)udiv_magic((unsigned)r, (unsigned)sp, mg);
+      ks = r - tl * sp;
+      t = tbase + tl;
+      c0 = (int)udiv_magic((unsigned)(ks * CH), (unsigned)sp, mg);
+      c1 = (int)udiv_magic((unsigned)((ks + 1) * CH), (unsigned)sp, mg);
+      slot = bid - (p.split0 == 1 ? p.nb_main : 0);
+    }
+  }
+  const bool full = (c0 == 0) & (c1 == CH);
+  int tile_m, tile_n, b;
+  {
+    int r = t;
+    const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
+    tile_m = r - q1 * p.tiles_m; r = q1;
+    const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
+    tile_n = r - q2 * p.tiles_n;
+    b = q2;                                               // (tiles are enumerated with one class: the workgroup owns all four)
+  }
+  const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
+  const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
+  const int H = p.Hin, W = p.Win;
+
+  // ---- per-lane patch elements (as conv_halo_kernel; the byte offset depends on the source's channel count) ----
+  unsigned pixi[NLOAD], lds_a[NLOAD];
+  bool pok[NLOAD];
+  const int cslot = tid & 7;
+  constexpr unsigned OOB = 0xfffffff0u;
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const int pp = (tid + 256 * k) >> 3;
+    const int py = pp / PW, px = pp - py * PW;
+    const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
+    pok[k] = pp < NPX && ih >= 0 && ih < H && iw >= 0 && iw < W;   // SAME: zeros outside
+    pixi[k] = (unsigned)(ih * W + iw);
+    lds_a[k] = pp < NPX ? (unsigned)(py * G::ROW_PITCH + px * G::PIX_BYTES + cslot * 16) : 0xffffffffu;
+  }
+  const size_t in0 = (size_t)H * W * p.C0 * 4, in1 = (size_t)H * W * p.C1 * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in0), 0, (int)in0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x1 + (size_t)b * in1), 0, (int)(in1 ? in1 : 16), 0x00020000);
+  const int S = p.ksteps;                                 // k-steps per class: 4 CH
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)4 * S * p.npad * ROW_BYTES), 0x00020000);
+  const int drow = lane >> 3, dslot = lane & 7;
+  const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + drow) * ROW_BYTES + dslot * 16);
+
+  // LayerNorm of the raw sources: mean as hi + lo floats and 1 / sigma per source
+  float inv_f[2] = {1.f, 1.f}, mu_hi[2] = {0.f, 0.f}, mu_lo[2] = {0.f, 0.f};
+  bool has_pad = false;
+  {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) bad |= (lds_a[k] != 0xffffffffu) && !pok[k];
+    has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
+  }
+  v4f araw[NLOAD], g4, be4;
+  int src_ld = 0;                                         // source of the patch held in araw
+  // patch of chunk c -> registers (+ gamma / beta of the lane's channels when that source is raw)
+#define MSI_PATCH_LOAD(c)                                                                                              \
+  {                                                                                                                    \
+    const int s_ = (c) >= p.cpt0 ? 1 : 0, cc_ = s_ ? (c) - p.cpt0 : (c);                                               \
+    const unsigned cb_ = (unsigned)((s_ ? p.C1 : p.C0) * 4);                                                           \
+    src_ld = s_;                                                                                                       \
+    if (s_ == 0) {                                                                                                     \
+      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
+            rsrc_a0, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));           \
+    } else {                                                                                                           \
+      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
+            rsrc_a1, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));           \
+    }                                                                                                                  \
+    const float *gp_ = (s_ ? p.ln_gamma1 : p.ln_gamma), *bp_ = (s_ ? p.ln_beta1 : p.ln_beta);                          \
+    if ((p.halo_apply >> s_) & 1) {                                                                                    \
+      g4 = *reinterpret_cast<const v4f *>(gp_ + cc_ * 32 + cslot * 4);                                                 \
+      be4 = *reinterpret_cast<const v4f *>(bp_ + cc_ * 32 + cslot * 4);                                                \
+    } else {   /* (same number of VMEM operations on both paths: the vmcnt arithmetic of the k-steps counts them) */   \
+      g4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16);                                                         \
+      be4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16 + 128);                                                  \
+    }                                                                                                                  \
+  }
+#define MSI_PATCH_STORE()                                                                                              \
+  {                                                                                                                    \
+    const bool ap_ = (p.halo_apply >> src_ld) & 1;                                                                     \
+    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};                                                          \
+    if (ap_) {                                                                                                         \
+      const float ih_ = src_ld ? inv_f[1] : inv_f[0], mh_ = src_ld ? mu_hi[1] : mu_hi[0], ml_ = src_ld ? mu_lo[1] : mu_lo[0]; \
+      s4 = ih_ * g4;                                                                                                   \
+      const v4f nh = {-mh_, -mh_, -mh_, -mh_}, nl = {-ml_, -ml_, -ml_, -ml_};                                          \
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
+      v4f y = araw[k_];                                                                                                \
+      if (ap_) {                                                                                                       \
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
+        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};                                                          \
+      }                                                                                                                \
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = y;                                    \
+    }                                                                                                                  \
+  }
+  // weights of k-step (class, tap, chunk c) -> ring stage st; packed blob: [class][tap * CH + c][npad][128 B]
+#define MSI_B_ISSUE(cls, tap, c, st)                                                                                   \
+  {                                                                                                                    \
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * ROW_BYTES;                                         \
+    const int soff_ = (((cls) * S + (tap) * CH + (c)) * p.npad) * ROW_BYTES;                                           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
+  }
+
+  // ---- MFMA side ----
+  const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
+  const unsigned a_base = lds_base + (unsigned)((2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 64);
+  unsigned b_q[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    b_q[q] = lds_base + G::A_BYTES + (wn * 32 + frow) * ROW_BYTES + (((fh * 4 + q) ^ fswz) << 4);
+  f32x16 acc[4][1][1];
+#pragma unroll
+  for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cl][0][0][r] = 0.f;
+
+  // k-step J of the chunk = class J / 4, tap J % 4, weights in ring stage st (run-time).  The DMA of the k-step PD ahead
+  // and (J == 0) the next chunk's patch loads are issued after the first MFMA quarter; before the closing barrier the
+  // NEXT k-step's weights must have landed: they were issued PD - 1 k-steps ago, so only what the last PD - 1 k-steps
+  // issued (2 DMA each, + the patch loads of J == 0 while they are that young) may still be in flight.
+  constexpr int NPL = NLOAD + 2;                          // VMEM operations of a patch load
+#define MSI_CTSTEP(J)                                                                                                  \
+  {                                                                                                                    \
+    constexpr int CLS_ = (J) >> 2, TAP_ = (J) & 3;                                                                     \
+    constexpr int PH_ = CLS_ >> 1, PWC_ = CLS_ & 1, TH_ = TAP_ >> 1, TW_ = TAP_ & 1;                                   \
+    constexpr int DR_ = PH_ ? TH_ : -TH_, DC_ = PWC_ ? TW_ : -TW_;                                                     \
+    constexpr int AOFF_ = (1 + DR_) * G::ROW_PITCH + (1 + DC_) * G::PIX_BYTES;                                         \
+    v4f a_[4], b_[4];                                                                                                  \
+    const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
+      a_[q_] = q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 16>(a_base)                        \
+             : q_ == 2 ? lds_read128<AOFF_ + 32>(a_base) : lds_read128<AOFF_ + 48>(a_base);                            \
+      b_[q_] = lds_read128<0>(b_q[q_] + bst_);                                                                         \
+    }                                                                                                                  \
+    bool issued_ = false;                                                                                              \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
+      if (q_ == 0) wait_lgkm<6>(a_[0], b_[0]);                                                                         \
+      if (q_ == 1) wait_lgkm<4>(a_[1], b_[1]);                                                                         \
+      if (q_ == 2) wait_lgkm<2>(a_[2], b_[2]);                                                                         \
+      if (q_ == 3) wait_lgkm<0>(a_[3], b_[3]);                                                                         \
+      acc[CLS_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[CLS_][0][0], 0, 0, 0);            \
+      acc[CLS_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[CLS_][0][0], 0, 0, 0);            \
+      acc[CLS_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[CLS_][0][0], 0, 0, 0);            \
+      acc[CLS_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[CLS_][0][0], 0, 0, 0);            \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if (q_ == 0) {                                                                                                   \
+        if ((J) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                              \
+        int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                       \
+        constexpr int JN_ = ((J) + PD) & 15;                                                                           \
+        if ((J) + PD < 16) { issued_ = true; MSI_B_ISSUE(JN_ >> 2, JN_ & 3, c, sn_) }                                  \
+        else if (c + 1 < c1) { issued_ = true; MSI_B_ISSUE(JN_ >> 2, JN_ & 3, c + 1, sn_) }                            \
+      }                                                                                                                \
+    }                                                                                                                  \
+    /* in flight allowed: the DMAs of the last PD - 1 = 2 k-steps (this one's and the previous one's), and the patch */ \
+    /* loads while J <= 1 (issued in J == 0 before its DMA)                                                          */ \
+    if (c + 1 < c1 && (J) == 0) wait_vmcnt<2 * 2 + NPL>();                                                             \
+    else if (c + 1 < c1 && (J) == 1) wait_vmcnt<2 * 2 + NPL>();                                                        \
+    else if (issued_) wait_vmcnt<2 * 2>();                                                                             \
+    else wait_vmcnt<0>();                                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
+  }
+
+  // ---- prologue: first patch, first PD weight k-steps, the sources' LayerNorm statistics ----
+  int c = c0, st = 0;
+  MSI_PATCH_LOAD(c0)
+  MSI_B_ISSUE(0, 0, c0, 0)
+  MSI_B_ISSUE(0, 1, c0, 1)
+  MSI_B_ISSUE(0, 2, c0, 2)
+  if (p.halo_apply) {
+    double *s_stat = reinterpret_cast<double *>(smem);
+    if (p.halo_apply & 1) {
+      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * 4, p.ln_inv_n, s_stat, tid);
+      const double mu = s_stat[0];
+      inv_f[0] = (float)s_stat[1]; mu_hi[0] = (float)mu; mu_lo[0] = (float)(mu - (double)mu_hi[0]);
+      __syncthreads();
+    }
+    if (p.halo_apply & 2) {
+      ln_mean_inv(p.ln_sums1 + (size_t)b * LN_SHARDS * 4, p.ln_inv_n1, s_stat, tid);
+      const double mu = s_stat[0];
+      inv_f[1] = (float)s_stat[1]; mu_hi[1] = (float)mu; mu_lo[1] = (float)(mu - (double)mu_hi[1]);
+      __syncthreads();
+    }
+  }
+  wait_vmcnt<0>();
+  MSI_PATCH_STORE()
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; c < c1; ++c) {
+    MSI_CTSTEP(0) MSI_CTSTEP(1) MSI_CTSTEP(2) MSI_CTSTEP(3) MSI_CTSTEP(4) MSI_CTSTEP(5) MSI_CTSTEP(6) MSI_CTSTEP(7)
+    MSI_CTSTEP(8) MSI_CTSTEP(9) MSI_CTSTEP(10) MSI_CTSTEP(11) MSI_CTSTEP(12) MSI_CTSTEP(13) MSI_CTSTEP(14) MSI_CTSTEP(15)
+    if (c + 1 < c1) {
+      MSI_PATCH_STORE()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+#undef MSI_CTSTEP
+#undef MSI_B_ISSUE
+#undef MSI_PATCH_STORE
+#undef MSI_PATCH_LOAD
+
+  // ---- epilogue: four class tiles ----
+  if (!full) {
+    constexpr int SLAB = 64 * 64 * 4;
+    if (p.tile_cnt == nullptr) {                          // separate fix-up launch (conv_fixup_kernel, class = blockIdx.y)
+#pragma unroll
+      for (int cl = 0; cl < 4; ++cl) {
+        const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 4 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
+        dump_acc<1, 1, 0>(acc[cl], rsrc_p, tid);
+      }
+      return;
+    }
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) {
+      const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 4 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
+      dump_acc<1, 1, 16>(acc[cl], rsrc_p, tid);
+    }
+    const int nsp = t < p.n_main ? p.split0 : p.split;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *s_old = reinterpret_cast<int *>(smem);
+    if (tid == 0)
+      *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_old != nsp - 1) return;
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) {
+      const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)(slot - ks) * 4 + cl) * (64 * 64)), 0, nsp * 4 * SLAB, 0x00020000);
+      sum_slabs<1, 1, 16>(acc[cl], rsrc_t, nsp, 4 * SLAB, tid);
+    }
+  }
+#pragma unroll
+  for (int cl = 0; cl < 4; ++cl) emit_tile<64, 64, MODE_CONVT>(p, acc[cl], tile_m, tile_n, cl, b, tid);
+#endif
+}
+
 // ---- halo-patch kernel, bf16 operands ----------------------------------------------------------------------------
 // Same idea as conv_halo_kernel at the shapes the 16x faster bf16 MFMA needs: at 4 MFMAs per wave and k-step the
 // 64x64 tile cannot be fed (the tap kernel's bf16 instantiations are bound by their L2 -> LDS traffic: 32 KB per k-step
@@ -1527,10 +1818,17 @@ conv_fixup_kernel(const ConvParams p) {
     b = q3;
   }
   constexpr int SLAB = BM * BN * 4;
-  const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(p.partial + (size_t)slot0 * (BM * BN)), 0, nsp * SLAB, 0x00020000);
   f32x16 acc[MT][NT];
-  sum_slabs<MT, NT, 0>(acc, rsrc_t, nsp, SLAB, tid);
+  if (MODE == MODE_CONVT && p.halo_tx) {   // convt_halo_kernel: four class slabs per K-range, class = blockIdx.y
+    cls = blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.partial + ((size_t)slot0 * 4 + cls) * (BM * BN)), 0, nsp * 4 * SLAB, 0x00020000);
+    sum_slabs<MT, NT, 0>(acc, rsrc_h, nsp, 4 * SLAB, tid);
+  } else {
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.partial + (size_t)slot0 * (BM * BN)), 0, nsp * SLAB, 0x00020000);
+    sum_slabs<MT, NT, 0>(acc, rsrc_t, nsp, SLAB, tid);
+  }
   emit_tile<BM, BN, MODE>(p, acc, tile_m, tile_n, cls, b, tid);
 #endif
 }
@@ -2053,6 +2351,7 @@ struct LayerLaunch {
   int skip_apply;   // this layer's output is consumed raw by the head, or normalised by its consumer's launch: no ln_apply launch
   int halo;         // conv_halo_kernel (fp32) / conv_halo_bf16_kernel instead of conv_igemm_kernel
   int hbm, hbn;     // bf16 halo tile: 128 x 128 or 256 x 64
+  int halo_t;       // convt_halo_kernel (conv-transpose, fp32): all four parity classes per workgroup
   int halo_apply;   // ... applying the producer's LayerNorm while staging the patch (the producer's buffer stays raw)
   unsigned ln_blocks;
 };
@@ -2205,11 +2504,21 @@ int plan_layers(msi_net_plan *pl) {
       else if (L.cout == 64 && L.in_h % 16 == 0 && L.rate == 1) { Q.halo = 1; Q.hbm = 256; Q.hbn = 64; }
       if (Q.halo) { BM = Q.hbm; BN = Q.hbn; max_split = 1; }
     }
+    // conv-transpose halo kernel (convt_halo_kernel; HALO bit 1, NOT the default -- measured slower, see the kernel):
+    // SAME conv-transposes (CoordNet), fp32, whole 4 x 16 input tiles and 32-channel chunks of both sources
+    Q.halo_t = (pl->opt[MSI_NET_OPT_HALO] & 2) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] &&
+               Q.tile == TILE_64x64 && L.kind == MODE_CONVT && !L.wrapt && L.in_h % 4 == 0 && L.in_w % 16 == 0 &&
+               L.c0 % 32 == 0 && L.c1 % 32 == 0;
+    if (Q.halo_t) {
+      Q.halo = 1;
+      p.nclass = 1;                                      // tiles are enumerated per (tile_m, tile_n, sample): a workgroup owns the 4 classes
+      if (L.cpt0 + L.cpt1 < max_split) max_split = L.cpt0 + L.cpt1;
+    }
     if (Q.halo) {
       p.halo_tx = L.in_w / 16;
       p.halo_xor = bf16 ? 0 : 8;
       p.mg_htx = p.halo_tx == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)p.halo_tx);
-      if (L.cpt0 < max_split) max_split = L.cpt0;      // K-ranges are whole chunks (bf16: whole tiles only)
+      if (!Q.halo_t && L.cpt0 < max_split) max_split = L.cpt0;      // K-ranges are whole chunks (bf16: whole tiles only)
     }
     plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], max_split, &Q.nblocks, &Q.nfix);
     // apply-ahead (see apply_ahead): this launch also normalises its source 0
@@ -2227,7 +2536,14 @@ int plan_layers(msi_net_plan *pl) {
       pl->launch[L.src0].skip_apply = 1;              // (the producer precedes its consumer in graph order)
     }
     Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
-    if ((size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * BM * BN * sizeof(float) > net.partial_bytes)
+    if (Q.halo_t && (size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * 4 * BM * BN * sizeof(float) > net.partial_bytes) {
+      // four slabs per K-range do not fit the partial-accumulator workspace -> the tap kernel
+      Q.halo_t = 0; Q.halo = 0;
+      p.halo_tx = 0; p.halo_xor = 0; p.nclass = L.nclass;
+      plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], MAX_SPLIT, &Q.nblocks, &Q.nfix);
+      Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
+    }
+    if ((size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * (Q.halo_t ? 4 : 1) * BM * BN * sizeof(float) > net.partial_bytes)
       return msi::fail(MSI_E_WORKSPACE, "conv %s: %d partial accumulators exceed the workspace", L.name, Q.nblocks);
     if (L.kind != MODE_HEAD) {
       const size_t per_sample = (size_t)L.out_h * L.out_w * L.cout;
@@ -2236,25 +2552,32 @@ int plan_layers(msi_net_plan *pl) {
       Q.ln_blocks = (unsigned)blocks;
     }
   }
-  // A layer whose EVERY consumer is a halo layer is never normalised in memory: its consumers apply its LayerNorm while
-  // staging their patches (a halo layer has one source, so its flag follows from that source alone)
+  // A layer whose EVERY consumer can apply its LayerNorm while staging a patch is never normalised in memory: halo conv
+  // layers (their one source; not the bf16 256x64 tile, which has no registers left for the fp32 -> bf16 staging and
+  // reads the bf16 copy) and conv-transpose halo layers (either source)
   for (int s = 0; s < MSI_NET_NUM_LAYERS - 1; ++s) {
-    int consumers = 0, halo_consumers = 0;
+    int consumers = 0, capable = 0;
     for (int li = s + 1; li < MSI_NET_NUM_LAYERS; ++li) {
       const Layer &L = net.layers[li];
       if (L.src0 == s || L.src1 == s) {
         ++consumers;
-        // (the bf16 256x64 tile has no registers left for the fp32 -> bf16 staging: it reads the bf16 copy)
-        if (pl->launch[li].halo && pl->launch[li].hbm != 256) ++halo_consumers;
+        const LayerLaunch &C = pl->launch[li];
+        if (C.halo_t || (C.halo && C.hbm != 256 && L.src0 == s)) ++capable;
       }
     }
-    if (consumers > 0 && consumers == halo_consumers) {
+    if (consumers > 0 && consumers == capable) {
       pl->launch[s].skip_apply = 1;
-      for (int li = s + 1; li < MSI_NET_NUM_LAYERS; ++li)
-        if (net.layers[li].src0 == s) {
-          pl->launch[li].halo_apply = 1;
-          pl->launch[li].p.ln_inv_n = 1.0 / net.layers[s].ln_count;
+      for (int li = s + 1; li < MSI_NET_NUM_LAYERS; ++li) {
+        const Layer &L = net.layers[li];
+        LayerLaunch &C = pl->launch[li];
+        if (C.halo_t) {
+          if (L.src0 == s) { C.p.halo_apply |= 1; C.p.ln_inv_n = 1.0 / net.layers[s].ln_count; }
+          if (L.src1 == s) { C.p.halo_apply |= 2; C.p.ln_inv_n1 = 1.0 / net.layers[s].ln_count; }
+        } else if (L.src0 == s) {
+          C.halo_apply = 1;
+          C.p.ln_inv_n = 1.0 / net.layers[s].ln_count;
         }
+      }
     }
   }
   return MSI_OK;
@@ -2694,6 +3017,25 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       } else {
         rc = Q.halo_apply ? msi::fail(MSI_E_UNSUPPORTED, "conv_halo_bf16: the 256x64 tile reads the bf16 operand copy")
                           : launch_halo_bf16<256, 64, 1, 0>(Q, p, stream);
+      }
+    } else if (Q.halo_t) {
+      if (p.halo_apply & 1) {
+        const Layer &S = net.layers[L.src0];
+        p.ln_sums = reinterpret_cast<const long long *>(ws + S.sums_off);
+        p.ln_gamma = packed + S.gamma_off;
+        p.ln_beta = packed + S.beta_off;
+      }
+      if (p.halo_apply & 2) {
+        const Layer &S = net.layers[L.src1];
+        p.ln_sums1 = reinterpret_cast<const long long *>(ws + S.sums_off);
+        p.ln_gamma1 = packed + S.gamma_off;
+        p.ln_beta1 = packed + S.beta_off;
+      }
+      hipLaunchKernelGGL(convt_halo_kernel, dim3(Q.nblocks), dim3(256), ConvtHaloGeom::LDS_BYTES, stream, p);
+      rc = msi::check_launch("convt_halo");
+      if (!rc && Q.nfix > 0 && p.tile_cnt == nullptr) {
+        hipLaunchKernelGGL((conv_fixup_kernel<64, 64, MODE_CONVT>), dim3(Q.nfix, 4), dim3(256), 0, stream, p);
+        rc = msi::check_launch("conv_fixup");
       }
     } else if (Q.halo) {
       if (Q.halo_apply) {

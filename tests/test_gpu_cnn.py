@@ -219,9 +219,10 @@ def test_fused_head_assembly_is_bit_identical(env, coord, b, h, w, d, ngf):
     assert torch.equal(p2, pred)
 
 
+@pytest.mark.parametrize("halo_opt", [1, 3])
 @pytest.mark.parametrize("coord,b,h,w,cin,nout,ngf", [(True, 1, 160, 320, 96, 32, 64), (False, 2, 32, 64, 32, 8, 32),
                                                      (True, 2, 16, 48, 64, 16, 32), (True, 1, 320, 640, 192, 64, 64)])
-def test_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, w, cin, nout, ngf):
+def test_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, w, cin, nout, ngf, halo_opt):
     """conv_halo_kernel (plan option HALO, default on: stride-1 3x3 fp32 layers stage one LDS-stationary halo patch per
     input chunk and apply the producer's LayerNorm on the way) against the tap-DMA kernel: same products, chunk-major
     instead of tap-major summation order -> equal to fp32 round-off; bitwise deterministic; K-ranges at chunk boundaries
@@ -230,6 +231,7 @@ def test_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, w, ci
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=29, randomize_affine=True)
     x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
     halo = MSI(weights=weights, coord_net=coord)
+    halo.net_options[N.NET_OPT_HALO] = halo_opt      # 1: the default; 3: + convt_halo_kernel on the conv-transposes (measured slower: opt-in)
     tap = MSI(weights=weights, coord_net=coord)
     tap.net_options[N.NET_OPT_HALO] = 0
     p1, p0 = halo.run_net(x, nout, ngf), tap.run_net(x, nout, ngf)
@@ -242,6 +244,7 @@ def test_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, w, ci
         assert torch.equal(halo.run_net(x, nout, ngf), p1)
     fix = MSI(weights=weights, coord_net=coord)
     fix.net_options[N.NET_OPT_FIXUP_KERNEL] = 1
+    fix.net_options[N.NET_OPT_HALO] = halo_opt
     assert torch.equal(fix.run_net(x, nout, ngf), p1)
     if h * w <= 160 * 320:
         ref = onets.forward(weights, x.cpu().numpy(), coord_net=coord)

@@ -28,7 +28,7 @@ def main():
         print("\n# per frame (%d frames): " % args.frames + ", ".join(
             "%s %.1f us" % (r[0].split("(")[0].split("::")[-1][:40], r[2] / 1e3 / args.frames) for r in rows[:8]))
     conv = c.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, lds_size, vgpr_count, accum_vgpr_count "
-                     "from kernels where name like '%conv_igemm%' or name like '%conv_halo%' order by start").fetchall()
+                     "from kernels where name like '%conv_igemm%' or name like '%conv_halo%' or name like '%convt_halo%' order by start").fetchall()
     if len(conv) >= 18:
         print("\n# conv launches of the last frame (graph order; tile<BM, BN, MODE, BF16> = conv_igemm_kernel, "
               "halo<RATE, APPLY> = conv_halo_kernel)")
@@ -42,7 +42,7 @@ def main():
         tot_us = 0.0
         # the 1x1 head is a conv_igemm launch (template MODE 2) only on the unfused path; on the fp32 blend_psv path it is
         # part of head_assemble_kernel and a frame has 17 conv launches
-        fused_tail = "conv_halo" in conv[-1][0] or ("Li2E" not in conv[-1][0] and ", 2, " not in conv[-1][0])
+        fused_tail = "conv_halo" in conv[-1][0] or "convt_halo" in conv[-1][0] or ("Li2E" not in conv[-1][0] and ", 2, " not in conv[-1][0])
         nl = 17 if fused_tail else 18
         ha = c.execute("select start, end from kernels where name like '%head_assemble%' order by start").fetchall()
         for nm, r, fl in zip(names[:nl], conv[-nl:], flops[:nl]):
@@ -54,7 +54,7 @@ def main():
             fx = [f for (s0, e), f in zip([x for x in fix if r[2] <= x[0] < r[2] + 200000], fx) if not nxt or s0 < nxt[0]]
             fus = sum(fx[:1])
             tot_us += us + fus
-            kind = "halo" if "conv_halo" in r[0] else "tile"
+            kind = "halo" if "conv_halo" in r[0] else ("halo_convT" if "convt_halo" in r[0] else "tile")
             print("%-10s %s<%s> blocks=%d lds=%d vgpr=%d agpr=%d  %8.1f us + fixup %5.1f us  %6.1f TFLOP/s (%4.1f%%, BASELINE shapes)" % (
                 nm, kind, tmpl, (r[3] // r[6]) * r[4] * r[5], r[7], r[8], r[9], us, fus, fl / (us + fus) / 1e6,
                 100 * fl / (us + fus) / 1e6 / bench.PEAK_FP32_MFMA_TFLOPS))
