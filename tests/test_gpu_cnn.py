@@ -249,3 +249,36 @@ def test_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, w, ci
     if h * w <= 160 * 320:
         ref = onets.forward(weights, x.cpu().numpy(), coord_net=coord)
         assert np.abs(p1.cpu().numpy() - ref).max() <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_size_network_properties_without_the_oracle(env, dtype):
+    """Size-independent properties of msi_train_net (wrap padding along W, no CoordNet) at the BASELINE size 640x320, ngf 64,
+    where the CPU oracle is too slow to be the checker:
+      * W-roll equivariance: every layer wraps along W and the strides multiply to 8, so rolling the input by a multiple of
+        8 columns rolls the prediction by the same amount -- this walks every tile seam, halo column, wrap column and
+        K-range boundary of the tap, halo and conv-transpose kernels through different positions of the tile grid;
+      * gain invariance: LayerNorm (eps 1e-12) removes a power-of-two gain of the input exactly up to rounding of the
+        statistics."""
+    torch, MSI, nets, N, onets = env
+    cin, nout, ngf = 96, 32, 64
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=False, seed=123, randomize_affine=True)
+    m = MSI(weights=weights, coord_net=False, dtype=dtype)
+    x = torch.rand((1, 320, 640, cin), device="cuda") * 2 - 1
+    if dtype == "bf16":
+        x = x.bfloat16()
+    base = m.run_net(x, nout, ngf).clone()
+    assert bool(torch.isfinite(base).all())
+    # fp32: only the summation order changes (which tiles are split, which wave sums which LayerNorm shard): measured 8e-5 on
+    # the tanh prediction after 17 layers with random gamma / beta -- a seam or wrap-column bug shows at 1e-2 and above;
+    # bf16: rounding flips of activations on top
+    tol = 3e-4 if dtype == "f32" else 4e-2
+    for shift in (8, 56, 328):
+        rolled = m.run_net(torch.roll(x, shifts=shift, dims=2).contiguous(), nout, ngf)
+        d = (rolled - torch.roll(base, shifts=shift, dims=2)).abs()
+        assert float(d.max()) <= tol, (shift, float(d.max()))
+        if dtype == "bf16":
+            assert float(d.mean()) <= 3e-3, (shift, float(d.mean()))
+    gained = m.run_net((x.float() * 4.0).to(x.dtype), nout, ngf)     # exact in fp32 and in bf16
+    d = (gained - base).abs()
+    assert float(d.max()) <= tol, float(d.max())
