@@ -628,7 +628,9 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
   const int j_raw = blockIdx.x * 64 + threadIdx.x;
   const int i = blockIdx.y;
   const int b = blockIdx.z;
-  const int seg = threadIdx.y;
+  // (a wavefront is one threadIdx.y: telling the compiler keeps the layer index -- and with it the per-layer buffer
+  // descriptor -- in SGPRs; without it every gather sat in a readfirstlane waterfall loop, ~12 instructions each)
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const bool valid = j_raw < R.out_w;
   const int j = valid ? j_raw : R.out_w - 1;      // (lanes past the row end compute a duplicate and store nothing: no early return before the barrier)
   __shared__ float s_part[RENDER_SEGS][64][5];
