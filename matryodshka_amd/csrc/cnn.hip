@@ -598,14 +598,17 @@ conv_igemm_kernel(const ConvParams p) {
   {
     // tile order: M tiles fastest (measured on the same box: 3.03 ms per frame vs 3.11 ms with N tiles
     // fastest and 3.09 ms for the previous 3-D grid without the tail split)
+    // conv-transpose: the parity class is the FASTEST index -- the four classes of an M tile read the same input pixels,
+    // and as neighbours in the order they run on the same XCD at about the same time (one fetch into its L2 instead of
+    // four through HBM: the bf16 conv-transposes were bound by exactly that traffic)
     int r = t;
+    const int q0 = (int)udiv_magic((unsigned)r, (unsigned)p.nclass, p.mg_nc);
+    cls = r - q0 * p.nclass; r = q0;
     const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
     tile_m = r - q1 * p.tiles_m; r = q1;
     const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
-    tile_n = r - q2 * p.tiles_n; r = q2;
-    const int q3 = (int)udiv_magic((unsigned)r, (unsigned)p.nclass, p.mg_nc);
-    cls = r - q3 * p.nclass;
-    b = q3;
+    tile_n = r - q2 * p.tiles_n;
+    b = q2;
   }
   const int ph = cls >> 1, pw = cls & 1;
   const int mtot = p.Mh * p.Mw;
@@ -1808,14 +1811,14 @@ conv_fixup_kernel(const ConvParams p) {
                                   : (t < p.n_main ? t * p.split0 : p.nb_main + (t - p.n_main) * p.split);
   int tile_m, tile_n, cls, b;
   {
-    int r = t;   // same order as conv_igemm_kernel: M tiles fastest
+    int r = t;   // same order as conv_igemm_kernel: class fastest, then M tiles
+    const int q0 = (int)udiv_magic((unsigned)r, (unsigned)p.nclass, p.mg_nc);
+    cls = r - q0 * p.nclass; r = q0;
     const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
     tile_m = r - q1 * p.tiles_m; r = q1;
     const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
-    tile_n = r - q2 * p.tiles_n; r = q2;
-    const int q3 = (int)udiv_magic((unsigned)r, (unsigned)p.nclass, p.mg_nc);
-    cls = r - q3 * p.nclass;
-    b = q3;
+    tile_n = r - q2 * p.tiles_n;
+    b = q2;
   }
   constexpr int SLAB = BM * BN * 4;
   f32x16 acc[MT][NT];
