@@ -75,10 +75,16 @@ constexpr int DEFAULT_CUS = 256;  // MI355X; the plan queries hipDeviceProp.mult
 constexpr int MAX_SPLIT = 8;
 constexpr int CONV_SLOTS_PER_CU = 5;   // 64x64 workgroups (32 KB of LDS each) resident per CU
 constexpr double LN_EPS = 1e-12;  // slim.layer_norm variance epsilon [TF-knowledge]
-// LayerNorm sums: [sample][LN_SHARDS][4] signed 64-bit fixed point {S1 hi, S1 lo, S2 hi, S2 lo},
-// value = hi * 2^-8 + lo * 2^-52 (hi carries the integer part and 8 fraction bits, lo the next 44)
-constexpr int LN_SHARDS = 64;
-constexpr double LN_HI_SCALE = 256.0, LN_LO_SCALE = 17592186044416.0 /* 2^44, applied to the residue of S * 2^8 */;
+// LayerNorm sums: [sample][LN_SHARDS][LN_WORDS] signed 64-bit fixed point {sum x * 2^24, sum x^2 * 2^16}: integer
+// addition is associative, so the totals do not depend on the arrival order (bitwise reproducible); a wave's share is
+// rounded to 2^-24 / 2^-16 absolute (<= 4e-4 / 0.1 over the 12 800 waves of the largest layer, against totals of 1e6 /
+// 1e7 and more: 1e-9 relative, the variance keeps ten digits when mean^2 is 1e6 times the variance).  Range: |sum x| <
+// 5e11 and sum x^2 < 1.4e14 per sample, i.e. an rms activation below ~3 000 on the largest layer (LayerNorm'd networks
+// sit at 1e0..1e2); a wave's share must stay below 2^51 after scaling (mean x^2 < 3e7 over its 1 024 values).
+// (Until r02 the sums were exact, hi * 2^-8 + lo * 2^-52 in two words each: four atomics and four fp64 -> int64
+// conversions per wave and tile cost 68 us per frame in matrix time, 2.7 % of the network.)
+constexpr int LN_SHARDS = 64, LN_WORDS = 2;
+constexpr double LN_S1_SCALE = 16777216.0 /* 2^24 */, LN_S2_SCALE = 65536.0 /* 2^16 */;
 constexpr int AP_FLAG_STRIDE = 16;  // ints between two row counters of the apply-ahead hand-off: one counter per 64-byte line
 constexpr int HEAD_MAX_C = 256;   // the head's fused LayerNorm keeps scale | shift of its source in LDS
 
@@ -202,39 +208,47 @@ __device__ __forceinline__ void wait_lgkm_frag(v4f (&a)[MT], v4f (&b)[NT]) {
 }
 
 // ---- shared device helpers of the epilogue ----------------------------------------------------
-__device__ __forceinline__ float wave_sum(float x) {   // butterfly: every lane gets the total, fixed order
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-  return x;
+// Sum over the 64 lanes, returned to every lane (wave-uniform), fixed order.  DPP moves (quad swaps, row mirrors, the
+// gfx9 row broadcasts) instead of __shfl_xor: that compiles to ds_bpermute_b32, five dependent trips through the LDS
+// crossbar per sum (~600 cycles of latency in every tile's epilogue; the epilogue's length is what keeps a workgroup
+// slot away from the k-loop).
+__device__ __forceinline__ float wave_sum(float x) {
+#define MSI_DPP_ADD(CTRL, ROWMASK)                                                                                     \
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xf, true))
+  MSI_DPP_ADD(0xB1, 0xf);    // quad_perm [1,0,3,2]
+  MSI_DPP_ADD(0x4E, 0xf);    // quad_perm [2,3,0,1]
+  MSI_DPP_ADD(0x141, 0xf);   // row_half_mirror
+  MSI_DPP_ADD(0x140, 0xf);   // row_mirror: every lane holds its 16-lane row's sum
+  MSI_DPP_ADD(0x142, 0xa);   // row_bcast:15 -> rows 1 and 3 add the row before them
+  MSI_DPP_ADD(0x143, 0xc);   // row_bcast:31 -> rows 2 and 3 add rows 0 + 1
+#undef MSI_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
-// One wave's exact share of a LayerNorm sum: S -> (hi, lo) fixed point, two integer atomics (no return value).
-__device__ __forceinline__ void ln_atomic_add(long long *dst, double S) {
-  const double sh = S * LN_HI_SCALE;             // exact (power of two)
-  const double r = rint(sh);
-  const long long hi = (long long)r;
-  const long long lo = (long long)rint((sh - r) * LN_LO_SCALE);   // residue in [-0.5, 0.5]: exact difference, |lo| <= 2^43
-  __hip_atomic_fetch_add(dst, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_add(dst + 1, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// One wave's share of a LayerNorm sum as a fixed-point integer atomic (no return value).  x_scaled = S * scale with
+// |x_scaled| < 2^51: adding 1.5 * 2^52 leaves round-to-nearest-even(x_scaled) in the low mantissa bits -- two VALU
+// instead of the emulated fp64 -> int64 conversion.
+__device__ __forceinline__ void ln_atomic_add(long long *dst, double x_scaled) {
+  const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
+  const double t = x_scaled + MAGIC;
+  const long long v = __builtin_bit_cast(long long, t) - __builtin_bit_cast(long long, MAGIC);
+  __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// mean and 1 / sqrt(var + eps) of one sample from its LN_SHARDS x 4 fixed-point sums -> s_stat[0..1] (LDS).
+// mean and 1 / sqrt(var + eps) of one sample from its LN_SHARDS x LN_WORDS fixed-point sums -> s_stat[0..1] (LDS).
 // Called by all 256 threads (ends with a barrier); wave 0 adds the shards (integers: exact, any order).
 __device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n, double *s_stat, int tid) {
   static_assert(LN_SHARDS == 64, "one shard per lane of wave 0");
   if (tid < 64) {
-    const long long *s = sums + (size_t)tid * 4;
-    long long h1 = s[0], l1 = s[1], h2 = s[2], l2 = s[3];
+    const long long *s = sums + (size_t)tid * LN_WORDS;
+    long long h1 = s[0], h2 = s[1];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       h1 += __shfl_xor(h1, off, 64);
-      l1 += __shfl_xor(l1, off, 64);
       h2 += __shfl_xor(h2, off, 64);
-      l2 += __shfl_xor(l2, off, 64);
     }
     if (tid == 0) {
-      const double S1 = (double)h1 * (1.0 / LN_HI_SCALE) + (double)l1 * (1.0 / (LN_HI_SCALE * LN_LO_SCALE));
-      const double S2 = (double)h2 * (1.0 / LN_HI_SCALE) + (double)l2 * (1.0 / (LN_HI_SCALE * LN_LO_SCALE));
+      const double S1 = (double)h1 * (1.0 / LN_S1_SCALE), S2 = (double)h2 * (1.0 / LN_S2_SCALE);
       const double mu = S1 * inv_n;
       double var = S2 * inv_n - mu * mu;
       var = var > 0.0 ? var : 0.0;
@@ -304,7 +318,7 @@ __device__ __forceinline__ void sum_slabs(f32x16 (&acc)[MT][NT], __amdgpu_buffer
 // accumulates the LayerNorm sums of what it stores.
 // Statistics: d = x - pivot with a wave-uniform sample pivot (no cancellation: |d| ~ sigma), s1 = sum d,
 // s2 = sum d^2 in fp32 over the wave's 1024 values, then sum x = n P + s1, sum x^2 = s2 + 2 P s1 + n P^2 in
-// fp64 and an exact fixed-point atomic add (ln_atomic_add).
+// fp64 and a fixed-point integer atomic add (ln_atomic_add).
 // INTERIOR: whole tile inside the output, no row / channel masks anywhere (the common case; epilogue VALU
 // is paid in matrix throughput of the co-resident workgroups).
 template <int BM, int BN, int MODE, bool INTERIOR>
@@ -398,9 +412,9 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
     const float wcnt = INTERIOR ? (float)(MT * NT * 16 * 64) : wave_sum(cnt);
     if (lane == 0 && wcnt > 0.f) {
       const double P = (double)pivot, n = (double)wcnt, a = (double)s1;
-      long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * 4;   // (any spread will do)
-      ln_atomic_add(dst, n * P + a);
-      ln_atomic_add(dst + 2, (double)s2 + 2.0 * P * a + n * P * P);
+      long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * LN_WORDS;   // (any spread will do)
+      ln_atomic_add(dst, (n * P + a) * LN_S1_SCALE);
+      ln_atomic_add(dst + 1, ((double)s2 + 2.0 * P * a + n * P * P) * LN_S2_SCALE);
     }
   }
 }
@@ -451,7 +465,7 @@ __device__ __forceinline__ void apply_ahead(const ConvParams &p, char *smem, int
     const int row = (int)(ur / upr), part = (int)(ur - (long)row * upr);
     if (b != cur_b) {   // (the sweep is in order: the sample changes at most a few times per workgroup)
       __syncthreads();
-      ln_mean_inv(p.ap_sums + (size_t)b * LN_SHARDS * 4, p.ap_inv_n, s_stat, tid);
+      ln_mean_inv(p.ap_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ap_inv_n, s_stat, tid);
       const double mu = s_stat[0], inv = s_stat[1];
       for (int c = tid; c < C; c += 256) {
         const double sc = inv * (double)p.ap_gamma[c];
@@ -794,7 +808,7 @@ _Pragma("unroll")                                                               
     __shared__ double s_hstat[2];
     s_haff = s_haff_store;
     if (p.ln_sums != nullptr) {
-      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * 4, p.ln_inv_n, s_hstat, tid);
+      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, s_hstat, tid);
       const double mu = s_hstat[0], inv = s_hstat[1];
       for (int c = tid; c < p.C0; c += 256) {
         const double sc = inv * (double)p.ln_gamma[c];
@@ -1189,7 +1203,7 @@ conv_halo_kernel(const ConvParams p) {
   MSI_B_ISSUE(c0, 1, 1)
   if (APPLY) {   // the sums' round trip rides on the patch's (s_stat sits in the A region: read back before the patch lands)
     double *s_stat = reinterpret_cast<double *>(smem);
-    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * 4, p.ln_inv_n, s_stat, tid);
+    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, s_stat, tid);
     const double mu = s_stat[0];
     inv_f = (float)s_stat[1];
     mu_hi = (float)mu;
@@ -1459,13 +1473,13 @@ convt_halo_kernel(const ConvParams p) {
   if (p.halo_apply) {
     double *s_stat = reinterpret_cast<double *>(smem);
     if (p.halo_apply & 1) {
-      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * 4, p.ln_inv_n, s_stat, tid);
+      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, s_stat, tid);
       const double mu = s_stat[0];
       inv_f[0] = (float)s_stat[1]; mu_hi[0] = (float)mu; mu_lo[0] = (float)(mu - (double)mu_hi[0]);
       __syncthreads();
     }
     if (p.halo_apply & 2) {
-      ln_mean_inv(p.ln_sums1 + (size_t)b * LN_SHARDS * 4, p.ln_inv_n1, s_stat, tid);
+      ln_mean_inv(p.ln_sums1 + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n1, s_stat, tid);
       const double mu = s_stat[0];
       inv_f[1] = (float)s_stat[1]; mu_hi[1] = (float)mu; mu_lo[1] = (float)(mu - (double)mu_hi[1]);
       __syncthreads();
@@ -1767,7 +1781,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
   if (PD == 2) MSI_B_ISSUE(c0, 1, 1)
   if (APPLY) {
     double *s_stat = reinterpret_cast<double *>(smem);
-    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * 4, p.ln_inv_n, s_stat, tid);
+    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, s_stat, tid);
     const double mu = s_stat[0];
     inv_f = (float)s_stat[1];
     mu_hi = (float)mu;
@@ -2073,7 +2087,7 @@ ln_finish_kernel(const long long *__restrict__ sums, double inv_n, const float *
                  const float *__restrict__ beta, int C, float *__restrict__ aff) {
   __shared__ double s_stat[2];
   const int b = blockIdx.x, tid = threadIdx.x;
-  ln_mean_inv(sums + (size_t)b * LN_SHARDS * 4, inv_n, s_stat, tid);
+  ln_mean_inv(sums + (size_t)b * LN_SHARDS * LN_WORDS, inv_n, s_stat, tid);
   const double mu = s_stat[0], inv = s_stat[1];
   for (int c = tid; c < C; c += 256) {
     const double sc = inv * (double)gamma[c];
@@ -2084,7 +2098,7 @@ ln_finish_kernel(const long long *__restrict__ sums, double inv_n, const float *
 
 // LayerNorm apply (+ ReLU), one launch per layer.  Every workgroup derives the affine of slim.layer_norm,
 //   scale = gamma * rsqrt(var + eps), shift = beta - mean * scale,
-// from the sample's 64 x 4 fixed-point sums (ln_mean_inv), keeps it in LDS, and applies
+// from the sample's 64 x 2 fixed-point sums (ln_mean_inv), keeps it in LDS, and applies
 // x = max(x*scale[c] + shift[c], 0) to its grid-stride slice (nets.py:401,485 arg_scope: normalizer, then the
 // default ReLU).  Workgroup 0 also publishes the affine (tests).
 // BF16OUT = 1: the normalised activation is written as bf16 to `yb` (the operand buffer of the bf16 path)
@@ -2097,7 +2111,7 @@ ln_apply_kernel(float *__restrict__ x, const long long *__restrict__ sums, doubl
   extern __shared__ __attribute__((aligned(16))) float s_aff[];  // scale[C] shift[C]
   __shared__ double s_stat[2];
   const int b = blockIdx.y, tid = threadIdx.x;
-  ln_mean_inv(sums + (size_t)b * LN_SHARDS * 4, inv_n, s_stat, tid);
+  ln_mean_inv(sums + (size_t)b * LN_SHARDS * LN_WORDS, inv_n, s_stat, tid);
   const double mu = s_stat[0], inv = s_stat[1];
   for (int c = tid; c < C; c += 256) {
     const double sc = inv * (double)gamma[c];
@@ -2166,7 +2180,7 @@ struct Layer {
   size_t gamma_off, beta_off, coord_off;  // floats inside the packed blob
   size_t raw_off, aff_off;                // bytes inside the workspace
   size_t act_off;                         // bf16 path: normalised bf16 activation (the next layer's operand)
-  size_t sums_off;                        // LayerNorm sums [B][LN_SHARDS][4] int64
+  size_t sums_off;                        // LayerNorm sums [B][LN_SHARDS][LN_WORDS] int64
   size_t flags_off;                       // apply-ahead row counters of THIS layer's output [B][out_h] ints
 };
 
@@ -2319,7 +2333,7 @@ int build_net(const msi_net_desc *d, int num_cus, Net &net) {
   size_t zoff = net.cnt_off + round_up((size_t)MSI_NET_NUM_LAYERS * CONV_SLOTS_PER_CU * num_cus * sizeof(int), 256);
   for (int i = 0; i < MSI_NET_NUM_LAYERS; ++i) {
     net.layers[i].sums_off = zoff;
-    if (net.layers[i].kind != MODE_HEAD) zoff += (size_t)d->batch * LN_SHARDS * 4 * sizeof(long long);
+    if (net.layers[i].kind != MODE_HEAD) zoff += (size_t)d->batch * LN_SHARDS * LN_WORDS * sizeof(long long);
   }
   for (int i = 0; i < MSI_NET_NUM_LAYERS; ++i) {
     net.layers[i].flags_off = zoff;
