@@ -2878,6 +2878,9 @@ int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value) {
     plan->num_cus = value;
   }
   if (option == MSI_NET_OPT_BIGTILE) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: bigtile %d", value);
+  if (option == MSI_NET_OPT_HALO) MSI_REQUIRE(value >= 0 && value <= 3, "net_plan_set_option: halo %d (bit 0 conv, bit 1 conv-transpose)", value);
+  if (option == MSI_NET_OPT_TAILSPLIT) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: tailsplit %d", value);
+  if (option == MSI_NET_OPT_F32_TILE) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: f32 tile %d", value);
   const int old = plan->opt[option];
   plan->opt[option] = value;
   int rc = plan_layers(plan);

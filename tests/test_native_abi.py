@@ -189,3 +189,41 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
         assert not hp[:, head.cout:, :].any()
         off = -(-(off + hp.size) // 64) * 64
     assert off == packed.size
+
+
+def test_plan_options_and_raw_layer_bookkeeping(native_lib):
+    """Host logic of the plan object (no GPU needed: the CU count falls back to the default part): option validation, and
+    which producers are left un-normalised in memory -- exactly those whose EVERY consumer applies the LayerNorm while
+    staging a halo patch (or is the fused head) -- per MSI_NET_OPT_HALO."""
+    import ctypes
+    from matryodshka_amd import nets, _native as N
+    lib = native_lib.lib
+    names = nets.LAYER_NAMES
+
+    def raw_layers(desc, halo):
+        h = ctypes.c_void_p()
+        assert lib.msi_net_plan_create(desc, ctypes.byref(h)) == 0
+        try:
+            assert lib.msi_net_plan_set_option(h, N.NET_OPT_HALO, halo) == 0
+            return [names[i] for i in range(17) if lib.msi_net_plan_layer_is_normalized(h, i) == 0]
+        finally:
+            lib.msi_net_plan_destroy(h)
+
+    desc = nets.make_desc(1, 320, 640, 192, 64, 64, True)                 # BASELINE configs[1]
+    assert raw_layers(desc, 0) == ["conv8_2"]                             # only the fused head applies on load
+    # halo conv layers: producers whose only consumer is a stride-1 3x3 layer (the encoder skips feed a conv-transpose too)
+    assert raw_layers(desc, 1) == ["conv3_1", "conv4_1", "conv4_2", "conv6_1", "conv6_2", "conv7_1", "conv8_1", "conv8_2"]
+    # + conv-transpose halo layers: their decoder inputs and the skip tensors as well -- except conv7_1's sources (conv6_3,
+    # conv2_2): at this size its four-slab K-ranges exceed the partial-accumulator workspace and the plan keeps the tap kernel
+    assert raw_layers(desc, 3) == ["conv1_2", "conv3_1", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv6_1",
+                                   "conv6_2", "conv7_1", "conv7_2", "conv8_1", "conv8_2"]
+    small = nets.make_desc(1, 16, 24, 24, 8, 12, True)                    # nothing tiles into 4 x 16 patches
+    assert raw_layers(small, 3) == ["conv8_2"]
+    bf = nets.make_desc(16, 320, 640, 384, 128, 64, True, dtype="bf16")   # configs[2]: 256x64 tiles read the bf16 copy
+    assert raw_layers(bf, 1) == ["conv3_1", "conv4_1", "conv4_2", "conv6_1", "conv6_2", "conv7_1"]
+    h = ctypes.c_void_p()
+    assert lib.msi_net_plan_create(desc, ctypes.byref(h)) == 0
+    for opt, bad in ((N.NET_OPT_HALO, 4), (N.NET_OPT_BIGTILE, 3), (N.NET_OPT_NUM_CUS, 2), (99, 0)):
+        assert lib.msi_net_plan_set_option(h, opt, bad) == -1
+    assert lib.msi_net_plan_layer_is_normalized(h, 17) == -1 and lib.msi_net_plan_layer_is_normalized(None, 0) == -1
+    lib.msi_net_plan_destroy(h)
