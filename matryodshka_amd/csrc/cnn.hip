@@ -1809,6 +1809,200 @@ conv_halo_bf16_kernel(const ConvParams p) {
 #endif
 }
 
+// ---- halo-patch kernel for the conv-transpose layers, bf16 operands ------------------------------------------------
+// The bf16 tap kernel is bound by its L2 -> LDS traffic, and a conv-transpose fetches every input element four times per
+// parity class.  Here a workgroup owns a (BM / 16) x 16 tile of the INPUT grid x BN channels for the TWO classes of one
+// output-row parity ph (pw = 0, 1): per 64-channel chunk of either source of the skip concat it stages the halo patch
+// once (from the bf16 operand copies) and runs 2 classes x 4 taps = 8 k-steps on it, each class into its own
+// accumulators (2 x MT x NT tiles = 128 registers).  Class (ph, pw), tap (th, tw) reads input row mh + (ph ? th : -th)
+// and column mw + (pw ? tw : -tw) (tap_delta): the row offset of th = 1 is the only run-time part of a fragment
+// address (two base registers), columns are immediates.  The two workgroups of a tile (ph = 0, 1) are neighbours in
+// the grid order (same XCD: the patch comes from HBM once).  Weights: the packed blob's [class][tap * CH + c] row
+// blocks through the conv kernel's DMA ring.  Whole tiles only.  Unlike the fp32 attempt (convt_halo_kernel, slower than
+// its tap kernel) this one replaces a kernel that is traffic-bound: configs[2] conv8_1 948 -> see profiles/r02_T_*.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+convt_halo_bf16_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef HaloGeomB<BM, BN, 1> G;
+  constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, MT = BM / 64, NT = BN / 64;
+  constexpr int NSTG = G::NSTG, PD = NSTG - 1, BI = BN / 32;
+  static_assert(NSTG == 3, "the k-step bookkeeping below assumes a prefetch distance of two");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int CH = p.cpt0 + p.cpt1;                         // 64-channel chunks of both sources
+  int t;
+  {
+    const int bid = blockIdx.x;
+    const int q = p.ntiles >> 3, r = p.ntiles & 7, xcd = bid & 7, local = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  int ph, tile_m, tile_n, b;
+  {   // row parity fastest (p.nclass = 2 here), then M tiles, N tiles, samples
+    int r = t;
+    ph = r & 1; r >>= 1;
+    const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
+    tile_m = r - q1 * p.tiles_m; r = q1;
+    const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
+    tile_n = r - q2 * p.tiles_n;
+    b = q2;
+  }
+  const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
+  const int oh0 = tyi * G::TH, ow0 = (tile_m - tyi * p.halo_tx) * 16;
+  const int H = p.Hin, W = p.Win;
+
+  unsigned pixi[NLOAD], lds_a[NLOAD];
+  bool pok[NLOAD];
+  const int cslot = tid & 7;
+  constexpr unsigned OOB = 0xfffffff0u;
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const int pp = (tid + 256 * k) >> 3;
+    const int py = pp / PW, px = pp - py * PW;
+    const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
+    pok[k] = pp < NPX && ih >= 0 && ih < H && iw >= 0 && iw < W;   // SAME: zeros outside
+    pixi[k] = (unsigned)(ih * W + iw);
+    lds_a[k] = pp < NPX ? (unsigned)(py * G::ROW_PITCH + px * G::PIX_BYTES + cslot * 16) : 0xffffffffu;
+  }
+  const size_t in0 = (size_t)H * W * p.C0 * 2, in1 = (size_t)H * W * p.C1 * 2;
+  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in0), 0, (int)in0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x1 + (size_t)b * in1), 0, (int)(in1 ? in1 : 16), 0x00020000);
+  const int S = p.ksteps;                                 // k-steps per class: 4 CH
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)4 * S * p.npad * ROW_BYTES), 0x00020000);
+  const int drow = lane >> 3, dslot = lane & 7;
+  const unsigned b_voff = (unsigned)((tile_n * BN + wave * (BN / 4) + drow) * ROW_BYTES + dslot * 16);
+
+  v4f araw[NLOAD];
+#define MSI_PATCH_LOAD(c)                                                                                              \
+  {                                                                                                                    \
+    const int s_ = (c) >= p.cpt0 ? 1 : 0, cc_ = s_ ? (c) - p.cpt0 : (c);                                               \
+    const unsigned cb_ = (unsigned)((s_ ? p.C1 : p.C0) * 2);                                                           \
+    if (s_ == 0) {                                                                                                     \
+      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
+            rsrc_a0, pok[k_] ? pixi[k_] * cb_ + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));                    \
+    } else {                                                                                                           \
+      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
+            rsrc_a1, pok[k_] ? pixi[k_] * cb_ + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));                    \
+    }                                                                                                                  \
+  }
+#define MSI_PATCH_STORE()                                                                                              \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = araw[k_];                             \
+  }
+  // weights of k-step (class, tap, chunk c) -> ring stage st (run-time)
+#define MSI_B_ISSUE(cls, tap, c, st)                                                                                   \
+  {                                                                                                                    \
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * (BN / 4) * ROW_BYTES;                                   \
+    const int soff_ = (((cls) * S + (tap) * CH + (c)) * p.npad) * ROW_BYTES;                                           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
+    if (BI == 4) {                                                                                                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 16 * ROW_BYTES, 0);         \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 24 * ROW_BYTES, 0);         \
+    }                                                                                                                  \
+  }
+
+  // ---- MFMA side ----
+  const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
+  // fragment base of tap row th = 0 (patch row 1 + local row) and of th = 1 (one row up for ph = 0, one down for ph = 1)
+  const unsigned a_base0 = lds_base + (unsigned)((1 + wm * (MT * 2) + (frow >> 4)) * G::ROW_PITCH + (frow & 15) * G::PIX_BYTES + fh * 16);
+  const unsigned a_base1 = ph ? a_base0 + G::ROW_PITCH : a_base0 - G::ROW_PITCH;
+  unsigned b_q[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    b_q[q] = lds_base + G::A_BYTES + (wn * (NT * 32) + frow) * ROW_BYTES + (((2 * q + fh) ^ fswz) << 4);
+  f32x16 acc[2][MT][NT];
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cl][i][j][r] = 0.f;
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+  // k-step J of the chunk: class pw = J / 4, tap (th, tw) = ((J / 2) & 1, J & 1); weights in ring stage st
+#define MSI_CQ(Q, PWC)                                                                                                 \
+  wait_lgkm_frag<(3 - (Q)) * (MT + NT), MT, NT>(fa_[Q], fb_[Q]);                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                                  \
+      acc[PWC][i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb_[Q][j_]),               \
+                                                                 __builtin_bit_cast(bf16x8, fa_[Q][i_]), acc[PWC][i_][j_], 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);
+#define MSI_CTSTEP(J)                                                                                                  \
+  {                                                                                                                    \
+    constexpr int PWC_ = (J) >> 2, TH_ = ((J) >> 1) & 1, TW_ = (J) & 1;                                                \
+    constexpr int COFF_ = (1 + (PWC_ ? TW_ : -TW_)) * G::PIX_BYTES;   /* column of the tap: immediate */                \
+    constexpr int AROW_ = 2 * G::ROW_PITCH;                                                                            \
+    const unsigned ab_ = TH_ ? a_base1 : a_base0;                                                                      \
+    v4f fa_[4][MT], fb_[4][NT];                                                                                        \
+    const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
+      const unsigned ba_ = b_q[q_] + bst_;                                                                             \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                                \
+        fa_[q_][i_] = i_ == 0 ? (q_ == 0 ? lds_read128<COFF_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 32>(ab_)            \
+                                : q_ == 2 ? lds_read128<COFF_ + 64>(ab_) : lds_read128<COFF_ + 96>(ab_))               \
+                    : i_ == 1 ? (q_ == 0 ? lds_read128<COFF_ + AROW_>(ab_) : q_ == 1 ? lds_read128<COFF_ + AROW_ + 32>(ab_) \
+                                : q_ == 2 ? lds_read128<COFF_ + AROW_ + 64>(ab_) : lds_read128<COFF_ + AROW_ + 96>(ab_)) \
+                    : i_ == 2 ? (q_ == 0 ? lds_read128<COFF_ + 2 * AROW_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 2 * AROW_ + 32>(ab_) \
+                                : q_ == 2 ? lds_read128<COFF_ + 2 * AROW_ + 64>(ab_) : lds_read128<COFF_ + 2 * AROW_ + 96>(ab_)) \
+                              : (q_ == 0 ? lds_read128<COFF_ + 3 * AROW_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 3 * AROW_ + 32>(ab_) \
+                                : q_ == 2 ? lds_read128<COFF_ + 3 * AROW_ + 64>(ab_) : lds_read128<COFF_ + 3 * AROW_ + 96>(ab_)); \
+      _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                                \
+        fb_[q_][j_] = j_ == 0 ? lds_read128<0>(ba_) : lds_read128<32 * ROW_BYTES>(ba_);                                \
+    }                                                                                                                  \
+    MSI_CQ(0, PWC_)                                                                                                    \
+    bool issued_;                                                                                                      \
+    {                                                                                                                  \
+      if ((J) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                                \
+      int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                         \
+      constexpr int JN_ = ((J) + PD) & 7;                                                                              \
+      issued_ = ((J) + PD < 8) || (c + 1 < c1);                                                                        \
+      if ((J) + PD < 8) { MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c, sn_) }                                          \
+      else if (c + 1 < c1) { MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_) }                                   \
+    }                                                                                                                  \
+    MSI_CQ(1, PWC_) MSI_CQ(2, PWC_) MSI_CQ(3, PWC_)                                                                    \
+    if ((J) == 0 && c + 1 < c1) wait_vmcnt<BI + NLOAD>();                                                              \
+    else if (issued_) wait_vmcnt<BI>();                                                                                \
+    else wait_vmcnt<0>();                                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
+  }
+
+  const int c0 = 0, c1 = CH;
+  int c = c0, st = 0;
+  MSI_PATCH_LOAD(c0)
+  MSI_B_ISSUE(2 * ph, 0, c0, 0)
+  MSI_B_ISSUE(2 * ph, 1, c0, 1)
+  wait_vmcnt<0>();
+  MSI_PATCH_STORE()
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; c < c1; ++c) {
+    MSI_CTSTEP(0) MSI_CTSTEP(1) MSI_CTSTEP(2) MSI_CTSTEP(3) MSI_CTSTEP(4) MSI_CTSTEP(5) MSI_CTSTEP(6) MSI_CTSTEP(7)
+    if (c + 1 < c1) {
+      MSI_PATCH_STORE()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+#undef MSI_CTSTEP
+#undef MSI_CQ
+#undef MSI_B_ISSUE
+#undef MSI_PATCH_STORE
+#undef MSI_PATCH_LOAD
+#pragma unroll
+  for (int pwc = 0; pwc < 2; ++pwc) emit_tile<BM, BN, MODE_CONVT>(p, acc[pwc], tile_m, tile_n, 2 * ph + pwc, b, tid);
+#endif
+}
+
 // Fix-up of the split tiles as a separate launch (plan option MSI_NET_OPT_FIXUP_KERNEL; the default is the in-launch
 // hand-off above): sums the K-range slabs of a tile in k order and runs the same epilogue.  One workgroup per split tile.
 template <int BM, int BN, int MODE>
@@ -2369,6 +2563,7 @@ struct LayerLaunch {
   int halo;         // conv_halo_kernel (fp32) / conv_halo_bf16_kernel instead of conv_igemm_kernel
   int hbm, hbn;     // bf16 halo tile: 128 x 128 or 256 x 64
   int halo_t;       // convt_halo_kernel (conv-transpose, fp32): all four parity classes per workgroup
+  int halo_tb;      // convt_halo_bf16_kernel (conv-transpose, bf16): the two classes of one output-row parity per workgroup
   int halo_apply;   // ... applying the producer's LayerNorm while staging the patch (the producer's buffer stays raw)
   unsigned ln_blocks;
 };
@@ -2531,6 +2726,14 @@ int plan_layers(msi_net_plan *pl) {
       p.nclass = 1;                                      // tiles are enumerated per (tile_m, tile_n, sample): a workgroup owns the 4 classes
       if (L.cpt0 + L.cpt1 < max_split) max_split = L.cpt0 + L.cpt1;
     }
+    // bf16 conv-transpose halo kernel (convt_halo_bf16_kernel): SAME conv-transposes, 64-channel chunks of both sources,
+    // whole 8 x 16 x 128 or 16 x 16 x 64 tiles, one workgroup per output-row parity (enumerated as two "classes")
+    if ((pl->opt[MSI_NET_OPT_HALO] & 1) && bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.kind == MODE_CONVT && !L.wrapt &&
+        L.in_w % 16 == 0 && L.c0 % 64 == 0 && L.c1 % 64 == 0 && bigmode != 0) {
+      if (L.cout % 128 == 0 && L.in_h % 8 == 0) { Q.halo_tb = 1; Q.hbm = 128; Q.hbn = 128; }
+      else if (L.cout == 64 && L.in_h % 8 == 0) { Q.halo_tb = 1; Q.hbm = 128; Q.hbn = 64; }   // (256 x 64 with two classes spills: 128 accumulator + 80 fragment registers)
+      if (Q.halo_tb) { Q.halo = 1; BM = Q.hbm; BN = Q.hbn; max_split = 1; p.nclass = 2; }
+    }
     if (Q.halo) {
       p.halo_tx = L.in_w / 16;
       p.halo_xor = bf16 ? 0 : 8;
@@ -2579,7 +2782,7 @@ int plan_layers(msi_net_plan *pl) {
       if (L.src0 == s || L.src1 == s) {
         ++consumers;
         const LayerLaunch &C = pl->launch[li];
-        if (C.halo_t || (C.halo && C.hbm != 256 && L.src0 == s)) ++capable;
+        if (C.halo_t || (C.halo && !C.halo_tb && C.hbm != 256 && L.src0 == s)) ++capable;   // (halo_tb reads the bf16 copies)
       }
     }
     if (consumers > 0 && consumers == capable) {
@@ -2590,7 +2793,7 @@ int plan_layers(msi_net_plan *pl) {
         if (C.halo_t) {
           if (L.src0 == s) { C.p.halo_apply |= 1; C.p.ln_inv_n = 1.0 / net.layers[s].ln_count; }
           if (L.src1 == s) { C.p.halo_apply |= 2; C.p.ln_inv_n1 = 1.0 / net.layers[s].ln_count; }
-        } else if (L.src0 == s) {
+        } else if (L.src0 == s && !C.halo_tb) {
           C.halo_apply = 1;
           C.p.ln_inv_n = 1.0 / net.layers[s].ln_count;
         }
@@ -2635,6 +2838,20 @@ int launch_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
   }
   hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, BN, RATE, APPLY>), dim3(Q.nblocks), dim3(256), lds, stream, p);
   return msi::check_launch("conv_halo_bf16");
+}
+
+template <int BM, int BN>
+int launch_convt_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stream) {
+  constexpr int lds = HaloGeomB<BM, BN, 1>::LDS_BYTES;
+  static thread_local bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(convt_halo_bf16_kernel<BM, BN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "convt_halo_bf16: %s", hipGetErrorString(e));
+    done = true;
+  }
+  hipLaunchKernelGGL((convt_halo_bf16_kernel<BM, BN>), dim3(Q.nblocks), dim3(256), lds, stream, p);
+  return msi::check_launch("convt_halo_bf16");
 }
 
 template <int BM, int BN>
@@ -3023,7 +3240,9 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
     p.dbg = (li == g_timing_layer) ? g_timing_buf : nullptr;
 #endif
     int rc;
-    if (Q.halo && bf16) {
+    if (Q.halo_tb) {
+      rc = Q.hbn == 128 ? launch_convt_halo_bf16<128, 128>(Q, p, stream) : launch_convt_halo_bf16<128, 64>(Q, p, stream);
+    } else if (Q.halo && bf16) {
       if (Q.halo_apply) {   // the patch comes from the producer's RAW fp32 output
         const Layer &S = net.layers[L.src0];
         p.x0 = ws + S.raw_off;
