@@ -288,8 +288,9 @@ typedef struct msi_net_plan msi_net_plan;
                                    /* -- bit-identical results; measured slower on MI355X (write-through hand-off), see DESIGN.md  */
 #define MSI_NET_OPT_HALO 8          /* bit 0 (default on): the stride-1 3x3 layers run the halo-patch kernels (conv_halo_kernel fp32, */
                                    /* conv_halo_bf16_kernel: one LDS-stationary halo patch per workgroup and input chunk, the          */
-                                   /* producer's LayerNorm applied while staging it); bit 1 (default off; measured slower): the fp32   */
-                                   /* conv-transposes run convt_halo_kernel (all four parity classes per workgroup); 0: tap-DMA kernel */
+                                   /* producer's LayerNorm applied while staging it) and the bf16 conv-transposes                      */
+                                   /* convt_halo_bf16_kernel; bit 1 (default off; measured slower): the fp32 conv-transposes run       */
+                                   /* convt_halo_kernel (all four parity classes per workgroup); 0: tap-DMA kernel everywhere          */
 #define MSI_NET_OPT_COUNT 9
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
