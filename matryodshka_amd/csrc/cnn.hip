@@ -1819,7 +1819,8 @@ conv_halo_bf16_kernel(const ConvParams p) {
 // address (two base registers), columns are immediates.  The two workgroups of a tile (ph = 0, 1) are neighbours in
 // the grid order (same XCD: the patch comes from HBM once).  Weights: the packed blob's [class][tap * CH + c] row
 // blocks through the conv kernel's DMA ring.  Whole tiles only.  Unlike the fp32 attempt (convt_halo_kernel, slower than
-// its tap kernel) this one replaces a kernel that is traffic-bound: configs[2] conv8_1 948 -> see profiles/r02_T_*.
+// its tap kernel) this one replaces a kernel that is traffic-bound: configs[2] conv8_1 963 -> 537 us, conv7_1 558 -> 416,
+// conv6_1 475 -> 390 per 16 frames (profiles/r02_T_bf16_convt_halo.txt).
 template <int BM, int BN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 convt_halo_bf16_kernel(const ConvParams p) {
