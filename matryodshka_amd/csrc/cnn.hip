@@ -80,9 +80,12 @@ constexpr double LN_EPS = 1e-12;  // slim.layer_norm variance epsilon [TF-knowle
 // rounded to 2^-24 / 2^-16 absolute (<= 4e-4 / 0.1 over the 12 800 waves of the largest layer, against totals of 1e6 /
 // 1e7 and more: 1e-9 relative, the variance keeps ten digits when mean^2 is 1e6 times the variance).  Range: |sum x| <
 // 5e11 and sum x^2 < 1.4e14 per sample, i.e. an rms activation below ~3 000 on the largest layer (LayerNorm'd networks
-// sit at 1e0..1e2); a wave's share must stay below 2^51 after scaling (mean x^2 < 3e7 over its 1 024 values).
-// (Until r02 the sums were exact, hi * 2^-8 + lo * 2^-52 in two words each: four atomics and four fp64 -> int64
-// conversions per wave and tile cost 68 us per frame in matrix time, 2.7 % of the network.)
+// sit at 1e0..1e2; fp32-grade statistics down to an rms of ~0.03, degrading gracefully below); one wave's share must stay
+// below 2^51 after scaling (mean x^2 < 3e7 over its 1 024 values: the same order as the range of the totals).
+// (Until r02 the sums were exact, hi * 2^-8 + lo * 2^-52 in two words each.  Measured, 6 interleaved repeats of the
+// network: this form 2.456 ms; exact with the same cheap rounding, four atomics per wave 2.474 ms; exact with the four
+// waves' shares combined through LDS, four atomics per workgroup 2.472 ms -- the atomics and the barrier cost what the
+// range buys, and the range is not needed here.)
 constexpr int LN_SHARDS = 64, LN_WORDS = 2;
 constexpr double LN_S1_SCALE = 16777216.0 /* 2^24 */, LN_S2_SCALE = 65536.0 /* 2^16 */;
 constexpr int AP_FLAG_STRIDE = 16;  // ints between two row counters of the apply-ahead hand-off: one counter per 64-byte line
