@@ -291,7 +291,8 @@ typedef struct msi_net_plan msi_net_plan;
                                    /* producer's LayerNorm applied while staging it) and the bf16 conv-transposes                      */
                                    /* convt_halo_bf16_kernel; bit 1 (default off; measured slower): the fp32 conv-transposes run       */
                                    /* convt_halo_kernel (all four parity classes per workgroup); 0: tap-DMA kernel everywhere          */
-#define MSI_NET_OPT_COUNT 9
+#define MSI_NET_OPT_HALO_SKIP 9     /* bit i = layer i (graph order) does NOT take a halo kernel although it qualifies (tuning)          */
+#define MSI_NET_OPT_COUNT 10
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
 int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);

@@ -2708,13 +2708,14 @@ int plan_layers(msi_net_plan *pl) {
       else if (pl->opt[MSI_NET_OPT_F32_TILE] == 2 && L.cout % 128 == 0) { Q.tile = TILE_64x128; BM = 64; BN = 128; }
     }
     // halo-patch kernel (conv_halo_kernel): stride-1 3x3 layers with one source, fp32, whole 4 x 16 tiles and 32-channel chunks
-    Q.halo = pl->opt[MSI_NET_OPT_HALO] && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && Q.tile == TILE_64x64 &&
+    const bool halo_ok = !((pl->opt[MSI_NET_OPT_HALO_SKIP] >> li) & 1);
+    Q.halo = halo_ok && pl->opt[MSI_NET_OPT_HALO] && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && Q.tile == TILE_64x64 &&
              L.kind == MODE_CONV && L.stride == 1 && L.src1 < 0 && L.in_h % 4 == 0 && L.in_w % 16 == 0 && L.c0 % 32 == 0 &&
              (L.rate == 1 || L.rate == 2);
     int max_split = MAX_SPLIT;
     // bf16 halo-patch kernel (conv_halo_bf16_kernel): the same layers with 64-channel chunks and whole
     // 8 x 16 pixel x 128 channel or 16 x 16 x 64 tiles
-    if (pl->opt[MSI_NET_OPT_HALO] && bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.kind == MODE_CONV && L.stride == 1 && L.src1 < 0 && L.in_w % 16 == 0 &&
+    if (halo_ok && pl->opt[MSI_NET_OPT_HALO] && bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.kind == MODE_CONV && L.stride == 1 && L.src1 < 0 && L.in_w % 16 == 0 &&
         L.c0 % 64 == 0 && bigmode != 0) {
       if (L.cout % 128 == 0 && L.in_h % 8 == 0 && (L.rate == 1 || L.rate == 2)) { Q.halo = 1; Q.hbm = 128; Q.hbn = 128; }
       else if (L.cout == 64 && L.in_h % 16 == 0 && L.rate == 1) { Q.halo = 1; Q.hbm = 256; Q.hbn = 64; }
@@ -2722,7 +2723,7 @@ int plan_layers(msi_net_plan *pl) {
     }
     // conv-transpose halo kernel (convt_halo_kernel; HALO bit 1, NOT the default -- measured slower, see the kernel):
     // SAME conv-transposes (CoordNet), fp32, whole 4 x 16 input tiles and 32-channel chunks of both sources
-    Q.halo_t = (pl->opt[MSI_NET_OPT_HALO] & 2) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] &&
+    Q.halo_t = halo_ok && (pl->opt[MSI_NET_OPT_HALO] & 2) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] &&
                Q.tile == TILE_64x64 && L.kind == MODE_CONVT && !L.wrapt && L.in_h % 4 == 0 && L.in_w % 16 == 0 &&
                L.c0 % 32 == 0 && L.c1 % 32 == 0;
     if (Q.halo_t) {
@@ -2732,7 +2733,7 @@ int plan_layers(msi_net_plan *pl) {
     }
     // bf16 conv-transpose halo kernel (convt_halo_bf16_kernel): SAME conv-transposes, 64-channel chunks of both sources,
     // whole 8 x 16 x 128 or 16 x 16 x 64 tiles, one workgroup per output-row parity (enumerated as two "classes")
-    if ((pl->opt[MSI_NET_OPT_HALO] & 1) && bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.kind == MODE_CONVT && !L.wrapt &&
+    if (halo_ok && (pl->opt[MSI_NET_OPT_HALO] & 1) && bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.kind == MODE_CONVT && !L.wrapt &&
         L.in_w % 16 == 0 && L.c0 % 64 == 0 && L.c1 % 64 == 0 && bigmode != 0) {
       if (L.cout % 128 == 0 && L.in_h % 8 == 0) { Q.halo_tb = 1; Q.hbm = 128; Q.hbn = 128; }
       else if (L.cout == 64 && L.in_h % 8 == 0) { Q.halo_tb = 1; Q.hbm = 128; Q.hbn = 64; }   // (256 x 64 with two classes spills: 128 accumulator + 80 fragment registers)

@@ -217,6 +217,13 @@ def test_plan_options_and_raw_layer_bookkeeping(native_lib):
     # conv2_2): at this size its four-slab K-ranges exceed the partial-accumulator workspace and the plan keeps the tap kernel
     assert raw_layers(desc, 3) == ["conv1_2", "conv3_1", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv6_1",
                                    "conv6_2", "conv7_1", "conv7_2", "conv8_1", "conv8_2"]
+    # HALO_SKIP takes layers out again: conv6_2 (layer 11) back on the tap kernel needs conv6_1 normalised in memory
+    h = ctypes.c_void_p()
+    assert lib.msi_net_plan_create(desc, ctypes.byref(h)) == 0
+    assert lib.msi_net_plan_set_option(h, N.NET_OPT_HALO_SKIP, 1 << 11) == 0
+    assert [names[i] for i in range(17) if lib.msi_net_plan_layer_is_normalized(h, i) == 0] == \
+        ["conv3_1", "conv4_1", "conv4_2", "conv6_2", "conv7_1", "conv8_1", "conv8_2"]
+    lib.msi_net_plan_destroy(h)
     small = nets.make_desc(1, 16, 24, 24, 8, 12, True)                    # nothing tiles into 4 x 16 patches
     assert raw_layers(small, 3) == ["conv8_2"]
     bf = nets.make_desc(16, 320, 640, 384, 128, 64, True, dtype="bf16")   # configs[2]: 256x64 tiles read the bf16 copy
