@@ -228,6 +228,23 @@ __device__ __forceinline__ float wave_sum(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
+// The same for a double (two 32-bit DPP moves + one v_add_f64 per step).
+__device__ __forceinline__ double wave_sum_f64(double x) {
+#define MSI_DPP_ADD64(CTRL, ROWMASK)                                                                                   \
+  {                                                                                                                    \
+    const long long b_ = __builtin_bit_cast(long long, x);                                                             \
+    const int lo_ = __builtin_amdgcn_update_dpp(0, (int)b_, CTRL, ROWMASK, 0xf, true);                                 \
+    const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(b_ >> 32), CTRL, ROWMASK, 0xf, true);                         \
+    x += __builtin_bit_cast(double, ((long long)hi_ << 32) | (unsigned)lo_);                                           \
+  }
+  MSI_DPP_ADD64(0xB1, 0xf) MSI_DPP_ADD64(0x4E, 0xf) MSI_DPP_ADD64(0x141, 0xf) MSI_DPP_ADD64(0x140, 0xf)
+  MSI_DPP_ADD64(0x142, 0xa) MSI_DPP_ADD64(0x143, 0xc)
+#undef MSI_DPP_ADD64
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
 // One wave's share of a LayerNorm sum as a fixed-point integer atomic (no return value).  x_scaled = S * scale with
 // |x_scaled| < 2^51: adding 1.5 * 2^52 leaves round-to-nearest-even(x_scaled) in the low mantissa bits -- two VALU
 // instead of the emulated fp64 -> int64 conversion.
@@ -243,15 +260,12 @@ __device__ __forceinline__ void ln_atomic_add(long long *dst, double x_scaled) {
 __device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n, double *s_stat, int tid) {
   static_assert(LN_SHARDS == 64, "one shard per lane of wave 0");
   if (tid < 64) {
+    // the 64 shards as doubles (|shard| < 2^63: rounding at 2^-53 relative, far below the 2^-24 / 2^-16 units) through
+    // the DPP reduction: no dependent trips through the LDS crossbar at the head of every consumer workgroup / ln_apply block
     const long long *s = sums + (size_t)tid * LN_WORDS;
-    long long h1 = s[0], h2 = s[1];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      h1 += __shfl_xor(h1, off, 64);
-      h2 += __shfl_xor(h2, off, 64);
-    }
+    const double h1 = wave_sum_f64((double)s[0]), h2 = wave_sum_f64((double)s[1]);
     if (tid == 0) {
-      const double S1 = (double)h1 * (1.0 / LN_S1_SCALE), S2 = (double)h2 * (1.0 / LN_S2_SCALE);
+      const double S1 = h1 * (1.0 / LN_S1_SCALE), S2 = h2 * (1.0 / LN_S2_SCALE);
       const double mu = S1 * inv_n;
       double var = S2 * inv_n - mu * mu;
       var = var > 0.0 ? var : 0.0;
