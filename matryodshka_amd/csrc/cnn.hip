@@ -340,7 +340,7 @@ __device__ __forceinline__ void sum_slabs(f32x16 (&acc)[MT][NT], __amdgpu_buffer
 // is paid in matrix throughput of the co-resident workgroups).
 template <int BM, int BN, int MODE, bool INTERIOR>
 __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m,
-                                               int tile_n, int cls, int b, int tid) {
+                                               int tile_n, int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre) {
   constexpr int MT = BM / 64, NT = BN / 64;
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5;
   const int ph = cls >> 1, pw = cls & 1;
@@ -389,7 +389,8 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
         v4f v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         if (ok) {
           if (has_cb) {   // cb_stride is Cout rounded up to 4: the whole float4 is in range
-            const v4f cb = *reinterpret_cast<const v4f *>(cbrow + n);
+            // (64x64 fp32 tiles: requested before the k-loop by load_coord_bias)
+            const v4f cb = (MT == 1 && NT == 1 && use_pre) ? cb_pre[g] : *reinterpret_cast<const v4f *>(cbrow + n);
             v.x += cb.x; v.y += cb.y; v.z += cb.z; v.w += cb.w;
           }
           if (MODE == MODE_HEAD) {   // (the packed bias is padded to a multiple of 4 as well)
@@ -438,11 +439,42 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
 
 template <int BM, int BN, int MODE>
 __device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n,
-                                          int cls, int b, int tid) {
+                                          int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre) {
   const bool interior = !(MODE == MODE_CONVT && p.wrap != 0) && (tile_m + 1) * BM <= p.Mh * p.Mw &&
                         (tile_n + 1) * BN <= p.Cout && (p.Cout & 3) == 0;
-  if (interior) emit_tile_impl<BM, BN, MODE, true>(p, acc, tile_m, tile_n, cls, b, tid);
-  else emit_tile_impl<BM, BN, MODE, false>(p, acc, tile_m, tile_n, cls, b, tid);
+  if (interior) emit_tile_impl<BM, BN, MODE, true>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre);
+  else emit_tile_impl<BM, BN, MODE, false>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre);
+}
+template <int BM, int BN, int MODE>
+__device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n,
+                                          int cls, int b, int tid) {
+  const v4f none[4] = {};
+  emit_tile<BM, BN, MODE>(p, acc, tile_m, tile_n, cls, b, tid, none, false);
+}
+
+// The CoordNet table values of this lane's pixel and 16 channels (64x64 tile, transposed accumulator layout), requested
+// BEFORE the k-loop and parked in 16 VGPRs: four loads whose round trip would otherwise open every tile's epilogue (the
+// epilogue's latency keeps a workgroup slot away from the k-loop).  Out-of-range pixels / channels are clamped (their
+// values are never used).  Zeros without CoordNet.
+__device__ __forceinline__ void load_coord_bias(const ConvParams &p, int tile_m, int tile_n, int tid, v4f (&cbv)[4]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) cbv[g] = v4f{0.f, 0.f, 0.f, 0.f};
+  if (p.coord_bias == nullptr) return;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5;
+  int m = tile_m * 64 + wm * 32 + (lane & 31);
+  if (p.halo_tx) {
+    const int local = wm * 32 + (lane & 31);
+    const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
+    m = (tyi * 4 + (local >> 4)) * p.Mw + (tile_m - tyi * p.halo_tx) * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor));
+  }
+  m = min(m, p.Mh * p.Mw - 1);
+  const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw), mw = m - mh * p.Mw;
+  const float *cbrow = p.coord_bias + (size_t)(mh * COORD_CLASSES + coord_class(mw, p.Mw)) * p.cb_stride;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n = min(tile_n * 64 + wn * 32 + 4 * half + 8 * g, p.cb_stride - 4);
+    cbv[g] = *reinterpret_cast<const v4f *>(cbrow + n);
+  }
 }
 
 
@@ -641,6 +673,9 @@ conv_igemm_kernel(const ConvParams p) {
     tile_n = r - q2 * p.tiles_n;
     b = q2;
   }
+  constexpr bool CB_PRE = BM == 64 && BN == 64 && MODE == MODE_CONV && !BF16;
+  v4f cbv[4];
+  if constexpr (CB_PRE) load_coord_bias(p, tile_m, tile_n, tid, cbv);   // in flight during the prologue and the k-loop
   const int ph = cls >> 1, pw = cls & 1;
   const int mtot = p.Mh * p.Mw;
   const int wrap_w = p.wrap ? p.Win : 0;
@@ -1011,7 +1046,7 @@ _Pragma("unroll")                                                               
         (void *)(p.partial + (size_t)(slot - ks) * (BM * BN)), 0, nsp * SLAB, 0x00020000);
     sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
   }
-  emit_tile<BM, BN, MODE>(p, acc, tile_m, tile_n, cls, b, tid);
+  emit_tile<BM, BN, MODE>(p, acc, tile_m, tile_n, cls, b, tid, cbv, CB_PRE && p.coord_bias != nullptr);
 #ifdef MSI_CONV_TIMING
   stamp();
 #endif
@@ -1092,6 +1127,8 @@ conv_halo_kernel(const ConvParams p) {
   const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
   const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
   const int H = p.Hin, W = p.Win, C = p.C0;
+  v4f cbv[4];
+  load_coord_bias(p, tile_m, tile_n, tid, cbv);           // in flight during the prologue and the k-loop
 
   // ---- per-lane patch elements: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 (= tid % 8) ----
   unsigned voff[NLOAD], lds_a[NLOAD];
@@ -1264,7 +1301,7 @@ conv_halo_kernel(const ConvParams p) {
     const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
     sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
   }
-  emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid);
+  emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, cbv, p.coord_bias != nullptr);
 #endif
 }
 
