@@ -2352,6 +2352,12 @@ ln_finish_kernel(const long long *__restrict__ sums, double inv_n, const float *
 // default ReLU).  Workgroup 0 also publishes the affine (tests).
 // BF16OUT = 1: the normalised activation is written as bf16 to `yb` (the operand buffer of the bf16 path)
 // and the fp32 raw output is left alone; 0: x is normalised in place.
+// tickets and LayerNorm sums of one forward start from zero
+__global__ void __launch_bounds__(256) zero_kernel(float4 *__restrict__ p, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) p[i] = float4{0.f, 0.f, 0.f, 0.f};
+}
+
 template <int BF16OUT>
 __global__ void __launch_bounds__(256)
 ln_apply_kernel(float *__restrict__ x, const long long *__restrict__ sums, double inv_n,
@@ -3253,8 +3259,14 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
   hipStream_t stream = msi::as_stream(stream_);
   char *ws = static_cast<char *>(workspace);
   // tickets of the in-launch fix-ups and the LayerNorm sums start from zero
-  hipError_t e = hipMemsetAsync(ws + net.zero_off, 0, net.zero_bytes, stream);
-  if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_forward: %s", hipGetErrorString(e));
+  // (a kernel of the library's own instead of hipMemsetAsync: the runtime's fill is a blit with its own barrier packets)
+  {
+    const size_t n16 = net.zero_bytes / 16;               // zero_off and zero_bytes are multiples of 256
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<float4 *>(ws + net.zero_off), n16);
+    int rc0 = msi::check_launch("zero");
+    if (rc0) return rc0;
+  }
   int *cnt = reinterpret_cast<int *>(ws + net.cnt_off);
   for (int li = 0; li < nlayers; ++li) {
     const Layer &L = net.layers[li];
