@@ -1129,6 +1129,21 @@ conv_halo_kernel(const ConvParams p) {
   const int H = p.Hin, W = p.Win, C = p.C0;
   v4f cbv[4];
   load_coord_bias(p, tile_m, tile_n, tid, cbv);           // in flight during the prologue and the k-loop
+  // the first two weight k-steps go out before the patch addresses are worked out (they depend on tile_n and the wave only)
+  const int S = p.ksteps;                                 // 9 CH
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)S * p.npad * ROW_BYTES), 0x00020000);
+  const int drow = lane >> 3, dslot = lane & 7;
+  const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + drow) * ROW_BYTES + dslot * 16);
+  {
+    char *sB0 = smem + G::A_BYTES + wave * 16 * ROW_BYTES;
+    const int so0 = c0 * p.npad * ROW_BYTES, so1 = (CH + c0) * p.npad * ROW_BYTES;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB0, 16, b_voff, so0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB0, 16, b_voff, so0, 8 * ROW_BYTES, 0);
+    {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB0 + G::B_STAGE), 16, b_voff, so1, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB0 + G::B_STAGE), 16, b_voff, so1, 8 * ROW_BYTES, 0);
+    }
+  }
 
   // ---- per-lane patch elements: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 (= tid % 8) ----
   unsigned voff[NLOAD], lds_a[NLOAD];
@@ -1147,10 +1162,6 @@ conv_halo_kernel(const ConvParams p) {
   }
   const size_t in_bytes = (size_t)H * W * C * 4;
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in_bytes), 0, (int)in_bytes, 0x00020000);
-  const int S = p.ksteps;                                 // 9 CH
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)S * p.npad * ROW_BYTES), 0x00020000);
-  const int drow = lane >> 3, dslot = lane & 7;
-  const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + drow) * ROW_BYTES + dslot * 16);
 
   // producer's LayerNorm: mean / inv once per workgroup; the per-channel affine per chunk (the lane's four channels)
   float inv_f = 1.f, mu_hi = 0.f, mu_lo = 0.f;
@@ -1252,9 +1263,7 @@ conv_halo_kernel(const ConvParams p) {
 
   // ---- prologue: first patch, first two weight k-steps ----
   int c = c0;
-  MSI_PATCH_LOAD(c0)
-  MSI_B_ISSUE(c0, 0, 0)
-  MSI_B_ISSUE(c0, 1, 1)
+  MSI_PATCH_LOAD(c0)                                      // (the weights of k-steps 0 and 1 are on their way already)
   if (APPLY) {   // the sums' round trip rides on the patch's (s_stat sits in the A region: read back before the patch lands)
     double *s_stat = reinterpret_cast<double *>(smem);
     ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, s_stat, tid);
