@@ -772,6 +772,14 @@ conv_igemm_kernel(const ConvParams p) {
     char *sA = smem + (stage) * STAGE_BYTES + wave * (BM / 4) * ROW_BYTES;                                                         \
     char *sB = smem + (stage) * STAGE_BYTES + BM * ROW_BYTES + wave * (BN / 4) * ROW_BYTES;                                        \
     const int soff_b = g_step * p.npad * ROW_BYTES;                                                                              \
+    /* the weights first: their addresses need no per-row work, so on a segment switch they are on their way while the */       \
+    /* A offsets are recomputed                                                                                           */       \
+    /* B rows [wave*BN/4 + 8i, +8): the instruction's immediate offset advances BOTH the source and the LDS address */                                        \
+    static_assert(BI <= 4, "B rows per wave: written out for immediate offsets");                                                \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 0, 0);                                  \
+    if (BI > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 8 * ROW_BYTES, 0);          \
+    if (BI > 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 16 * ROW_BYTES, 0);         \
+    if (BI > 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 24 * ROW_BYTES, 0);         \
     if (g_step < nreg) {                                                                                                         \
       if (g_new) {                                                                                                               \
         /* segment switch: tap -> (tap row, tap column) variant, all scalar; ~7 VALU per row */                                  \
@@ -826,12 +834,6 @@ _Pragma("unroll")                                                               
                                                    a_chunk16[i] < (unsigned)(cleft * ESZ) ? a_voff[i] : OOB, soff_a, 0, 0);         \
       }                                                                                                                          \
     }                                                                                                                            \
-    /* B rows [wave*BN/4 + 8i, +8): the instruction's immediate offset advances BOTH the source and the LDS address */                                        \
-    static_assert(BI <= 4, "B rows per wave: written out for immediate offsets");                                                \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 0, 0);                                  \
-    if (BI > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 8 * ROW_BYTES, 0);          \
-    if (BI > 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 16 * ROW_BYTES, 0);         \
-    if (BI > 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB, 16, b_voff, soff_b, 24 * ROW_BYTES, 0);         \
     /* advance (wave-uniform scalar state) */                                                                                    \
     ++g_step;                                                                                                                    \
     if (g_step < nreg) {                                                                                                         \
