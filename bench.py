@@ -86,23 +86,45 @@ def cnn_flops(h, w, cin, nout, ngf, coord):
     return sum(cnn_layer_flops(h, w, cin, nout, ngf, coord))
 
 
-def cnn_traffic():
-    """HBM bytes per frame of the conv kernels (conv_halo_kernel + conv_igemm_kernel launches) from the newest committed PMC passes
-    (profiles/r*_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per
-    the gfx950 note of MI355X_MICROARCH.md, made by tools/hbm_traffic.py which stamps the git commit it measured);
-    (None, None) if no profile is present."""
+def csrc_hash():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from -- what a traffic profile is
+    stamped with (tools/hbm_traffic.py) and what this run compares it to (the GPU box has no .git)."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "matryodshka_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "matryodshka_amd", "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(ROOT, "matryodshka_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "msi_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cnn_traffic(config=1, coord=True):
+    """HBM bytes per STEP of the conv launches (every kernel whose name starts with conv / convt) from the newest committed
+    PMC passes of this configuration (profiles/r*_hbm_traffic*.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    runs, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md, made by tools/hbm_traffic.py, which stamps the hash
+    of the kernel sources it measured).  Returns (bytes, source text, stale): stale = the profile was measured with
+    different kernel sources than the ones this run uses (or carries no hash: rounds 1-2); (None, None, None) if no
+    profile of the configuration is present."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic*.json")))
     for path in reversed(paths):
         try:
             with open(path) as f:
                 j = json.load(f)
-            conv = [v["hbm_bytes"] for k, v in j["kernels"].items() if k in ("conv_igemm_kernel", "conv_halo_kernel", "conv_fixup_kernel")]
-            return int(sum(conv)), \
-                "%s (commit %s)" % (os.path.relpath(path, ROOT), j.get("git_commit", "not recorded: round-1 profile"))
+            if int(j.get("config", 1)) != config or bool(j.get("coord_net", True)) != bool(coord):
+                continue
+            conv = [v["hbm_bytes"] for k, v in j["kernels"].items() if k.startswith("conv")]
+            stale = j.get("csrc_sha") != csrc_hash()
+            return int(sum(conv)), "%s (commit %s, csrc_sha %s)" % (
+                os.path.relpath(path, ROOT), j.get("git_commit", "not recorded"), j.get("csrc_sha", "not recorded")), stale
         except Exception:
             continue
-    return None, None
+    return None, None, None
 
 
 def geometry_bytes(h, w, d, psv_bytes=4):
@@ -131,6 +153,43 @@ def pp_inputs(seed, b, n):
     return ref, src, K, eye, src_pose, tgt_pose
 
 
+_ORIG_AFFINITY = None
+
+
+def pin_to_gpu_numa_node(device_index):
+    """Pin this rank's launch thread (and the threads it starts) to the CPUs local to its GPU: the PCI device's
+    `local_cpulist` under /sys (eight GPUs hang off two sockets; a rank launching from the far socket pays a cross-socket
+    hop per kernel launch, and batch-1 frames are 30 launches of ~3 ms).  Returns a dict for the JSON line; never fatal."""
+    global _ORIG_AFFINITY
+    info = {"pinned": False}
+    try:
+        _ORIG_AFFINITY = os.sched_getaffinity(0)
+        prop = torch.cuda.get_device_properties(device_index)
+        bus = "%04x:%02x:%02x.0" % (getattr(prop, "pci_domain_id", 0), prop.pci_bus_id, prop.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bus
+        with open(base + "/numa_node") as f:
+            info["numa_node"] = int(f.read().strip())
+        with open(base + "/local_cpulist") as f:
+            text = f.read().strip()
+        cpus = set()
+        for part in text.split(","):
+            if "-" in part:
+                lo, hi = part.split("-")
+                cpus.update(range(int(lo), int(hi) + 1))
+            elif part:
+                cpus.add(int(part))
+        allowed = os.sched_getaffinity(0)
+        cpus &= allowed
+        info["pci_bus"] = bus
+        if cpus and info["numa_node"] >= 0 and len(cpus) < len(allowed):
+            os.sched_setaffinity(0, cpus)
+            info["pinned"] = True
+        info["cpus"] = len(cpus) if cpus else len(allowed)
+    except Exception as e:      # no sysfs entry (containers), old torch, ...: run unpinned
+        info["error"] = "%s: %s" % (type(e).__name__, e)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +203,9 @@ def main():
     ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed steps before the --warmup steps")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--no-coord-net", action="store_true", help="msi_train_net instead of msi_coord_train_net")
+    ap.add_argument("--strong-frames", type=int, default=8,
+                    help="config 1: after the contract region, also time a FIXED batch of this many frames sharded over the "
+                         "ranks (strong-scaling reading of the same path, reported under `strong_scaling`; 0 = skip)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams consecutive frames are issued on (1 = strictly one frame at a time, the "
                          "default and the configuration BASELINE quotes; 2 = software-pipeline independent frames, "
@@ -162,6 +224,7 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()   # (ranks may share a GPU in the gloo functional test)
     torch.cuda.set_device(local_rank)                      # one process per GPU: rank r drives device LOCAL_RANK
     dev = torch.device("cuda", local_rank)
+    affinity = pin_to_gpu_numa_node(local_rank)
     if args.streams > 1 and args.config != 1:
         raise SystemExit("--streams applies to --config 1")
 
@@ -170,6 +233,9 @@ def main():
 
     if world > 1:
         mdist.init_process_group()
+        # the data path of an N-GPU run is RCCL over xGMI; anything else must be asked for explicitly (functional tests)
+        if not os.environ.get("MSI_DIST_BACKEND"):
+            assert torch.distributed.get_backend() == "nccl", "bench.py --gpus N runs on RCCL (backend nccl); got %s" % torch.distributed.get_backend()
 
     H, W, D = cfg["h"], cfg["w"], cfg["d"]
     coord = not args.no_coord_net
@@ -281,10 +347,12 @@ def main():
         for k in range(nsteps):
             result = step(k, ev if args.streams == 1 else None)
         torch.cuda.synchronize()
+        t_own = time.perf_counter()                              # this rank's own finish time (before the closing barrier)
         if world > 1:
             mdist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        own.append(t_own - t0)
         elapsed = mdist.max_over_ranks(elapsed, dev) if world > 1 else elapsed
         cnn_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(len(ev) // 2)]
         return elapsed, cnn_ms, result
@@ -298,8 +366,36 @@ def main():
             torch.cuda.synchronize()
     for k in range(max(args.warmup, args.streams)):
         step(k)
+    own = []                                                       # this rank's own time of every region
     elapsed, cnn_ms, result = timed_region(args.steps)             # the contract region: `value` comes from here
     repeats = [timed_region(args.steps)[0] for _ in range(max(0, args.repeats))]
+    per_rank_ms = mdist.gather_floats(own[0] / args.steps * 1e3, dev) if world > 1 else [own[0] / args.steps * 1e3]
+
+    # strong-scaling reading of the same path (config 1): a FIXED batch of --strong-frames frames sharded over the ranks,
+    # each rank running its shard as consecutive batch-1 frames; barrier + synchronize on both sides, max over ranks
+    strong = None
+    if args.config == 1 and args.strong_frames > 0 and args.streams == 1:
+        slo, shi = mdist.shard_frames(args.strong_frames, rank, world)
+        times = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            if world > 1:
+                mdist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(shi - slo):
+                step(k)
+            torch.cuda.synchronize()
+            if world > 1:
+                mdist.barrier()
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            times.append(mdist.max_over_ranks(t, dev) if world > 1 else t)
+        t = float(np.median(times))
+        strong = {"frames": args.strong_frames, "frames_of_rank0": shi - slo, "ms": round(t * 1e3, 4),
+                  "frames_per_s": round(args.strong_frames / t, 3), "regions_ms": [round(x * 1e3, 4) for x in times],
+                  "note": "fixed batch sharded over the ranks (dist.shard_frames), median of 5 regions; compare across --gpus N "
+                          "for the strong-scaling curve (`value` is the weak-scaling one)"}
 
     ranges = mdist.gather_ranges(lo, hi, dev) if world > 1 else [(lo, hi)]
     nccl_world = torch.distributed.get_world_size() if world > 1 else 1
@@ -336,7 +432,7 @@ def main():
                               "achieved_GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)})
     stages["cnn"].update({"bound": "mfma", "algorithmic_GFLOP": round(flops * nb / 1e9, 1),
                           "achieved_TFLOPps": round(flops * nb / (max(stage_ms["cnn"], 1e-9) * 1e-3) / 1e12, 2)})
-    traffic, traffic_src = cnn_traffic() if args.config == 1 else (None, None)
+    traffic, traffic_src, traffic_stale = cnn_traffic(args.config, coord)
 
     unit = "faces/s" if cfg["kind"] == "pp" else "frames/s"
     metric = "novel-view frames/sec, 640x320 ODS->32-sphere MSI infer+render" if args.config == 1 else \
@@ -355,6 +451,10 @@ def main():
                    "streams_per_gpu": args.streams},
         "distributed": {"world_size_env": world, "world_size_process_group": nccl_world, "backend": backend,
                         "frame_ranges_per_rank": ranges,
+                        "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+                        "rank_skew": {"max_ms": round(max(per_rank_ms), 4), "min_ms": round(min(per_rank_ms), 4),
+                                      "max_over_min": round(max(per_rank_ms) / max(min(per_rank_ms), 1e-9), 4)},
+                        "cpu_affinity_rank0": affinity,
                         "weight_broadcast_ms": None if broadcast_ms is None else round(broadcast_ms, 3),
                         "devices_visible": torch.cuda.device_count(), "device_of_rank0": torch.cuda.get_device_name(dev)},
         "repeats": {"ms_per_step": [round(r / args.steps * 1e3, 4) for r in [elapsed] + repeats],
@@ -363,14 +463,17 @@ def main():
         "roofline": {"kernel": "conv_halo_kernel + conv_igemm_kernel (the 3x3 / 4x4 conv launches of one forward, %s MFMA implicit GEMM)" % ("bf16" if bf16 else "fp32"),
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4), "traffic": traffic,
+                     "traffic_stale": traffic_stale,
                      "traffic_note": None if traffic is None else
-                     "HBM bytes per frame of the conv launches, %s (separate --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                     "gfx950 FETCH correction)" % traffic_src,
+                     "HBM bytes per step (%d frame(s)) of the conv launches, %s (separate --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                     "gfx950 FETCH correction)%s" % (nb, traffic_src, "; STALE: measured with other kernel sources than this "
+                     "run's (csrc_sha %s)" % csrc_hash() if traffic_stale else ""),
                      "launches_per_frame": 18, "algorithmic_flops_per_launch_set": flops * nb,
                      "ms_per_forward": round(cnn_ms_timed, 4),
                      "timed": "HIP events around msi_net_plan_forward on the launch stream INSIDE the timed region, mean of "
                               "%d forwards (conv launches + the remaining ln_apply launches: conservative for the conv kernels alone)" % max(len(cnn_ms), 1)},
         "stages": stages,
+        "strong_scaling": strong,
     }
 
     if world == 1 and args.config == 1 and not args.no_cpu_baseline:
@@ -389,6 +492,8 @@ def cpu_baseline(model, weights, inp, planes, coord, gpu_result, D):
     geometry is single-threaded."""
     from oracle.msi import MSI as OracleMSI
     from oracle import nets as onets
+    if _ORIG_AFFINITY:                      # the CPU leg runs on the whole host again, not on the launch thread's NUMA node
+        os.sched_setaffinity(0, _ORIG_AFFINITY)
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)

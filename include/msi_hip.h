@@ -48,6 +48,7 @@ extern "C" {
 #define MSI_E_LAUNCH (-2)
 #define MSI_E_UNSUPPORTED (-3)
 #define MSI_E_WORKSPACE (-4)
+#define MSI_E_RANGE (-5) /* msi_net_plan_status: a LayerNorm statistic left the range the kernels resolve */
 
 typedef void *msi_stream_t; /* hipStream_t */
 
@@ -222,8 +223,10 @@ int msi_mpi_render_f32(const float *rgba_native, const float *tgt_pose, const fl
  * (nets.py:387-450; coord_net=0): 14x conv3x3 (+|sin(lat)| coordinate channel,
  * nets.py:260-270), 3x conv-transpose 4x4 s2, LayerNorm over (H,W,C) + ReLU after
  * each, 1x1 tanh head with bias.  Implicit-GEMM on fp32 MFMA; LayerNorm sums are produced by the conv
- * epilogue (exact fixed-point accumulation) and applied with the ReLU by one in-place pass per layer (the
- * head applies its source's itself).  msi_train_net's conv-transposes are normalised over their uncropped
+ * epilogue -- order-independent 64-bit fixed-point accumulation (one word per sum, every wave's share rounded to one
+ * unit) inside a per-layer window whose exponent the packer derives from the weights; a forward whose statistics leave
+ * that window reports it through msi_net_plan_status instead of returning silently wrong values -- and applied with
+ * the ReLU by the consumer while it stages its input (halo-patch kernels, head) or by one in-place pass per layer.  msi_train_net's conv-transposes are normalised over their uncropped
  * (2H+10) x (2W+10) VALID output, as nets.py:423-435 does, before the [5:-5] crop. */
 typedef struct msi_net_desc {
   int32_t batch, height, width; /* height, width multiples of 8 */
@@ -301,6 +304,15 @@ size_t msi_net_plan_workspace_bytes(const msi_net_plan *plan);
  * convolution output (0: every consumer applies the LayerNorm itself while loading -- the head, halo-patch layers)?
  * -1: bad arguments.  (Tests / debugging; the frame loop does not need it.) */
 int32_t msi_net_plan_layer_is_normalized(const msi_net_plan *plan, int32_t layer);
+/* Health of the LAST forward that ran with `workspace` on `stream` (synchronises the stream: call it after a frame,
+ * not inside the frame loop's hot path): MSI_OK, or MSI_E_RANGE with the reason in msi_last_error_string when a
+ * LayerNorm sum overflowed its fixed-point window (bit 1 of *status_bits: raw outputs > ~3000x the scale the weights
+ * predict, or non-finite input) or a variance fell below its resolution (bit 2: < ~1e-3 of that scale, or a constant
+ * layer); bit 0: an apply-ahead wait timed out.  status_bits may be NULL.  The word is reset by the next forward. */
+#define MSI_NET_STATUS_APPLY_AHEAD_TIMEOUT 1
+#define MSI_NET_STATUS_LN_OVERFLOW 2
+#define MSI_NET_STATUS_LN_UNDERFLOW 4
+int32_t msi_net_plan_status(const msi_net_plan *plan, const void *workspace, msi_stream_t stream, int32_t *status_bits);
 /* net_input [B,H,W,in_channels] (fp32, or bf16 when desc.dtype = MSI_DTYPE_BF16) -> pred [B,H,W,num_outputs] fp32. */
 int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
                          void *workspace, size_t workspace_bytes, msi_stream_t stream);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "msi_net_plan_set_option": (_I, [_P, _I, _I]),
     "msi_net_plan_workspace_bytes": (c_size_t, [_P]),
     "msi_net_plan_layer_is_normalized": (_I, [_P, _I]),
+    "msi_net_plan_status": (_I, [_P, _P, _P, POINTER(c_int32)]),
     "msi_net_plan_forward": (_I, [_P, _P, _P, _P, _P, c_size_t, _P]),
     "msi_net_plan_forward_rgba": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "msi_net_forward_f32": (_I, [POINTER(NetDesc), _P, _P, _P, _P, c_size_t, _P]),

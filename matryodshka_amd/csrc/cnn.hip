@@ -75,19 +75,24 @@ constexpr int DEFAULT_CUS = 256;  // MI355X; the plan queries hipDeviceProp.mult
 constexpr int MAX_SPLIT = 8;
 constexpr int CONV_SLOTS_PER_CU = 5;   // 64x64 workgroups (32 KB of LDS each) resident per CU
 constexpr double LN_EPS = 1e-12;  // slim.layer_norm variance epsilon [TF-knowledge]
-// LayerNorm sums: [sample][LN_SHARDS][LN_WORDS] signed 64-bit fixed point {sum x * 2^24, sum x^2 * 2^16}: integer
-// addition is associative, so the totals do not depend on the arrival order (bitwise reproducible); a wave's share is
-// rounded to 2^-24 / 2^-16 absolute (<= 4e-4 / 0.1 over the 12 800 waves of the largest layer, against totals of 1e6 /
-// 1e7 and more: 1e-9 relative, the variance keeps ten digits when mean^2 is 1e6 times the variance).  Range: |sum x| <
-// 5e11 and sum x^2 < 1.4e14 per sample, i.e. an rms activation below ~3 000 on the largest layer (LayerNorm'd networks
-// sit at 1e0..1e2; fp32-grade statistics down to an rms of ~0.03, degrading gracefully below); one wave's share must stay
-// below 2^51 after scaling (mean x^2 < 3e7 over its 1 024 values: the same order as the range of the totals).
+// LayerNorm sums: [sample][LN_SHARDS][LN_WORDS] signed 64-bit fixed point {sum x * S1, sum x^2 * S2}: integer addition is
+// associative, so the totals do not depend on the arrival order (bitwise reproducible); a wave's share is rounded to one
+// unit (1 / S1, 1 / S2).  S1 = 2^(24 - e), S2 = 2^(16 - 2 e) with a PER-LAYER exponent e = round(log2(expected rms of the
+// layer's raw output)) that the host derives from the weights at pack time (ln_scale_exponent: sqrt(K) * rms(w) * rms of a
+// LayerNorm + ReLU'd input) and stores in the packed blob: LayerNorm removes any weight scale, so the fixed-point window
+// has to follow it.  About e the window is the one measured in r02: fp32-grade statistics for an rms within
+// [0.03, 3000] x 2^e on the largest layer (|sum x| < 5e11 / S1', sum x^2 < 1.4e14 / S2' per sample; a wave's scaled share
+// below 2^51).  Outside it the result is NOT silently wrong: a share beyond the range sets MSI_NET_STATUS_LN_OVERFLOW, a
+// total of sum x^2 below ~1e6 sqrt(waves) units (variance resolved to fewer than six digits) sets
+// MSI_NET_STATUS_LN_UNDERFLOW in the status word of the forward's workspace (msi_net_plan_status).
 // (Until r02 the sums were exact, hi * 2^-8 + lo * 2^-52 in two words each.  Measured, 6 interleaved repeats of the
 // network: this form 2.456 ms; exact with the same cheap rounding, four atomics per wave 2.474 ms; exact with the four
-// waves' shares combined through LDS, four atomics per workgroup 2.472 ms -- the atomics and the barrier cost what the
-// range buys, and the range is not needed here.)
+// waves' shares combined through LDS, four atomics per workgroup 2.472 ms.)
 constexpr int LN_SHARDS = 64, LN_WORDS = 2;
-constexpr double LN_S1_SCALE = 16777216.0 /* 2^24 */, LN_S2_SCALE = 65536.0 /* 2^16 */;
+constexpr int LN_S1_BITS = 24, LN_S2_BITS = 16;   // S1 = 2^(24 - e), S2 = 2^(16 - 2 e)
+constexpr int LN_SCL_DOUBLES = 4;                 // per layer in the packed blob: S1, S2, 1 / S1, 1 / S2
+constexpr double LN_UNDERFLOW_UNITS_SQ = 1e12;    // (1e6 units)^2 per contributing wave, see ln_mean_inv
+enum { STATUS_APPLY_AHEAD_TIMEOUT = 1, STATUS_LN_OVERFLOW = 2, STATUS_LN_UNDERFLOW = 4 };
 constexpr int AP_FLAG_STRIDE = 16;  // ints between two row counters of the apply-ahead hand-off: one counter per 64-byte line
 constexpr int HEAD_MAX_C = 256;   // the head's fused LayerNorm keeps scale | shift of its source in LDS
 
@@ -99,6 +104,9 @@ struct ConvParams {
   const char *wpk;           // packed weights [nclass][ksteps][npad][128 B], slots pre-swizzled
   const float *coord_bias;   // CoordNet: contribution of the |sin(lat)| channel, [Mh][COORD_CLASSES][cb_stride] fp32, or null
   int cb_stride;
+  const double *ln_scl;      // fixed-point scales of THIS layer's LayerNorm sums {S1, S2, 1 / S1, 1 / S2} (packed blob)
+  const double *ln_scl_src, *ln_scl_src1;   // ... of the source layers whose sums ln_sums / ln_sums1 (ap_sums) are
+  int *status;               // the plan's status word (STATUS_* bits, zeroed per forward)
   const long long *ln_sums;  // head, fp32 only: the LayerNorm sums of the source layer; its affine (+ ReLU) is applied while
                              // loading (the source buffer then holds the RAW conv output); null = source already normalised
   const float *ln_gamma, *ln_beta;   // ... with the source layer's gamma / beta
@@ -248,8 +256,12 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 // One wave's share of a LayerNorm sum as a fixed-point integer atomic (no return value).  x_scaled = S * scale with
 // |x_scaled| < 2^51: adding 1.5 * 2^52 leaves round-to-nearest-even(x_scaled) in the low mantissa bits -- two VALU
 // instead of the emulated fp64 -> int64 conversion.
-__device__ __forceinline__ void ln_atomic_add(long long *dst, double x_scaled) {
+__device__ __forceinline__ void ln_atomic_add(long long *dst, double x_scaled, int *status) {
   const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
+  if (!(fabs(x_scaled) < 2251799813685248.0 /* 2^51 */)) {   // (also NaN / inf): outside the fixed-point window
+    if (status) __hip_atomic_fetch_or(status, STATUS_LN_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   const double t = x_scaled + MAGIC;
   const long long v = __builtin_bit_cast(long long, t) - __builtin_bit_cast(long long, MAGIC);
   __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -257,7 +269,7 @@ __device__ __forceinline__ void ln_atomic_add(long long *dst, double x_scaled) {
 
 // mean and 1 / sqrt(var + eps) of one sample from its LN_SHARDS x LN_WORDS fixed-point sums -> s_stat[0..1] (LDS).
 // Called by all 256 threads (ends with a barrier); wave 0 adds the shards (integers: exact, any order).
-__device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n, double *s_stat, int tid) {
+__device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n, const double *scl, int *status, double *s_stat, int tid) {
   static_assert(LN_SHARDS == 64, "one shard per lane of wave 0");
   if (tid < 64) {
     // the 64 shards as doubles (|shard| < 2^63: rounding at 2^-53 relative, far below the 2^-24 / 2^-16 units) through
@@ -265,7 +277,11 @@ __device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n,
     const long long *s = sums + (size_t)tid * LN_WORDS;
     const double h1 = wave_sum_f64((double)s[0]), h2 = wave_sum_f64((double)s[1]);
     if (tid == 0) {
-      const double S1 = h1 * (1.0 / LN_S1_SCALE), S2 = h2 * (1.0 / LN_S2_SCALE);
+      const double S1 = h1 * scl[2], S2 = h2 * scl[3];
+      // resolution: every wave's share is rounded to one unit, so the total carries ~0.5 sqrt(waves) units of rounding
+      // noise; below ~1e6 sqrt(waves) units of sum x^2 the variance is resolved to less than six digits
+      if (status && h2 * h2 < LN_UNDERFLOW_UNITS_SQ * (1.0 / (inv_n * 1024.0) + 1.0))
+        __hip_atomic_fetch_or(status, STATUS_LN_UNDERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const double mu = S1 * inv_n;
       double var = S2 * inv_n - mu * mu;
       var = var > 0.0 ? var : 0.0;
@@ -431,8 +447,8 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
     if (lane == 0 && wcnt > 0.f) {
       const double P = (double)pivot, n = (double)wcnt, a = (double)s1;
       long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * LN_WORDS;   // (any spread will do)
-      ln_atomic_add(dst, (n * P + a) * LN_S1_SCALE);
-      ln_atomic_add(dst + 1, ((double)s2 + 2.0 * P * a + n * P * P) * LN_S2_SCALE);
+      ln_atomic_add(dst, (n * P + a) * p.ln_scl[0], p.status);
+      ln_atomic_add(dst + 1, ((double)s2 + 2.0 * P * a + n * P * P) * p.ln_scl[1], p.status);
     }
   }
 }
@@ -514,7 +530,7 @@ __device__ __forceinline__ void apply_ahead(const ConvParams &p, char *smem, int
     const int row = (int)(ur / upr), part = (int)(ur - (long)row * upr);
     if (b != cur_b) {   // (the sweep is in order: the sample changes at most a few times per workgroup)
       __syncthreads();
-      ln_mean_inv(p.ap_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ap_inv_n, s_stat, tid);
+      ln_mean_inv(p.ap_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ap_inv_n, p.ln_scl_src, p.status, s_stat, tid);
       const double mu = s_stat[0], inv = s_stat[1];
       for (int c = tid; c < C; c += 256) {
         const double sc = inv * (double)p.ap_gamma[c];
@@ -593,7 +609,7 @@ __device__ __forceinline__ void rows_wait(const ConvParams &p, int b, int r0, in
       const int *f = p.ap_flags + ((size_t)b * p.Hin + r) * AP_FLAG_STRIDE;
       while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.ap_units_per_row) {
         __builtin_amdgcn_s_sleep(32);
-        if (++spins > (1 << 20)) { *p.ap_err = 1; r = r0; break; }   // ~1 s: something is badly wrong; do not hang the GPU
+        if (++spins > (1 << 20)) { __hip_atomic_fetch_or(p.ap_err, STATUS_APPLY_AHEAD_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r = r0; break; }   // ~1 s: something is badly wrong; do not hang the GPU
       }
     }
   }
@@ -862,7 +878,7 @@ _Pragma("unroll")                                                               
     __shared__ double s_hstat[2];
     s_haff = s_haff_store;
     if (p.ln_sums != nullptr) {
-      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, s_hstat, tid);
+      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_hstat, tid);
       const double mu = s_hstat[0], inv = s_hstat[1];
       for (int c = tid; c < p.C0; c += 256) {
         const double sc = inv * (double)p.ln_gamma[c];
@@ -1268,7 +1284,7 @@ conv_halo_kernel(const ConvParams p) {
   MSI_PATCH_LOAD(c0)                                      // (the weights of k-steps 0 and 1 are on their way already)
   if (APPLY) {   // the sums' round trip rides on the patch's (s_stat sits in the A region: read back before the patch lands)
     double *s_stat = reinterpret_cast<double *>(smem);
-    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, s_stat, tid);
+    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
     const double mu = s_stat[0];
     inv_f = (float)s_stat[1];
     mu_hi = (float)mu;
@@ -1538,13 +1554,13 @@ convt_halo_kernel(const ConvParams p) {
   if (p.halo_apply) {
     double *s_stat = reinterpret_cast<double *>(smem);
     if (p.halo_apply & 1) {
-      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, s_stat, tid);
+      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
       const double mu = s_stat[0];
       inv_f[0] = (float)s_stat[1]; mu_hi[0] = (float)mu; mu_lo[0] = (float)(mu - (double)mu_hi[0]);
       __syncthreads();
     }
     if (p.halo_apply & 2) {
-      ln_mean_inv(p.ln_sums1 + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n1, s_stat, tid);
+      ln_mean_inv(p.ln_sums1 + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n1, p.ln_scl_src1, p.status, s_stat, tid);
       const double mu = s_stat[0];
       inv_f[1] = (float)s_stat[1]; mu_hi[1] = (float)mu; mu_lo[1] = (float)(mu - (double)mu_hi[1]);
       __syncthreads();
@@ -1846,7 +1862,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
   if (PD == 2) MSI_B_ISSUE(c0, 1, 1)
   if (APPLY) {
     double *s_stat = reinterpret_cast<double *>(smem);
-    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, s_stat, tid);
+    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
     const double mu = s_stat[0];
     inv_f = (float)s_stat[1];
     mu_hi = (float)mu;
@@ -2216,7 +2232,7 @@ head_assemble_kernel(const HeadAsmParams p) {
     const int row = e >> 3, j = e & 7;
     const int ks = row / BN, n = row - ks * BN;
     braw[k] = v4f{0.f, 0.f, 0.f, 0.f};                          // local rows >= 2 lg: zero
-    if (e < nb && n < l_cpred)   // (the slot swizzle of a packed row depends on (row >> 1) & 7: lg % 16 == 0 or one group -- host-checked)
+    if (e < nb && n < l_cpred)   // (a packed row keeps the slot swizzle of its GLOBAL row (gcol(n) >> 1) & 7: see fswz_b below)
       braw[k] = *reinterpret_cast<const v4f *>(p.wpk + ((size_t)ks * p.npad + gcol(n)) * (ROW_BYTES / 4) + j * 4);
   }
   // 2. affine of the source's LayerNorm (precomputed once per forward by ln_finish_kernel: 6 400 workgroups deriving it
@@ -2343,11 +2359,11 @@ head_assemble_kernel(const HeadAsmParams p) {
 // The affine of one layer's LayerNorm, scale | shift per channel, for consumers that apply it themselves while loading
 // (head_assemble_kernel): one workgroup per sample.
 __global__ void __launch_bounds__(256)
-ln_finish_kernel(const long long *__restrict__ sums, double inv_n, const float *__restrict__ gamma,
-                 const float *__restrict__ beta, int C, float *__restrict__ aff) {
+ln_finish_kernel(const long long *__restrict__ sums, double inv_n, const double *__restrict__ scl, int *status,
+                 const float *__restrict__ gamma, const float *__restrict__ beta, int C, float *__restrict__ aff) {
   __shared__ double s_stat[2];
   const int b = blockIdx.x, tid = threadIdx.x;
-  ln_mean_inv(sums + (size_t)b * LN_SHARDS * LN_WORDS, inv_n, s_stat, tid);
+  ln_mean_inv(sums + (size_t)b * LN_SHARDS * LN_WORDS, inv_n, scl, status, s_stat, tid);
   const double mu = s_stat[0], inv = s_stat[1];
   for (int c = tid; c < C; c += 256) {
     const double sc = inv * (double)gamma[c];
@@ -2371,13 +2387,13 @@ __global__ void __launch_bounds__(256) zero_kernel(float4 *__restrict__ p, size_
 
 template <int BF16OUT>
 __global__ void __launch_bounds__(256)
-ln_apply_kernel(float *__restrict__ x, const long long *__restrict__ sums, double inv_n,
-                const float *__restrict__ gamma, const float *__restrict__ beta, size_t per_sample, int C,
+ln_apply_kernel(float *__restrict__ x, const long long *__restrict__ sums, double inv_n, const double *__restrict__ scl,
+                int *status, const float *__restrict__ gamma, const float *__restrict__ beta, size_t per_sample, int C,
                 float *__restrict__ aff, unsigned short *__restrict__ yb) {
   extern __shared__ __attribute__((aligned(16))) float s_aff[];  // scale[C] shift[C]
   __shared__ double s_stat[2];
   const int b = blockIdx.y, tid = threadIdx.x;
-  ln_mean_inv(sums + (size_t)b * LN_SHARDS * LN_WORDS, inv_n, s_stat, tid);
+  ln_mean_inv(sums + (size_t)b * LN_SHARDS * LN_WORDS, inv_n, scl, (blockIdx.x == 0 ? status : nullptr), s_stat, tid);
   const double mu = s_stat[0], inv = s_stat[1];
   for (int c = tid; c < C; c += 256) {
     const double sc = inv * (double)gamma[c];
@@ -2444,6 +2460,7 @@ struct Layer {
   size_t packed_off;               // floats: weights, then gamma, beta (or bias), then the CoordNet bias table
   size_t packed_w_floats;
   size_t gamma_off, beta_off, coord_off;  // floats inside the packed blob
+  size_t lnscl_off;                       // floats inside the packed blob: LN_SCL_DOUBLES doubles (8-byte aligned)
   size_t raw_off, aff_off;                // bytes inside the workspace
   size_t act_off;                         // bf16 path: normalised bf16 activation (the next layer's operand)
   size_t sums_off;                        // LayerNorm sums [B][LN_SHARDS][LN_WORDS] int64
@@ -2563,7 +2580,8 @@ int build_net(const msi_net_desc *d, int num_cus, Net &net) {
     L.packed_w_floats = (size_t)L.nclass * L.ksteps * L.npad * (ROW_BYTES / 4);   // 128-byte rows in both types
     L.gamma_off = L.packed_off + L.packed_w_floats;
     L.beta_off = L.gamma_off + round_up(L.cout, 4);
-    L.coord_off = L.beta_off + round_up(L.cout, 4);
+    L.lnscl_off = L.beta_off + round_up(L.cout, 4);
+    L.coord_off = L.lnscl_off + 2 * LN_SCL_DOUBLES;
     koff = L.coord_off + (L.has_coord ? (size_t)L.out_h * COORD_CLASSES * round_up(L.cout, 4) : 0);
     koff = round_up(koff, 64);
     // workspace
@@ -2876,17 +2894,27 @@ int plan_layers(msi_net_plan *pl) {
   return MSI_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the function ON A DEVICE: set once per (instantiation,
+// device) -- `done` is a per-instantiation bit mask over the device ordinal, so a thread that drives a second GPU sets
+// the attribute there as well (ordinals >= 64: set on every launch).
+inline int set_max_lds(const void *fn, int lds, unsigned long long &done, const char *what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && ((done >> dev) & 1ull)) return MSI_OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  if (tracked) done |= 1ull << dev;
+  return MSI_OK;
+}
+
 template <int BM, int BN, int MODE, int BF16>
 int launch_conv_mode(const LayerLaunch &Q, const ConvParams &p, hipStream_t stream) {
   const size_t lds = (size_t)NSTAGE * (BM + BN) * ROW_BYTES;
   if (lds > 64 * 1024) {
-    static thread_local bool done = false;
-    if (!done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, MODE, BF16>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "conv: %s", hipGetErrorString(e));
-      done = true;
-    }
+    static thread_local unsigned long long done = 0;
+    int rc0 = set_max_lds(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, MODE, BF16>), (int)lds, done, "conv");
+    if (rc0) return rc0;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE, BF16>), dim3(Q.nblocks + p.n_apply), dim3(256), lds, stream, p);
   int rc = msi::check_launch("conv_igemm");
@@ -2902,13 +2930,9 @@ int launch_conv_mode(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
 template <int BM, int BN, int RATE, int APPLY>
 int launch_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stream) {
   constexpr int lds = HaloGeomB<BM, BN, RATE>::LDS_BYTES;
-  static thread_local bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_bf16_kernel<BM, BN, RATE, APPLY>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "conv_halo_bf16: %s", hipGetErrorString(e));
-    done = true;
-  }
+  static thread_local unsigned long long done = 0;
+  int rc0 = set_max_lds(reinterpret_cast<const void *>(conv_halo_bf16_kernel<BM, BN, RATE, APPLY>), lds, done, "conv_halo_bf16");
+  if (rc0) return rc0;
   hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, BN, RATE, APPLY>), dim3(Q.nblocks), dim3(256), lds, stream, p);
   return msi::check_launch("conv_halo_bf16");
 }
@@ -2916,13 +2940,9 @@ int launch_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
 template <int BM, int BN>
 int launch_convt_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stream) {
   constexpr int lds = HaloGeomB<BM, BN, 1>::LDS_BYTES;
-  static thread_local bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(convt_halo_bf16_kernel<BM, BN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "convt_halo_bf16: %s", hipGetErrorString(e));
-    done = true;
-  }
+  static thread_local unsigned long long done = 0;
+  int rc0 = set_max_lds(reinterpret_cast<const void *>(convt_halo_bf16_kernel<BM, BN>), lds, done, "convt_halo_bf16");
+  if (rc0) return rc0;
   hipLaunchKernelGGL((convt_halo_bf16_kernel<BM, BN>), dim3(Q.nblocks), dim3(256), lds, stream, p);
   return msi::check_launch("convt_halo_bf16");
 }
@@ -3057,6 +3077,31 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
       }
     }
     const size_t wf = L.param_floats - (L.kind == MODE_HEAD ? (size_t)L.cout : (size_t)2 * L.cout);
+    if (L.kind != MODE_HEAD) {
+      // fixed-point window of this layer's LayerNorm sums (see LN_S1_BITS): e = round(log2(expected rms of the raw output)),
+      // expected rms = sqrt(K) * rms(w) * rms(input), K = products per output, rms(input) = 0.5 for the sweep volume
+      // (images in [-1, 1]) and sqrt(mean(gamma^2) / 2 + mean(beta^2)) for a LayerNorm + ReLU'd producer
+      double sw = 0.0;
+      for (size_t i = 0; i < wf; ++i) sw += (double)w[i] * (double)w[i];
+      const double rms_w = sqrt(sw / (double)(wf ? wf : 1));
+      auto in_ms = [&](int src) -> double {
+        if (src < 0) return 0.25;
+        const Layer &S = net.layers[src];
+        const float *g = params + S.param_off + (S.param_floats - 2 * (size_t)S.cout), *be = g + S.cout;
+        double sg = 0.0, sb = 0.0;
+        for (int c = 0; c < S.cout; ++c) { sg += (double)g[c] * g[c]; sb += (double)be[c] * be[c]; }
+        return 0.5 * sg / S.cout + sb / S.cout;
+      };
+      double ms_in = in_ms(L.src0);
+      if (L.src1 >= 0) ms_in = (ms_in * L.c0 + in_ms(L.src1) * L.c1) / (double)(L.c0 + L.c1);
+      const double K = (L.kind == MODE_CONV ? 9.0 : 4.0) * (double)(L.cin + L.has_coord);
+      const double est = sqrt(K * ms_in) * rms_w;
+      int e = (est > 0.0 && std::isfinite(est)) ? (int)lrint(log2(est)) : 0;
+      e = e < -60 ? -60 : (e > 60 ? 60 : e);
+      const double scl[LN_SCL_DOUBLES] = {ldexp(1.0, LN_S1_BITS - e), ldexp(1.0, LN_S2_BITS - 2 * e),
+                                          ldexp(1.0, -(LN_S1_BITS - e)), ldexp(1.0, -(LN_S2_BITS - 2 * e))};
+      memcpy(packed + L.lnscl_off, scl, sizeof(scl));
+    }
     if (L.kind == MODE_HEAD) {
       memcpy(packed + L.gamma_off, w + wf, L.cout * sizeof(float));  // biases
     } else {
@@ -3192,6 +3237,21 @@ int32_t msi_net_plan_layer_is_normalized(const msi_net_plan *plan, int32_t layer
 static int run_layers(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
                       void *workspace, size_t workspace_bytes, msi_stream_t stream_, int nlayers);
 
+int32_t msi_net_plan_status(const msi_net_plan *plan, const void *workspace, msi_stream_t stream_, int32_t *status_bits) {
+  MSI_REQUIRE(plan && workspace, "net_plan_status: null pointer");
+  hipStream_t stream = msi::as_stream(stream_);
+  int word = 0;
+  hipError_t e = hipMemcpyAsync(&word, static_cast<const char *>(workspace) + plan->net.err_off, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_plan_status: %s", hipGetErrorString(e));
+  if (status_bits) *status_bits = word;
+  if (word == 0) return MSI_OK;
+  return msi::fail(MSI_E_RANGE, "net_plan_status: 0x%x:%s%s%s", word,
+                   (word & STATUS_LN_OVERFLOW) ? " a LayerNorm sum left its fixed-point window (raw convolution output far above the scale the weights predict: non-finite or mis-scaled input?)" : "",
+                   (word & STATUS_LN_UNDERFLOW) ? " a LayerNorm variance is below the resolution of its fixed-point window (raw convolution output far below the scale the weights predict, or constant)" : "",
+                   (word & STATUS_APPLY_AHEAD_TIMEOUT) ? " an apply-ahead wait timed out" : "");
+}
+
 int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
                          void *workspace, size_t workspace_bytes, msi_stream_t stream_) {
   MSI_REQUIRE(pred, "net_forward: null pointer");
@@ -3232,8 +3292,9 @@ int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, con
   q.bias = packed + H.gamma_off;
   float *aff = reinterpret_cast<float *>(ws + S.aff_off);
   hipLaunchKernelGGL(ln_finish_kernel, dim3(desc->batch), dim3(256), 0, stream,
-                     reinterpret_cast<const long long *>(ws + S.sums_off), 1.0 / S.ln_count, packed + S.gamma_off,
-                     packed + S.beta_off, S.cout, aff);
+                     reinterpret_cast<const long long *>(ws + S.sums_off), 1.0 / S.ln_count,
+                     reinterpret_cast<const double *>(packed + S.lnscl_off), reinterpret_cast<int *>(ws + net.err_off),
+                     packed + S.gamma_off, packed + S.beta_off, S.cout, aff);
   rc = msi::check_launch("ln_finish");
   if (rc) return rc;
   q.aff = aff;
@@ -3302,6 +3363,11 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
     }
     p.y = L.kind == MODE_HEAD ? pred : reinterpret_cast<float *>(ws + L.raw_off);
     p.sums = L.kind == MODE_HEAD ? nullptr : reinterpret_cast<long long *>(ws + L.sums_off);
+    auto scl_of = [&](int li2) { return reinterpret_cast<const double *>(packed + net.layers[li2].lnscl_off); };
+    p.ln_scl = L.kind == MODE_HEAD ? nullptr : scl_of(li);
+    p.ln_scl_src = L.src0 >= 0 ? scl_of(L.src0) : nullptr;
+    p.ln_scl_src1 = L.src1 >= 0 ? scl_of(L.src1) : nullptr;
+    p.status = reinterpret_cast<int *>(ws + net.err_off);
     p.partial = reinterpret_cast<float *>(ws + net.partial_off);
     p.tile_cnt = Q.inlaunch ? cnt + (size_t)li * CONV_SLOTS_PER_CU * plan->num_cus : nullptr;
     if (p.n_apply > 0) {
@@ -3392,11 +3458,11 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       const size_t lds = (size_t)2 * L.cout * sizeof(float);
       const long long *sums = reinterpret_cast<const long long *>(ws + L.sums_off);
       if (bf16)
-        hipLaunchKernelGGL(ln_apply_kernel<1>, grid, dim3(256), lds, stream, raw, sums, 1.0 / L.ln_count,
+        hipLaunchKernelGGL(ln_apply_kernel<1>, grid, dim3(256), lds, stream, raw, sums, 1.0 / L.ln_count, scl_of(li), p.status,
                            packed + L.gamma_off, packed + L.beta_off, per_sample, L.cout, aff,
                            reinterpret_cast<unsigned short *>(ws + L.act_off));
       else
-        hipLaunchKernelGGL(ln_apply_kernel<0>, grid, dim3(256), lds, stream, raw, sums, 1.0 / L.ln_count,
+        hipLaunchKernelGGL(ln_apply_kernel<0>, grid, dim3(256), lds, stream, raw, sums, 1.0 / L.ln_count, scl_of(li), p.status,
                            packed + L.gamma_off, packed + L.beta_off, per_sample, L.cout, aff,
                            static_cast<unsigned short *>(nullptr));
       rc = msi::check_launch("ln_apply");

@@ -51,6 +51,14 @@ def gather_ranges(lo, hi, device):
     return [(int(o[0]), int(o[1])) for o in out]
 
 
+def gather_floats(value, device):
+    """[value of rank 0, rank 1, ...] (one small all_gather: bench.py's per-rank step times)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def _coll_device(device):
     """Collectives run on the GPU with nccl (RCCL) and on the host with gloo."""
     return torch.device("cpu") if dist.get_backend() == "gloo" else device

@@ -82,8 +82,10 @@ def load_image(path):
 def evaluate_one(result_root, model_name, example):
     """eval.py:127-145 without the E-LPIPS term: (ssim, psnr) of output_tgt_* against tgt_image_*."""
     d = os.path.join(result_root, model_name, example)
-    tgt = load_image(sorted(glob.glob(os.path.join(d, "tgt_image_*")))[0])
-    pred = load_image(sorted(glob.glob(os.path.join(d, "output_tgt_*")))[0])
+    tgts, preds = sorted(glob.glob(os.path.join(d, "tgt_image_*"))), sorted(glob.glob(os.path.join(d, "output_tgt_*")))
+    if not tgts or not preds:
+        raise FileNotFoundError("%s: needs tgt_image_* and output_tgt_* (run the harness with 'tgt_image' in --test_outputs)" % d)
+    tgt, pred = load_image(tgts[0]), load_image(preds[0])
     return ssim(pred, tgt, 255.0), psnr(pred, tgt, 255.0)
 
 
@@ -103,14 +105,42 @@ def evaluate_consecutive_one(result_root, model_name, pair):
     return float(np.abs(t1 - t2).mean()), float(np.abs(z1 - z2).mean())
 
 
+def _example_dirs(result_root, model_name):
+    root = os.path.join(result_root, model_name)
+    return [e for e in os.listdir(root) if not e.endswith(".txt") and os.path.isdir(os.path.join(root, e))]
+
+
 def collect_examples(result_root, model_names):
-    """eval.py collect_examples: example directories present for every model."""
+    """eval.py:62-78: the NON-video example directories present for every model (`step.txt` and every entry whose name
+    contains 'video' are skipped; an example missing for some model is an error there: `assert not skipped`)."""
     counts = {}
     for m in model_names:
-        for e in os.listdir(os.path.join(result_root, m)):
-            if os.path.isdir(os.path.join(result_root, m, e)):
-                counts[e] = counts.get(e, 0) + 1
-    return sorted(k for k, v in counts.items() if v == len(model_names))
+        for e in _example_dirs(result_root, m):
+            if "video" in e:
+                continue
+            counts[e] = counts.get(e, 0) + 1
+    skipped = sorted(k for k, v in counts.items() if v != len(model_names))
+    if skipped:
+        raise ValueError("examples missing for some model: %s" % ", ".join(skipped[:5]))
+    return sorted(counts)
+
+
+def collect_video_consecutive_examples(result_root, model_names, scene_names):
+    """eval.py:102-126: per scene (an entry is a frame of scene s when its name contains 'video' and s), the frame
+    directories present for every model sorted by name, as consecutive pairs WITHIN the scene: [scene][pair] -> (e0, e1)."""
+    out = []
+    for scene in scene_names:
+        counts = {}
+        for m in model_names:
+            for e in _example_dirs(result_root, m):
+                if "video" in e and scene in e:
+                    counts[e] = counts.get(e, 0) + 1
+        skipped = sorted(k for k, v in counts.items() if v != len(model_names))
+        if skipped:
+            raise ValueError("video frames missing for some model: %s" % ", ".join(skipped[:5]))
+        frames = sorted(counts)
+        out.append([(frames[j], frames[j + 1]) for j in range(len(frames) - 1)])
+    return out
 
 
 def main(argv=None):
@@ -118,7 +148,9 @@ def main(argv=None):
     ap.add_argument("--result_root", default="results")
     ap.add_argument("--model_names", default="msi-hip", help="comma-separated experiment names under result_root")
     ap.add_argument("--output_table", default="eval.json")
-    ap.add_argument("--video", action="store_true", help="frame-to-frame differences of 'video_*' examples (eval.py:147-174)")
+    ap.add_argument("--video", action="store_true",
+                    help="eval_type on_video (eval.py:185-215): frame-to-frame differences of the 'video' examples, per scene")
+    ap.add_argument("--videos", default="room_0 room_2 office_0 apartment_0", help="scene names of the video examples (eval.py:43)")
     a = ap.parse_args(argv)
     models = [m for m in a.model_names.split(",") if m]
     examples = collect_examples(a.result_root, models)
@@ -130,9 +162,11 @@ def main(argv=None):
     table["mean_ssim"] = [float(np.mean([r[i] for r in table["ssim"]])) for i in range(len(models))] if examples else []
     table["mean_psnr"] = [float(np.mean([r[i] for r in table["psnr"]])) for i in range(len(models))] if examples else []
     if a.video:
-        vids = [e for e in examples if e.startswith("video")]
-        table["consecutive"] = [[list(evaluate_consecutive_one(a.result_root, m, (vids[j], vids[j + 1]))) for m in models]
-                                for j in range(len(vids) - 1)]
+        scenes = [s for s in a.videos.split(" ") if s]
+        pairs = collect_video_consecutive_examples(a.result_root, models, scenes)
+        table["video_scenes"] = scenes
+        table["consecutive"] = [[{"frames": list(pr), "diffs": [list(evaluate_consecutive_one(a.result_root, m, pr)) for m in models]}
+                                 for pr in scene_pairs] for scene_pairs in pairs]
     with open(a.output_table, "w") as f:
         json.dump(table, f)
     print("Output written to %s" % a.output_table)

@@ -10,6 +10,10 @@ to --height x --width (datasets.py:513-515), runs infer_msi + the equirect RGB /
   <output_root>/<experiment>/<scene>_<ref><src><tgt>/{tgt_image,output_tgt,output_depth}_<dir>.png,
   src_image/ref_image, psv_plane_%.3d.png, blend_weights.npy, blend_weight_%.3d.png, alphas.npy,
   msi_alpha_%.2d.png, msi_rgb_%.2d.png, and <output_root>/<experiment>/step.txt.
+Modes (test.py:76-78): `--test_type` concatenates on_video (directory names `video_[<prefix>_]<scene>_...`, :209-217),
+high_res (after the low-res pass, the high-res re-render of :283-394 from the saved blend_weights.npy / alphas.npy and
+`--hres_image_dir`: output_hrestgt_* / output_hresdepth_*), high_res_only (only that); `--input_type PP` takes perspective
+camera lines (`scene ref src tgt input_offset tgt_offset`, datasets.py:427-437) through the plane-sweep / mpi_render_view path.
 `--checkpoint` reads a TF V2 checkpoint directly (tf_checkpoint.py), `--weights` an .npz of the TF variables
 (see nets.variable_shapes); without either Xavier-initialised
 weights are used (there is no network access for the pretrained checkpoint), step.txt then says 0.
@@ -52,15 +56,46 @@ def load_image(path, height, width):
     return resize_area(img, height, width)
 
 
-def parse_camera_files(pattern):
-    """Yields (scene_id, (id_ref, id_src, id_tgt), baseline, tgt_pos[3]) per non-empty line."""
+def parse_camera_files(pattern, input_type="ODS"):
+    """Yields (scene_id, (id_ref, id_src, id_tgt), camera) per non-empty line: camera = [baseline, tx, ty, tz] for ODS
+    lines (datasets.py:413-425) or [input_offset, tgt_offset] for perspective ones (datasets.py:427-437)."""
+    nf = 8 if input_type == "ODS" else 6
     for path in sorted(glob.glob(pattern)):
         with open(path) as f:
             for line in f.read().split("\n"):
                 parts = line.split(" ")
-                if len(parts) < 8:
+                if len(parts) < nf:
                     continue
-                yield parts[0], tuple(parts[1:4]), float(parts[4]), [float(x) for x in parts[5:8]]
+                yield parts[0], tuple(parts[1:4]), [float(x) for x in parts[4:nf]]
+
+
+def write_layer_outputs(outs, jouts, src, ref, num_planes, test_outputs, output_dir, dirname, which_color_pred):
+    """The input images and per-layer files of test.py:246-281 (shared by the ODS and PP paths)."""
+    if "src_image" in test_outputs:
+        write_image(os.path.join(output_dir, "src_image_%s.png" % dirname), src[0].numpy() * 255.0)
+    if "ref_image" in test_outputs:
+        write_image(os.path.join(output_dir, "ref_image_%s.png" % dirname), ref[0].numpy() * 255.0)
+    if "psv" in test_outputs:
+        psv = outs["psv"].cpu().numpy()
+        for j in range(num_planes):
+            write_image(os.path.join(output_dir, "psv_plane_%.3d.png" % j), (psv[0, :, :, j * 3:(j + 1) * 3] + 1.) / 2. * 255)
+    if "blend" in which_color_pred and "blend_weights" in test_outputs:      # test.py:262
+        bw = outs["blend_weights"].cpu().numpy()
+        np.save(os.path.join(output_dir, "blend_weights.npy"), bw)
+        for i in range(num_planes):
+            write_image(os.path.join(output_dir, "blend_weight_%.3d.png" % i), bw[0, :, :, i] * 255.0)
+    if "alphas" in test_outputs:
+        np.save(os.path.join(output_dir, "alphas.npy"), outs["alphas"].cpu().numpy())
+    if "rgba_layers" in test_outputs:
+        rgba = outs["rgba_layers"].cpu().numpy()
+        for i in range(num_planes):
+            write_image(os.path.join(output_dir, "msi_alpha_%.2d.png" % i), rgba[0, :, :, i, 3] * 255.0)
+            write_image(os.path.join(output_dir, "msi_rgb_%.2d.png" % i), (rgba[0, :, :, i, :3] + 1.) / 2. * 255)
+        if jouts is not None:        # test.py:276-280
+            jr = jouts["rgba_layers"].cpu().numpy()
+            for i in range(num_planes):
+                write_image(os.path.join(output_dir, "jitter_msi_alpha_%.2d.png" % i), jr[0, :, :, i, 3] * 255.0)
+                write_image(os.path.join(output_dir, "jitter_msi_rgb_%.2d.png" % i), (jr[0, :, :, i, :3] + 1.) / 2. * 255)
 
 
 def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_outputs, output_dir, dirname,
@@ -94,10 +129,6 @@ def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_o
                         model.deprocess_image(jrgb)[0].cpu().numpy())
             write_image(os.path.join(output_dir, "jitter_output_depth_%s.png" % dirname),
                         model.deprocess_depth_image(jdep)[0].cpu().numpy())
-    if "src_image" in test_outputs:
-        write_image(os.path.join(output_dir, "src_image_%s.png" % dirname), src[0].numpy() * 255.0)
-    if "ref_image" in test_outputs:
-        write_image(os.path.join(output_dir, "ref_image_%s.png" % dirname), ref[0].numpy() * 255.0)
     if "src_output_image" in test_outputs:
         o = model.msi_render_ods_view(outs["rgba_layers"], -1, eye, pos, planes, intr)
         write_image(os.path.join(output_dir, "output_src_%s.png" % dirname), model.deprocess_image(o)[0].cpu().numpy())
@@ -109,43 +140,92 @@ def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_o
             o = model.msi_render_perspective_view(outs["rgba_layers"], eye, pos, planes, intr, viewing_window=vw)
             write_image(os.path.join(output_dir, "output_ptgt%d_%s.png" % (vw, dirname)),
                         model.deprocess_image(o)[0].cpu().numpy())
-    if "psv" in test_outputs:
-        psv = outs["psv"].cpu().numpy()
-        for j in range(num_planes):
-            write_image(os.path.join(output_dir, "psv_plane_%.3d.png" % j), (psv[0, :, :, j * 3:(j + 1) * 3] + 1.) / 2. * 255)
-    if "blend" in which_color_pred and "blend_weights" in test_outputs:      # test.py:262
-        bw = outs["blend_weights"].cpu().numpy()
-        np.save(os.path.join(output_dir, "blend_weights.npy"), bw)
-        for i in range(num_planes):
-            write_image(os.path.join(output_dir, "blend_weight_%.3d.png" % i), bw[0, :, :, i] * 255.0)
-    if "alphas" in test_outputs:
-        np.save(os.path.join(output_dir, "alphas.npy"), outs["alphas"].cpu().numpy())
-    if "rgba_layers" in test_outputs:
-        rgba = outs["rgba_layers"].cpu().numpy()
-        for i in range(num_planes):
-            write_image(os.path.join(output_dir, "msi_alpha_%.2d.png" % i), rgba[0, :, :, i, 3] * 255.0)
-            write_image(os.path.join(output_dir, "msi_rgb_%.2d.png" % i), (rgba[0, :, :, i, :3] + 1.) / 2. * 255)
-        if jouts is not None:        # test.py:276-280
-            jr = jouts["rgba_layers"].cpu().numpy()
-            for i in range(num_planes):
-                write_image(os.path.join(output_dir, "jitter_msi_alpha_%.2d.png" % i), jr[0, :, :, i, 3] * 255.0)
-                write_image(os.path.join(output_dir, "jitter_msi_rgb_%.2d.png" % i), (jr[0, :, :, i, :3] + 1.) / 2. * 255)
+    write_layer_outputs(outs, jouts, src, ref, num_planes, test_outputs, output_dir, dirname, which_color_pred)
     return outs
+
+
+def sample_dirname(scene, ids, test_type="", prefix=""):
+    """test.py:209-217: `[video_[<prefix>_]]<scene>_<ref><src><tgt>`."""
+    if "on_video" in test_type:
+        name = "video_" + ("%s_" % prefix if prefix else "") + scene
+    else:
+        name = scene
+    return name + "_%s%s%s" % (ids[0], ids[1], ids[2])
+
+
+def run_sample_pp(model, images, input_offset, tgt_offset, planes, num_planes, ngf, test_outputs, output_dir, dirname,
+                  which_color_pred="blend_psv"):
+    """input_type=PP (test.py:51; data_loader.py:205-226): perspective pair, source camera shifted by -input_offset along
+    x, target by -tgt_offset, intrinsics fx = cx = W/2, fy = cy = H/2; plane-sweep volume at the slerp mid-point pose
+    (train.py:118-121), target view by mpi_render_view through tgt_pose @ interp_pose_inv (msi.py:644-646).  The MPI path
+    has no depth render (the reference has none either)."""
+    import torch
+    from . import poses
+    ref, src, tgt = (torch.from_numpy(np.ascontiguousarray(x[None])) for x in images)
+    h, w = images[0].shape[:2]
+    eye = np.eye(4, dtype=np.float32)[None]
+    src_pose, tgt_pose = eye.copy(), eye.copy()
+    src_pose[0, 0, 3] = -input_offset
+    tgt_pose[0, 0, 3] = -tgt_offset
+    K = np.array([[[0.5 * w, 0, 0.5 * w], [0, 0.5 * h, 0.5 * h], [0, 0, 1]]], dtype=np.float32)
+    interp_inv = np.linalg.inv(poses.interpolate_pose(eye, src_pose).astype(np.float64)).astype(np.float32)
+    outs, net_input = model.infer_msi(src, ref, None, None, eye, src_pose, K, which_color_pred, num_planes, planes,
+                                      extra_outputs="blend_weights alphas psv", ngf=ngf, ref_pose_inv=interp_inv)
+    os.makedirs(output_dir, exist_ok=True)
+    if "tgt_image" in test_outputs:
+        rgb = model.mpi_render_view(outs["rgba_layers"], np.matmul(tgt_pose, interp_inv).astype(np.float32), planes, K)
+        write_image(os.path.join(output_dir, "tgt_image_%s.png" % dirname), tgt[0].numpy() * 255.0)
+        write_image(os.path.join(output_dir, "output_tgt_%s.png" % dirname), model.deprocess_image(rgb)[0].cpu().numpy())
+    write_layer_outputs(outs, None, src, ref, num_planes, test_outputs, output_dir, dirname, which_color_pred)
+    return outs
+
+
+def run_hres_sample(model, hres_images, baseline, tgt_pos, planes, output_dir, dirname):
+    """The high-res pass of test.py:283-394 for one sample: the low-res blend weights / alphas the first pass saved
+    (blend_weights.npy, alphas.npy, test.py:264-271) are upsampled (align_corners), the layers re-assembled from the
+    high-res sweep volume and rendered -- one fused device pass (MSI.msi_render_equirect_hres) instead of the
+    reference's per-plane sess.run + numpy composite -- and written as test.py:383-394 does: (x + 1) / 2 * 255 and
+    depth * 255, clipped and truncated to uint8 by write_image."""
+    import torch
+    bw_path, al_path = os.path.join(output_dir, "blend_weights.npy"), os.path.join(output_dir, "alphas.npy")
+    if not (os.path.exists(bw_path) and os.path.exists(al_path)):
+        raise FileNotFoundError("%s: the high-res pass needs blend_weights.npy and alphas.npy of the low-res pass "
+                                "(run without high_res_only first, with blend_weights and alphas in --test_outputs)" % output_dir)
+    bw, al = np.load(bw_path), np.load(al_path)
+    ref, src = (torch.from_numpy(np.ascontiguousarray(x[None])) for x in hres_images[:2])
+    eye = np.eye(4, dtype=np.float32)[None]
+    intr = np.array([[[baseline, 0, 0], [0, 1, 0], [0, 0, 1]]], dtype=np.float32)
+    pos = np.asarray(tgt_pos, dtype=np.float32)[None]
+    rgb, dep = model.msi_render_equirect_hres(bw, al, ref, src, eye, eye, eye, pos, planes, intr)
+    os.makedirs(output_dir, exist_ok=True)
+    print("Saving high-res output to %s" % output_dir)
+    write_image(os.path.join(output_dir, "output_hrestgt_%s.png" % dirname), ((rgb[0].cpu().numpy() + 1.) / 2.) * 255.)
+    write_image(os.path.join(output_dir, "output_hresdepth_%s.png" % dirname), dep[0].cpu().numpy() * 255.)
+    return rgb, dep
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--cameras_glob", default="glob/test/ods/*.txt")
     ap.add_argument("--image_dir", default="glob/test_640x320")
+    ap.add_argument("--hres_image_dir", default="glob/test_4096x2048", help="high-resolution images of the same samples (test.py:42)")
     ap.add_argument("--output_root", default="results")
     ap.add_argument("--experiment_name", default="msi-hip")
     ap.add_argument("--weights", default="", help=".npz of TF variables (net/<layer>/weights ...)")
     ap.add_argument("--checkpoint", default="", help="TF checkpoint prefix or directory (test.py:192-202: "
                     "<checkpoint_dir>/<experiment_name>); read without TensorFlow (matryodshka_amd/tf_checkpoint.py)")
     ap.add_argument("--step", type=int, default=0, help="global step recorded in step.txt (test.py:225-229)")
+    ap.add_argument("--input_type", default="ODS", choices=["ODS", "PP"],
+                    help="ODS pairs (camera lines `scene ref src tgt baseline tx ty tz`) or perspective pairs (`scene ref src tgt "
+                         "input_offset tgt_offset`, datasets.py:427-437) -- test.py:51")
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--hres_height", type=int, default=2048, help="loader.py:34")
+    ap.add_argument("--hres_width", type=int, default=4096, help="loader.py:35")
     ap.add_argument("--num_msi_planes", type=int, default=32)
+    ap.add_argument("--num_psv_planes", type=int, default=32,
+                    help="test.py:60; must equal --num_msi_planes: the reference indexes the source volume with num_msi_planes "
+                         "(msi.py:138), so other combinations are not defined there either")
     ap.add_argument("--min_depth", type=float, default=1.0)
     ap.add_argument("--max_depth", type=float, default=100.0)
     ap.add_argument("--ngf", type=int, default=64)
@@ -157,12 +237,21 @@ def main(argv=None):
                     help="blend_psv | blend_bg | blend_bg_psv | alpha_only (test.py:55-56)")
     ap.add_argument("--transform_inverse_reg", action="store_true",
                     help="also infer with a jittered sweep pose and write jitter_output_* (test.py:141-147, 160-165)")
-    ap.add_argument("--rot_factor", type=float, default=0.0)
-    ap.add_argument("--tr_factor", type=float, default=0.0)
+    ap.add_argument("--rot_factor", type=float, default=1.0, help="test.py:72")
+    ap.add_argument("--tr_factor", type=float, default=1.0, help="test.py:73")
     ap.add_argument("--random_seed", type=int, default=8964)
-    ap.add_argument("--test_outputs", default="src_image_ref_image_tgt_image_psv_rgba_layers_blend_weights_alphas")
+    ap.add_argument("--test_type", default="",
+                    help="concatenate with _: on_video (directory names video_[<prefix>_]<scene>_..., test.py:209-217), high_res "
+                         "(low-res pass, then the high-res re-render of test.py:283-394), high_res_only (only the latter)")
+    ap.add_argument("--prefix", default="", help="test.py:78: prefix of on_video directory names")
+    ap.add_argument("--test_outputs", default="rgba_layers_src_image_ref_image_tgt_image_blend_weights_alphas",
+                    help="test.py:79-82")
     ap.add_argument("--num_runs", type=int, default=-1)
     args = ap.parse_args(argv)
+    if args.num_psv_planes != args.num_msi_planes:
+        raise SystemExit("--num_psv_planes must equal --num_msi_planes (msi.py:138 indexes the source volume with num_msi_planes)")
+    if "high_res" in args.test_type and args.input_type != "ODS":
+        raise SystemExit("--test_type high_res is the ODS path (test.py:283-394)")
 
     from . import MSI, nets
     d = args.num_msi_planes
@@ -175,32 +264,47 @@ def main(argv=None):
         weights = dict(np.load(args.weights))
     else:
         weights = nets.init_weights(6 * d, nout, args.ngf, coord)
-    if (args.checkpoint or args.weights) and not coord:
-        w0 = nets._lookup(weights, "conv1_1/weights")
-        coord = w0.shape[2] == 6 * d + 1          # nets.py:260-270: CoordNet appends one input channel
-    model = MSI(weights=weights, coord_net=coord)
-    jitter = None
-    if args.transform_inverse_reg:
-        from . import poses
-        jitter = poses.random_rotation(args.rot_factor, args.tr_factor, np.random.RandomState(args.random_seed))
+    # with weights the network (CoordNet or not) follows from conv1_1/weights' input channels unless the flag insists
+    model = MSI(weights=weights, coord_net=True if coord else None, input_type=args.input_type)
+    # test.py:112 evaluates tf_random_rotation INSIDE the graph: every sess.run (every sample) draws a new jitter pose;
+    # here one seeded generator is advanced per sample
+    jitter_rng = np.random.RandomState(args.random_seed) if args.transform_inverse_reg else None
     planes = model.inv_depths(args.min_depth, args.max_depth, d)
     exp_dir = os.path.join(args.output_root, args.experiment_name)
     os.makedirs(exp_dir, exist_ok=True)
+    samples = list(parse_camera_files(args.cameras_glob, args.input_type))
+    if args.num_runs >= 0:
+        samples = samples[:args.num_runs]
     n = 0
-    for scene, ids, baseline, tgt_pos in parse_camera_files(args.cameras_glob):
-        if 0 <= args.num_runs <= n:
-            break
-        images = [load_image(os.path.join(args.image_dir, "%s_pos%s.jpeg" % (scene, i)), args.height, args.width)
-                  for i in ids]
-        dirname = "%s_%s%s%s" % (scene, ids[0], ids[1], ids[2])
-        out_dir = os.path.join(exp_dir, dirname)
-        print("Saving to %s" % out_dir)
-        if n == 0:
-            with open(os.path.join(exp_dir, "step.txt"), "w") as f:
-                f.write("%d" % args.step)
-        run_sample(model, images, baseline, tgt_pos, planes, d, args.ngf, args.test_outputs, out_dir, dirname,
-                   which_color_pred=args.which_color_pred, jitter_pose=jitter)
-        n += 1
+    if "high_res_only" not in args.test_type:
+        for scene, ids, cam in samples:
+            images = [load_image(os.path.join(args.image_dir, "%s_pos%s.jpeg" % (scene, i)), args.height, args.width)
+                      for i in ids]
+            dirname = sample_dirname(scene, ids, args.test_type, args.prefix)
+            out_dir = os.path.join(exp_dir, dirname)
+            print("Saving to %s" % out_dir)
+            if n == 0:
+                with open(os.path.join(exp_dir, "step.txt"), "w") as f:
+                    f.write("%d" % args.step)
+            if args.input_type == "PP":
+                run_sample_pp(model, images, cam[0], cam[1], planes, d, args.ngf, args.test_outputs, out_dir, dirname,
+                              which_color_pred=args.which_color_pred)
+            else:
+                jitter = None
+                if jitter_rng is not None:
+                    from . import poses
+                    jitter = poses.random_rotation(args.rot_factor, args.tr_factor, jitter_rng)
+                run_sample(model, images, cam[0], cam[1:4], planes, d, args.ngf, args.test_outputs, out_dir, dirname,
+                           which_color_pred=args.which_color_pred, jitter_pose=jitter)
+            model.network_status()           # raises if a LayerNorm statistic left the range the kernels resolve
+            n += 1
+    if "high_res" in args.test_type:
+        for scene, ids, cam in samples:
+            hres = [load_image(os.path.join(args.hres_image_dir, "%s_pos%s.jpeg" % (scene, i)), args.hres_height, args.hres_width)
+                    for i in ids[:2]]
+            dirname = sample_dirname(scene, ids, args.test_type, args.prefix)
+            run_hres_sample(model, hres, cam[0], cam[1:4], planes, os.path.join(exp_dir, dirname), dirname)
+            n += "high_res_only" in args.test_type
     print("processed %d samples" % n)
     return n
 

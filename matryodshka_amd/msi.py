@@ -26,17 +26,44 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _on_own_device(cls):
+    """Every public method runs with the model's device current: the native library launches on the stream it is
+    handed, plans read the CU count of the current device, and per-device kernel attributes are set on first use --
+    a caller driving several GPUs from one thread must not have to remember torch.cuda.set_device."""
+    import functools
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def inner(self, *args, **kwargs):
+            if torch.cuda.current_device() == self.device.index:
+                return fn(self, *args, **kwargs)
+            with torch.cuda.device(self.device):
+                return fn(self, *args, **kwargs)
+        return inner
+
+    for name, fn in list(vars(cls).items()):
+        if callable(fn) and not name.startswith("__") and not isinstance(fn, (staticmethod, classmethod)) and name != "inv_depths":
+            setattr(cls, name, wrap(fn))
+    return cls
+
+
+@_on_own_device
 class MSI(object):
     """Class definition for the MSI inference module (reference: msi.py:33-38)."""
 
     COLOR_SCHEMES = {'blend_psv': 0, 'blend_bg': 1, 'blend_bg_psv': 2, 'alpha_only': 3}   # MSI_COLOR_* of msi_hip.h
 
-    def __init__(self, weights=None, coord_net=False, device=None, input_type='ODS', dtype='f32'):
+    def __init__(self, weights=None, coord_net=None, device=None, input_type='ODS', dtype='f32'):
         """coord_net: FLAGS.coord_net (test.py:52, default False = msi_train_net; the released ODS models are run with
-        --coord_net = msi_coord_train_net, scripts/test/ods-wotemp-elpips-coord-reg.sh)."""
+        --coord_net = msi_coord_train_net, scripts/test/ods-wotemp-elpips-coord-reg.sh).  None (default): taken from the
+        weights -- CoordNet's conv1_1/weights carry one extra input channel (nets.py:260-270), and the sweep volume's
+        6 D channels are even -- or False without weights."""
         if not torch.cuda.is_available():
             raise RuntimeError("matryodshka_amd.MSI needs a HIP device (no CPU fallback)")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._coord_explicit = coord_net is not None
         self.coord_net = bool(coord_net)
         if input_type not in ('ODS', 'PP'):
             raise ValueError("input_type must be 'ODS' or 'PP' (FLAGS.input_type, msi.py:1157-1161)")
@@ -89,6 +116,17 @@ class MSI(object):
 
     def load_weights(self, weights):
         """weights: dict TF-variable-name -> array (see nets.variable_shapes)."""
+        try:
+            cin_w = int(nets._lookup(weights, "conv1_1/weights").shape[2])
+        except (KeyError, AttributeError, IndexError):
+            cin_w = None
+        if cin_w is not None:
+            has_coord = cin_w % 2 == 1            # 6 D sweep channels (+ 1 for CoordNet's |sin(lat)| channel)
+            if not self._coord_explicit:
+                self.coord_net = has_coord
+            elif has_coord != self.coord_net:
+                raise ValueError("MSI(coord_net=%s) but conv1_1/weights has %d input channels: these are %s weights"
+                                 % (self.coord_net, cin_w, "CoordNet (msi_coord_train_net)" if has_coord else "msi_train_net"))
         self._weights = weights
         self._blob_cache.clear()
         self._packed_cache.clear()
@@ -116,6 +154,17 @@ class MSI(object):
             pw = (plan, ws)
             self._ws_cache[key] = pw
         return desc, packed, pw[1]
+
+    def network_status(self):
+        """msi_net_plan_status of the LAST network forward of this model: raises MsiError (MSI_E_RANGE) when a LayerNorm
+        statistic left the fixed-point window the kernels resolve (mis-scaled or non-finite input; see include/msi_hip.h).
+        Synchronises the stream -- call it after a frame, not inside a timed loop.  Returns the status bits (0)."""
+        if getattr(self, "_last_forward", None) is None:
+            return 0
+        plan, ws = self._last_forward
+        bits = N.c_int32(0)
+        N.check(N.lib.msi_net_plan_status(plan.handle, ws.data_ptr(), self._stream(), N.ctypes.byref(bits)), "msi_net_plan_status")
+        return int(bits.value)
 
     def _plan(self, batch, height, width, in_channels, num_outputs, ngf):
         self._net(batch, height, width, in_channels, num_outputs, ngf)
@@ -272,6 +321,7 @@ class MSI(object):
         plan = self._plan(b, h, w, cin, num_outputs, ngf)
         N.check(N.lib.msi_net_plan_forward(plan.handle, packed.data_ptr(), net_input.data_ptr(), pred.data_ptr(),
                                            ws.data_ptr(), ws.numel(), self._stream()), "msi_net_plan_forward")
+        self._last_forward = (plan, ws)
         return pred
 
     def infer_layers(self, net_input, num_msi_planes, ngf=64, extra_outputs='', which_color_pred='blend_psv',
@@ -305,6 +355,7 @@ class MSI(object):
         N.check(N.lib.msi_net_plan_forward_rgba(plan.handle, packed.data_ptr(), net_input.data_ptr(), rgba.data_ptr(),
                                                 _ptr(bw), _ptr(al), 0, ws.data_ptr(), ws.numel(), self._stream(), ev),
                 "msi_net_plan_forward_rgba")
+        self._last_forward = (plan, ws)
         pred = {'rgba_layers': rgba.permute(0, 2, 3, 1, 4)}
         if bw is not None:
             pred['blend_weights'] = bw

@@ -50,20 +50,38 @@ def test_ssim_against_a_direct_2d_formulation():
         E.ssim(x[:8], y[:8])                     # smaller than the 11x11 window
 
 
-def test_result_tree_evaluation(tmp_path):
+def _write_example(root, ex, rng, depth_level):
     from PIL import Image
+    d = root / ex
+    d.mkdir(parents=True)
+    tgt = rng.randint(0, 255, (16, 32, 3)).astype(np.uint8)
+    out = np.clip(tgt.astype(int) + 3, 0, 255).astype(np.uint8)
+    Image.fromarray(tgt).save(str(d / ("tgt_image_%s.png" % ex)))
+    Image.fromarray(out).save(str(d / ("output_tgt_%s.png" % ex)))
+    Image.fromarray(np.full((16, 32, 3), depth_level, np.uint8)).save(str(d / ("output_depth_%s.png" % ex)))
+
+
+def test_result_tree_evaluation(tmp_path):
+    """eval.py:62-78 / :102-126: video frames are NOT scored for SSIM / PSNR, and consecutive pairs never cross scenes."""
     rng = np.random.RandomState(1)
-    for k, ex in enumerate(("video_s_000001002", "video_s_003004005")):
-        d = tmp_path / "m" / ex
-        d.mkdir(parents=True)
-        tgt = rng.randint(0, 255, (16, 32, 3)).astype(np.uint8)
-        out = np.clip(tgt.astype(int) + 3, 0, 255).astype(np.uint8)
-        Image.fromarray(tgt).save(str(d / ("tgt_image_%s.png" % ex)))
-        Image.fromarray(out).save(str(d / ("output_tgt_%s.png" % ex)))
-        Image.fromarray(np.full((16, 32, 3), 10 * k, np.uint8)).save(str(d / ("output_depth_%s.png" % ex)))
-    (tmp_path / "m" / "step.txt").write_text("0")
-    table = E.main(["--result_root", str(tmp_path), "--model_names", "m", "--output_table", str(tmp_path / "t.json"), "--video"])
-    assert table["examples"] == ["video_s_000001002", "video_s_003004005"]
+    root = tmp_path / "m"
+    for ex in ("room_0_000001002", "office_0_003004005"):             # plain test examples
+        _write_example(root, ex, rng, 0)
+    for k, ex in enumerate(("video_room_0_001", "video_room_0_002", "video_room_0_003")):
+        _write_example(root, ex, rng, 10 * k)
+    for k, ex in enumerate(("video_office_0_001", "video_office_0_002")):
+        _write_example(root, ex, rng, 100 + 7 * k)
+    (root / "step.txt").write_text("0")
+    table = E.main(["--result_root", str(tmp_path), "--model_names", "m", "--output_table", str(tmp_path / "t.json"),
+                    "--video", "--videos", "room_0 office_0"])
+    assert table["examples"] == ["office_0_003004005", "room_0_000001002"]          # no 'video' entry, no step.txt
     assert all(30 < p[0] < 45 for p in table["psnr"]) and all(0.9 < s[0] <= 1 for s in table["ssim"])
-    assert abs(table["consecutive"][0][0][1] - 10.0) < 1e-6       # depth images differ by exactly 10 grey levels
+    cons = table["consecutive"]
+    assert [len(c) for c in cons] == [2, 1]                                         # pairs per scene, none across scenes
+    assert cons[0][0]["frames"] == ["video_room_0_001", "video_room_0_002"] and cons[1][0]["frames"] == ["video_office_0_001", "video_office_0_002"]
+    assert abs(cons[0][0]["diffs"][0][1] - 10.0) < 1e-6 and abs(cons[1][0]["diffs"][0][1] - 7.0) < 1e-6
     assert json.load(open(str(tmp_path / "t.json")))["model_names"] == ["m"]
+    # a directory without tgt_image_* is a clear error, not an IndexError
+    (root / "broken_example").mkdir()
+    with pytest.raises(FileNotFoundError):
+        E.main(["--result_root", str(tmp_path), "--model_names", "m", "--output_table", str(tmp_path / "t2.json")])

@@ -282,3 +282,49 @@ def test_full_size_network_properties_without_the_oracle(env, dtype):
     gained = m.run_net((x.float() * 4.0).to(x.dtype), nout, ngf)     # exact in fp32 and in bf16
     d = (gained - base).abs()
     assert float(d.max()) <= tol, float(d.max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("gain", [1e-4, 1e4])
+def test_layernorm_is_invariant_to_the_weight_scale(env, gain, dtype):
+    """LayerNorm (eps 1e-12) removes any scale of a layer's weights.  The LayerNorm sums are one-word fixed point inside
+    a per-layer window whose exponent the packer takes from the weights (cnn.hip: LN_S1_BITS), so the window follows the
+    scale: the prediction of a network whose conv / conv-transpose weights are ALL multiplied by 1e-4 or 1e4 (a power of
+    two close to it: exact) equals the unscaled one, and msi_net_plan_status stays clean."""
+    torch, MSI, nets, N, onets = env
+    b, h, w, cin, nout, ngf = 1, 32, 64, 48, 16, 16
+    g = float(2.0 ** round(np.log2(gain)))
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=41, randomize_affine=True)
+    scaled = {k: (v * np.float32(g) if k.endswith("/weights") and not k.startswith("color_pred") else v) for k, v in weights.items()}
+    x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
+    if dtype == "bf16":
+        x = x.bfloat16()
+    m0, m1 = MSI(weights=weights, coord_net=True, dtype=dtype), MSI(weights=scaled, coord_net=True, dtype=dtype)
+    p0, p1 = m0.run_net(x, nout, ngf), m1.run_net(x, nout, ngf)
+    assert m0.network_status() == 0 and m1.network_status() == 0
+    # (power-of-two gain: products and sums scale exactly; the CoordNet table and the statistics round identically up to
+    # the fixed-point unit, which scales with the window)
+    assert float((p1 - p0).abs().max()) <= (2e-5 if dtype == "f32" else 2e-2)
+
+
+def test_status_reports_statistics_outside_the_fixed_point_window(env):
+    """An input 2^14 times larger / smaller than the [-1, 1] sweep volume the packer assumes pushes conv1_1's raw output out of
+    its window: the forward must SAY so (MSI_E_RANGE through MSI.network_status), not return silently wrong values; the
+    next, in-range forward is clean again."""
+    torch, MSI, nets, N, onets = env
+    b, h, w, cin, nout, ngf = 1, 32, 64, 48, 16, 16
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=43, randomize_affine=True)
+    m = MSI(weights=weights, coord_net=True)
+    x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
+    m.run_net(x, nout, ngf)
+    assert m.network_status() == 0
+    for gain, word in ((2.0 ** 14, "overflow"), (2.0 ** -14, "below the resolution")):
+        m.run_net(x * gain, nout, ngf)
+        with pytest.raises(N.MsiError) as ei:
+            m.network_status()
+        assert "LayerNorm" in str(ei.value) and ("left its fixed-point window" in str(ei.value) if word == "overflow" else word in str(ei.value))
+    m.run_net(torch.full_like(x, float("nan")), nout, ngf)
+    with pytest.raises(N.MsiError):
+        m.network_status()
+    m.run_net(x, nout, ngf)
+    assert m.network_status() == 0

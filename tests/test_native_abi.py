@@ -153,6 +153,16 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
         # next layer's packed offset: walk by the library's own rule (64-float alignment)
         r4 = -(-info.cout // 4) * 4
         off = off_next + 2 * r4
+        # the fixed-point window of the layer's LayerNorm sums: four doubles {S1, S2, 1/S1, 1/S2} = 2^(24 - e), 2^(16 - 2e)
+        # and their inverses, e from the weights (exact powers of two, consistent with each other)
+        scl = packed[off:off + 8].view(np.float64)
+        if info.kind != nets.KIND_HEAD:
+            e = 24 - int(np.log2(scl[0]))
+            assert scl[0] == 2.0 ** (24 - e) and scl[1] == 2.0 ** (16 - 2 * e) and scl[2] == 1.0 / scl[0] and scl[3] == 1.0 / scl[1]
+            assert -8 <= e <= 8, (name, e)         # Xavier weights, unit gamma: raw outputs of order one
+        else:
+            assert not scl.any()
+        off += 8
         if info.has_coord:
             # CoordNet bias table: sum over the in-image taps of coord[ih] * w[kh, kw, cin, n]
             tab = packed[off:off + info.out_h * 5 * r4].reshape(info.out_h, 5, r4)

@@ -132,21 +132,30 @@ def _slice_key(name, extents):
     return key
 
 
-def _assemble_fixture(tmp_path, interval=16, per_block=20):
+def _assemble_fixture(tmp_path, interval=16, per_block=20, tensors=None, part=None, part_name="net/part/weights", split=4):
+    """Writes a TF V2 bundle byte by byte (NOT with tf_checkpoint.write_checkpoint): two data shards, multi-restart table
+    blocks, Adam slots, and one variable partitioned along axis 0 at `split`.  tensors / part: the plain variables and
+    the partitioned one (default: a synthetic set; tests/test_gpu_harness.py passes the variables of a real small net)."""
     rng = np.random.RandomState(42)
-    tensors = {}
-    for i in range(23):                                       # enough plain variables for multi-restart blocks
-        tensors["net/conv%02d/weights" % i] = rng.normal(size=(3, 3, 2, 4)).astype(np.float32)
-        tensors["net/conv%02d/weights/Adam" % i] = np.zeros((3, 3, 2, 4), np.float32)
-        tensors["net/conv%02d/weights/Adam_1" % i] = np.ones((3, 3, 2, 4), np.float32)
-    tensors["beta1_power"] = np.array(0.9 ** 7, np.float32)
-    tensors["beta2_power"] = np.array(0.999 ** 7, np.float32)
-    tensors["global_step"] = np.array(7, np.int64)
-    part = rng.normal(size=(6, 5)).astype(np.float32)         # partitioned along axis 0: rows [0,4) and [4,6)
+    if tensors is None:
+        tensors = {}
+        for i in range(23):                                   # enough plain variables for multi-restart blocks
+            tensors["net/conv%02d/weights" % i] = rng.normal(size=(3, 3, 2, 4)).astype(np.float32)
+            tensors["net/conv%02d/weights/Adam" % i] = np.zeros((3, 3, 2, 4), np.float32)
+            tensors["net/conv%02d/weights/Adam_1" % i] = np.ones((3, 3, 2, 4), np.float32)
+        tensors["beta1_power"] = np.array(0.9 ** 7, np.float32)
+        tensors["beta2_power"] = np.array(0.999 ** 7, np.float32)
+        tensors["global_step"] = np.array(7, np.int64)
+    else:
+        tensors = dict(tensors)
+    if part is None:
+        part = rng.normal(size=(6, 5)).astype(np.float32)     # partitioned along axis 0: rows [0,4) and [4,6)
+    rest = [(0, -1)] * (part.ndim - 1)
+    ext0, ext1 = [(0, split)] + rest, [(split, part.shape[0] - split)] + rest
     shards = [bytearray(), bytearray()]
     pairs = [(b"", b"\x08\x02")]                              # BundleHeaderProto: num_shards = 2
-    k0, k1 = _slice_key("net/part/weights", [(0, 4), (0, -1)]), _slice_key("net/part/weights", [(4, 2), (0, -1)])
-    for key, arr, sid in ((k0, part[:4], 0), (k1, part[4:], 1)):
+    k0, k1 = _slice_key(part_name, ext0), _slice_key(part_name, ext1)
+    for key, arr, sid in ((k0, part[:split], 0), (k1, part[split:], 1)):
         raw = np.ascontiguousarray(arr).tobytes()
         pairs.append((key, _entry_bytes(1, arr.shape, sid, len(shards[sid]), len(raw), _mask(_crc32c_bitwise(raw)))))
         shards[sid] += raw
@@ -157,8 +166,7 @@ def _assemble_fixture(tmp_path, interval=16, per_block=20):
         dt = {np.dtype(np.float32): 1, np.dtype(np.int64): 9}[arr.dtype]
         named.append((name.encode(), _entry_bytes(dt, arr.shape, sid, len(shards[sid]), len(raw), _mask(_crc32c_bitwise(raw)))))
         shards[sid] += raw
-    named.append((b"net/part/weights", _entry_bytes(1, part.shape, 0, 0, 0, None,
-                                                    slices=[[(0, 4), (0, -1)], [(4, 2), (0, -1)]])))
+    named.append((part_name.encode(), _entry_bytes(1, part.shape, 0, 0, 0, None, slices=[ext0, ext1])))
     pairs += sorted(named)
     assert [p[0] for p in pairs] == sorted(p[0] for p in pairs)          # a table's keys are sorted
     out, index = b"", []
@@ -179,7 +187,7 @@ def _assemble_fixture(tmp_path, interval=16, per_block=20):
     open(prefix + ".index", "wb").write(out)
     for sid in (0, 1):
         open("%s.data-%05d-of-00002" % (prefix, sid), "wb").write(bytes(shards[sid]))
-    tensors["net/part/weights"] = part
+    tensors[part_name] = part
     return prefix, tensors
 
 

@@ -1,20 +1,25 @@
 #!/usr/bin/env python
-"""HBM bytes per frame and per kernel from two rocprofv3 PMC passes over the same bench command
+"""HBM bytes per bench step and per kernel from two rocprofv3 PMC passes over the same bench command
 (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each with --kernel-trace only, as the gfx950 section of
 /opt/skills/guides/MI355X_MICROARCH.md prescribes: counters are in KB; FETCH_SIZE reports half of
 the bytes of wide coalesced reads on gfx950 and is doubled here).
 
-    python tools/hbm_traffic.py fetch_results.db write_results.db FRAMES [GIT_COMMIT] > profiles/rNN_hbm_traffic.json
+    python tools/hbm_traffic.py fetch_results.db write_results.db [--config N] [--no-coord-net] [--commit HASH] \
+        > profiles/rNN_hbm_traffic[_configN].json
 
-FRAMES = 0: counted from the render_kernel launches (one per frame).
-
-GIT_COMMIT: the commit the measured library was built from (bench.py prints it next to `roofline.traffic`, so a
-stale profile is visible); the GPU box has no .git, pass `git rev-parse --short HEAD` from the build container.
+The number of profiled steps is counted from the render launches (one per bench step).  The profile is stamped with
+`csrc_sha` = bench.csrc_hash() of the kernel sources it was measured with (computed on the GPU box, where there is no
+.git); bench.py recomputes the hash and reports `traffic_stale` when the sources have changed since.  `--commit` is the
+human-readable companion (`git rev-parse --short HEAD` from the build container).
 """
+import argparse
 import json
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(db, counter):
@@ -32,25 +37,36 @@ def per_kernel(db, counter):
 
 
 def main():
-    fetch_db, write_db, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    commit = sys.argv[4] if len(sys.argv) > 4 else "unknown"
-    f = per_kernel(fetch_db, "FETCH_SIZE")
-    w = per_kernel(write_db, "WRITE_SIZE")
-    if frames == 0:   # one render_kernel launch per frame (rgb + depth in one pass)
-        frames = f["render_kernel"][0]
-        assert frames == w["render_kernel"][0], "the two passes ran different frame counts"
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_db")
+    ap.add_argument("write_db")
+    ap.add_argument("--config", type=int, default=1)
+    ap.add_argument("--no-coord-net", action="store_true")
+    ap.add_argument("--commit", default="unknown")
+    a = ap.parse_args()
+    import bench
+    f = per_kernel(a.fetch_db, "FETCH_SIZE")
+    w = per_kernel(a.write_db, "WRITE_SIZE")
+    rk = "render_kernel" if "render_kernel" in f else "mpi_render_kernel"
+    steps = f[rk][0]
+    assert steps == w[rk][0], "the two passes ran different step counts"
+    cfg = bench.CONFIGS[a.config]
     kernels = {}
     for k in sorted(set(f) | set(w)):
         n = f.get(k, w.get(k))[0]
-        rd = 2.0 * 1024.0 * f.get(k, [0, 0.0])[1] / frames     # KB -> B, x2 (gfx950 FETCH_SIZE correction)
-        wr = 1024.0 * w.get(k, [0, 0.0])[1] / frames
-        kernels[k] = {"launches_per_frame": round(n / frames, 2), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
+        rd = 2.0 * 1024.0 * f.get(k, [0, 0.0])[1] / steps     # KB -> B, x2 (gfx950 FETCH_SIZE correction)
+        wr = 1024.0 * w.get(k, [0, 0.0])[1] / steps
+        kernels[k] = {"launches_per_step": round(n / steps, 2), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
                       "hbm_bytes": int(rd + wr)}
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes with --kernel-trace only, over "
-                       "`python bench.py --steps 3 --warmup 1 --repeats 0 --prewarm 0 --no-cpu-baseline` (%d frames, 640x320, 32 spheres, B=1). "
-                       "Counters are KB; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md (calibration: "
-                       "assemble_kernel reads 209.7 MB algorithmic, ln_apply_kernel 367 MB)." % frames,
-               "git_commit": commit, "kernels": kernels}, sys.stdout, indent=1)
+                       "`python bench.py --config %d%s --steps 3 --warmup 1 --repeats 0 --prewarm 0 --no-cpu-baseline` (%d steps counted "
+                       "from the %s launches). Counters are KB; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md "
+                       "(calibration: assemble_kernel reads 209.7 MB algorithmic, ln_apply_kernel 367 MB). Bytes are PER STEP "
+                       "(= per frame at config 1; a step of config 2/3/4 is a batch)." % (
+                           a.config, " --no-coord-net" if a.no_coord_net else "", steps, rk),
+               "config": a.config, "coord_net": not a.no_coord_net, "workload": cfg["name"],
+               "frames_per_step": cfg["per_rank"] or cfg["total"],
+               "git_commit": a.commit, "csrc_sha": bench.csrc_hash(), "kernels": kernels}, sys.stdout, indent=1)
     print()
 
 
