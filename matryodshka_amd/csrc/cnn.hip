@@ -271,13 +271,14 @@ __device__ __forceinline__ void ln_atomic_add(long long *dst, double x_scaled, i
 // Called by all 256 threads (ends with a barrier); wave 0 adds the shards (integers: exact, any order).
 __device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n, const double *scl, int *status, double *s_stat, int tid) {
   static_assert(LN_SHARDS == 64, "one shard per lane of wave 0");
+  const double inv_s1 = scl[2], inv_s2 = scl[3];   // (uniform address: scalar loads, issued before the shards')
   if (tid < 64) {
     // the 64 shards as doubles (|shard| < 2^63: rounding at 2^-53 relative, far below the 2^-24 / 2^-16 units) through
     // the DPP reduction: no dependent trips through the LDS crossbar at the head of every consumer workgroup / ln_apply block
     const long long *s = sums + (size_t)tid * LN_WORDS;
     const double h1 = wave_sum_f64((double)s[0]), h2 = wave_sum_f64((double)s[1]);
     if (tid == 0) {
-      const double S1 = h1 * scl[2], S2 = h2 * scl[3];
+      const double S1 = h1 * inv_s1, S2 = h2 * inv_s2;
       // resolution: every wave's share is rounded to one unit, so the total carries ~0.5 sqrt(waves) units of rounding
       // noise; below ~1e6 sqrt(waves) units of sum x^2 the variance is resolved to less than six digits
       if (status && h2 * h2 < LN_UNDERFLOW_UNITS_SQ * (1.0 / (inv_n * 1024.0) + 1.0))
@@ -366,6 +367,10 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
   const bool has_cb = MODE == MODE_CONV && p.coord_bias != nullptr;
   const bool want_stats = MODE != MODE_HEAD && p.sums != nullptr;
   const float pivot = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0][0][0])));
+  // (scalar loads at the head of the epilogue: inside the lane-0 branch below they would be vector loads with a memory
+  // round trip between the wave reduction and the atomics, at the end of every tile)
+  double scl_s1 = 0.0, scl_s2 = 0.0;
+  if (want_stats) { scl_s1 = p.ln_scl[0]; scl_s2 = p.ln_scl[1]; }
   float s1 = 0.f, s2 = 0.f, cnt = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -447,8 +452,8 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
     if (lane == 0 && wcnt > 0.f) {
       const double P = (double)pivot, n = (double)wcnt, a = (double)s1;
       long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * LN_WORDS;   // (any spread will do)
-      ln_atomic_add(dst, (n * P + a) * p.ln_scl[0], p.status);
-      ln_atomic_add(dst + 1, ((double)s2 + 2.0 * P * a + n * P * P) * p.ln_scl[1], p.status);
+      ln_atomic_add(dst, (n * P + a) * scl_s1, p.status);
+      ln_atomic_add(dst + 1, ((double)s2 + 2.0 * P * a + n * P * P) * scl_s2, p.status);
     }
   }
 }
@@ -494,6 +499,8 @@ __device__ __forceinline__ void load_coord_bias(const ConvParams &p, int tile_m,
 }
 
 
+#ifdef MSI_EXPERIMENTS   // measured-slower variants (apply-ahead, fp32 128x64 / 64x128 tiles) are compiled only on request:
+// MSI_CNN_DEFINES=-DMSI_EXPERIMENTS python -m matryodshka_amd.build --force; the default library has no kernel with spills
 // ---- apply-ahead: LayerNorm + ReLU of the producer inside the consumer's launch ------------------------------
 // The LayerNorm of layer N needs all of layer N (global statistics), so it cannot be folded into N's epilogue, and the
 // k-loop of layer N+1 has no VALU slot for it; as a launch of its own it is an HBM-bound pass (read + write every
@@ -616,6 +623,8 @@ __device__ __forceinline__ void rows_wait(const ConvParams &p, int b, int r0, in
   __syncthreads();
 }
 
+#endif  // MSI_EXPERIMENTS
+
 // amdgpu_waves_per_eu: with a dynamic LDS size hipcc cannot see that five 32 KB workgroups share a CU
 // and spends registers freely (116 for the 64x64 tile => four waves per SIMD); five need <= 96.
 // BF16 = 0: fp32 operands, 32 channels per k-step, v_mfma_f32_32x32x2_f32 (16 per k-step and wave);
@@ -648,14 +657,20 @@ conv_igemm_kernel(const ConvParams p) {
   // XCD-aware order for the whole tiles: workgroup b runs on XCD b % 8 (observed, speed only) and
   // each XCD has a private L2; consecutive tiles share halo rows and weights, so every XCD gets a
   // CONTIGUOUS range of tiles instead of every eighth one (bijective remap).
+#ifdef MSI_EXPERIMENTS
   if (p.n_apply > 0 && (int)blockIdx.x < p.n_apply) {   // apply-ahead workgroup (see apply_ahead)
     apply_ahead(p, smem, tid);
     return;
   }
+#endif
   const int S = p.ksteps;
   int t, k0 = 0, k1 = S, ks = 0, slot = 0;   // slot: index of this K-range's partial accumulator
   {
+#ifdef MSI_EXPERIMENTS
     const int bid = (int)blockIdx.x - p.n_apply;   // (n_apply is a multiple of 8: the XCD of a tile workgroup is still bid % 8)
+#else
+    const int bid = (int)blockIdx.x;
+#endif
     if (bid < p.nb_main && p.split0 == 1) {
       const int q = p.n_main >> 3, r = p.n_main & 7, xcd = bid & 7, local = bid >> 3;
       t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
@@ -698,6 +713,7 @@ conv_igemm_kernel(const ConvParams p) {
   const bool wrapt = MODE == MODE_CONVT && p.wrap != 0;
   // apply-ahead: source 0 is being normalised by the first workgroups of this launch; the tile needs input rows
   // [ap_r0, ap_r1] of it (source 1, the skip, was normalised by an earlier launch).  Probe their counters now.
+#ifdef MSI_EXPERIMENTS
   int ap_r0 = 0, ap_r1 = -1, ap_probe = 0;
   if (p.n_apply > 0) {
     const int m_lo = tile_m * BM, m_hi = min(m_lo + BM, mtot) - 1;
@@ -709,6 +725,7 @@ conv_igemm_kernel(const ConvParams p) {
     ap_r1 = min(ap_r1, p.Hin - 1);
     ap_probe = rows_probe(p, b, ap_r0, ap_r1, tid);
   }
+#endif
 
   // ---- DMA lane mapping: instruction i of this wave fills LDS rows [wave*BM/4 + 8i, +8);
   // lane -> (row = lane>>3, 16-byte slot = lane&7); the slot holds data chunk slot ^ ((row>>1)&7).
@@ -868,7 +885,9 @@ _Pragma("unroll")                                                               
     }                                                                                                                            \
   }
 
+#ifdef MSI_EXPERIMENTS
   if (p.n_apply > 0) rows_wait(p, b, ap_r0, ap_r1, ap_probe, tid, reinterpret_cast<int *>(smem));   // (LDS is still unused)
+#endif
 
   // fp32 head: the affine of its source's LayerNorm (scale | shift per channel) from the source's sums -> LDS; the
   // k-step issue applies it (+ ReLU) while loading, so the source is read RAW and never normalised in memory
@@ -1334,33 +1353,28 @@ conv_halo_kernel(const ConvParams p) {
 
 // ---- halo-patch kernel for the conv-transpose layers (4x4, stride 2, SAME; fp32) ----------------------------------
 // Output (2 mh + ph, 2 mw + pw) of parity class (ph, pw) reads input rows mh + {0, ph ? +1 : -1} and columns
-// mw + {0, pw ? +1 : -1} (tap_delta): over the four classes a 4 x 16 tile of the INPUT grid needs exactly the
-// 6 x 18 halo patch of the 3x3 kernel.  One workgroup therefore stages that patch once per 32-channel chunk and runs
-// 4 classes x 4 taps = 16 k-steps on it, each class into its own accumulator tile: the 8 x 32 output pixels of the
-// tile x 64 channels.  Compared with the tap kernel (one class per workgroup, four tap fetches per input element and
-// class) every input element is fetched once (+ halo) instead of 16 times, the chunk switch comes every 16 k-steps,
-// and both sources of the skip concat may be RAW (p.halo_apply bit per source): their LayerNorm + ReLU is applied
-// while staging, so neither the decoder input nor the skip tensor needs an ln_apply launch for this consumer.
-// Weights: 4-stage DMA ring (49 KB of LDS: three workgroups per CU, which is also what 64 accumulator registers
-// allow), run-time stage index; k order per class: chunk-major, tap-minor.  K-ranges of split tiles: whole chunks;
-// a partial tile dumps four slabs (class-minor) and the last arriver sums each class in ascending k.
-// MEASURED (profiles/r02_E_convt_halo_kernel_stats.txt): correct (every parity / determinism test passes with it on) and
-// SLOWER than the tap kernel, which is why it sits behind plan option HALO bit 1 (default off): conv8_1 218 vs 200 us
-// (three workgroups per CU instead of five), conv6_1 266 vs 199 us -- 200 four-class tiles on 256 CUs must be cut into
-// five K-ranges each, and the partial-accumulator traffic is four slabs per range (64 MB written + read for a 13 MB
-// output), conv7_1's ranges do not even fit the workspace.  The tap kernel's one-class tiles are four times lighter and
-// balance better; at fp32 its sixteen-fold tap fetch is not what limits it.  Dropping the four ln_apply launches of
-// these layers' sources (32 us) does not pay for that.
-struct ConvtHaloGeom : HaloGeom<1> {
-  static constexpr int NSTG = 4;
-  static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
-};
+// mw + {0, pw ? +1 : -1} (tap_delta).  A workgroup owns a 4 x 16 tile of the INPUT grid x 64 channels for the TWO classes
+// of one output-row parity ph (pw = 0, 1): per 32-channel chunk of either source of the skip concat it stages the 6 x 18
+// halo patch ONCE -- through registers, so that a RAW source gets its producer's LayerNorm + ReLU on the way
+// (p.halo_apply bit per source: neither the decoder input nor the skip tensor needs an ln_apply launch for this consumer)
+// -- and runs 2 classes x 4 taps = 8 k-steps on it, each class into its own accumulator tile (2 x 16 registers).
+// Class pw, tap (th, tw) reads patch row 1 + (ph ? th : -th) (the only run-time part of a fragment address: two base
+// registers) and column 1 + (pw ? tw : -tw) (immediate).  The two workgroups of a tile (ph = 0, 1) are grid neighbours
+// (same XCD: the patch comes from HBM once).  Weights: 3-stage DMA ring with a run-time stage index (8 k-steps per chunk
+// do not divide by 3; four stages would leave three workgroups per CU instead of four), k order per class: chunk-major,
+// tap-minor over the tap-major packed blob.  K-ranges of split tiles: whole chunks; a partial tile dumps two slabs
+// (class-minor) and the last arriver sums each class in ascending k.
+// History: the r02 form of this kernel owned all FOUR classes (64 accumulator registers -> three workgroups per CU, four
+// slabs per K-range) and lost to the tap kernel (conv8_1 218 vs 200 us, profiles/r02_E_convt_halo_kernel_stats.txt);
+// the two-class form keeps the halo kernels' four workgroups per CU and halves the tile visits per output.
+struct ConvtHaloGeom : HaloGeom<1> {};
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 convt_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef ConvtHaloGeom G;
   constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, NSTG = G::NSTG, PD = NSTG - 1;
+  static_assert(NSTG == 3 && PD == 2, "prefetch distance two");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1386,24 +1400,40 @@ convt_halo_kernel(const ConvParams p) {
     }
   }
   const bool full = (c0 == 0) & (c1 == CH);
-  int tile_m, tile_n, b;
-  {
+  int ph, tile_m, tile_n, b;
+  {   // row parity fastest (p.nclass = 2 here), then M tiles, N tiles, samples
     int r = t;
+    ph = r & 1; r >>= 1;
     const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
     tile_m = r - q1 * p.tiles_m; r = q1;
     const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
     tile_n = r - q2 * p.tiles_n;
-    b = q2;                                               // (tiles are enumerated with one class: the workgroup owns all four)
+    b = q2;
   }
   const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
   const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
   const int H = p.Hin, W = p.Win;
 
+  // the first two weight k-steps (class pw = 0, taps 0 and 1 of chunk c0) go out before the patch addresses are worked out
+  const int S = p.ksteps;                                 // k-steps per class: 4 CH
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)4 * S * p.npad * ROW_BYTES), 0x00020000);
+  const int drow = lane >> 3, dslot = lane & 7;
+  const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + drow) * ROW_BYTES + dslot * 16);
+  // weights of k-step (class, tap, chunk c) -> ring stage st; packed blob: [class][tap * CH + c][npad][128 B]
+#define MSI_B_ISSUE(cls, tap, c, st)                                                                                   \
+  {                                                                                                                    \
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * ROW_BYTES;                                         \
+    const int soff_ = (((cls) * S + (tap) * CH + (c)) * p.npad) * ROW_BYTES;                                           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
+  }
+  MSI_B_ISSUE(2 * ph, 0, c0, 0)
+  MSI_B_ISSUE(2 * ph, 1, c0, 1)
+
   // ---- per-lane patch elements (as conv_halo_kernel; the byte offset depends on the source's channel count) ----
   unsigned pixi[NLOAD], lds_a[NLOAD];
   bool pok[NLOAD];
   const int cslot = tid & 7;
-  constexpr unsigned OOB = 0xfffffff0u;
 #pragma unroll
   for (int k = 0; k < NLOAD; ++k) {
     const int pp = (tid + 256 * k) >> 3;
@@ -1416,10 +1446,6 @@ convt_halo_kernel(const ConvParams p) {
   const size_t in0 = (size_t)H * W * p.C0 * 4, in1 = (size_t)H * W * p.C1 * 4;
   const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in0), 0, (int)in0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x1 + (size_t)b * in1), 0, (int)(in1 ? in1 : 16), 0x00020000);
-  const int S = p.ksteps;                                 // k-steps per class: 4 CH
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)4 * S * p.npad * ROW_BYTES), 0x00020000);
-  const int drow = lane >> 3, dslot = lane & 7;
-  const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + drow) * ROW_BYTES + dslot * 16);
 
   // LayerNorm of the raw sources: mean as hi + lo floats and 1 / sigma per source
   float inv_f[2] = {1.f, 1.f}, mu_hi[2] = {0.f, 0.f}, mu_lo[2] = {0.f, 0.f};
@@ -1475,45 +1501,38 @@ convt_halo_kernel(const ConvParams p) {
       if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = y;                                    \
     }                                                                                                                  \
   }
-  // weights of k-step (class, tap, chunk c) -> ring stage st; packed blob: [class][tap * CH + c][npad][128 B]
-#define MSI_B_ISSUE(cls, tap, c, st)                                                                                   \
-  {                                                                                                                    \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * ROW_BYTES;                                         \
-    const int soff_ = (((cls) * S + (tap) * CH + (c)) * p.npad) * ROW_BYTES;                                           \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
-  }
 
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
   const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
-  const unsigned a_base = lds_base + (unsigned)((2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 64);
+  // fragment base of tap row th = 0 (patch row 1 + local row) and of th = 1 (one row up for ph = 0, one down for ph = 1)
+  const unsigned a_base0 = lds_base + (unsigned)((1 + 2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 64);
+  const unsigned a_base1 = ph ? a_base0 + G::ROW_PITCH : a_base0 - G::ROW_PITCH;
   unsigned b_q[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     b_q[q] = lds_base + G::A_BYTES + (wn * 32 + frow) * ROW_BYTES + (((fh * 4 + q) ^ fswz) << 4);
-  f32x16 acc[4][1][1];
+  f32x16 acc[2][1][1];
 #pragma unroll
-  for (int cl = 0; cl < 4; ++cl)
+  for (int cl = 0; cl < 2; ++cl)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[cl][0][0][r] = 0.f;
 
-  // k-step J of the chunk = class J / 4, tap J % 4, weights in ring stage st (run-time).  The DMA of the k-step PD ahead
-  // and (J == 0) the next chunk's patch loads are issued after the first MFMA quarter; before the closing barrier the
-  // NEXT k-step's weights must have landed: they were issued PD - 1 k-steps ago, so only what the last PD - 1 k-steps
-  // issued (2 DMA each, + the patch loads of J == 0 while they are that young) may still be in flight.
+  // k-step J of the chunk = class pw = J / 4, tap (th, tw) = ((J / 2) & 1, J & 1), weights in ring stage st (run-time).
+  // The DMA of the k-step PD = 2 ahead and (J == 0) the next chunk's patch loads are issued after the first MFMA quarter;
+  // before the closing barrier the NEXT k-step's weights must have landed: they were issued one k-step ago, so only what
+  // THIS k-step issued (2 DMA, + the patch loads of J == 0) may still be in flight (in-order return).
   constexpr int NPL = NLOAD + 2;                          // VMEM operations of a patch load
 #define MSI_CTSTEP(J)                                                                                                  \
   {                                                                                                                    \
-    constexpr int CLS_ = (J) >> 2, TAP_ = (J) & 3;                                                                     \
-    constexpr int PH_ = CLS_ >> 1, PWC_ = CLS_ & 1, TH_ = TAP_ >> 1, TW_ = TAP_ & 1;                                   \
-    constexpr int DR_ = PH_ ? TH_ : -TH_, DC_ = PWC_ ? TW_ : -TW_;                                                     \
-    constexpr int AOFF_ = (1 + DR_) * G::ROW_PITCH + (1 + DC_) * G::PIX_BYTES;                                         \
+    constexpr int PWC_ = (J) >> 2, TH_ = ((J) >> 1) & 1, TW_ = (J) & 1;                                                \
+    constexpr int COFF_ = (1 + (PWC_ ? TW_ : -TW_)) * G::PIX_BYTES;   /* column of the tap: immediate */                \
+    const unsigned ab_ = TH_ ? a_base1 : a_base0;                                                                      \
     v4f a_[4], b_[4];                                                                                                  \
     const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
-      a_[q_] = q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 16>(a_base)                        \
-             : q_ == 2 ? lds_read128<AOFF_ + 32>(a_base) : lds_read128<AOFF_ + 48>(a_base);                            \
+      a_[q_] = q_ == 0 ? lds_read128<COFF_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 16>(ab_)                              \
+             : q_ == 2 ? lds_read128<COFF_ + 32>(ab_) : lds_read128<COFF_ + 48>(ab_);                                  \
       b_[q_] = lds_read128<0>(b_q[q_] + bst_);                                                                         \
     }                                                                                                                  \
     bool issued_ = false;                                                                                              \
@@ -1522,35 +1541,29 @@ convt_halo_kernel(const ConvParams p) {
       if (q_ == 1) wait_lgkm<4>(a_[1], b_[1]);                                                                         \
       if (q_ == 2) wait_lgkm<2>(a_[2], b_[2]);                                                                         \
       if (q_ == 3) wait_lgkm<0>(a_[3], b_[3]);                                                                         \
-      acc[CLS_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[CLS_][0][0], 0, 0, 0);            \
-      acc[CLS_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[CLS_][0][0], 0, 0, 0);            \
-      acc[CLS_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[CLS_][0][0], 0, 0, 0);            \
-      acc[CLS_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[CLS_][0][0], 0, 0, 0);            \
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[PWC_][0][0], 0, 0, 0);            \
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[PWC_][0][0], 0, 0, 0);            \
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[PWC_][0][0], 0, 0, 0);            \
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[PWC_][0][0], 0, 0, 0);            \
       __builtin_amdgcn_sched_barrier(0);                                                                               \
       if (q_ == 0) {                                                                                                   \
         if ((J) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                              \
         int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                       \
-        constexpr int JN_ = ((J) + PD) & 15;                                                                           \
-        if ((J) + PD < 16) { issued_ = true; MSI_B_ISSUE(JN_ >> 2, JN_ & 3, c, sn_) }                                  \
-        else if (c + 1 < c1) { issued_ = true; MSI_B_ISSUE(JN_ >> 2, JN_ & 3, c + 1, sn_) }                            \
+        constexpr int JN_ = ((J) + PD) & 7;                                                                            \
+        if ((J) + PD < 8) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c, sn_) }                        \
+        else if (c + 1 < c1) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_) }                 \
       }                                                                                                                \
     }                                                                                                                  \
-    /* in flight allowed: the DMAs of the last PD - 1 = 2 k-steps (this one's and the previous one's), and the patch */ \
-    /* loads while J <= 1 (issued in J == 0 before its DMA)                                                          */ \
-    if (c + 1 < c1 && (J) == 0) wait_vmcnt<2 * 2 + NPL>();                                                             \
-    else if (c + 1 < c1 && (J) == 1) wait_vmcnt<2 * 2 + NPL>();                                                        \
-    else if (issued_) wait_vmcnt<2 * 2>();                                                                             \
+    if ((J) == 0 && c + 1 < c1) wait_vmcnt<2 + NPL>();                                                                 \
+    else if (issued_) wait_vmcnt<2>();                                                                                 \
     else wait_vmcnt<0>();                                                                                              \
     __builtin_amdgcn_s_barrier();                                                                                      \
     st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
   }
 
-  // ---- prologue: first patch, first PD weight k-steps, the sources' LayerNorm statistics ----
+  // ---- prologue: first patch (the first two weight k-steps are on their way), the sources' LayerNorm statistics ----
   int c = c0, st = 0;
   MSI_PATCH_LOAD(c0)
-  MSI_B_ISSUE(0, 0, c0, 0)
-  MSI_B_ISSUE(0, 1, c0, 1)
-  MSI_B_ISSUE(0, 2, c0, 2)
   if (p.halo_apply) {
     double *s_stat = reinterpret_cast<double *>(smem);
     if (p.halo_apply & 1) {
@@ -1572,7 +1585,6 @@ convt_halo_kernel(const ConvParams p) {
   __builtin_amdgcn_s_barrier();
   for (; c < c1; ++c) {
     MSI_CTSTEP(0) MSI_CTSTEP(1) MSI_CTSTEP(2) MSI_CTSTEP(3) MSI_CTSTEP(4) MSI_CTSTEP(5) MSI_CTSTEP(6) MSI_CTSTEP(7)
-    MSI_CTSTEP(8) MSI_CTSTEP(9) MSI_CTSTEP(10) MSI_CTSTEP(11) MSI_CTSTEP(12) MSI_CTSTEP(13) MSI_CTSTEP(14) MSI_CTSTEP(15)
     if (c + 1 < c1) {
       MSI_PATCH_STORE()
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1584,20 +1596,20 @@ convt_halo_kernel(const ConvParams p) {
 #undef MSI_PATCH_STORE
 #undef MSI_PATCH_LOAD
 
-  // ---- epilogue: four class tiles ----
+  // ---- epilogue: two class tiles ----
   if (!full) {
     constexpr int SLAB = 64 * 64 * 4;
     if (p.tile_cnt == nullptr) {                          // separate fix-up launch (conv_fixup_kernel, class = blockIdx.y)
 #pragma unroll
-      for (int cl = 0; cl < 4; ++cl) {
-        const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 4 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
+      for (int cl = 0; cl < 2; ++cl) {
+        const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 2 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
         dump_acc<1, 1, 0>(acc[cl], rsrc_p, tid);
       }
       return;
     }
 #pragma unroll
-    for (int cl = 0; cl < 4; ++cl) {
-      const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 4 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
+    for (int cl = 0; cl < 2; ++cl) {
+      const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 2 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
       dump_acc<1, 1, 16>(acc[cl], rsrc_p, tid);
     }
     const int nsp = t < p.n_main ? p.split0 : p.split;
@@ -1609,13 +1621,13 @@ convt_halo_kernel(const ConvParams p) {
     __syncthreads();
     if (*s_old != nsp - 1) return;
 #pragma unroll
-    for (int cl = 0; cl < 4; ++cl) {
-      const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)(slot - ks) * 4 + cl) * (64 * 64)), 0, nsp * 4 * SLAB, 0x00020000);
-      sum_slabs<1, 1, 16>(acc[cl], rsrc_t, nsp, 4 * SLAB, tid);
+    for (int cl = 0; cl < 2; ++cl) {
+      const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)(slot - ks) * 2 + cl) * (64 * 64)), 0, nsp * 2 * SLAB, 0x00020000);
+      sum_slabs<1, 1, 16>(acc[cl], rsrc_t, nsp, 2 * SLAB, tid);
     }
   }
 #pragma unroll
-  for (int cl = 0; cl < 4; ++cl) emit_tile<64, 64, MODE_CONVT>(p, acc[cl], tile_m, tile_n, cl, b, tid);
+  for (int cl = 0; cl < 2; ++cl) emit_tile<64, 64, MODE_CONVT>(p, acc[cl], tile_m, tile_n, 2 * ph + cl, b, tid);
 #endif
 }
 
@@ -2112,11 +2124,12 @@ conv_fixup_kernel(const ConvParams p) {
   }
   constexpr int SLAB = BM * BN * 4;
   f32x16 acc[MT][NT];
-  if (MODE == MODE_CONVT && p.halo_tx) {   // convt_halo_kernel: four class slabs per K-range, class = blockIdx.y
-    cls = blockIdx.y;
+  if (MODE == MODE_CONVT && p.halo_tx) {   // convt_halo_kernel: the tile index carries ph, two class slabs (pw = blockIdx.y) per K-range
+    const int pwc = blockIdx.y;
+    cls = 2 * cls + pwc;                   // (nclass = 2 in this enumeration: `cls` decoded above is ph)
     const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.partial + ((size_t)slot0 * 4 + cls) * (BM * BN)), 0, nsp * 4 * SLAB, 0x00020000);
-    sum_slabs<MT, NT, 0>(acc, rsrc_h, nsp, 4 * SLAB, tid);
+        (void *)(p.partial + ((size_t)slot0 * 2 + pwc) * (BM * BN)), 0, nsp * 2 * SLAB, 0x00020000);
+    sum_slabs<MT, NT, 0>(acc, rsrc_h, nsp, 2 * SLAB, tid);
   } else {
     const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(p.partial + (size_t)slot0 * (BM * BN)), 0, nsp * SLAB, 0x00020000);
@@ -2652,7 +2665,7 @@ struct LayerLaunch {
   int skip_apply;   // this layer's output is consumed raw by the head, or normalised by its consumer's launch: no ln_apply launch
   int halo;         // conv_halo_kernel (fp32) / conv_halo_bf16_kernel instead of conv_igemm_kernel
   int hbm, hbn;     // bf16 halo tile: 128 x 128 or 256 x 64
-  int halo_t;       // convt_halo_kernel (conv-transpose, fp32): all four parity classes per workgroup
+  int halo_t;       // convt_halo_kernel (conv-transpose, fp32): the two classes of one output-row parity per workgroup
   int halo_tb;      // convt_halo_bf16_kernel (conv-transpose, bf16): the two classes of one output-row parity per workgroup
   int halo_apply;   // ... applying the producer's LayerNorm while staging the patch (the producer's buffer stays raw)
   unsigned ln_blocks;
@@ -2807,14 +2820,14 @@ int plan_layers(msi_net_plan *pl) {
       else if (L.cout == 64 && L.in_h % 16 == 0 && L.rate == 1) { Q.halo = 1; Q.hbm = 256; Q.hbn = 64; }
       if (Q.halo) { BM = Q.hbm; BN = Q.hbn; max_split = 1; }
     }
-    // conv-transpose halo kernel (convt_halo_kernel; HALO bit 1, NOT the default -- measured slower, see the kernel):
-    // SAME conv-transposes (CoordNet), fp32, whole 4 x 16 input tiles and 32-channel chunks of both sources
+    // conv-transpose halo kernel (convt_halo_kernel; HALO bit 1, default on): SAME conv-transposes (CoordNet), fp32, whole
+    // 4 x 16 input tiles and 32-channel chunks of both sources; one workgroup per output-row parity (enumerated as two "classes")
     Q.halo_t = halo_ok && (pl->opt[MSI_NET_OPT_HALO] & 2) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] &&
                Q.tile == TILE_64x64 && L.kind == MODE_CONVT && !L.wrapt && L.in_h % 4 == 0 && L.in_w % 16 == 0 &&
                L.c0 % 32 == 0 && L.c1 % 32 == 0;
     if (Q.halo_t) {
       Q.halo = 1;
-      p.nclass = 1;                                      // tiles are enumerated per (tile_m, tile_n, sample): a workgroup owns the 4 classes
+      p.nclass = 2;                                      // tiles are enumerated per (ph, tile_m, tile_n, sample): a workgroup owns pw = 0, 1
       if (L.cpt0 + L.cpt1 < max_split) max_split = L.cpt0 + L.cpt1;
     }
     // bf16 conv-transpose halo kernel (convt_halo_bf16_kernel): SAME conv-transposes, 64-channel chunks of both sources,
@@ -2847,14 +2860,14 @@ int plan_layers(msi_net_plan *pl) {
       pl->launch[L.src0].skip_apply = 1;              // (the producer precedes its consumer in graph order)
     }
     Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
-    if (Q.halo_t && (size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * 4 * BM * BN * sizeof(float) > net.partial_bytes) {
-      // four slabs per K-range do not fit the partial-accumulator workspace -> the tap kernel
+    if (Q.halo_t && (size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * 2 * BM * BN * sizeof(float) > net.partial_bytes) {
+      // two slabs per K-range do not fit the partial-accumulator workspace -> the tap kernel
       Q.halo_t = 0; Q.halo = 0;
       p.halo_tx = 0; p.halo_xor = 0; p.nclass = L.nclass;
       plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], MAX_SPLIT, &Q.nblocks, &Q.nfix);
       Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
     }
-    if ((size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * (Q.halo_t ? 4 : 1) * BM * BN * sizeof(float) > net.partial_bytes)
+    if ((size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * (Q.halo_t ? 2 : 1) * BM * BN * sizeof(float) > net.partial_bytes)
       return msi::fail(MSI_E_WORKSPACE, "conv %s: %d partial accumulators exceed the workspace", L.name, Q.nblocks);
     if (L.kind != MODE_HEAD) {
       const size_t per_sample = (size_t)L.out_h * L.out_w * L.cout;
@@ -2964,12 +2977,14 @@ int launch_conv(const LayerLaunch &Q, const ConvParams &p, int bf16, hipStream_t
       case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 0>(Q, p, stream);
       default: return launch_conv_mode<BM, BN, MODE_HEAD, 0>(Q, p, stream);
     }
+#ifdef MSI_EXPERIMENTS
   } else if constexpr (BM * BN == 128 * 64) {
     switch (p.mode) {
       case MODE_CONV: return launch_conv_mode<BM, BN, MODE_CONV, 0>(Q, p, stream);
       case MODE_CONVT: return launch_conv_mode<BM, BN, MODE_CONVT, 0>(Q, p, stream);
       default: return msi::fail(MSI_E_UNSUPPORTED, "conv: fp32 head uses the 64x64 tile");
     }
+#endif
   } else {
     return msi::fail(MSI_E_UNSUPPORTED, "conv: the fp32 path is built for the 64x64, 128x64 and 64x128 tiles");
   }
@@ -3194,7 +3209,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_HEAD_FUSE_LN] = 1;
   pl->opt[MSI_NET_OPT_NUM_CUS] = pl->num_cus;
   pl->opt[MSI_NET_OPT_APPLY_AHEAD] = 0;   // measured r02_h: correct and bit-identical, but 2.69 vs 2.56 ms per network
-  pl->opt[MSI_NET_OPT_HALO] = 1;
+  pl->opt[MSI_NET_OPT_HALO] = 3;
   pl->opt[MSI_NET_OPT_F32_TILE] = 0;
   pl->opt[MSI_NET_OPT_F32_TILE_MASK] = 0;
   int rc = plan_layers(pl);
@@ -3216,6 +3231,11 @@ int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value) {
   if (option == MSI_NET_OPT_HALO) MSI_REQUIRE(value >= 0 && value <= 3, "net_plan_set_option: halo %d (bit 0 conv, bit 1 conv-transpose)", value);
   if (option == MSI_NET_OPT_TAILSPLIT) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: tailsplit %d", value);
   if (option == MSI_NET_OPT_F32_TILE) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: f32 tile %d", value);
+#ifndef MSI_EXPERIMENTS
+  if ((option == MSI_NET_OPT_F32_TILE || option == MSI_NET_OPT_F32_TILE_MASK || option == MSI_NET_OPT_APPLY_AHEAD) && value != 0)
+    return msi::fail(MSI_E_UNSUPPORTED, "net_plan_set_option: option %d is an experiment this library was not built with "
+                     "(MSI_CNN_DEFINES=-DMSI_EXPERIMENTS python -m matryodshka_amd.build --force)", option);
+#endif
   const int old = plan->opt[option];
   plan->opt[option] = value;
   int rc = plan_layers(plan);
@@ -3418,7 +3438,7 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       hipLaunchKernelGGL(convt_halo_kernel, dim3(Q.nblocks), dim3(256), ConvtHaloGeom::LDS_BYTES, stream, p);
       rc = msi::check_launch("convt_halo");
       if (!rc && Q.nfix > 0 && p.tile_cnt == nullptr) {
-        hipLaunchKernelGGL((conv_fixup_kernel<64, 64, MODE_CONVT>), dim3(Q.nfix, 4), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_fixup_kernel<64, 64, MODE_CONVT>), dim3(Q.nfix, 2), dim3(256), 0, stream, p);
         rc = msi::check_launch("conv_fixup");
       }
     } else if (Q.halo) {
@@ -3445,7 +3465,11 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
     switch (Q.tile) {
       case TILE_128x128: rc = launch_conv<128, 128>(Q, p, bf16, stream); break;
       case TILE_128x64: rc = launch_conv<128, 64>(Q, p, bf16, stream); break;
+#ifdef MSI_EXPERIMENTS
       case TILE_64x128: rc = bf16 ? msi::fail(MSI_E_UNSUPPORTED, "conv: 64x128 is an fp32 tile") : launch_conv<64, 128>(Q, p, 0, stream); break;
+#else
+      case TILE_64x128: rc = msi::fail(MSI_E_UNSUPPORTED, "conv: the 64x128 fp32 tile is an experiment (MSI_EXPERIMENTS)"); break;
+#endif
       default: rc = launch_conv<64, 64>(Q, p, bf16, stream); break;
     }
     if (rc) return rc;

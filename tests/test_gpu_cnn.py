@@ -164,6 +164,13 @@ def test_apply_ahead_equals_separate_layernorm_launches(env, dtype, coord, b, h,
     launch, behind per-row counters, against one ln_apply launch per layer -- the same arithmetic on the same sums, so the
     prediction and every activation are bit-identical; the wait never times out (error word stays 0)."""
     torch, MSI, nets, N, onets = env
+    import ctypes
+    probe = ctypes.c_void_p()
+    assert N.lib.msi_net_plan_create(nets.make_desc(1, 16, 32, 24, 8, 16, True), ctypes.byref(probe)) == 0
+    built = N.lib.msi_net_plan_set_option(probe, N.NET_OPT_APPLY_AHEAD, 1) == 0
+    N.lib.msi_net_plan_destroy(probe)
+    if not built:
+        pytest.skip("apply-ahead is a measured-slower experiment: build with MSI_CNN_DEFINES=-DMSI_EXPERIMENTS to test it")
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=21, randomize_affine=True)
     x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
     if dtype == "bf16":
@@ -231,14 +238,14 @@ def test_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, w, ci
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=29, randomize_affine=True)
     x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
     halo = MSI(weights=weights, coord_net=coord)
-    halo.net_options[N.NET_OPT_HALO] = halo_opt      # 1: the default; 3: + convt_halo_kernel on the conv-transposes (measured slower: opt-in)
+    halo.net_options[N.NET_OPT_HALO] = halo_opt      # 3: the default; 1: the conv-transposes stay on the tap kernel
     tap = MSI(weights=weights, coord_net=coord)
     tap.net_options[N.NET_OPT_HALO] = 0
     p1, p0 = halo.run_net(x, nout, ngf), tap.run_net(x, nout, ngf)
     plan = halo._plan(b, h, w, cin, nout, ngf)
     raw_layers = [i for i in range(17) if N.lib.msi_net_plan_layer_is_normalized(plan.handle, i) == 0]
     if h % 32 == 0 and w % 128 == 0:                 # every level tiles into 4 x 16 patches:
-        assert len(raw_layers) >= 8, raw_layers      # conv3_1, conv4_1/2, conv6_1/2, conv7_1, conv8_1 (+ conv8_2: head)
+        assert len(raw_layers) >= (8 if halo_opt == 1 or not coord else 14), raw_layers   # (3: everything but the stride-2 layers' sources)
     assert float((p1 - p0).abs().max()) <= 2e-5
     for _ in range(5):
         assert torch.equal(halo.run_net(x, nout, ngf), p1)
@@ -286,25 +293,33 @@ def test_full_size_network_properties_without_the_oracle(env, dtype):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("gain", [1e-4, 1e4])
-def test_layernorm_is_invariant_to_the_weight_scale(env, gain, dtype):
-    """LayerNorm (eps 1e-12) removes any scale of a layer's weights.  The LayerNorm sums are one-word fixed point inside
-    a per-layer window whose exponent the packer takes from the weights (cnn.hip: LN_S1_BITS), so the window follows the
-    scale: the prediction of a network whose conv / conv-transpose weights are ALL multiplied by 1e-4 or 1e4 (a power of
-    two close to it: exact) equals the unscaled one, and msi_net_plan_status stays clean."""
+def test_layernorm_follows_the_weight_scale(env, gain, dtype):
+    """The LayerNorm sums are one-word fixed point inside a per-layer window whose exponent the packer takes from the
+    weights (cnn.hip: LN_S1_BITS), so the window follows any scale of the weights: a network whose conv / conv-transpose
+    weights are ALL multiplied by 2^-13 (~1e-4) or 2^13 (~1e4) still matches the ORACLE run on the same scaled weights
+    (fp64 two-pass statistics, eps 1e-12 -- which is why the small gain is not exactly invariant: var ~1e-8 against
+    eps 1e-12 moves the prediction by ~2e-4, in the reference too) and msi_net_plan_status stays clean; the large gain
+    also reproduces the unscaled prediction (LayerNorm removes it)."""
     torch, MSI, nets, N, onets = env
     b, h, w, cin, nout, ngf = 1, 32, 64, 48, 16, 16
     g = float(2.0 ** round(np.log2(gain)))
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=41, randomize_affine=True)
     scaled = {k: (v * np.float32(g) if k.endswith("/weights") and not k.startswith("color_pred") else v) for k, v in weights.items()}
-    x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
+    xh = np.random.RandomState(5).uniform(-1, 1, size=(b, h, w, cin)).astype(np.float32)
+    x = torch.from_numpy(xh).cuda()
     if dtype == "bf16":
         x = x.bfloat16()
     m0, m1 = MSI(weights=weights, coord_net=True, dtype=dtype), MSI(weights=scaled, coord_net=True, dtype=dtype)
     p0, p1 = m0.run_net(x, nout, ngf), m1.run_net(x, nout, ngf)
     assert m0.network_status() == 0 and m1.network_status() == 0
-    # (power-of-two gain: products and sums scale exactly; the CoordNet table and the statistics round identically up to
-    # the fixed-point unit, which scales with the window)
-    assert float((p1 - p0).abs().max()) <= (2e-5 if dtype == "f32" else 2e-2)
+    ref = onets.forward(scaled, x.float().cpu().numpy(), coord_net=True, bf16=dtype == "bf16")
+    err = np.abs(p1.cpu().numpy() - ref)
+    if dtype == "f32":
+        assert err.max() <= 1e-4, err.max()
+    else:
+        assert err.max() <= 4e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+    if g > 1:
+        assert float((p1 - p0).abs().max()) <= (2e-5 if dtype == "f32" else 4e-2)
 
 
 def test_status_reports_statistics_outside_the_fixed_point_window(env):
