@@ -1364,9 +1364,14 @@ conv_halo_kernel(const ConvParams p) {
 // do not divide by 3; four stages would leave three workgroups per CU instead of four), k order per class: chunk-major,
 // tap-minor over the tap-major packed blob.  K-ranges of split tiles: whole chunks; a partial tile dumps two slabs
 // (class-minor) and the last arriver sums each class in ascending k.
-// History: the r02 form of this kernel owned all FOUR classes (64 accumulator registers -> three workgroups per CU, four
-// slabs per K-range) and lost to the tap kernel (conv8_1 218 vs 200 us, profiles/r02_E_convt_halo_kernel_stats.txt);
-// the two-class form keeps the halo kernels' four workgroups per CU and halves the tile visits per output.
+// MEASURED, twice.  r02: all FOUR classes per workgroup (64 accumulator registers -> three workgroups per CU, four slabs per
+// K-range) lost to the tap kernel (conv8_1 218 vs 200 us, profiles/r02_E_convt_halo_kernel_stats.txt).  r03: this two-class
+// form (four workgroups per CU, 125 VGPRs, no scratch) is correct -- every parity / determinism / fix-up-equality test passes
+// with it on -- and still loses: conv6_1 223 vs 197 us, conv7_1 210 vs 195, conv8_1 214 vs 202; it drops six ln_apply launches
+// (77 -> 35 us per frame) but makes conv2_1 / conv3_1 / conv4_1 APPLY layers (+10 us): network 2.525-2.532 ms against
+// 2.476-2.485 ms with the tap kernel (two interleaved repeats, profiles/r03_b_convt_halo2_kernel_stats.txt).  The tap kernel's
+// k-loop has no VALU at all and five workgroups per CU; here every chunk costs ~120 VALU (patch affine + ReLU through
+// registers, run-time ring stage, per-source address selects) per 8 192 matrix cycles.  Plan option HALO bit 1, default off.
 struct ConvtHaloGeom : HaloGeom<1> {};
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
@@ -2820,7 +2825,7 @@ int plan_layers(msi_net_plan *pl) {
       else if (L.cout == 64 && L.in_h % 16 == 0 && L.rate == 1) { Q.halo = 1; Q.hbm = 256; Q.hbn = 64; }
       if (Q.halo) { BM = Q.hbm; BN = Q.hbn; max_split = 1; }
     }
-    // conv-transpose halo kernel (convt_halo_kernel; HALO bit 1, default on): SAME conv-transposes (CoordNet), fp32, whole
+    // conv-transpose halo kernel (convt_halo_kernel; HALO bit 1, NOT the default -- measured slower, see the kernel): SAME conv-transposes (CoordNet), fp32, whole
     // 4 x 16 input tiles and 32-channel chunks of both sources; one workgroup per output-row parity (enumerated as two "classes")
     Q.halo_t = halo_ok && (pl->opt[MSI_NET_OPT_HALO] & 2) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] &&
                Q.tile == TILE_64x64 && L.kind == MODE_CONVT && !L.wrapt && L.in_h % 4 == 0 && L.in_w % 16 == 0 &&
@@ -3209,7 +3214,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_HEAD_FUSE_LN] = 1;
   pl->opt[MSI_NET_OPT_NUM_CUS] = pl->num_cus;
   pl->opt[MSI_NET_OPT_APPLY_AHEAD] = 0;   // measured r02_h: correct and bit-identical, but 2.69 vs 2.56 ms per network
-  pl->opt[MSI_NET_OPT_HALO] = 3;
+  pl->opt[MSI_NET_OPT_HALO] = 1;   // (bit 1, the fp32 conv-transpose halo kernel: measured slower than the tap kernel + ln_apply, see the kernel)
   pl->opt[MSI_NET_OPT_F32_TILE] = 0;
   pl->opt[MSI_NET_OPT_F32_TILE_MASK] = 0;
   int rc = plan_layers(pl);
