@@ -252,8 +252,14 @@ typedef struct msi_layer_info {
   uint64_t param_offset;  /* float offset of `weights` in the parameter blob   */
   uint64_t param_floats;  /* weights + gamma + beta (or + biases)              */
   uint64_t raw_offset;    /* BYTE offset of the raw (pre-LayerNorm) output in  */
-                          /* the workspace; (uint64)-1 for the head             */
+                          /* the workspace; (uint64)-1 for the head.  fp32     */
+                          /* plans: fp32 [B,H,W,cout]; bf16 plans: fp16 of     */
+                          /* x * 2^-e, e = the layer's LayerNorm window (below) */
   uint64_t affine_offset; /* BYTE offset of scale[cout] shift[cout] in the ws  */
+  uint64_t ln_scale_offset; /* FLOAT offset in the PACKED blob of four doubles */
+                          /* {S1, S2, 1/S1, 1/S2}, S1 = 2^(24 - e), S2 =       */
+                          /* 2^(16 - 2e): the fixed-point window of the layer's */
+                          /* LayerNorm sums; 2^e = 2^24 / S1                    */
 } msi_layer_info;
 
 /* Parameter blob ("reference layout"), fp32, layers in graph order; per layer
@@ -297,7 +303,10 @@ typedef struct msi_net_plan msi_net_plan;
                                    /* LayerNorm applied while staging);                                                                */
                                    /* 0: tap-DMA kernel everywhere                                                                     */
 #define MSI_NET_OPT_HALO_SKIP 9     /* bit i = layer i (graph order) does NOT take a halo kernel although it qualifies (tuning)          */
-#define MSI_NET_OPT_COUNT 10
+#define MSI_NET_OPT_UNIFORM_SPLIT 10 /* s >= 2: layers with one to two 64x64 tiles per CU cut EVERY tile into s equal K-ranges (tuning; 0 = default split) */
+#define MSI_NET_OPT_BF16_STAGE_RAW 11 /* bf16 plans: bit 0 the 256x64 conv tile (conv8_2), bit 1 the 128x64 conv-transpose tile (conv8_1) read their  */
+                                      /* sources RAW (fp16) and apply the producer's LayerNorm while staging (default 1: bit 1 measured slower); 0: from ln_apply's bf16 copies */
+#define MSI_NET_OPT_COUNT 12
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
 int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);

@@ -355,7 +355,12 @@ __device__ __forceinline__ void sum_slabs(f32x16 (&acc)[MT][NT], __amdgpu_buffer
 // fp64 and a fixed-point integer atomic add (ln_atomic_add).
 // INTERIOR: whole tile inside the output, no row / channel masks anywhere (the common case; epilogue VALU
 // is paid in matrix throughput of the co-resident workgroups).
-template <int BM, int BN, int MODE, bool INTERIOR>
+// RAW16 (the layers of a bf16 plan): the raw output is stored as fp16 of x * 2^-e, e = the exponent of the layer's
+// LayerNorm window (S1 = 2^(24 - e): the value the packer expects the output's rms to be near, so the fp16 range sits
+// around it) -- half the bytes of the fp32 raw outputs that bound the bf16 layers, 11 significand bits against the 8 of
+// the bf16 operand it becomes after the affine (measured on the oracle: mean |bf16 path - fp32 oracle| + 0.3 %; a bf16
+// raw output would be + 19 %).  The statistics are taken from the fp32 accumulators as before.
+template <int BM, int BN, int MODE, bool INTERIOR, int RAW16>
 __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m,
                                                int tile_n, int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre) {
   constexpr int MT = BM / 64, NT = BN / 64;
@@ -370,7 +375,9 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
   // (scalar loads at the head of the epilogue: inside the lane-0 branch below they would be vector loads with a memory
   // round trip between the wave reduction and the atomics, at the end of every tile)
   double scl_s1 = 0.0, scl_s2 = 0.0;
-  if (want_stats) { scl_s1 = p.ln_scl[0]; scl_s2 = p.ln_scl[1]; }
+  if (want_stats || RAW16) { scl_s1 = p.ln_scl[0]; scl_s2 = p.ln_scl[1]; }
+  const float raw_mul = RAW16 ? (float)(scl_s1 * (1.0 / 16777216.0)) : 1.f;   // 2^-e
+  constexpr int YSZ = RAW16 ? 2 : 4;                                          // bytes per stored element
   float s1 = 0.f, s2 = 0.f, cnt = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -399,7 +406,7 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
       opix = (size_t)b * mtot + m;
     }
     const float *cbrow = has_cb ? p.coord_bias + (size_t)(mh * COORD_CLASSES + coord_class(mw, p.Mw)) * p.cb_stride : nullptr;
-    float *yrow = p.y + opix * p.Cout;
+    char *yrow = reinterpret_cast<char *>(p.y) + opix * p.Cout * YSZ;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int nb = tile_n * BN + wn * (NT * 32) + j * 32 + 4 * half;
@@ -418,8 +425,13 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
             const v4f bs = *reinterpret_cast<const v4f *>(p.bias + n);
             v.x = tanhf(v.x + bs.x); v.y = tanhf(v.y + bs.y); v.z = tanhf(v.z + bs.z); v.w = tanhf(v.w + bs.w);
           }
-          if (sok) {
-            float *dst = yrow + n;
+          if (sok && RAW16) {   // (Cout % 4 == 0 in a bf16 plan: whole 8-byte pieces)
+            typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+            typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+            const h2_t lo = {(_Float16)(v.x * raw_mul), (_Float16)(v.y * raw_mul)}, hi = {(_Float16)(v.z * raw_mul), (_Float16)(v.w * raw_mul)};
+            *reinterpret_cast<u2_t *>(yrow + n * 2) = u2_t{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+          } else if (sok) {
+            float *dst = reinterpret_cast<float *>(yrow) + n;
             if (vec_ok) {
               *reinterpret_cast<v4f *>(dst) = v;
             } else {
@@ -458,19 +470,19 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
   }
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int RAW16 = 0>
 __device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n,
                                           int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre) {
   const bool interior = !(MODE == MODE_CONVT && p.wrap != 0) && (tile_m + 1) * BM <= p.Mh * p.Mw &&
                         (tile_n + 1) * BN <= p.Cout && (p.Cout & 3) == 0;
-  if (interior) emit_tile_impl<BM, BN, MODE, true>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre);
-  else emit_tile_impl<BM, BN, MODE, false>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre);
+  if (interior) emit_tile_impl<BM, BN, MODE, true, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre);
+  else emit_tile_impl<BM, BN, MODE, false, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre);
 }
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int RAW16 = 0>
 __device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n,
                                           int cls, int b, int tid) {
   const v4f none[4] = {};
-  emit_tile<BM, BN, MODE>(p, acc, tile_m, tile_n, cls, b, tid, none, false);
+  emit_tile<BM, BN, MODE, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, none, false);
 }
 
 // The CoordNet table values of this lane's pixel and 16 channels (64x64 tile, transposed accumulator layout), requested
@@ -1083,7 +1095,7 @@ _Pragma("unroll")                                                               
         (void *)(p.partial + (size_t)(slot - ks) * (BM * BN)), 0, nsp * SLAB, 0x00020000);
     sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
   }
-  emit_tile<BM, BN, MODE>(p, acc, tile_m, tile_n, cls, b, tid, cbv, CB_PRE && p.coord_bias != nullptr);
+  emit_tile<BM, BN, MODE, (BF16 && MODE != MODE_HEAD) ? 1 : 0>(p, acc, tile_m, tile_n, cls, b, tid, cbv, CB_PRE && p.coord_bias != nullptr);
 #ifdef MSI_CONV_TIMING
   stamp();
 #endif
@@ -1644,7 +1656,7 @@ convt_halo_kernel(const ConvParams p) {
 // wave 32 MT x 32 NT of it (16 MFMAs = 512 matrix cycles per k-step), the chunk is 64 channels (the 128-byte rows of
 // the packed weights, one k-step per tap), and the patch is staged through registers once per chunk:
 //   APPLY = 0: from the bf16 operand copy (the network input, or what ln_apply wrote),
-//   APPLY = 1: from the producer's RAW fp32 output, its LayerNorm + ReLU applied and rounded to bf16 (round to nearest
+//   APPLY = 1: from the producer's RAW output (fp16 of x * 2^-e, see emit_tile_impl RAW16), its LayerNorm + ReLU applied and rounded to bf16 (round to nearest
 //              even, v_cvt_pk_bf16_f32) on the way -- the producer then has no ln_apply launch and no bf16 copy.
 // Weights: NSTG-stage DMA ring of BN rows (three stages where two workgroups per CU still fit, else two), the stage
 // index is a run-time scalar (4 VALU adds per 512-cycle k-step).  Whole tiles only (big grids: no K split).
@@ -1675,8 +1687,8 @@ conv_halo_bf16_kernel(const ConvParams p) {
   typedef HaloGeomB<BM, BN, RATE> G;
   constexpr int R = RATE, PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, MT = BM / 64, NT = BN / 64;
   constexpr int NSTG = G::NSTG, PD = NSTG - 1, BI = BN / 32;   // BI: weight DMA instructions per wave and k-step
-  constexpr int NRAW = APPLY ? 2 * NLOAD : NLOAD;               // 16-byte patch loads per thread and chunk
-  constexpr int NPL = NRAW + (APPLY ? 4 : 0);                   // ... plus gamma / beta of the thread's 8 channels
+  constexpr int NRAW = NLOAD;                                   // 16-byte patch loads per thread and chunk (bf16 copy, or fp16 raw)
+  constexpr int NPL = NRAW;                                     // VMEM operations of a patch load
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1700,7 +1712,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
   const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
   const int oh0 = tyi * G::TH, ow0 = (tile_m - tyi * p.halo_tx) * 16;
   const int H = p.Hin, W = p.Win, C = p.C0;
-  constexpr int ESZ = APPLY ? 4 : 2;                      // bytes per source element
+  constexpr int ESZ = 2;                                  // bytes per source element: the bf16 operand copy, or (APPLY) the producer's fp16 raw output
 
   // ---- per-lane patch slots: e = tid + 256 k -> patch pixel e / 8, 8-channel slot e % 8 (= tid % 8) ----
   unsigned voff[NLOAD], lds_a[NLOAD];
@@ -1724,7 +1736,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
   const int drow = lane >> 3, dslot = lane & 7;
   const unsigned b_voff = (unsigned)((tile_n * BN + wave * (BN / 4) + drow) * ROW_BYTES + dslot * 16);
 
-  float inv_f = 1.f, mu_hi = 0.f, mu_lo = 0.f;
+  int c_ld = 0;                                           // chunk of the patch held in araw
   bool has_pad = false;
   if (APPLY) {
     bool bad = false;
@@ -1732,40 +1744,32 @@ conv_halo_bf16_kernel(const ConvParams p) {
     for (int k = 0; k < NLOAD; ++k) bad |= (lds_a[k] != 0xffffffffu) && !pok[k];
     has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
   }
-  v4f araw[NRAW], g8[2], be8[2];
+  v4f araw[NRAW];   // (eight bf16 operands, or eight fp16 raw values, per 16-byte slot)
+  float *s_tab = reinterpret_cast<float *>(smem + G::LDS_BYTES);   // APPLY: scale[C] | shift[C] of the source's LayerNorm
 #define MSI_PATCH_LOAD(c)                                                                                              \
   {                                                                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
-      if (APPLY) {                                                                                                     \
-        araw[2 * k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], (c) * 256, 0)); \
-        araw[2 * k_ + 1] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_] + 16, (c) * 256, 0)); \
-      } else {                                                                                                         \
-        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], (c) * 128, 0)); \
-      }                                                                                                                \
-    }                                                                                                                  \
-    if (APPLY) {                                                                                                       \
-      g8[0] = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 64 + cslot * 8);                                       \
-      g8[1] = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 64 + cslot * 8 + 4);                                   \
-      be8[0] = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 64 + cslot * 8);                                       \
-      be8[1] = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 64 + cslot * 8 + 4);                                   \
-    }                                                                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], (c) * 128, 0)); \
+    if (APPLY) c_ld = (c);                                                                                             \
   }
 #define MSI_PATCH_STORE()                                                                                              \
   {                                                                                                                    \
     v4f s_[2], t_[2];                                                                                                  \
-    if (APPLY) {                                                                                                       \
-      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};                          \
-      _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                               \
-        s_[h_] = inv_f * g8[h_];                                                                                       \
-        t_[h_] = __builtin_elementwise_fma(nl, s_[h_], __builtin_elementwise_fma(nh, s_[h_], be8[h_]));                \
-      }                                                                                                                \
+    if (APPLY) {   /* the thread's eight channels of chunk c_ld: four ds_read_b128 from the table built in the prologue */ \
+      const float *sp_ = s_tab + c_ld * 64 + cslot * 8;                                                                \
+      s_[0] = *reinterpret_cast<const v4f *>(sp_); s_[1] = *reinterpret_cast<const v4f *>(sp_ + 4);                    \
+      t_[0] = *reinterpret_cast<const v4f *>(sp_ + C); t_[1] = *reinterpret_cast<const v4f *>(sp_ + C + 4);            \
     }                                                                                                                  \
     _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
       v4f o_;                                                                                                          \
       if (APPLY) {                                                                                                     \
         const v4f z_ = {0.f, 0.f, 0.f, 0.f};                                                                           \
-        v4f y0 = __builtin_elementwise_max(__builtin_elementwise_fma(araw[2 * k_], s_[0], t_[0]), z_);                 \
-        v4f y1 = __builtin_elementwise_max(__builtin_elementwise_fma(araw[2 * k_ + 1], s_[1], t_[1]), z_);             \
+        typedef _Float16 h8_t __attribute__((ext_vector_type(8)));                                                     \
+        const h8_t hx_ = __builtin_bit_cast(h8_t, araw[k_]);   /* eight fp16 raw values x * 2^-e (s_ carries 2^e) */    \
+        const v4f x0_ = {(float)hx_[0], (float)hx_[1], (float)hx_[2], (float)hx_[3]};                                  \
+        const v4f x1_ = {(float)hx_[4], (float)hx_[5], (float)hx_[6], (float)hx_[7]};                                  \
+        v4f y0 = __builtin_elementwise_max(__builtin_elementwise_fma(x0_, s_[0], t_[0]), z_);                          \
+        v4f y1 = __builtin_elementwise_max(__builtin_elementwise_fma(x1_, s_[1], t_[1]), z_);                          \
         if (has_pad && !pok[k_]) { y0 = z_; y1 = z_; }   /* padding is zero AFTER the normalisation */                 \
         unsigned w0, w1, w2, w3;                                                                                       \
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w0) : "v"(y0.x), "v"(y0.y));                                         \
@@ -1878,12 +1882,20 @@ conv_halo_bf16_kernel(const ConvParams p) {
   MSI_B_ISSUE(c0, 0, 0)
   if (PD == 2) MSI_B_ISSUE(c0, 1, 1)
   if (APPLY) {
+    // the affine of the source's LayerNorm for every input channel, once per workgroup: scale = 2^e inv gamma (the stored
+    // raw value is fp16 of x * 2^-e), shift = beta - mean inv gamma with the mean as hi + lo floats, fp32 operations only
+    // (the expressions ln_apply's fp32 table would give up to the last bit are not needed: the result is rounded to bf16)
     double *s_stat = reinterpret_cast<double *>(smem);
     ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
     const double mu = s_stat[0];
-    inv_f = (float)s_stat[1];
-    mu_hi = (float)mu;
-    mu_lo = (float)(mu - (double)mu_hi);
+    const float inv_f = (float)s_stat[1], mu_hi = (float)mu, mu_lo = (float)(mu - (double)mu_hi);
+    const float up_f = (float)(p.ln_scl_src[2] * 16777216.0);   // 2^e of the source layer's window
+    __syncthreads();
+    for (int ch = tid; ch < C; ch += 256) {
+      const float su = inv_f * p.ln_gamma[ch];
+      s_tab[C + ch] = __builtin_fmaf(-mu_lo, su, __builtin_fmaf(-mu_hi, su, p.ln_beta[ch]));
+      s_tab[ch] = up_f * su;
+    }
     __syncthreads();
   }
   wait_vmcnt<0>();
@@ -1903,7 +1915,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
 #undef MSI_B_ISSUE
 #undef MSI_PATCH_STORE
 #undef MSI_PATCH_LOAD
-  emit_tile<BM, BN, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid);
+  emit_tile<BM, BN, MODE_CONV, 1>(p, acc, tile_m, tile_n, 0, b, tid);
 #endif
 }
 
@@ -1919,7 +1931,10 @@ conv_halo_bf16_kernel(const ConvParams p) {
 // blocks through the conv kernel's DMA ring.  Whole tiles only.  Unlike the fp32 attempt (convt_halo_kernel, slower than
 // its tap kernel) this one replaces a kernel that is traffic-bound: configs[2] conv8_1 963 -> 537 us, conv7_1 558 -> 416,
 // conv6_1 475 -> 390 per 16 frames (profiles/r02_T_bf16_convt_halo.txt).
-template <int BM, int BN>
+// APPLY = 1 (r03): a source whose bit is set in p.halo_apply is read from its producer's RAW output (fp16 of x * 2^-e) with
+// the producer's LayerNorm + ReLU + bf16 rounding applied while staging, as conv_halo_bf16_kernel<.., 1> does; the other
+// source (if any) still comes from its bf16 operand copy.  Both encodings are 16 bytes per 8-channel slot.
+template <int BM, int BN, int APPLY>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 convt_halo_bf16_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1973,11 +1988,31 @@ convt_halo_bf16_kernel(const ConvParams p) {
   const int drow = lane >> 3, dslot = lane & 7;
   const unsigned b_voff = (unsigned)((tile_n * BN + wave * (BN / 4) + drow) * ROW_BYTES + dslot * 16);
 
-  v4f araw[NLOAD];
+  v4f araw[NLOAD], g8[2], be8[2];
+  int src_ld = 0;                                         // source of the patch held in araw
+  float inv0 = 1.f, inv1 = 1.f, mh0 = 0.f, mh1 = 0.f, ml0 = 0.f, ml1 = 0.f, up0 = 1.f, up1 = 1.f;   // (scalars, not arrays: no scratch)
+  bool has_pad = false;
+  if (APPLY) {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) bad |= (lds_a[k] != 0xffffffffu) && !pok[k];
+    has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
+  }
+  constexpr int NPL = NLOAD + (APPLY ? 4 : 0);            // VMEM operations of a patch load
 #define MSI_PATCH_LOAD(c)                                                                                              \
   {                                                                                                                    \
     const int s_ = (c) >= p.cpt0 ? 1 : 0, cc_ = s_ ? (c) - p.cpt0 : (c);                                               \
     const unsigned cb_ = (unsigned)((s_ ? p.C1 : p.C0) * 2);                                                           \
+    src_ld = s_;                                                                                                       \
+    if (APPLY) {   /* gamma / beta of the thread's 8 channels (dummy rows when this source is not raw: the vmcnt  */   \
+      /* arithmetic of the k-steps counts the same number of VMEM operations on both paths)                      */   \
+      const bool raw_ = (p.halo_apply >> s_) & 1;                                                                      \
+      const float *gb_ = raw_ ? (s_ ? p.ln_gamma1 : p.ln_gamma) : reinterpret_cast<const float *>(p.wpk);              \
+      const float *bb_ = raw_ ? (s_ ? p.ln_beta1 : p.ln_beta) : reinterpret_cast<const float *>(p.wpk);                \
+      const float *gp_ = gb_ + (raw_ ? cc_ * 64 : 0) + cslot * 8, *bp_ = bb_ + (raw_ ? cc_ * 64 : 64) + cslot * 8;     \
+      g8[0] = *reinterpret_cast<const v4f *>(gp_); g8[1] = *reinterpret_cast<const v4f *>(gp_ + 4);                     \
+      be8[0] = *reinterpret_cast<const v4f *>(bp_); be8[1] = *reinterpret_cast<const v4f *>(bp_ + 4);                   \
+    }                                                                                                                  \
     if (s_ == 0) {                                                                                                     \
       _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
         araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
@@ -1990,8 +2025,38 @@ convt_halo_bf16_kernel(const ConvParams p) {
   }
 #define MSI_PATCH_STORE()                                                                                              \
   {                                                                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
-      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = araw[k_];                             \
+    const bool ap_ = APPLY && ((p.halo_apply >> src_ld) & 1);                                                          \
+    v4f s_[2], t_[2];                                                                                                  \
+    if (ap_) {                                                                                                         \
+      const float ih_ = src_ld ? inv1 : inv0, mh_ = src_ld ? mh1 : mh0, ml_ = src_ld ? ml1 : ml0;                       \
+      const float uf_ = src_ld ? up1 : up0;                                                                            \
+      const v4f nh = {-mh_, -mh_, -mh_, -mh_}, nl = {-ml_, -ml_, -ml_, -ml_};                                          \
+      _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                               \
+        const v4f su_ = ih_ * g8[h_];                                                                                  \
+        t_[h_] = __builtin_elementwise_fma(nl, su_, __builtin_elementwise_fma(nh, su_, be8[h_]));                      \
+        s_[h_] = uf_ * su_;                                                                                            \
+      }                                                                                                                \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
+      v4f o_ = araw[k_];                                                                                               \
+      if (ap_) {                                                                                                       \
+        const v4f z_ = {0.f, 0.f, 0.f, 0.f};                                                                           \
+        typedef _Float16 h8_t __attribute__((ext_vector_type(8)));                                                     \
+        const h8_t hx_ = __builtin_bit_cast(h8_t, araw[k_]);                                                           \
+        const v4f x0_ = {(float)hx_[0], (float)hx_[1], (float)hx_[2], (float)hx_[3]};                                  \
+        const v4f x1_ = {(float)hx_[4], (float)hx_[5], (float)hx_[6], (float)hx_[7]};                                  \
+        v4f y0 = __builtin_elementwise_max(__builtin_elementwise_fma(x0_, s_[0], t_[0]), z_);                          \
+        v4f y1 = __builtin_elementwise_max(__builtin_elementwise_fma(x1_, s_[1], t_[1]), z_);                          \
+        if (has_pad && !pok[k_]) { y0 = z_; y1 = z_; }   /* padding is zero AFTER the normalisation */                 \
+        unsigned w0, w1, w2, w3;                                                                                       \
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w0) : "v"(y0.x), "v"(y0.y));                                         \
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1) : "v"(y0.z), "v"(y0.w));                                         \
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2) : "v"(y1.x), "v"(y1.y));                                         \
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w3) : "v"(y1.z), "v"(y1.w));                                         \
+        o_ = __builtin_bit_cast(v4f, u32x4_t{w0, w1, w2, w3});                                                         \
+      }                                                                                                                \
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = o_;                                   \
+    }                                                                                                                  \
   }
   // weights of k-step (class, tap, chunk c) -> ring stage st (run-time)
 #define MSI_B_ISSUE(cls, tap, c, st)                                                                                   \
@@ -2068,7 +2133,7 @@ convt_halo_bf16_kernel(const ConvParams p) {
       else if (c + 1 < c1) { MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_) }                                   \
     }                                                                                                                  \
     MSI_CQ(1, PWC_) MSI_CQ(2, PWC_) MSI_CQ(3, PWC_)                                                                    \
-    if ((J) == 0 && c + 1 < c1) wait_vmcnt<BI + NLOAD>();                                                              \
+    if ((J) == 0 && c + 1 < c1) wait_vmcnt<BI + NPL>();                                                                \
     else if (issued_) wait_vmcnt<BI>();                                                                                \
     else wait_vmcnt<0>();                                                                                              \
     __builtin_amdgcn_s_barrier();                                                                                      \
@@ -2080,6 +2145,23 @@ convt_halo_bf16_kernel(const ConvParams p) {
   MSI_PATCH_LOAD(c0)
   MSI_B_ISSUE(2 * ph, 0, c0, 0)
   MSI_B_ISSUE(2 * ph, 1, c0, 1)
+  if (APPLY && p.halo_apply) {
+    double *s_stat = reinterpret_cast<double *>(smem);
+    if (p.halo_apply & 1) {
+      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
+      const double mu = s_stat[0];
+      inv0 = (float)s_stat[1]; mh0 = (float)mu; ml0 = (float)(mu - (double)mh0);
+      up0 = (float)(p.ln_scl_src[2] * 16777216.0);
+      __syncthreads();
+    }
+    if (p.halo_apply & 2) {
+      ln_mean_inv(p.ln_sums1 + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n1, p.ln_scl_src1, p.status, s_stat, tid);
+      const double mu = s_stat[0];
+      inv1 = (float)s_stat[1]; mh1 = (float)mu; ml1 = (float)(mu - (double)mh1);
+      up1 = (float)(p.ln_scl_src1[2] * 16777216.0);
+      __syncthreads();
+    }
+  }
   wait_vmcnt<0>();
   MSI_PATCH_STORE()
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2098,13 +2180,13 @@ convt_halo_bf16_kernel(const ConvParams p) {
 #undef MSI_PATCH_STORE
 #undef MSI_PATCH_LOAD
 #pragma unroll
-  for (int pwc = 0; pwc < 2; ++pwc) emit_tile<BM, BN, MODE_CONVT>(p, acc[pwc], tile_m, tile_n, 2 * ph + pwc, b, tid);
+  for (int pwc = 0; pwc < 2; ++pwc) emit_tile<BM, BN, MODE_CONVT, 1>(p, acc[pwc], tile_m, tile_n, 2 * ph + pwc, b, tid);
 #endif
 }
 
 // Fix-up of the split tiles as a separate launch (plan option MSI_NET_OPT_FIXUP_KERNEL; the default is the in-launch
 // hand-off above): sums the K-range slabs of a tile in k order and runs the same epilogue.  One workgroup per split tile.
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int RAW16 = 0>
 __global__ void __launch_bounds__(256)
 conv_fixup_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2140,7 +2222,7 @@ conv_fixup_kernel(const ConvParams p) {
         (void *)(p.partial + (size_t)slot0 * (BM * BN)), 0, nsp * SLAB, 0x00020000);
     sum_slabs<MT, NT, 0>(acc, rsrc_t, nsp, SLAB, tid);
   }
-  emit_tile<BM, BN, MODE>(p, acc, tile_m, tile_n, cls, b, tid);
+  emit_tile<BM, BN, MODE, RAW16>(p, acc, tile_m, tile_n, cls, b, tid);
 #endif
 }
 
@@ -2240,7 +2322,15 @@ head_assemble_kernel(const HeadAsmParams p) {
     const int e = tid + 256 * k;
     const int r = e / nchunk, c = (e - r * nchunk) * 4;
     araw[k] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (e < HA_TP * nchunk && c < p.C0) araw[k] = *reinterpret_cast<const v4f *>(p.x + (size_t)(p0 + r) * p.C0 + c);
+    if (e < HA_TP * nchunk && c < p.C0) {
+      if (BF16IN) {   // a bf16 plan keeps conv8_2's raw output as fp16 of x * 2^-e (the affine of ln_finish_kernel carries 2^e)
+        typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+        const h4_t h = *reinterpret_cast<const h4_t *>(reinterpret_cast<const _Float16 *>(p.x) + (size_t)(p0 + r) * p.C0 + c);
+        araw[k] = v4f{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+      } else {
+        araw[k] = *reinterpret_cast<const v4f *>(p.x + (size_t)(p0 + r) * p.C0 + c);
+      }
+    }
   }
   const int nb = p.ksteps * BN * 8;
   v4f braw[B_PER_THREAD];
@@ -2378,14 +2468,15 @@ head_assemble_kernel(const HeadAsmParams p) {
 // (head_assemble_kernel): one workgroup per sample.
 __global__ void __launch_bounds__(256)
 ln_finish_kernel(const long long *__restrict__ sums, double inv_n, const double *__restrict__ scl, int *status,
-                 const float *__restrict__ gamma, const float *__restrict__ beta, int C, float *__restrict__ aff) {
+                 const float *__restrict__ gamma, const float *__restrict__ beta, int C, float *__restrict__ aff, int raw16) {
   __shared__ double s_stat[2];
   const int b = blockIdx.x, tid = threadIdx.x;
   ln_mean_inv(sums + (size_t)b * LN_SHARDS * LN_WORDS, inv_n, scl, status, s_stat, tid);
   const double mu = s_stat[0], inv = s_stat[1];
+  const double up = raw16 ? scl[2] * 16777216.0 : 1.0;   // 2^e: the consumer reads the raw output as fp16 of x * 2^-e
   for (int c = tid; c < C; c += 256) {
     const double sc = inv * (double)gamma[c];
-    aff[(size_t)b * 2 * C + c] = (float)sc;
+    aff[(size_t)b * 2 * C + c] = (float)(sc * up);
     aff[(size_t)b * 2 * C + C + c] = (float)((double)beta[c] - mu * sc);
   }
 }
@@ -2413,19 +2504,27 @@ ln_apply_kernel(float *__restrict__ x, const long long *__restrict__ sums, doubl
   const int b = blockIdx.y, tid = threadIdx.x;
   ln_mean_inv(sums + (size_t)b * LN_SHARDS * LN_WORDS, inv_n, scl, (blockIdx.x == 0 ? status : nullptr), s_stat, tid);
   const double mu = s_stat[0], inv = s_stat[1];
+  // BF16OUT: the raw output is fp16 of x * 2^-e (emit_tile_impl RAW16): the scale applied to it carries 2^e (exact)
+  const double up = BF16OUT ? scl[2] * 16777216.0 : 1.0;
   for (int c = tid; c < C; c += 256) {
     const double sc = inv * (double)gamma[c];
     const float fs = (float)sc, ft = (float)((double)beta[c] - mu * sc);
-    s_aff[c] = fs;
+    s_aff[c] = BF16OUT ? (float)(sc * up) : fs;
     s_aff[C + c] = ft;
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0) {      // (published for the tests: the affine of the UNSCALED raw output)
       aff[(size_t)b * 2 * C + c] = fs;
       aff[(size_t)b * 2 * C + C + c] = ft;
     }
   }
   __syncthreads();
 
+  typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+  const h4_t *xh = reinterpret_cast<const h4_t *>(reinterpret_cast<const _Float16 *>(x) + (size_t)b * per_sample);
   v4f *xv = reinterpret_cast<v4f *>(x + (size_t)b * per_sample);
+  auto get = [&](size_t i) __attribute__((always_inline)) -> v4f {
+    if (BF16OUT == 1) { const h4_t h = xh[i]; return v4f{(float)h.x, (float)h.y, (float)h.z, (float)h.w}; }
+    return xv[i];
+  };
   const size_t nvec = per_sample / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   auto apply = [](v4f v, const v4f s4, const v4f t4) __attribute__((always_inline)) -> v4f {
@@ -2451,11 +2550,11 @@ ln_apply_kernel(float *__restrict__ x, const long long *__restrict__ sums, doubl
     const int c = (tid * 4) % C;
     const v4f s4 = *reinterpret_cast<const v4f *>(s_aff + c);
     const v4f t4 = *reinterpret_cast<const v4f *>(s_aff + C + c);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < nvec; i += stride) put(i, apply(xv[i], s4, t4));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < nvec; i += stride) put(i, apply(get(i), s4, t4));
   } else {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < nvec; i += stride) {
       const int c = (int)((i * 4) % C);
-      put(i, apply(xv[i], *reinterpret_cast<const v4f *>(s_aff + c), *reinterpret_cast<const v4f *>(s_aff + C + c)));
+      put(i, apply(get(i), *reinterpret_cast<const v4f *>(s_aff + c), *reinterpret_cast<const v4f *>(s_aff + C + c)));
     }
   }
 }
@@ -2689,7 +2788,8 @@ struct msi_net_plan {
 namespace {
 
 // Work decomposition of one layer ("tail split", see the kernel) for a BM x BN tile.
-void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tailsplit, int max_split, int *nblocks, int *nfix) {
+void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tailsplit, int max_split, int *nblocks, int *nfix,
+                int uniform_split = 0) {
   const int mtot = p.Mh * p.Mw;
   p.tiles_m = (mtot + BM - 1) / BM;
   p.tiles_n = (p.Cout + BN - 1) / BN;
@@ -2720,8 +2820,13 @@ void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tails
     }
     if (best > 1) { p.split = best; p.n_main = p.ntiles - remq; }
   }
+  // Uniform split (plan option UNIFORM_SPLIT = s >= 2): layers with between one and two tiles per CU (the 40x80 ones: 400
+  // tiles on 256 CUs) cut EVERY tile into s equal K-ranges instead of halves of the first group + sixths of the rest
+  const bool uniform = uniform_split >= 2 && BM * BN == 64 * 64 && tailsplit && p.ntiles >= num_cus && p.ntiles < 2 * num_cus &&
+                       uniform_split <= max_split && p.ksteps >= 2 * MAX_SPLIT;
+  if (uniform) { p.n_main = 0; p.split0 = 1; p.split = uniform_split; }
   const int rem = p.ntiles % num_cus;
-  if (BM * BN == 64 * 64 && p.split == 1 &&   // (big tiles are only chosen for big grids)
+  if (!uniform && BM * BN == 64 * 64 && p.split == 1 &&   // (big tiles are only chosen for big grids)
       rem != 0 && p.ntiles > num_cus / 2 && p.ksteps >= 2 * MAX_SPLIT && tailsplit && !(tailsplit == 2 && p.ntiles >= Q)) {
     int best = 1;
     double best_cost = 1.0;   // time of the tail in tile-times: ceil(rem*s/CUs)/s
@@ -2849,9 +2954,10 @@ int plan_layers(msi_net_plan *pl) {
       p.mg_htx = p.halo_tx == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)p.halo_tx);
       if (!Q.halo_t && L.cpt0 < max_split) max_split = L.cpt0;      // K-ranges are whole chunks (bf16: whole tiles only)
     }
-    plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], max_split, &Q.nblocks, &Q.nfix);
+    plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], max_split, &Q.nblocks, &Q.nfix,
+               pl->opt[MSI_NET_OPT_UNIFORM_SPLIT]);
     // apply-ahead (see apply_ahead): this launch also normalises its source 0
-    if (pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.src0 >= 0 && L.kind != MODE_HEAD && L.c0 <= 512 && L.c0 % 4 == 0 &&
+    if (pl->opt[MSI_NET_OPT_APPLY_AHEAD] && !bf16 && L.src0 >= 0 && L.kind != MODE_HEAD && L.c0 <= 512 && L.c0 % 4 == 0 &&   // (bf16: fp16 raw outputs, r03)
         ((long)L.in_w * L.c0) % 4 == 0) {
       constexpr int UNIT_VEC = 2048;   // float4 per unit: 32 KB of fp32
       p.ap_row_vec = L.in_w * L.c0 / 4;
@@ -2882,8 +2988,9 @@ int plan_layers(msi_net_plan *pl) {
     }
   }
   // A layer whose EVERY consumer can apply its LayerNorm while staging a patch is never normalised in memory: halo conv
-  // layers (their one source; not the bf16 256x64 tile, which has no registers left for the fp32 -> bf16 staging and
-  // reads the bf16 copy) and conv-transpose halo layers (either source)
+  // layers (their one source) and conv-transpose halo layers (either source).  (Until r03 the bf16 256x64 tile and the
+  // bf16 conv-transpose halo kernel read bf16 copies only: with fp32 raw outputs they had no registers for the staging;
+  // the fp16 raw output is 16 bytes per 8-channel slot like the copy.)
   for (int s = 0; s < MSI_NET_NUM_LAYERS - 1; ++s) {
     int consumers = 0, capable = 0;
     for (int li = s + 1; li < MSI_NET_NUM_LAYERS; ++li) {
@@ -2891,7 +2998,10 @@ int plan_layers(msi_net_plan *pl) {
       if (L.src0 == s || L.src1 == s) {
         ++consumers;
         const LayerLaunch &C = pl->launch[li];
-        if (C.halo_t || (C.halo && !C.halo_tb && C.hbm != 256 && L.src0 == s)) ++capable;   // (halo_tb reads the bf16 copies)
+        // (bf16 conv-transposes: only the 128 x 64 tile has registers for the staging -- 128 x 128 with APPLY spills)
+        const int stage_raw = pl->opt[MSI_NET_OPT_BF16_STAGE_RAW];   // bit 0: the 256 x 64 conv tile, bit 1: the 128 x 64 conv-transpose tile
+        if (C.halo_t || (C.halo_tb && C.hbn == 64 && (stage_raw & 2)) ||
+            (C.halo && !C.halo_tb && L.src0 == s && (!bf16 || (L.c0 <= 512 && (C.hbm != 256 || (stage_raw & 1)))))) ++capable;
       }
     }
     if (consumers > 0 && consumers == capable) {
@@ -2899,10 +3009,10 @@ int plan_layers(msi_net_plan *pl) {
       for (int li = s + 1; li < MSI_NET_NUM_LAYERS; ++li) {
         const Layer &L = net.layers[li];
         LayerLaunch &C = pl->launch[li];
-        if (C.halo_t) {
+        if (C.halo_t || C.halo_tb) {
           if (L.src0 == s) { C.p.halo_apply |= 1; C.p.ln_inv_n = 1.0 / net.layers[s].ln_count; }
           if (L.src1 == s) { C.p.halo_apply |= 2; C.p.ln_inv_n1 = 1.0 / net.layers[s].ln_count; }
-        } else if (L.src0 == s && !C.halo_tb) {
+        } else if (L.src0 == s) {
           C.halo_apply = 1;
           C.p.ln_inv_n = 1.0 / net.layers[s].ln_count;
         }
@@ -2938,7 +3048,7 @@ int launch_conv_mode(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
   int rc = msi::check_launch("conv_igemm");
   if (rc || Q.nfix == 0 || p.tile_cnt != nullptr) return rc;
   if constexpr (BM * BN == 64 * 64) {   // (big tiles are never split)
-    hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, MODE>), dim3(Q.nfix), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, MODE, (BF16 && MODE != MODE_HEAD) ? 1 : 0>), dim3(Q.nfix), dim3(256), 0, stream, p);
     return msi::check_launch("conv_fixup");
   } else {
     return msi::fail(MSI_E_UNSUPPORTED, "conv: split big tile");
@@ -2947,7 +3057,8 @@ int launch_conv_mode(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
 
 template <int BM, int BN, int RATE, int APPLY>
 int launch_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stream) {
-  constexpr int lds = HaloGeomB<BM, BN, RATE>::LDS_BYTES;
+  constexpr int lds = HaloGeomB<BM, BN, RATE>::LDS_BYTES + (APPLY ? 8 * 512 : 0);   // + scale | shift of <= 512 input channels (4 KB: two workgroups per CU still fit)
+  if (APPLY && p.C0 > 512) return msi::fail(MSI_E_UNSUPPORTED, "conv_halo_bf16: APPLY with more than 512 input channels");
   static thread_local unsigned long long done = 0;
   int rc0 = set_max_lds(reinterpret_cast<const void *>(conv_halo_bf16_kernel<BM, BN, RATE, APPLY>), lds, done, "conv_halo_bf16");
   if (rc0) return rc0;
@@ -2955,13 +3066,13 @@ int launch_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
   return msi::check_launch("conv_halo_bf16");
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int APPLY>
 int launch_convt_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stream) {
   constexpr int lds = HaloGeomB<BM, BN, 1>::LDS_BYTES;
   static thread_local unsigned long long done = 0;
-  int rc0 = set_max_lds(reinterpret_cast<const void *>(convt_halo_bf16_kernel<BM, BN>), lds, done, "convt_halo_bf16");
+  int rc0 = set_max_lds(reinterpret_cast<const void *>(convt_halo_bf16_kernel<BM, BN, APPLY>), lds, done, "convt_halo_bf16");
   if (rc0) return rc0;
-  hipLaunchKernelGGL((convt_halo_bf16_kernel<BM, BN>), dim3(Q.nblocks), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((convt_halo_bf16_kernel<BM, BN, APPLY>), dim3(Q.nblocks), dim3(256), lds, stream, p);
   return msi::check_launch("convt_halo_bf16");
 }
 
@@ -3027,6 +3138,7 @@ int msi_net_layer_info(const msi_net_desc *desc, int32_t layer, msi_layer_info *
   out->in_h = L.in_h; out->in_w = L.in_w; out->out_h = L.out_h; out->out_w = L.out_w;
   out->param_offset = L.param_off; out->param_floats = L.param_floats;
   out->raw_offset = (uint64_t)L.raw_off; out->affine_offset = (uint64_t)L.aff_off;
+  out->ln_scale_offset = (uint64_t)L.lnscl_off;
   return MSI_OK;
 }
 
@@ -3217,6 +3329,9 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_HALO] = 1;   // (bit 1, the fp32 conv-transpose halo kernel: measured slower than the tap kernel + ln_apply, see the kernel)
   pl->opt[MSI_NET_OPT_F32_TILE] = 0;
   pl->opt[MSI_NET_OPT_F32_TILE_MASK] = 0;
+  pl->opt[MSI_NET_OPT_UNIFORM_SPLIT] = 0;
+  pl->opt[MSI_NET_OPT_BF16_STAGE_RAW] = 1;   // (bit 1, conv8_1 staging its raw sources: measured 50 us per 16 frames SLOWER -- ~180 VALU per chunk
+                                               // against 2 048 matrix cycles of the 128 x 64 tile; bit 0, conv8_2: 130 us faster.  Three interleaved repeats)
   int rc = plan_layers(pl);
   if (rc) { delete pl; return rc; }
   *out = pl;
@@ -3319,7 +3434,7 @@ int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, con
   hipLaunchKernelGGL(ln_finish_kernel, dim3(desc->batch), dim3(256), 0, stream,
                      reinterpret_cast<const long long *>(ws + S.sums_off), 1.0 / S.ln_count,
                      reinterpret_cast<const double *>(packed + S.lnscl_off), reinterpret_cast<int *>(ws + net.err_off),
-                     packed + S.gamma_off, packed + S.beta_off, S.cout, aff);
+                     packed + S.gamma_off, packed + S.beta_off, S.cout, aff, bf16);
   rc = msi::check_launch("ln_finish");
   if (rc) return rc;
   q.aff = aff;
@@ -3411,7 +3526,25 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
 #endif
     int rc;
     if (Q.halo_tb) {
-      rc = Q.hbn == 128 ? launch_convt_halo_bf16<128, 128>(Q, p, stream) : launch_convt_halo_bf16<128, 64>(Q, p, stream);
+      if (p.halo_apply & 1) {   // source 0 / 1 are read RAW (fp16), their LayerNorm applied while staging
+        const Layer &S = net.layers[L.src0];
+        p.x0 = ws + S.raw_off;
+        p.ln_sums = reinterpret_cast<const long long *>(ws + S.sums_off);
+        p.ln_gamma = packed + S.gamma_off;
+        p.ln_beta = packed + S.beta_off;
+      }
+      if (p.halo_apply & 2) {
+        const Layer &S = net.layers[L.src1];
+        p.x1 = ws + S.raw_off;
+        p.ln_sums1 = reinterpret_cast<const long long *>(ws + S.sums_off);
+        p.ln_gamma1 = packed + S.gamma_off;
+        p.ln_beta1 = packed + S.beta_off;
+      }
+      // (the 128 x 128 tile with APPLY needs more than the 256 registers of two waves per SIMD -- 120 bytes of scratch inside
+      // the chunk loop -- and is not built: the plan only marks sources of the 128 x 64 tile as raw)
+      if (p.halo_apply) rc = Q.hbn == 128 ? msi::fail(MSI_E_UNSUPPORTED, "convt_halo_bf16: APPLY is built for the 128x64 tile")
+                                          : launch_convt_halo_bf16<128, 64, 1>(Q, p, stream);
+      else rc = Q.hbn == 128 ? launch_convt_halo_bf16<128, 128, 0>(Q, p, stream) : launch_convt_halo_bf16<128, 64, 0>(Q, p, stream);
     } else if (Q.halo && bf16) {
       if (Q.halo_apply) {   // the patch comes from the producer's RAW fp32 output
         const Layer &S = net.layers[L.src0];
@@ -3424,8 +3557,7 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
         if (L.rate == 1) rc = Q.halo_apply ? launch_halo_bf16<128, 128, 1, 1>(Q, p, stream) : launch_halo_bf16<128, 128, 1, 0>(Q, p, stream);
         else rc = Q.halo_apply ? launch_halo_bf16<128, 128, 2, 1>(Q, p, stream) : launch_halo_bf16<128, 128, 2, 0>(Q, p, stream);
       } else {
-        rc = Q.halo_apply ? msi::fail(MSI_E_UNSUPPORTED, "conv_halo_bf16: the 256x64 tile reads the bf16 operand copy")
-                          : launch_halo_bf16<256, 64, 1, 0>(Q, p, stream);
+        rc = Q.halo_apply ? launch_halo_bf16<256, 64, 1, 1>(Q, p, stream) : launch_halo_bf16<256, 64, 1, 0>(Q, p, stream);
       }
     } else if (Q.halo_t) {
       if (p.halo_apply & 1) {

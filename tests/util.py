@@ -92,3 +92,17 @@ def count_equal_11(psv, pre_images, d, round_fn=None):
                 ch = s * 3 * d + 3 * j
                 out[s, k, j] = int(np.all(psv[k, :, :, ch:ch + 3].astype(np.float32) == ref[None, None, :], axis=-1).sum())
     return out
+
+
+def read_raw_output(ws, packed, info, batch, dtype):
+    """A layer's raw (pre-LayerNorm) convolution output [B,H,W,C] as float32 numpy from a plan's workspace (torch uint8
+    tensor): fp32 plans store fp32; bf16 plans store fp16 of x * 2^-e, with 2^e = 2^24 / S1 from the layer's LayerNorm
+    window in the packed blob (include/msi_hip.h: msi_layer_info.ln_scale_offset)."""
+    import torch
+    n = batch * info.out_h * info.out_w * info.cout
+    shape = (batch, info.out_h, info.out_w, info.cout)
+    if dtype == "f32":
+        return ws[info.raw_offset:info.raw_offset + 4 * n].view(torch.float32).reshape(shape).cpu().numpy()
+    scl = packed[info.ln_scale_offset:info.ln_scale_offset + 8].cpu().numpy().view(np.float64)
+    up = np.float32(16777216.0 / scl[0])
+    return ws[info.raw_offset:info.raw_offset + 2 * n].view(torch.float16).reshape(shape).float().cpu().numpy() * up
