@@ -175,6 +175,18 @@ __device__ __forceinline__ unsigned udiv_magic(unsigned x, unsigned d, unsigned 
   return q;
 }
 
+// tanh of the 1x1 head (nets.py:509-515) as (e^{2|x|} - 1) / (e^{2|x|} + 1) on the hardware exp2 / rcp (1 ulp each): absolute error
+// 2.0e-7 over [-20, 20] (measured against fp64 on 2^24 points: tools/ubench/tanh_err.hip; the gate is 1e-3), 8 VALU
+// instead of the ~35 of the library routine -- the fused tail runs sixteen of them per lane on two of its four waves, which,
+// with the integer divisions of its index arithmetic, made that HBM-bound kernel VALU-bound.  Used by BOTH head paths (fused tail
+// and stand-alone head), which therefore stay bit-identical to each other.
+__device__ __forceinline__ float msi_tanh(float x) {
+  const float xa = fminf(fabsf(x), 15.0f);                              // tanh(15) = 1 - 2e-13: 1.0f in fp32
+  const float t = __builtin_amdgcn_exp2f(xa * 2.8853900817779268f);     // e^(2 |x|)
+  const float r = (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f);
+  return x != x ? x : __builtin_copysignf(r, x);
+}
+
 __device__ __forceinline__ int coord_class(int mw, int Mw) {
   return mw < 2 ? mw : (mw >= Mw - 2 ? 3 + (mw - (Mw - 2)) : 2);
 }
@@ -423,7 +435,7 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
           }
           if (MODE == MODE_HEAD) {   // (the packed bias is padded to a multiple of 4 as well)
             const v4f bs = *reinterpret_cast<const v4f *>(p.bias + n);
-            v.x = tanhf(v.x + bs.x); v.y = tanhf(v.y + bs.y); v.z = tanhf(v.z + bs.z); v.w = tanhf(v.w + bs.w);
+            v.x = msi_tanh(v.x + bs.x); v.y = msi_tanh(v.y + bs.y); v.z = msi_tanh(v.z + bs.z); v.w = msi_tanh(v.w + bs.w);
           }
           if (sok && RAW16) {   // (Cout % 4 == 0 in a bf16 plan: whole 8-byte pieces)
             typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
@@ -2249,6 +2261,8 @@ struct HeadAsmParams {
   float *pred_out;           // optional [B,H,W,2D] (tanh output)
   int C0, ksteps, npad, nd, hw;
   int lg;                    // layers per workgroup: D / gridDim.y (a multiple of 4, <= HA_LG)
+  unsigned mg_vpp, mg_nchunk, mg_hw;   // udiv_magic multipliers of the 16-byte vectors per pixel of the sweep-volume tile, of the
+                             // 16-byte chunks per pixel of the activation tile, of H * W (run-time integer divisions are ~25 VALU each)
   long npix_total;
 };
 
@@ -2285,7 +2299,7 @@ head_assemble_kernel(const HeadAsmParams p) {
   auto gcol = [&](int n) __attribute__((always_inline)) -> int { return n < lg ? g * lg + n : nd + g * lg + (n - lg); };
 
   const long p0 = (long)blockIdx.x * HA_TP;
-  const int b = (int)(p0 / p.hw);                               // (H * W is a multiple of 32: a tile never straddles samples)
+  const int b = (int)udiv_magic((unsigned)p0, (unsigned)p.hw, p.mg_hw);   // (H * W is a multiple of 32: a tile never straddles samples; B * H * W < 2^32, host-checked)
   // 1. every global load of the workgroup goes out first and is parked in registers: the sweep-volume tile, the raw
   //    activations (C0 <= 64: at most two float4 per thread), the weight rows -- ONE memory round trip per workgroup
   constexpr int PSV_PER_THREAD = BF16IN ? 3 : 6;                // 32 x 6 lg elements in 16-byte vectors / 256 threads, lg <= 32
@@ -2307,7 +2321,7 @@ head_assemble_kernel(const HeadAsmParams p) {
         if (gridDim.y == 1) {   // the whole tile is contiguous: no index arithmetic in front of the loads
           q[k] = reinterpret_cast<const float4 *>(gp)[v];
         } else {
-          const int px = v / vpp, w = v - px * vpp;
+          const int px = (int)udiv_magic((unsigned)v, (unsigned)vpp, p.mg_vpp), w = v - px * vpp;
           const int r = w >= vpr ? 1 : 0, idx = w - r * vpr;
           const int start = r == 0 ? 3 * g * lg : 3 * (nd + g * lg);
           q[k] = *reinterpret_cast<const float4 *>(gp + ((size_t)px * c_psv + start + idx * PSV_VEC) * ESZ);
@@ -2317,19 +2331,24 @@ head_assemble_kernel(const HeadAsmParams p) {
   }
   const int nchunk = p.ksteps * 8;                              // 16-byte chunks per pixel (zero beyond C0)
   v4f araw[2];
+  if (BF16IN) {
+    // a bf16 plan keeps conv8_2's raw output as fp16 of x * 2^-e (the affine of ln_finish_kernel carries 2^e): thread t loads
+    // the 16 bytes that hold its two chunks e = 2 t, 2 t + 1 (eight channels) -- one 16-byte load per thread, as in the fp32 form
+    typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+    const int e = 2 * tid, r = (int)udiv_magic((unsigned)e, (unsigned)nchunk, p.mg_nchunk), c = (e - r * nchunk) * 4;
+    araw[0] = araw[1] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (e < HA_TP * nchunk && c < p.C0) {   // (C0 % 8 == 0 in a bf16 plan: both chunks are in range together)
+      const h8_t h = *reinterpret_cast<const h8_t *>(reinterpret_cast<const _Float16 *>(p.x) + (size_t)(p0 + r) * p.C0 + c);
+      araw[0] = v4f{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      araw[1] = v4f{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+    }
+  } else {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int e = tid + 256 * k;
-    const int r = e / nchunk, c = (e - r * nchunk) * 4;
-    araw[k] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (e < HA_TP * nchunk && c < p.C0) {
-      if (BF16IN) {   // a bf16 plan keeps conv8_2's raw output as fp16 of x * 2^-e (the affine of ln_finish_kernel carries 2^e)
-        typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-        const h4_t h = *reinterpret_cast<const h4_t *>(reinterpret_cast<const _Float16 *>(p.x) + (size_t)(p0 + r) * p.C0 + c);
-        araw[k] = v4f{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
-      } else {
-        araw[k] = *reinterpret_cast<const v4f *>(p.x + (size_t)(p0 + r) * p.C0 + c);
-      }
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 256 * k;
+      const int r = (int)udiv_magic((unsigned)e, (unsigned)nchunk, p.mg_nchunk), c = (e - r * nchunk) * 4;
+      araw[k] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (e < HA_TP * nchunk && c < p.C0) araw[k] = *reinterpret_cast<const v4f *>(p.x + (size_t)(p0 + r) * p.C0 + c);
     }
   }
   const int nb = p.ksteps * BN * 8;
@@ -2352,9 +2371,9 @@ head_assemble_kernel(const HeadAsmParams p) {
   //    rows of every k-step of the packed blob as they are (pre-swizzled by their GLOBAL row)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int e = tid + 256 * k;
+    const int e = BF16IN ? 2 * tid + k : tid + 256 * k;   // (the chunk araw[k] holds: see the loads above)
     if (e < HA_TP * nchunk) {
-      const int r = e / nchunk, ch = e - r * nchunk;
+      const int r = (int)udiv_magic((unsigned)e, (unsigned)nchunk, p.mg_nchunk), ch = e - r * nchunk;
       const int c = ch * 4;
       v4f y = {0.f, 0.f, 0.f, 0.f};
       if (c < p.C0) {                                           // C0 % 4 == 0
@@ -2406,7 +2425,7 @@ head_assemble_kernel(const HeadAsmParams p) {
       if (n < l_cpred) {                                        // 2 lg is a multiple of 8: whole float4 in range
         const int gn = gcol(n);
         const v4f bs = *reinterpret_cast<const v4f *>(p.bias + gn);
-        v4f t = {tanhf(acc[4 * gg] + bs.x), tanhf(acc[4 * gg + 1] + bs.y), tanhf(acc[4 * gg + 2] + bs.z), tanhf(acc[4 * gg + 3] + bs.w)};
+        v4f t = {msi_tanh(acc[4 * gg] + bs.x), msi_tanh(acc[4 * gg + 1] + bs.y), msi_tanh(acc[4 * gg + 2] + bs.z), msi_tanh(acc[4 * gg + 3] + bs.w)};
         if (p.pred_out) *reinterpret_cast<v4f *>(p.pred_out + (p0 + px) * c_pred + gn) = t;
         t.x = (t.x + 1.0f) / 2.0f; t.y = (t.y + 1.0f) / 2.0f; t.z = (t.z + 1.0f) / 2.0f; t.w = (t.w + 1.0f) / 2.0f;
         float *dst = l_pred + px * s_pred + n;
@@ -2425,7 +2444,7 @@ head_assemble_kernel(const HeadAsmParams p) {
   for (int k = 0; k < PSV_PER_THREAD; ++k) {
     const int v = tid + 256 * k;
     if (v < nv_psv) {
-      const int px = v / vpp, w = v - px * vpp;                 // (run r of the pixel starts at local column r * run_len)
+      const int px = (int)udiv_magic((unsigned)v, (unsigned)vpp, p.mg_vpp), w = v - px * vpp;   // (run r of the pixel starts at local column r * run_len)
       float *dst = l_psv + px * s_psv + w * PSV_VEC;
       if (BF16IN) {
         const unsigned w0 = __builtin_bit_cast(unsigned, q[k].x), w1 = __builtin_bit_cast(unsigned, q[k].y);
@@ -2448,7 +2467,9 @@ head_assemble_kernel(const HeadAsmParams p) {
     const long off = pp - (long)b * p.hw;
     const float *rp = l_psv + px * s_psv;
     const float *rq = l_pred + px * s_pred;
-    for (int d = tid / HA_TP; d < lg; d += 256 / HA_TP) {
+    float4 *dst = p.rgba + ((long)b * nd + g * lg + tid / HA_TP) * p.hw + off;   // (one 64-bit multiply per thread, not per layer)
+    const long dstep = (long)(256 / HA_TP) * p.hw;
+    for (int d = tid / HA_TP; d < lg; d += 256 / HA_TP, dst += dstep) {
       const float *fg = rp + d * 3;
       const float *bg = rp + (lg + d) * 3;
       const float w = rq[d];
@@ -2458,7 +2479,7 @@ head_assemble_kernel(const HeadAsmParams p) {
       o.y = w * fg[1] + omw * bg[1];
       o.z = w * fg[2] + omw * bg[2];
       o.w = rq[lg + d];
-      p.rgba[((long)b * nd + g * lg + d) * p.hw + off] = o;
+      *dst = o;
     }
   }
 #endif
@@ -3447,6 +3468,15 @@ int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, con
   q.nd = nd; q.hw = desc->height * desc->width;
   q.npix_total = (long)desc->batch * q.hw;
   q.lg = nd / ng;
+  {
+    auto magic = [](unsigned d) { return d == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / d); };
+    const int vec = bf16 ? 8 : 4;                                  // elements per 16-byte vector of the sweep volume
+    const unsigned vpp = (unsigned)((ng == 1 ? 6 * nd : 2 * 3 * q.lg) / vec);
+    q.mg_vpp = magic(vpp);
+    q.mg_nchunk = magic((unsigned)(q.ksteps * 8));
+    q.mg_hw = magic((unsigned)q.hw);
+    if (q.npix_total >= (1L << 32)) return msi::fail(MSI_E_UNSUPPORTED, "net_forward_rgba: more than 2^32 pixels per batch");
+  }
   constexpr int BN = 64;
   size_t r_bytes = (size_t)q.ksteps * (HA_TP + BN) * ROW_BYTES;
   if (r_bytes < (size_t)HA_TP * (6 * q.lg + 1) * sizeof(float)) r_bytes = (size_t)HA_TP * (6 * q.lg + 1) * sizeof(float);

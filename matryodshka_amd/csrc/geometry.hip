@@ -422,7 +422,9 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
     constexpr int WAVE_ELEMS = 384 * NS;
     __shared__ __attribute__((aligned(16))) OutT s_out[4][WAVE_ELEMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pl = lane / ng, dg = lane - pl * ng;
+    unsigned plq = __umulhi((unsigned)lane, ng_magic);      // lane / ng by multiply-high (+ one correction), like idx / ng above
+    if ((unsigned)lane - plq * (unsigned)ng >= (unsigned)ng) ++plq;
+    const int pl = (int)plq, dg = lane - pl * ng;
     OutT *w = s_out[wave];
 #pragma unroll
     for (int sidx = 0; sidx < 2; ++sidx)

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""High-res re-render (test.py:283-394) at the reference's default sizes: network at 640x320, layers re-assembled and rendered
+at --hres_width x --hres_height (loader.py:34-35: 4096x2048) in one device pass (MSI.msi_render_equirect_hres).  Prints the time
+and a finiteness / range check; at sizes the CPU oracle finishes (<= 1280x640) the parity tests cover the same path."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--hres_height", type=int, default=2048)
+ap.add_argument("--hres_width", type=int, default=4096)
+ap.add_argument("--planes", type=int, default=32)
+a = ap.parse_args()
+from matryodshka_amd import MSI, nets
+from tests.util import make_inputs
+d = a.planes
+m = MSI(weights=nets.init_weights(6 * d, 2 * d, 64, True), coord_net=True)
+low = make_inputs(1, 1, 320, 640)
+hi = make_inputs(2, 1, a.hres_height, a.hres_width)
+planes = m.inv_depths(1.0, 100.0, d)
+pred, _ = m.infer_msi(torch.from_numpy(low["src_image"]), torch.from_numpy(low["ref_image"]), None, None, low["ref_pose"], low["src_pose"],
+                      low["intrinsics"], "blend_psv", d, planes, extra_outputs="blend_weights alphas")
+ref, src = torch.from_numpy(hi["ref_image"]).cuda(), torch.from_numpy(hi["src_image"]).cuda()
+for it in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rgb, dep = m.msi_render_equirect_hres(pred["blend_weights"], pred["alphas"], ref, src, low["ref_pose"], low["src_pose"],
+                                          low["tgt_pose_rt"], low["tgt_pos"], planes, low["intrinsics"])
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+print("hres %dx%d x %d planes: %.1f ms; rgb finite %s range [%.3f, %.3f]; depth range [%.3f, %.3f]; peak memory %.1f GB" % (
+    a.hres_width, a.hres_height, d, t * 1e3, bool(torch.isfinite(rgb).all()), float(rgb.min()), float(rgb.max()),
+    float(dep.min()), float(dep.max()), torch.cuda.max_memory_allocated() / 1e9))
+# self-consistency at full size: the image is smooth band-limited noise, so the 2x box-downsampled high-res render must be close to
+# the render of the 2x box-downsampled inputs (same layers, same target): a gross addressing error (32-bit overflow) shows as O(1)
+if a.hres_height % 2 == 0 and a.hres_width % 2 == 0:
+    def down(x):
+        b, h, w, c = x.shape
+        return x.reshape(b, h // 2, 2, w // 2, 2, c).float().mean(dim=(2, 4))
+    half = lambda x: down(x.float() / 255.0)
+    rgb2, dep2 = m.msi_render_equirect_hres(pred["blend_weights"], pred["alphas"], half(ref), half(src), low["ref_pose"], low["src_pose"],
+                                            low["tgt_pose_rt"], low["tgt_pos"], planes, low["intrinsics"])
+    e = (down(rgb) - rgb2).abs()
+    print("2x-downsampled full-size render vs render at half size: max %.4f mean %.5f" % (float(e.max()), float(e.mean())))
