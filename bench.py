@@ -200,7 +200,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=4,
                     help="extra timed regions of --steps steps after the contract one (reported under `repeats`; the "
                          "headline `value` is always the first region right after the warm-up)")
-    ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed steps before the --warmup steps")
+    ap.add_argument("--prewarm", type=float, default=None,
+                    help="seconds of untimed steps before the --warmup steps (default 0.5 at --config 1; 4.0 at the batched "
+                         "configurations, whose first second under load contains a slow transient: 19 vs 11.4 ms per step at config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--no-coord-net", action="store_true", help="msi_train_net instead of msi_coord_train_net")
     ap.add_argument("--strong-frames", type=int, default=8,
@@ -212,6 +214,8 @@ def main():
                          "each still batch 1, to fill the tile-quantisation tails of the small layers; config 1 only)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.prewarm is None:
+        args.prewarm = 0.5 if args.config == 1 else 4.0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -608,6 +608,12 @@ constexpr int RENDER_SEGS = 4;   // layer segments per pixel (threads in y)
 // ODS eye (intersect_ods, :328-365) or the hard-coded perspective crop (intersect_perspective, :367-401)
 enum RayModel { RAY_EQUIRECT = 0, RAY_ODS = 1, RAY_PERSPECTIVE = 2 };
 
+// (i / len) of projector.py:242 per layer: a Python double division converted to an fp32 tensor constant.  Tabulated on the
+// host (kernel argument, read with a scalar load: the layer index is wave-uniform) -- as an expression in the kernel it was an
+// emulated fp64 division, ~25 half-rate instructions per (thread, layer), a fifth of the render kernel's VALU time.
+constexpr int DEPTH_FRAC_MAX = 128;
+struct DepthFrac { float f[DEPTH_FRAC_MAX]; };
+
 struct RayParams {
   int out_h, out_w;        // target image size (== layer size except for RAY_PERSPECTIVE)
   float order;             // RAY_ODS: +1 left eye / -1 right eye
@@ -620,7 +626,7 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
               const float *__restrict__ tgt_pos, const float *__restrict__ intrinsics,
               const float *__restrict__ depths, const float *__restrict__ trig, int batch, int height,
               int width, int nd, float *__restrict__ out_rgb, float *__restrict__ out_depth,
-              float4 *__restrict__ out_layers, PixConsts K, RayParams R) {
+              float4 *__restrict__ out_layers, PixConsts K, RayParams R, DepthFrac F) {
   // block = 64 pixels of one target row x RENDER_SEGS layer segments: a pixel's D layers are split over RENDER_SEGS
   // threads (same lane, different waves), each compositing its contiguous range of layers from transparent black,
   //   C <- rgb a + C (1-a),   T <- T (1-a),
@@ -753,7 +759,7 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
       if (d == 0) {
         od = 0.0f;   // projector.py:239-240
       } else {       // projector.py:242: (i / len) * alpha + output * (1 - alpha)
-        const float frac = (float)((double)d / (double)nd);
+        const float frac = nd <= DEPTH_FRAC_MAX ? F.f[d] : (float)((double)d / (double)nd);
         od = frac * al + od * (1.0f - al);
       }
     }
@@ -1240,9 +1246,11 @@ static int render_common(int mode, int ray, const float *rgba_native, const floa
   const float4 *src = reinterpret_cast<const float4 *>(rgba_native);
   float4 *lay = reinterpret_cast<float4 *>(out_layers);
   hipStream_t s = msi::as_stream(stream);
+  DepthFrac F;
+  for (int d = 0; d < DEPTH_FRAC_MAX; ++d) F.f[d] = d < num_planes ? (float)((double)d / (double)num_planes) : 0.0f;
 #define MSI_LAUNCH_RENDER(M, RY)                                                                       \
   hipLaunchKernelGGL((render_kernel<M, RY>), grid, block, 0, s, src, pose, tgt_pos, intrinsics, depths, \
-                     trig, batch, height, width, num_planes, out_rgb, out_depth, lay, K, R)
+                     trig, batch, height, width, num_planes, out_rgb, out_depth, lay, K, R, F)
   if (ray == RAY_EQUIRECT) {
     switch (mode) {
       case RENDER_RGB: MSI_LAUNCH_RENDER(RENDER_RGB, RAY_EQUIRECT); break;
