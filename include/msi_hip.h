@@ -306,7 +306,8 @@ typedef struct msi_net_plan msi_net_plan;
 #define MSI_NET_OPT_UNIFORM_SPLIT 10 /* s >= 2: layers with one to two 64x64 tiles per CU cut EVERY tile into s equal K-ranges (tuning; 0 = default split) */
 #define MSI_NET_OPT_BF16_STAGE_RAW 11 /* bf16 plans: bit 0 the 256x64 conv tile (conv8_2), bit 1 the 128x64 conv-transpose tile (conv8_1) read their  */
                                       /* sources RAW (fp16) and apply the producer's LayerNorm while staging (default 1: bit 1 measured slower); 0: from ln_apply's bf16 copies */
-#define MSI_NET_OPT_COUNT 12
+#define MSI_NET_OPT_SPLIT_OVERHEAD 12 /* k-steps of prologue + epilogue a K-range visit is charged in the tail-split cost model (tuning; 0 = r01 rule) */
+#define MSI_NET_OPT_COUNT 13
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
 int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);

@@ -2810,7 +2810,7 @@ namespace {
 
 // Work decomposition of one layer ("tail split", see the kernel) for a BM x BN tile.
 void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tailsplit, int max_split, int *nblocks, int *nfix,
-                int uniform_split = 0) {
+                int uniform_split = 0, int split_overhead = 0) {
   const int mtot = p.Mh * p.Mw;
   p.tiles_m = (mtot + BM - 1) / BM;
   p.tiles_n = (p.Cout + BN - 1) / BN;
@@ -2850,9 +2850,12 @@ void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tails
   if (!uniform && BM * BN == 64 * 64 && p.split == 1 &&   // (big tiles are only chosen for big grids)
       rem != 0 && p.ntiles > num_cus / 2 && p.ksteps >= 2 * MAX_SPLIT && tailsplit && !(tailsplit == 2 && p.ntiles >= Q)) {
     int best = 1;
-    double best_cost = 1.0;   // time of the tail in tile-times: ceil(rem*s/CUs)/s
+    // time of the tail in k-steps: ceil(rem * s / CUs) rounds of K / s k-steps, each visit paying `split_overhead` k-steps of
+    // prologue + epilogue (plan option SPLIT_OVERHEAD; 0 = the r01 rule, which minimises ceil(rem * s / CUs) / s alone)
+    const double K = (double)p.ksteps, ovh = (double)split_overhead;
+    double best_cost = K + ovh;
     for (int sp = 2; sp <= max_split; ++sp) {
-      const double cost = (double)((rem * sp + num_cus - 1) / num_cus) / sp;
+      const double cost = (double)((rem * sp + num_cus - 1) / num_cus) * (K / sp + ovh);
       if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
     }
     if (best > 1) { p.split = best; p.n_main = p.ntiles - rem; }
@@ -2861,7 +2864,7 @@ void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tails
     // the first group in two.  Measured (r01): 2.750 -> 2.72 ms per frame, flat over 2..4 x 5..8.
     if (p.n_main == num_cus && p.split > 1 && p.ksteps >= 4 * MAX_SPLIT && max_split >= 2) {
       p.split0 = 2;
-      p.split = p.split > 6 ? 6 : p.split;   // remainder ranges not much shorter than the halves
+      if (split_overhead == 0) p.split = p.split > 6 ? 6 : p.split;   // remainder ranges not much shorter than the halves
     }
   }
   p.nb_main = p.n_main * p.split0;
@@ -2976,7 +2979,7 @@ int plan_layers(msi_net_plan *pl) {
       if (!Q.halo_t && L.cpt0 < max_split) max_split = L.cpt0;      // K-ranges are whole chunks (bf16: whole tiles only)
     }
     plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], max_split, &Q.nblocks, &Q.nfix,
-               pl->opt[MSI_NET_OPT_UNIFORM_SPLIT]);
+               pl->opt[MSI_NET_OPT_UNIFORM_SPLIT], pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD]);
     // apply-ahead (see apply_ahead): this launch also normalises its source 0
     if (pl->opt[MSI_NET_OPT_APPLY_AHEAD] && !bf16 && L.src0 >= 0 && L.kind != MODE_HEAD && L.c0 <= 512 && L.c0 % 4 == 0 &&   // (bf16: fp16 raw outputs, r03)
         ((long)L.in_w * L.c0) % 4 == 0) {
@@ -3351,6 +3354,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_F32_TILE] = 0;
   pl->opt[MSI_NET_OPT_F32_TILE_MASK] = 0;
   pl->opt[MSI_NET_OPT_UNIFORM_SPLIT] = 0;
+  pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD] = 0;
   pl->opt[MSI_NET_OPT_BF16_STAGE_RAW] = 1;   // (bit 1, conv8_1 staging its raw sources: measured 50 us per 16 frames SLOWER -- ~180 VALU per chunk
                                                // against 2 048 matrix cycles of the 128 x 64 tile; bit 0, conv8_2: 130 us faster.  Three interleaved repeats)
   int rc = plan_layers(pl);
