@@ -2286,13 +2286,20 @@ head_assemble_kernel(const HeadAsmParams p) {
   const int c_psv = 6 * nd, c_pred = 2 * nd;                    // global row lengths
   const int l_cpsv = 6 * lg, l_cpred = 2 * lg;                  // local ones
   const int s_psv = l_cpsv + 1, s_pred = l_cpred + 1;           // odd row strides (see assemble_kernel)
+  // BF16IN (r03): the kernel was sensitive to its occupancy (three workgroups per CU instead of four: +14 %), and its LDS footprint
+  // was the head's WEIGHTS (16 KB) next to the activations, and the bf16 sweep tile widened to fp32 (24.7 KB).  A bf16 plan therefore
+  // (a) fetches the two active waves' weight fragments straight from the packed blob into registers (L2-resident, 8 x 16 bytes per
+  // lane) -- no B tile in LDS -- and (b) keeps the sweep tile as packed bf16 with a row stride of 3 lg + 1 dwords (odd: conflict-free
+  // for the 32 pixels of a half-wave), widened on the way out: 21 KB per workgroup, six to seven workgroups per CU.
+  const int s_psv16 = 3 * lg + 1;                               // dwords per pixel row of the packed-bf16 sweep tile
   // LDS: [affine 2 C0 | stat | R | pred tile]; R holds A (ksteps x 32 rows) | B (ksteps x BN rows) during the GEMM and
   // the sweep-volume tile afterwards (33.6 KB per workgroup at lg = 32: four workgroups per CU, like assemble_kernel)
   float *s_aff = reinterpret_cast<float *>(smem);
   char *sR = smem + 2 * 64 * 4 + 64;
   char *sA = sR;
   char *sB = sA + p.ksteps * HA_TP * ROW_BYTES;
-  const size_t r_bytes = max((size_t)p.ksteps * (HA_TP + BN) * ROW_BYTES, (size_t)HA_TP * s_psv * sizeof(float));
+  const size_t r_bytes = BF16IN ? max((size_t)p.ksteps * HA_TP * ROW_BYTES, (size_t)HA_TP * s_psv16 * sizeof(unsigned))
+                                : max((size_t)p.ksteps * (HA_TP + BN) * ROW_BYTES, (size_t)HA_TP * s_psv * sizeof(float));
   float *l_psv = reinterpret_cast<float *>(sR);
   float *l_pred = reinterpret_cast<float *>(sR + ((r_bytes + 15) & ~(size_t)15));
   // local output column -> global one (in float4 groups: lg % 4 == 0)
@@ -2353,14 +2360,32 @@ head_assemble_kernel(const HeadAsmParams p) {
   }
   const int nb = p.ksteps * BN * 8;
   v4f braw[B_PER_THREAD];
+  v4f wfrag[2][4];                                              // BF16IN, waves 0 / 1: the weight fragments of the lane's output column
+  if (BF16IN) {
+    if (wave < 2) {
+      const int frow = lane & 31, fh = lane >> 5;
+      const int nloc = wave * 32 + frow;
+      const int gn = gcol(nloc < l_cpred ? nloc : 0);
+      const int fswz = (gn >> 1) & 7;                           // (a packed row's slots are swizzled by its GLOBAL row)
 #pragma unroll
-  for (int k = 0; k < B_PER_THREAD; ++k) {
-    const int e = tid + 256 * k;
-    const int row = e >> 3, j = e & 7;
-    const int ks = row / BN, n = row - ks * BN;
-    braw[k] = v4f{0.f, 0.f, 0.f, 0.f};                          // local rows >= 2 lg: zero
-    if (e < nb && n < l_cpred)   // (a packed row keeps the slot swizzle of its GLOBAL row (gcol(n) >> 1) & 7: see fswz_b below)
-      braw[k] = *reinterpret_cast<const v4f *>(p.wpk + ((size_t)ks * p.npad + gcol(n)) * (ROW_BYTES / 4) + j * 4);
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          wfrag[ks][qq] = v4f{0.f, 0.f, 0.f, 0.f};
+          if (ks < p.ksteps && nloc < l_cpred)
+            wfrag[ks][qq] = *reinterpret_cast<const v4f *>(p.wpk + ((size_t)ks * p.npad + gn) * (ROW_BYTES / 4) + (((fh * 4 + qq) ^ fswz) << 2));
+        }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < B_PER_THREAD; ++k) {
+      const int e = tid + 256 * k;
+      const int row = e >> 3, j = e & 7;
+      const int ks = row / BN, n = row - ks * BN;
+      braw[k] = v4f{0.f, 0.f, 0.f, 0.f};                          // local rows >= 2 lg: zero
+      if (e < nb && n < l_cpred)   // (a packed row keeps the slot swizzle of its GLOBAL row (gcol(n) >> 1) & 7: see fswz_b below)
+        braw[k] = *reinterpret_cast<const v4f *>(p.wpk + ((size_t)ks * p.npad + gcol(n)) * (ROW_BYTES / 4) + j * 4);
+    }
   }
   // 2. affine of the source's LayerNorm (precomputed once per forward by ln_finish_kernel: 6 400 workgroups deriving it
   //    from the sums themselves put two more dependent round trips on every workgroup's critical path)
@@ -2392,10 +2417,12 @@ head_assemble_kernel(const HeadAsmParams p) {
       *reinterpret_cast<v4f *>(sA + (ks * HA_TP + r) * ROW_BYTES + ((chunk ^ ((r >> 1) & 7)) << 4)) = y;
     }
   }
+  if (!BF16IN) {
 #pragma unroll
-  for (int k = 0; k < B_PER_THREAD; ++k) {
-    const int e = tid + 256 * k;
-    if (e < nb) *reinterpret_cast<v4f *>(sB + (e >> 3) * ROW_BYTES + ((e & 7) << 4)) = braw[k];
+    for (int k = 0; k < B_PER_THREAD; ++k) {
+      const int e = tid + 256 * k;
+      if (e < nb) *reinterpret_cast<v4f *>(sB + (e >> 3) * ROW_BYTES + ((e & 7) << 4)) = braw[k];
+    }
   }
   __syncthreads();
   // 4. the GEMM: wave w owns local output columns [32 w, 32 w + 32) of the 32 pixels; 5. bias + tanh (-> optional pred),
@@ -2411,7 +2438,8 @@ head_assemble_kernel(const HeadAsmParams p) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const v4f a = *reinterpret_cast<const v4f *>(sA + (ks * HA_TP + frow) * ROW_BYTES + (((fh * 4 + qq) ^ fswz_a) << 4));
-        const v4f w = *reinterpret_cast<const v4f *>(sB + (ks * BN + wave * 32 + frow) * ROW_BYTES + (((fh * 4 + qq) ^ fswz_b) << 4));
+        const v4f w = BF16IN ? (ks == 0 ? wfrag[0][qq] : wfrag[1][qq])
+                             : *reinterpret_cast<const v4f *>(sB + (ks * BN + wave * 32 + frow) * ROW_BYTES + (((fh * 4 + qq) ^ fswz_b) << 4));
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a.z, acc, 0, 0, 0);
@@ -2445,15 +2473,12 @@ head_assemble_kernel(const HeadAsmParams p) {
     const int v = tid + 256 * k;
     if (v < nv_psv) {
       const int px = (int)udiv_magic((unsigned)v, (unsigned)vpp, p.mg_vpp), w = v - px * vpp;   // (run r of the pixel starts at local column r * run_len)
-      float *dst = l_psv + px * s_psv + w * PSV_VEC;
-      if (BF16IN) {
-        const unsigned w0 = __builtin_bit_cast(unsigned, q[k].x), w1 = __builtin_bit_cast(unsigned, q[k].y);
-        const unsigned w2 = __builtin_bit_cast(unsigned, q[k].z), w3 = __builtin_bit_cast(unsigned, q[k].w);
-        dst[0] = __builtin_bit_cast(float, w0 << 16); dst[1] = __builtin_bit_cast(float, w0 & 0xffff0000u);
-        dst[2] = __builtin_bit_cast(float, w1 << 16); dst[3] = __builtin_bit_cast(float, w1 & 0xffff0000u);
-        dst[4] = __builtin_bit_cast(float, w2 << 16); dst[5] = __builtin_bit_cast(float, w2 & 0xffff0000u);
-        dst[6] = __builtin_bit_cast(float, w3 << 16); dst[7] = __builtin_bit_cast(float, w3 & 0xffff0000u);
+      if (BF16IN) {   // eight bf16 = four dwords, as they are (element e of the local row = half e & 1 of dword e >> 1)
+        unsigned *dst = reinterpret_cast<unsigned *>(l_psv) + px * s_psv16 + w * 4;
+        dst[0] = __builtin_bit_cast(unsigned, q[k].x); dst[1] = __builtin_bit_cast(unsigned, q[k].y);
+        dst[2] = __builtin_bit_cast(unsigned, q[k].z); dst[3] = __builtin_bit_cast(unsigned, q[k].w);
       } else {
+        float *dst = l_psv + px * s_psv + w * PSV_VEC;
         dst[0] = q[k].x; dst[1] = q[k].y; dst[2] = q[k].z; dst[3] = q[k].w;
       }
     }
@@ -2469,9 +2494,24 @@ head_assemble_kernel(const HeadAsmParams p) {
     const float *rq = l_pred + px * s_pred;
     float4 *dst = p.rgba + ((long)b * nd + g * lg + tid / HA_TP) * p.hw + off;   // (one 64-bit multiply per thread, not per layer)
     const long dstep = (long)(256 / HA_TP) * p.hw;
+    const unsigned *rp16 = reinterpret_cast<const unsigned *>(l_psv) + px * s_psv16;
     for (int d = tid / HA_TP; d < lg; d += 256 / HA_TP, dst += dstep) {
-      const float *fg = rp + d * 3;
-      const float *bg = rp + (lg + d) * 3;
+      float fgv[3], bgv[3];
+      if (BF16IN) {   // elements 3 d .. 3 d + 2 and 3 (lg + d) .. + 2 of the packed-bf16 row: two dwords each, widened exactly
+        const int ef = 3 * d, eb = 3 * (lg + d);
+        const unsigned f0 = rp16[ef >> 1], f1 = rp16[(ef >> 1) + 1], b0 = rp16[eb >> 1], b1 = rp16[(eb >> 1) + 1];
+        const unsigned long long fw = ((unsigned long long)f1 << 32 | f0) >> ((ef & 1) * 16), bw = ((unsigned long long)b1 << 32 | b0) >> ((eb & 1) * 16);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          fgv[c] = __builtin_bit_cast(float, (unsigned)(fw >> (16 * c)) << 16);
+          bgv[c] = __builtin_bit_cast(float, (unsigned)(bw >> (16 * c)) << 16);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { fgv[c] = rp[d * 3 + c]; bgv[c] = rp[(lg + d) * 3 + c]; }
+      }
+      const float *fg = fgv;
+      const float *bg = bgv;
       const float w = rq[d];
       const float omw = 1.0f - w;
       float4 o;
@@ -3484,6 +3524,10 @@ int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, con
   constexpr int BN = 64;
   size_t r_bytes = (size_t)q.ksteps * (HA_TP + BN) * ROW_BYTES;
   if (r_bytes < (size_t)HA_TP * (6 * q.lg + 1) * sizeof(float)) r_bytes = (size_t)HA_TP * (6 * q.lg + 1) * sizeof(float);
+  if (bf16) {   // no weight tile in LDS, packed-bf16 sweep tile (see the kernel)
+    r_bytes = (size_t)q.ksteps * HA_TP * ROW_BYTES;
+    if (r_bytes < (size_t)HA_TP * (3 * q.lg + 1) * sizeof(unsigned)) r_bytes = (size_t)HA_TP * (3 * q.lg + 1) * sizeof(unsigned);
+  }
   const size_t lds = 2 * 64 * 4 + 64 + ((r_bytes + 15) & ~(size_t)15) + (size_t)HA_TP * (2 * q.lg + 1) * sizeof(float);
   const dim3 grid((unsigned)(q.npix_total / HA_TP), (unsigned)ng);
   if (bf16) hipLaunchKernelGGL(head_assemble_kernel<1>, grid, dim3(256), lds, stream, q);
