@@ -372,9 +372,176 @@ __device__ __forceinline__ void sum_slabs(f32x16 (&acc)[MT][NT], __amdgpu_buffer
 // around it) -- half the bytes of the fp32 raw outputs that bound the bf16 layers, 11 significand bits against the 8 of
 // the bf16 operand it becomes after the affine (measured on the oracle: mean |bf16 path - fp32 oracle| + 0.3 %; a bf16
 // raw output would be + 19 %).  The statistics are taken from the fp32 accumulators as before.
+constexpr int EPI_STAGE_BYTES = 48 * 1024;   // emit_whole_tile's staging strips (four waves x MT x 32 pixels x (row + 16 bytes)): what a caller that stages must own
+#ifndef MSI_EPI_ABLATE   // timing experiments only: 1 no stores, 2 no statistics atomics, 4 no statistics arithmetic
+#define MSI_EPI_ABLATE 0
+#endif
+#ifdef MSI_CONV_TIMING
+#define MSI_STAMP(k) { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 12 + (k)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define MSI_STAMP(k)
+#endif
+// Whole tiles of the conv / conv-transpose layers (r03).  What the epilogue costs is neither its instruction count nor its bytes but
+// its DEPENDENT steps and its write REQUESTS (tools/conv_timing.py --bf16 stamps every workgroup's phases; before: 13-15 k cycles per
+// tile, a fifth to a third of a workgroup's life, ~50 cycles per VALU instruction in the element-wise form with a uniform branch
+// between 4-value groups, and 32 requests of 16 bytes per store instruction):
+//  * phases of MT x NT x 8 independent packed two-float instructions over the WHOLE tile: y = x 2^-e (RAW16; exact), fp16
+//    conversion, ... , d = y - P, s1 += d, s2 += d d (four accumulator pairs each) -- one wave per SIMD and workgroup has nobody to
+//    hide a dependent instruction behind, and across waves a SIMD does not overlap VALU with the neighbour's MFMAs
+//    (tools/ubench/mfma_valu_overlap.hip: split-waves time >= the sum);
+//  * stage != nullptr (the halo kernels: LDS is free once the k-loop's last barrier is behind): the wave's MT x 32 pixels x 32 NT
+//    channels go through a wave-private LDS strip and leave as 16-byte pieces of whole pixel rows -- a store instruction covers
+//    64 / NP pixels x (NP x 16 contiguous bytes) instead of 32 pixels x 16 (32) bytes, through one buffer descriptor per sample with
+//    a lane offset and scalar (row, column) steps (no 64-bit address arithmetic per store).
+// RAW16 statistics are taken in the scaled unit (the same numbers times a power of two: sum y 2^24 = sum x S1, sum y^2 2^16 =
+// sum x^2 S2).
+template <int BM, int BN, int MODE, int RAW16, bool CB, bool STAGED>
+__device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n, int cls,
+                                                int b, int tid, const v4f (&cb_pre)[4], bool use_pre, float pivot, float raw_mul,
+                                                double scl_s1, double scl_s2, char *stage) {
+  constexpr int MT = BM / 64, NT = BN / 64, NG = NT * 4, YSZ = RAW16 ? 2 : 4;
+  constexpr int ROWB = NT * 32 * YSZ, PITCH = ROWB + 16, NP = ROWB / 16, PPI = 64 / NP, NRD = 32 / PPI;
+  constexpr bool FITS = 4 * MT * 32 * PITCH <= EPI_STAGE_BYTES;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5;
+  const int ph = cls >> 1, pw = cls & 1;
+  const int mtot = p.Mh * p.Mw;
+  const bool want_stats = p.sums != nullptr;
+  const float pv_s = pivot * raw_mul;
+  const v2f rm = {raw_mul, raw_mul}, pv = {pv_s, pv_s};
+  const int nbw = tile_n * BN + wn * (NT * 32), nb0 = nbw + 4 * half;
+  const size_t sample_bytes = (size_t)(MODE == MODE_CONVT ? p.Hout * p.Wout : mtot) * p.Cout * YSZ;
+  constexpr bool staged = STAGED;
+  static_assert(!STAGED || FITS, "staging strips");
+  const int tyi = p.halo_tx ? (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx) : 0;
+  const int txi = tile_m - tyi * p.halo_tx;
+  MSI_STAMP(6)
+  // ---- the lane's own pixels (coord-bias rows; direct stores) ----
+  char *yp[MT];
+  const float *cbp[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    yp[i] = nullptr; cbp[i] = nullptr;
+    if (CB || !staged) {
+      int m = tile_m * BM + wm * (MT * 32) + i * 32 + (lane & 31);
+      if (p.halo_tx) {   // (BM / 16) x 16 spatial tile: local pixel = 16 * row + column
+        const int local = wm * (MT * 32) + i * 32 + (lane & 31);
+        m = (tyi * (BM / 16) + (local >> 4)) * p.Mw + txi * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor));
+      }
+      int mh = 0, mw = 0;
+      if (MODE == MODE_CONVT || CB) {
+        mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw);
+        mw = m - mh * p.Mw;
+      }
+      const size_t opix = MODE == MODE_CONVT ? ((size_t)b * p.Hout + (2 * mh + ph)) * p.Wout + (2 * mw + pw) : (size_t)b * mtot + m;
+      yp[i] = reinterpret_cast<char *>(p.y) + (opix * p.Cout + nb0) * YSZ;
+      if (CB) cbp[i] = p.coord_bias + (size_t)(mh * COORD_CLASSES + coord_class(mw, p.Mw)) * p.cb_stride + nb0;
+    }
+  }
+  // ---- per 32-pixel block: values (+ coord bias), scale, LayerNorm sums, conversion, LDS strip / direct stores ----
+  char *wst = stage + wave * (MT * 32 * PITCH);
+  // the lane's pixel -> its slot of the 32-pixel block (row, true column)
+  const int slot = p.halo_tx ? ((lane & 16) | ((lane & 15) ^ (((lane >> 4) & 1) * p.halo_xor))) : (lane & 31);
+  char *wp = wst + slot * PITCH + half * (4 * YSZ);
+  v2f s1v[4] = {}, s2v[4] = {};
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    v2f ya[NG], yc[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      ya[q] = v2f{acc[i][q >> 2][4 * (q & 3)], acc[i][q >> 2][4 * (q & 3) + 1]};
+      yc[q] = v2f{acc[i][q >> 2][4 * (q & 3) + 2], acc[i][q >> 2][4 * (q & 3) + 3]};
+    }
+    if (CB) {
+      v4f cb[NG];
+#pragma unroll
+      for (int q = 0; q < NG; ++q)
+        cb[q] = (MT == 1 && NT == 1 && use_pre) ? cb_pre[q & 3] : *reinterpret_cast<const v4f *>(cbp[i] + (q >> 2) * 32 + 8 * (q & 3));
+#pragma unroll
+      for (int q = 0; q < NG; ++q) { ya[q] += v2f{cb[q].x, cb[q].y}; yc[q] += v2f{cb[q].z, cb[q].w}; }
+    }
+    if (RAW16) {
+#pragma unroll
+      for (int q = 0; q < NG; ++q) { ya[q] *= rm; yc[q] *= rm; }
+    }
+    u2_t hw[NG];
+    if (RAW16) {
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        const h2_t lo = {(_Float16)ya[q].x, (_Float16)ya[q].y}, hi = {(_Float16)yc[q].x, (_Float16)yc[q].y};
+        hw[q] = u2_t{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+      }
+    }
+    if (!(MSI_EPI_ABLATE & 1)) {
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        char *dst = staged ? wp + i * (32 * PITCH) : yp[i];
+        if (RAW16) *reinterpret_cast<u2_t *>(dst + ((q >> 2) * 32 + 8 * (q & 3)) * 2) = hw[q];
+        else *reinterpret_cast<v4f *>(dst + ((q >> 2) * 32 + 8 * (q & 3)) * 4) = v4f{ya[q].x, ya[q].y, yc[q].x, yc[q].y};
+      }
+    }
+    if (want_stats && !(MSI_EPI_ABLATE & 4)) {
+#pragma unroll
+      for (int q = 0; q < NG; ++q) { ya[q] -= pv; yc[q] -= pv; }
+#pragma unroll
+      for (int q = 0; q < NG; ++q) { s1v[q & 3] += ya[q]; s1v[q & 3] += yc[q]; }
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        s2v[q & 3] = __builtin_elementwise_fma(ya[q], ya[q], s2v[q & 3]);
+        s2v[q & 3] = __builtin_elementwise_fma(yc[q], yc[q], s2v[q & 3]);
+      }
+    }
+  }
+  MSI_STAMP(11)
+  const v2f t1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]), t2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]);
+  float s1 = t1.x + t1.y, s2 = t2.x + t2.y;
+  // ---- the strip's pieces -> memory ----
+  if (staged && !(MSI_EPI_ABLATE & 1)) {
+    const char *rp = wst + (lane / NP) * PITCH + (lane % NP) * 16;
+    v4f pc[MT][NRD];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int k = 0; k < NRD; ++k) pc[i][k] = *reinterpret_cast<const v4f *>(rp + (i * 32 + k * PPI) * PITCH);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.y) + (size_t)b * sample_bytes, 0, (int)(unsigned)sample_bytes, 0x00020000);
+    const int rowb = p.Cout * YSZ;                      // bytes per output pixel
+    int pix0, rowstep, colstep;                        // the lane's first pixel; what one tile row / column is in output pixels
+    if (p.halo_tx) {
+      const int r0 = tyi * (BM / 16) + wm * (MT * 2), c0 = txi * 16 + lane / NP;
+      if (MODE == MODE_CONVT) { pix0 = (2 * r0 + ph) * p.Wout + 2 * c0 + pw; rowstep = 2 * p.Wout; colstep = 2; }
+      else { pix0 = r0 * p.Mw + c0; rowstep = p.Mw; colstep = 1; }
+    } else {
+      pix0 = tile_m * BM + wm * (MT * 32) + lane / NP; rowstep = 16; colstep = 1;   // (linear pixels: a "row" is 16 of them)
+    }
+    const unsigned v0 = (unsigned)pix0 * (unsigned)rowb + (unsigned)(nbw * YSZ + (lane % NP) * 16);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int k = 0; k < NRD; ++k) {
+        const int ro = 2 * i + ((k * PPI) >> 4), co = (k * PPI) & 15;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pc[i][k]), rsrc_y, v0, (ro * rowstep + co * colstep) * rowb, 0);
+      }
+  }
+  MSI_STAMP(7)
+  if (want_stats) {
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    MSI_STAMP(8)
+    if (lane == 0 && !(MSI_EPI_ABLATE & 2)) {
+      const double P = (double)pv_s, n = (double)(MT * NT * 16 * 64), a = (double)s1;
+      const double u1 = RAW16 ? 16777216.0 : scl_s1, u2 = RAW16 ? 65536.0 : scl_s2;
+      long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * LN_WORDS;   // (any spread will do)
+      ln_atomic_add(dst, (n * P + a) * u1, p.status);
+      ln_atomic_add(dst + 1, ((double)s2 + 2.0 * P * a + n * P * P) * u2, p.status);
+    }
+    MSI_STAMP(9)
+  }
+}
+
 template <int BM, int BN, int MODE, bool INTERIOR, int RAW16>
 __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m,
-                                               int tile_n, int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre) {
+                                               int tile_n, int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre, char *stage) {
   constexpr int MT = BM / 64, NT = BN / 64;
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5;
   const int ph = cls >> 1, pw = cls & 1;
@@ -391,6 +558,22 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
   const float raw_mul = RAW16 ? (float)(scl_s1 * (1.0 / 16777216.0)) : 1.f;   // 2^-e
   constexpr int YSZ = RAW16 ? 2 : 4;                                          // bytes per stored element
   float s1 = 0.f, s2 = 0.f, cnt = 0.f;
+  if constexpr (INTERIOR && MODE != MODE_HEAD) {
+    // (staged stores: the caller owns EPI_STAGE_BYTES of free LDS, 32-bit offsets reach the sample, the pixel steps are uniform)
+    constexpr bool FITS = 4 * (BM / 64) * 32 * ((BN / 64) * 32 * (RAW16 ? 2 : 4) + 16) <= EPI_STAGE_BYTES;
+    const size_t sample_bytes = (size_t)(MODE == MODE_CONVT ? p.Hout * p.Wout : p.Mh * p.Mw) * p.Cout * (RAW16 ? 2 : 4);
+    const bool staged = FITS && stage != nullptr && sample_bytes < 0xfffffff0ull && (p.halo_tx != 0 || MODE == MODE_CONV);
+    if constexpr (FITS) {
+      if (staged) {
+        if (has_cb) emit_whole_tile<BM, BN, MODE, RAW16, true, true>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
+        else emit_whole_tile<BM, BN, MODE, RAW16, false, true>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
+        return;
+      }
+    }
+    if (has_cb) emit_whole_tile<BM, BN, MODE, RAW16, true, false>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
+    else emit_whole_tile<BM, BN, MODE, RAW16, false, false>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     int m = tile_m * BM + wm * (MT * 32) + i * 32 + (lane & 31);
@@ -437,7 +620,8 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
             const v4f bs = *reinterpret_cast<const v4f *>(p.bias + n);
             v.x = msi_tanh(v.x + bs.x); v.y = msi_tanh(v.y + bs.y); v.z = msi_tanh(v.z + bs.z); v.w = msi_tanh(v.w + bs.w);
           }
-          if (sok && RAW16) {   // (Cout % 4 == 0 in a bf16 plan: whole 8-byte pieces)
+          if (MSI_EPI_ABLATE & 1) {
+          } else if (sok && RAW16) {   // (Cout % 4 == 0 in a bf16 plan: whole 8-byte pieces)
             typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
             typedef unsigned u2_t __attribute__((ext_vector_type(2)));
             const h2_t lo = {(_Float16)(v.x * raw_mul), (_Float16)(v.y * raw_mul)}, hi = {(_Float16)(v.z * raw_mul), (_Float16)(v.w * raw_mul)};
@@ -453,7 +637,7 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
               if (n + 3 < p.Cout) dst[3] = v.w;
             }
           }
-          if (want_stats) {
+          if (want_stats && !(MSI_EPI_ABLATE & 4)) {
             const float dx = v.x - pivot, dy = v.y - pivot, dz = v.z - pivot, dw = v.w - pivot;
             if (INTERIOR || n + 3 < p.Cout) {
               s1 += (dx + dy) + (dz + dw);
@@ -473,7 +657,7 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     const float wcnt = INTERIOR ? (float)(MT * NT * 16 * 64) : wave_sum(cnt);
-    if (lane == 0 && wcnt > 0.f) {
+    if (lane == 0 && wcnt > 0.f && !(MSI_EPI_ABLATE & 2)) {
       const double P = (double)pivot, n = (double)wcnt, a = (double)s1;
       long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * LN_WORDS;   // (any spread will do)
       ln_atomic_add(dst, (n * P + a) * scl_s1, p.status);
@@ -484,17 +668,17 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
 
 template <int BM, int BN, int MODE, int RAW16 = 0>
 __device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n,
-                                          int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre) {
+                                          int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre, char *stage = nullptr) {
   const bool interior = !(MODE == MODE_CONVT && p.wrap != 0) && (tile_m + 1) * BM <= p.Mh * p.Mw &&
                         (tile_n + 1) * BN <= p.Cout && (p.Cout & 3) == 0;
-  if (interior) emit_tile_impl<BM, BN, MODE, true, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre);
-  else emit_tile_impl<BM, BN, MODE, false, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre);
+  if (interior) emit_tile_impl<BM, BN, MODE, true, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, stage);
+  else emit_tile_impl<BM, BN, MODE, false, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, nullptr);
 }
 template <int BM, int BN, int MODE, int RAW16 = 0>
 __device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n,
-                                          int cls, int b, int tid) {
+                                          int cls, int b, int tid, char *stage = nullptr) {
   const v4f none[4] = {};
-  emit_tile<BM, BN, MODE, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, none, false);
+  emit_tile<BM, BN, MODE, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, none, false, stage);
 }
 
 // The CoordNet table values of this lane's pixel and 16 channels (64x64 tile, transposed accumulator layout), requested
@@ -1058,7 +1242,7 @@ _Pragma("unroll")                                                               
   const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
   auto stamp = [&]() __attribute__((always_inline)) {
     if (p.dbg && tid == 0) {
-      unsigned long long *o = p.dbg + (size_t)blockIdx.x * 6;
+      unsigned long long *o = p.dbg + (size_t)blockIdx.x * 12;
       o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
       o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: wave, simd, cu, sh, se ...
       o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // XCC_ID
@@ -1696,6 +1880,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 conv_halo_bf16_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int ABL = MSI_HALO_ABLATE;
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
   typedef HaloGeomB<BM, BN, RATE> G;
   constexpr int R = RATE, PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, MT = BM / 64, NT = BN / 64;
   constexpr int NSTG = G::NSTG, PD = NSTG - 1, BI = BN / 32;   // BI: weight DMA instructions per wave and k-step
@@ -1914,6 +2101,9 @@ conv_halo_bf16_kernel(const ConvParams p) {
   MSI_PATCH_STORE()
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
   for (; c < c1; ++c) {
     MSI_HTAP(0) MSI_HTAP(1) MSI_HTAP(2) MSI_HTAP(3) MSI_HTAP(4) MSI_HTAP(5) MSI_HTAP(6) MSI_HTAP(7) MSI_HTAP(8)
     if (c + 1 < c1 && !(ABL & 2)) {
@@ -1927,7 +2117,21 @@ conv_halo_bf16_kernel(const ConvParams p) {
 #undef MSI_B_ISSUE
 #undef MSI_PATCH_STORE
 #undef MSI_PATCH_LOAD
-  emit_tile<BM, BN, MODE_CONV, 1>(p, acc, tile_m, tile_n, 0, b, tid);
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef MSI_EPI_PRIO
+  __builtin_amdgcn_s_setprio(MSI_EPI_PRIO);
+#endif
+  emit_tile<BM, BN, MODE_CONV, 1>(p, acc, tile_m, tile_n, 0, b, tid, smem);   // (the k-loop ended with a barrier: LDS is free)
+#ifdef MSI_CONV_TIMING
+  if (p.dbg && tid == 0) {
+    unsigned long long *o = p.dbg + (size_t)blockIdx.x * 12;
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
+    o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+  }
+#endif
 #endif
 }
 
@@ -2192,7 +2396,10 @@ convt_halo_bf16_kernel(const ConvParams p) {
 #undef MSI_PATCH_STORE
 #undef MSI_PATCH_LOAD
 #pragma unroll
-  for (int pwc = 0; pwc < 2; ++pwc) emit_tile<BM, BN, MODE_CONVT, 1>(p, acc[pwc], tile_m, tile_n, 2 * ph + pwc, b, tid);
+  for (int pwc = 0; pwc < 2; ++pwc) {   // (LDS is free: the k-loop ended with a barrier)
+    emit_tile<BM, BN, MODE_CONVT, 1>(p, acc[pwc], tile_m, tile_n, 2 * ph + pwc, b, tid, smem);
+    __builtin_amdgcn_sched_barrier(0);   // one class after the other: interleaved, the two epilogues do not fit the register file
+  }
 #endif
 }
 
@@ -3121,7 +3328,11 @@ int launch_conv_mode(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
 
 template <int BM, int BN, int RATE, int APPLY>
 int launch_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stream) {
+#ifdef MSI_ONE_PER_CU   // timing experiment: one workgroup per CU (no co-resident workgroup's MFMAs)
+  constexpr int lds = 100 * 1024;
+#else
   constexpr int lds = HaloGeomB<BM, BN, RATE>::LDS_BYTES + (APPLY ? 8 * 512 : 0);   // + scale | shift of <= 512 input channels (4 KB: two workgroups per CU still fit)
+#endif
   if (APPLY && p.C0 > 512) return msi::fail(MSI_E_UNSUPPORTED, "conv_halo_bf16: APPLY with more than 512 input channels");
   static thread_local unsigned long long done = 0;
   int rc0 = set_max_lds(reinterpret_cast<const void *>(conv_halo_bf16_kernel<BM, BN, RATE, APPLY>), lds, done, "conv_halo_bf16");

@@ -3,7 +3,8 @@
 e.g. tools/_variants/libmsi_timing.so installed as matryodshka_amd/libmsi_hip.so):
 s_memtime stamps at kernel entry, k-loop start, k-loop end and exit of every workgroup.
 
-    python tools/conv_timing.py [layer ...]
+    python tools/conv_timing.py [--bf16] [--batch N] [layer ...]
+(--bf16: the bf16 plan's conv_halo_bf16_kernel layers at batch N; stamps are 100 MHz s_memtime ticks, 10 ns each)
 """
 import ctypes
 import os
@@ -20,16 +21,23 @@ lib.msi_debug_conv_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.msi_debug_conv_timing.restype = None
 names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3",
          "conv6_1", "conv6_2", "conv6_3", "conv7_1", "conv7_2", "conv8_1", "conv8_2", "color_pred"]
-layers = [int(a) for a in sys.argv[1:]] or [0, 1, 4, 7, 16]
-m = MSI(weights=nets.init_weights(192, 64, 64, True), coord_net=True)
-x = torch.rand((1, 320, 640, 192), device="cuda") * 2 - 1
+argv = sys.argv[1:]
+bf16 = "--bf16" in argv
+batch = int(argv[argv.index("--batch") + 1]) if "--batch" in argv else 1
+argv = [a for i, a in enumerate(argv) if a != "--bf16" and a != "--batch" and (i == 0 or argv[i - 1] != "--batch")]
+layers = [int(a) for a in argv] or [0, 1, 4, 7, 16]
+planes = 64 if bf16 else 32
+m = MSI(weights=nets.init_weights(6 * planes, 2 * planes, 64, True), coord_net=True, dtype="bf16" if bf16 else "f32")
+x = torch.rand((batch, 320, 640, 6 * planes), device="cuda") * 2 - 1
+if bf16:
+    x = x.to(torch.bfloat16)
 for _ in range(3):
-    m.run_net(x, 64, 64)
-buf = torch.zeros((8192, 6), dtype=torch.int64, device="cuda")
+    m.run_net(x, 2 * planes, 64)
+buf = torch.zeros((16384, 12), dtype=torch.int64, device="cuda")
 for li in layers:
     buf.zero_()
     lib.msi_debug_conv_timing(ctypes.c_void_p(buf.data_ptr()), li)
-    m.run_net(x, 64, 64)
+    m.run_net(x, 2 * planes, 64)
     torch.cuda.synchronize()
     lib.msi_debug_conv_timing(None, -1)
     t = buf.cpu().numpy().astype(np.int64)
@@ -39,6 +47,11 @@ for li in layers:
     dur = t[:, 3] - t[:, 0]
     print("%-10s blocks %5d  span %8d ticks | per block: prologue %6.0f  loop %8.0f  epilogue %6.0f  total %8.0f (min %d max %d) | sum(block time)/span = %.2f resident blocks" % (
         names[li], len(t), span, pro.mean(), loop.mean(), epi.mean(), dur.mean(), dur.min(), dur.max(), dur.sum() / span))
+    if t[:, 6].any():   # stamps inside the epilogue (whole-tile path of emit_tile_impl): entry, stores issued, wave sums, atomics
+        e = t[t[:, 6] != 0]
+        print("           epilogue: values -> LDS strip written +%6.0f (from entry)" % ((e[:, 11] - e[:, 6]).mean()))
+        print("           epilogue: loop end -> entry %6.0f | element loop (stores issued) %6.0f | wave sums %6.0f | atomics %6.0f | -> exit stamp %6.0f" % (
+            (e[:, 6] - e[:, 2]).mean(), (e[:, 7] - e[:, 6]).mean(), (e[:, 8] - e[:, 7]).mean(), (e[:, 9] - e[:, 8]).mean(), (e[:, 3] - e[:, 9]).mean()))
     # per CU (XCC_ID, HW_ID se/sh/cu): time-average number of resident workgroups and of workgroups inside the k-loop
     hw, xcc = t[:, 4], t[:, 5] & 0xf
     cu_key = (xcc << 16) | (((hw >> 13) & 0x7) << 12) | (((hw >> 12) & 0x1) << 8) | ((hw >> 8) & 0xf)   # se[15:13] sh[12] cu[11:8]
