@@ -307,7 +307,10 @@ typedef struct msi_net_plan msi_net_plan;
 #define MSI_NET_OPT_BF16_STAGE_RAW 11 /* bf16 plans: bit 0 the 256x64 conv tile (conv8_2), bit 1 the 128x64 conv-transpose tile (conv8_1) read their  */
                                       /* sources RAW (fp16) and apply the producer's LayerNorm while staging (default 1: bit 1 measured slower); 0: from ln_apply's bf16 copies */
 #define MSI_NET_OPT_SPLIT_OVERHEAD 12 /* k-steps of prologue + epilogue a K-range visit is charged in the tail-split cost model (tuning; 0 = r01 rule) */
-#define MSI_NET_OPT_COUNT 13
+#define MSI_NET_OPT_BF16_WAVES 13 /* waves per workgroup of the bf16 halo-patch conv kernel's 128x128 tile: 8 (default; 4 x 2 waves of 32 pixels x 64 channels: */
+                                  /* four waves per SIMD with two workgroups per CU, so that a workgroup's prologue / epilogue has neighbours to hide behind) */
+                                  /* or 4 (r02 shape).  The 256x64 tile always runs four (eight measured slower) */
+#define MSI_NET_OPT_COUNT 14
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
 int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);

@@ -281,6 +281,11 @@ __device__ __forceinline__ void ln_atomic_add(long long *dst, double x_scaled, i
 
 // mean and 1 / sqrt(var + eps) of one sample from its LN_SHARDS x LN_WORDS fixed-point sums -> s_stat[0..1] (LDS).
 // Called by all 256 threads (ends with a barrier); wave 0 adds the shards (integers: exact, any order).
+// This sits at the head of every consumer workgroup / ln_apply block, one wave per SIMD with nobody to hide a dependent
+// instruction behind (tools/conv_timing.py: ~20 cycles per dependent step next to a neighbour's MFMAs), so it is written for few
+// STEPS: DPP reductions (below), and (r03) 1 / sqrt as v_rsq_f64 + two Newton steps -- 8 dependent fp64 operations, within 2 ulp of
+// the ~50-instruction sqrt + division sequence and far inside the float it is rounded to.  (The 64 shards through two LDS integer
+// atomics instead of the DPP trees: measured, the prologue of conv3_2 went from 9.8 k to 27 k cycles.)
 __device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n, const double *scl, int *status, double *s_stat, int tid) {
   static_assert(LN_SHARDS == 64, "one shard per lane of wave 0");
   const double inv_s1 = scl[2], inv_s2 = scl[3];   // (uniform address: scalar loads, issued before the shards')
@@ -298,8 +303,12 @@ __device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n,
       const double mu = S1 * inv_n;
       double var = S2 * inv_n - mu * mu;
       var = var > 0.0 ? var : 0.0;
+      const double x = var + LN_EPS, hx = 0.5 * x;
+      double r = __builtin_amdgcn_rsq(x);
+      r = r * (1.5 - hx * r * r);
+      r = r * (1.5 - hx * r * r);
       s_stat[0] = mu;
-      s_stat[1] = 1.0 / sqrt(var + LN_EPS);
+      s_stat[1] = r;
     }
   }
   __syncthreads();
@@ -377,7 +386,7 @@ constexpr int EPI_STAGE_BYTES = 48 * 1024;   // emit_whole_tile's staging strips
 #define MSI_EPI_ABLATE 0
 #endif
 #ifdef MSI_CONV_TIMING
-#define MSI_STAMP(k) { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 12 + (k)] = __builtin_amdgcn_s_memtime(); }
+#define MSI_STAMP(k) { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime(); }
 #else
 #define MSI_STAMP(k)
 #endif
@@ -395,13 +404,13 @@ constexpr int EPI_STAGE_BYTES = 48 * 1024;   // emit_whole_tile's staging strips
 //    a lane offset and scalar (row, column) steps (no 64-bit address arithmetic per store).
 // RAW16 statistics are taken in the scaled unit (the same numbers times a power of two: sum y 2^24 = sum x S1, sum y^2 2^16 =
 // sum x^2 S2).
-template <int BM, int BN, int MODE, int RAW16, bool CB, bool STAGED>
-__device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n, int cls,
+template <int BM, int BN, int MODE, int RAW16, bool CB, bool STAGED, int WR>
+__device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&acc)[BM / (32 * WR)][BN / 64], int tile_m, int tile_n, int cls,
                                                 int b, int tid, const v4f (&cb_pre)[4], bool use_pre, float pivot, float raw_mul,
                                                 double scl_s1, double scl_s2, char *stage) {
-  constexpr int MT = BM / 64, NT = BN / 64, NG = NT * 4, YSZ = RAW16 ? 2 : 4;
+  constexpr int MT = BM / (32 * WR), NT = BN / 64, NG = NT * 4, YSZ = RAW16 ? 2 : 4;   // WR x 2 waves
   constexpr int ROWB = NT * 32 * YSZ, PITCH = ROWB + 16, NP = ROWB / 16, PPI = 64 / NP, NRD = 32 / PPI;
-  constexpr bool FITS = 4 * MT * 32 * PITCH <= EPI_STAGE_BYTES;
+  constexpr bool FITS = 2 * WR * MT * 32 * PITCH <= EPI_STAGE_BYTES;
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
   typedef unsigned u2_t __attribute__((ext_vector_type(2)));
@@ -417,7 +426,7 @@ __device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&ac
   static_assert(!STAGED || FITS, "staging strips");
   const int tyi = p.halo_tx ? (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx) : 0;
   const int txi = tile_m - tyi * p.halo_tx;
-  MSI_STAMP(6)
+  MSI_STAMP(16)
   // ---- the lane's own pixels (coord-bias rows; direct stores) ----
   char *yp[MT];
   const float *cbp[MT];
@@ -494,7 +503,7 @@ __device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&ac
       }
     }
   }
-  MSI_STAMP(11)
+  MSI_STAMP(21)
   const v2f t1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]), t2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]);
   float s1 = t1.x + t1.y, s2 = t2.x + t2.y;
   // ---- the strip's pieces -> memory ----
@@ -524,10 +533,10 @@ __device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&ac
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pc[i][k]), rsrc_y, v0, (ro * rowstep + co * colstep) * rowb, 0);
       }
   }
-  MSI_STAMP(7)
+  MSI_STAMP(17)
   if (want_stats) {
     s1 = wave_sum(s1); s2 = wave_sum(s2);
-    MSI_STAMP(8)
+    MSI_STAMP(18)
     if (lane == 0 && !(MSI_EPI_ABLATE & 2)) {
       const double P = (double)pv_s, n = (double)(MT * NT * 16 * 64), a = (double)s1;
       const double u1 = RAW16 ? 16777216.0 : scl_s1, u2 = RAW16 ? 65536.0 : scl_s2;
@@ -535,14 +544,14 @@ __device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&ac
       ln_atomic_add(dst, (n * P + a) * u1, p.status);
       ln_atomic_add(dst + 1, ((double)s2 + 2.0 * P * a + n * P * P) * u2, p.status);
     }
-    MSI_STAMP(9)
+    MSI_STAMP(19)
   }
 }
 
-template <int BM, int BN, int MODE, bool INTERIOR, int RAW16>
-__device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m,
+template <int BM, int BN, int MODE, bool INTERIOR, int RAW16, int WR>
+__device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc)[BM / (32 * WR)][BN / 64], int tile_m,
                                                int tile_n, int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre, char *stage) {
-  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int MT = BM / (32 * WR), NT = BN / 64;   // WR x 2 waves, 32 MT x 32 NT each
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5;
   const int ph = cls >> 1, pw = cls & 1;
   const int mtot = p.Mh * p.Mw;
@@ -560,18 +569,18 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
   float s1 = 0.f, s2 = 0.f, cnt = 0.f;
   if constexpr (INTERIOR && MODE != MODE_HEAD) {
     // (staged stores: the caller owns EPI_STAGE_BYTES of free LDS, 32-bit offsets reach the sample, the pixel steps are uniform)
-    constexpr bool FITS = 4 * (BM / 64) * 32 * ((BN / 64) * 32 * (RAW16 ? 2 : 4) + 16) <= EPI_STAGE_BYTES;
+    constexpr bool FITS = 2 * WR * MT * 32 * (NT * 32 * (RAW16 ? 2 : 4) + 16) <= EPI_STAGE_BYTES;
     const size_t sample_bytes = (size_t)(MODE == MODE_CONVT ? p.Hout * p.Wout : p.Mh * p.Mw) * p.Cout * (RAW16 ? 2 : 4);
     const bool staged = FITS && stage != nullptr && sample_bytes < 0xfffffff0ull && (p.halo_tx != 0 || MODE == MODE_CONV);
     if constexpr (FITS) {
       if (staged) {
-        if (has_cb) emit_whole_tile<BM, BN, MODE, RAW16, true, true>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
-        else emit_whole_tile<BM, BN, MODE, RAW16, false, true>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
+        if (has_cb) emit_whole_tile<BM, BN, MODE, RAW16, true, true, WR>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
+        else emit_whole_tile<BM, BN, MODE, RAW16, false, true, WR>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
         return;
       }
     }
-    if (has_cb) emit_whole_tile<BM, BN, MODE, RAW16, true, false>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
-    else emit_whole_tile<BM, BN, MODE, RAW16, false, false>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
+    if (has_cb) emit_whole_tile<BM, BN, MODE, RAW16, true, false, WR>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
+    else emit_whole_tile<BM, BN, MODE, RAW16, false, false, WR>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, pivot, raw_mul, scl_s1, scl_s2, stage);
     return;
   }
 #pragma unroll
@@ -666,19 +675,19 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
   }
 }
 
-template <int BM, int BN, int MODE, int RAW16 = 0>
-__device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n,
+template <int BM, int BN, int MODE, int RAW16 = 0, int WR = 2>
+__device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / (32 * WR)][BN / 64], int tile_m, int tile_n,
                                           int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre, char *stage = nullptr) {
   const bool interior = !(MODE == MODE_CONVT && p.wrap != 0) && (tile_m + 1) * BM <= p.Mh * p.Mw &&
                         (tile_n + 1) * BN <= p.Cout && (p.Cout & 3) == 0;
-  if (interior) emit_tile_impl<BM, BN, MODE, true, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, stage);
-  else emit_tile_impl<BM, BN, MODE, false, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, nullptr);
+  if (interior) emit_tile_impl<BM, BN, MODE, true, RAW16, WR>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, stage);
+  else emit_tile_impl<BM, BN, MODE, false, RAW16, WR>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, nullptr);
 }
-template <int BM, int BN, int MODE, int RAW16 = 0>
-__device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int tile_m, int tile_n,
+template <int BM, int BN, int MODE, int RAW16 = 0, int WR = 2>
+__device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / (32 * WR)][BN / 64], int tile_m, int tile_n,
                                           int cls, int b, int tid, char *stage = nullptr) {
   const v4f none[4] = {};
-  emit_tile<BM, BN, MODE, RAW16>(p, acc, tile_m, tile_n, cls, b, tid, none, false, stage);
+  emit_tile<BM, BN, MODE, RAW16, WR>(p, acc, tile_m, tile_n, cls, b, tid, none, false, stage);
 }
 
 // The CoordNet table values of this lane's pixel and 16 channels (64x64 tile, transposed accumulator layout), requested
@@ -1242,7 +1251,7 @@ _Pragma("unroll")                                                               
   const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
   auto stamp = [&]() __attribute__((always_inline)) {
     if (p.dbg && tid == 0) {
-      unsigned long long *o = p.dbg + (size_t)blockIdx.x * 12;
+      unsigned long long *o = p.dbg + (size_t)blockIdx.x * 24;
       o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
       o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: wave, simd, cu, sh, se ...
       o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // XCC_ID
@@ -1334,6 +1343,9 @@ conv_halo_kernel(const ConvParams p) {
   typedef HaloGeom<RATE> G;
   constexpr int R = RATE, PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
   constexpr int MT = 1, NT = 1;
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1522,6 +1534,9 @@ conv_halo_kernel(const ConvParams p) {
   MSI_PATCH_STORE()
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
   for (; c < c1; ++c) {
     MSI_HTAP(0) MSI_HTAP(1) MSI_HTAP(2) MSI_HTAP(3) MSI_HTAP(4) MSI_HTAP(5) MSI_HTAP(6) MSI_HTAP(7) MSI_HTAP(8)
     if (c + 1 < c1) {   // every wave has read the last tap of this chunk (closing barrier of tap 8): swap the patch
@@ -1536,11 +1551,25 @@ conv_halo_kernel(const ConvParams p) {
 #undef MSI_PATCH_LOAD
 
   // ---- epilogue: as conv_igemm_kernel ----
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if (p.dbg && tid == 0) {
+      unsigned long long *o = p.dbg + (size_t)blockIdx.x * 24;
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
+      o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+      o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+    }
+  };
+#endif
   if (!full) {
     constexpr int SLAB = 64 * 64 * 4;
     const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)slot * (64 * 64)), 0, SLAB, 0x00020000);
     if (p.tile_cnt == nullptr) {
       dump_acc<MT, NT, 0>(acc, rsrc_p, tid);
+#ifdef MSI_CONV_TIMING
+      stamp();
+#endif
       return;
     }
     dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
@@ -1556,6 +1585,9 @@ conv_halo_kernel(const ConvParams p) {
     sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
   }
   emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, cbv, p.coord_bias != nullptr);
+#ifdef MSI_CONV_TIMING
+  stamp();
+#endif
 #endif
 }
 
@@ -1875,8 +1907,8 @@ struct HaloGeomB {
 #ifndef MSI_HALO_ABLATE   // timing experiments only (tools/_variants): 1 no weight DMA, 2 no patch traffic, 4 no k-step barrier, 8 no fragment reads
 #define MSI_HALO_ABLATE 0
 #endif
-template <int BM, int BN, int RATE, int APPLY>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+template <int BM, int BN, int RATE, int APPLY, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2)))
 conv_halo_bf16_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int ABL = MSI_HALO_ABLATE;
@@ -1884,8 +1916,10 @@ conv_halo_bf16_kernel(const ConvParams p) {
   const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
   typedef HaloGeomB<BM, BN, RATE> G;
-  constexpr int R = RATE, PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, MT = BM / 64, NT = BN / 64;
-  constexpr int NSTG = G::NSTG, PD = NSTG - 1, BI = BN / 32;   // BI: weight DMA instructions per wave and k-step
+  constexpr int NTHR = 64 * NW, WR = NW / 2;                   // NW = 4 or 8 waves in WR x 2: a wave owns 32 MT x 32 NT of the tile
+  constexpr int R = RATE, PW = G::PW, NPX = G::NPX, NLOAD = (NPX * 8 + NTHR - 1) / NTHR, MT = BM / (32 * WR), NT = BN / 64;
+  constexpr int NSTG = G::NSTG, PD = NSTG - 1, BI = BN / (8 * NW);   // BI: weight DMA instructions per wave and k-step (8 rows each)
+  static_assert(BI == 1 || BI == 2 || BI == 4, "weight rows per wave");
   constexpr int NRAW = NLOAD;                                   // 16-byte patch loads per thread and chunk (bf16 copy, or fp16 raw)
   constexpr int NPL = NRAW;                                     // VMEM operations of a patch load
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1920,7 +1954,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
   constexpr unsigned OOB = 0xfffffff0u;
 #pragma unroll
   for (int k = 0; k < NLOAD; ++k) {
-    const int pp = (tid + 256 * k) >> 3;
+    const int pp = (tid + NTHR * k) >> 3;
     const int py = pp / PW, px = pp - py * PW;
     const int ih = oh0 - R + py;
     int iw = ow0 - R + px;
@@ -1933,7 +1967,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in_bytes), 0, (int)(in_bytes < 0xfffffff0u ? in_bytes : 0xfffffff0u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)p.ksteps * p.npad * ROW_BYTES), 0x00020000);
   const int drow = lane >> 3, dslot = lane & 7;
-  const unsigned b_voff = (unsigned)((tile_n * BN + wave * (BN / 4) + drow) * ROW_BYTES + dslot * 16);
+  const unsigned b_voff = (unsigned)((tile_n * BN + wave * (BN / NW) + drow) * ROW_BYTES + dslot * 16);
 
   int c_ld = 0;                                           // chunk of the patch held in araw
   bool has_pad = false;
@@ -1985,10 +2019,10 @@ conv_halo_bf16_kernel(const ConvParams p) {
   // weights of k-step (chunk c, tap) -> ring stage st (run-time); the packed blob is tap-major: row block tap * CH + c
 #define MSI_B_ISSUE(c, tap, st)                                                                                        \
   {                                                                                                                    \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * (BN / 4) * ROW_BYTES;                                   \
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * (BN / NW) * ROW_BYTES;                                  \
     const int soff_ = ((tap) * CH + (c)) * p.npad * ROW_BYTES;                                                         \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
+    if (BI >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0); \
     if (BI == 4) {                                                                                                     \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 16 * ROW_BYTES, 0);         \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 24 * ROW_BYTES, 0);         \
@@ -2077,27 +2111,40 @@ conv_halo_bf16_kernel(const ConvParams p) {
   // ---- prologue: first patch, first PD weight k-steps ----
   const int c0 = 0, c1 = CH;
   int c = c0, st = 0;
+  MSI_STAMP(6)
   MSI_PATCH_LOAD(c0)
   MSI_B_ISSUE(c0, 0, 0)
   if (PD == 2) MSI_B_ISSUE(c0, 1, 1)
+  MSI_STAMP(7)
   if (APPLY) {
     // the affine of the source's LayerNorm for every input channel, once per workgroup: scale = 2^e inv gamma (the stored
     // raw value is fp16 of x * 2^-e), shift = beta - mean inv gamma with the mean as hi + lo floats, fp32 operations only
     // (the expressions ln_apply's fp32 table would give up to the last bit are not needed: the result is rounded to bf16)
     double *s_stat = reinterpret_cast<double *>(smem);
+    // (gamma / beta of the thread's <= 2 channels are requested BEFORE the statistics' round trip, not after it)
+    const int ch0 = tid < C ? tid : 0, ch1 = tid + NTHR < C ? tid + NTHR : 0;
+    const float g0 = p.ln_gamma[ch0], b0 = p.ln_beta[ch0], g1 = p.ln_gamma[ch1], b1 = p.ln_beta[ch1];
     ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
+    MSI_STAMP(8)
     const double mu = s_stat[0];
     const float inv_f = (float)s_stat[1], mu_hi = (float)mu, mu_lo = (float)(mu - (double)mu_hi);
     const float up_f = (float)(p.ln_scl_src[2] * 16777216.0);   // 2^e of the source layer's window
     __syncthreads();
-    for (int ch = tid; ch < C; ch += 256) {
-      const float su = inv_f * p.ln_gamma[ch];
-      s_tab[C + ch] = __builtin_fmaf(-mu_lo, su, __builtin_fmaf(-mu_hi, su, p.ln_beta[ch]));
-      s_tab[ch] = up_f * su;
+    if (tid < C) {
+      const float su = inv_f * g0;
+      s_tab[C + tid] = __builtin_fmaf(-mu_lo, su, __builtin_fmaf(-mu_hi, su, b0));
+      s_tab[tid] = up_f * su;
+    }
+    if (tid + NTHR < C) {
+      const float su = inv_f * g1;
+      s_tab[C + tid + NTHR] = __builtin_fmaf(-mu_lo, su, __builtin_fmaf(-mu_hi, su, b1));
+      s_tab[tid + NTHR] = up_f * su;
     }
     __syncthreads();
   }
+  MSI_STAMP(9)
   wait_vmcnt<0>();
+  MSI_STAMP(10)
   MSI_PATCH_STORE()
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -2123,10 +2170,10 @@ conv_halo_bf16_kernel(const ConvParams p) {
 #ifdef MSI_EPI_PRIO
   __builtin_amdgcn_s_setprio(MSI_EPI_PRIO);
 #endif
-  emit_tile<BM, BN, MODE_CONV, 1>(p, acc, tile_m, tile_n, 0, b, tid, smem);   // (the k-loop ended with a barrier: LDS is free)
+  emit_tile<BM, BN, MODE_CONV, 1, WR>(p, acc, tile_m, tile_n, 0, b, tid, smem);   // (the k-loop ended with a barrier: LDS is free)
 #ifdef MSI_CONV_TIMING
   if (p.dbg && tid == 0) {
-    unsigned long long *o = p.dbg + (size_t)blockIdx.x * 12;
+    unsigned long long *o = p.dbg + (size_t)blockIdx.x * 24;
     o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
     o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
     o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
@@ -3326,18 +3373,19 @@ int launch_conv_mode(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
   }
 }
 
-template <int BM, int BN, int RATE, int APPLY>
+template <int BM, int BN, int RATE, int APPLY, int NW>
 int launch_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stream) {
 #ifdef MSI_ONE_PER_CU   // timing experiment: one workgroup per CU (no co-resident workgroup's MFMAs)
   constexpr int lds = 100 * 1024;
 #else
   constexpr int lds = HaloGeomB<BM, BN, RATE>::LDS_BYTES + (APPLY ? 8 * 512 : 0);   // + scale | shift of <= 512 input channels (4 KB: two workgroups per CU still fit)
 #endif
+  static_assert(lds >= EPI_STAGE_BYTES, "the epilogue's staging strips");
   if (APPLY && p.C0 > 512) return msi::fail(MSI_E_UNSUPPORTED, "conv_halo_bf16: APPLY with more than 512 input channels");
   static thread_local unsigned long long done = 0;
-  int rc0 = set_max_lds(reinterpret_cast<const void *>(conv_halo_bf16_kernel<BM, BN, RATE, APPLY>), lds, done, "conv_halo_bf16");
+  int rc0 = set_max_lds(reinterpret_cast<const void *>(conv_halo_bf16_kernel<BM, BN, RATE, APPLY, NW>), lds, done, "conv_halo_bf16");
   if (rc0) return rc0;
-  hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, BN, RATE, APPLY>), dim3(Q.nblocks), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, BN, RATE, APPLY, NW>), dim3(Q.nblocks), dim3(64 * NW), lds, stream, p);
   return msi::check_launch("conv_halo_bf16");
 }
 
@@ -3606,6 +3654,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_F32_TILE_MASK] = 0;
   pl->opt[MSI_NET_OPT_UNIFORM_SPLIT] = 0;
   pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD] = 0;
+  pl->opt[MSI_NET_OPT_BF16_WAVES] = 8;
   pl->opt[MSI_NET_OPT_BF16_STAGE_RAW] = 1;   // (bit 1, conv8_1 staging its raw sources: measured 50 us per 16 frames SLOWER -- ~180 VALU per chunk
                                                // against 2 048 matrix cycles of the 128 x 64 tile; bit 0, conv8_2: 130 us faster.  Three interleaved repeats)
   int rc = plan_layers(pl);
@@ -3627,6 +3676,7 @@ int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value) {
   if (option == MSI_NET_OPT_HALO) MSI_REQUIRE(value >= 0 && value <= 3, "net_plan_set_option: halo %d (bit 0 conv, bit 1 conv-transpose)", value);
   if (option == MSI_NET_OPT_TAILSPLIT) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: tailsplit %d", value);
   if (option == MSI_NET_OPT_F32_TILE) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: f32 tile %d", value);
+  if (option == MSI_NET_OPT_BF16_WAVES) MSI_REQUIRE(value == 4 || value == 8, "net_plan_set_option: bf16 waves %d (4 or 8)", value);
 #ifndef MSI_EXPERIMENTS
   if ((option == MSI_NET_OPT_F32_TILE || option == MSI_NET_OPT_F32_TILE_MASK || option == MSI_NET_OPT_APPLY_AHEAD) && value != 0)
     return msi::fail(MSI_E_UNSUPPORTED, "net_plan_set_option: option %d is an experiment this library was not built with "
@@ -3842,12 +3892,16 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
         p.ln_gamma = packed + S.gamma_off;
         p.ln_beta = packed + S.beta_off;
       }
+      const bool w8 = plan->opt[MSI_NET_OPT_BF16_WAVES] == 8;
+#define MSI_HB(BM_, BN_, R_, A_) (w8 ? launch_halo_bf16<BM_, BN_, R_, A_, 8>(Q, p, stream) : launch_halo_bf16<BM_, BN_, R_, A_, 4>(Q, p, stream))
       if (Q.hbm == 128) {
-        if (L.rate == 1) rc = Q.halo_apply ? launch_halo_bf16<128, 128, 1, 1>(Q, p, stream) : launch_halo_bf16<128, 128, 1, 0>(Q, p, stream);
-        else rc = Q.halo_apply ? launch_halo_bf16<128, 128, 2, 1>(Q, p, stream) : launch_halo_bf16<128, 128, 2, 0>(Q, p, stream);
-      } else {
-        rc = Q.halo_apply ? launch_halo_bf16<256, 64, 1, 1>(Q, p, stream) : launch_halo_bf16<256, 64, 1, 0>(Q, p, stream);
+        if (L.rate == 1) rc = Q.halo_apply ? MSI_HB(128, 128, 1, 1) : MSI_HB(128, 128, 1, 0);
+        else rc = Q.halo_apply ? MSI_HB(128, 128, 2, 1) : MSI_HB(128, 128, 2, 0);
+      } else {   // (the 256 x 64 tile stays at four waves: eight do not fit their 128 registers -- 44-64 bytes of scratch -- and were
+                 // measured slower, conv8_2 27.8 k -> 32.9 k cycles per workgroup)
+        rc = Q.halo_apply ? launch_halo_bf16<256, 64, 1, 1, 4>(Q, p, stream) : launch_halo_bf16<256, 64, 1, 0, 4>(Q, p, stream);
       }
+#undef MSI_HB
     } else if (Q.halo_t) {
       if (p.halo_apply & 1) {
         const Layer &S = net.layers[L.src0];

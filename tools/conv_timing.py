@@ -33,7 +33,7 @@ if bf16:
     x = x.to(torch.bfloat16)
 for _ in range(3):
     m.run_net(x, 2 * planes, 64)
-buf = torch.zeros((16384, 12), dtype=torch.int64, device="cuda")
+buf = torch.zeros((16384, 24), dtype=torch.int64, device="cuda")
 for li in layers:
     buf.zero_()
     lib.msi_debug_conv_timing(ctypes.c_void_p(buf.data_ptr()), li)
@@ -42,11 +42,21 @@ for li in layers:
     lib.msi_debug_conv_timing(None, -1)
     t = buf.cpu().numpy().astype(np.int64)
     t = t[t[:, 0] != 0]
+    if len(t) == 0:
+        print("%-10s no stamps (kernel without them)" % names[li])
+        continue
     pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
     span = t[:, 3].max() - t[:, 0].min()
     dur = t[:, 3] - t[:, 0]
     print("%-10s blocks %5d  span %8d ticks | per block: prologue %6.0f  loop %8.0f  epilogue %6.0f  total %8.0f (min %d max %d) | sum(block time)/span = %.2f resident blocks" % (
         names[li], len(t), span, pro.mean(), loop.mean(), epi.mean(), dur.mean(), dur.min(), dur.max(), dur.sum() / span))
+    if t[:, 6].any() and t[:, 10].any():   # stamps inside the prologue of conv_halo_bf16_kernel
+        e = t[t[:, 6] != 0]
+        ln = (e[:, 8] - e[:, 7]).mean() if e[:, 8].any() else 0.0
+        tb = (e[:, 9] - e[:, 8]).mean() if e[:, 8].any() else (e[:, 9] - e[:, 7]).mean()
+        print("           prologue: index setup %6.0f | patch + weight requests %6.0f | statistics %6.0f | affine table %6.0f | patch arrives %6.0f | patch -> LDS + barrier %6.0f" % (
+            (e[:, 6] - e[:, 0]).mean(), (e[:, 7] - e[:, 6]).mean(), ln, tb, (e[:, 10] - e[:, 9]).mean(), (e[:, 1] - e[:, 10]).mean()))
+    t = np.concatenate([t[:, :6], t[:, 16:22]], axis=1)
     if t[:, 6].any():   # stamps inside the epilogue (whole-tile path of emit_tile_impl): entry, stores issued, wave sums, atomics
         e = t[t[:, 6] != 0]
         print("           epilogue: values -> LDS strip written +%6.0f (from entry)" % ((e[:, 11] - e[:, 6]).mean()))
