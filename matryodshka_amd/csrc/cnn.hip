@@ -2167,9 +2167,6 @@ conv_halo_bf16_kernel(const ConvParams p) {
 #ifdef MSI_CONV_TIMING
   const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
-#ifdef MSI_EPI_PRIO
-  __builtin_amdgcn_s_setprio(MSI_EPI_PRIO);
-#endif
   emit_tile<BM, BN, MODE_CONV, 1, WR>(p, acc, tile_m, tile_n, 0, b, tid, smem);   // (the k-loop ended with a barrier: LDS is free)
 #ifdef MSI_CONV_TIMING
   if (p.dbg && tid == 0) {

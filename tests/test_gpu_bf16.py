@@ -207,6 +207,33 @@ def test_bf16_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, 
         assert e.max() <= 4e-2 and e.mean() <= 3e-3, (e.max(), e.mean())
 
 
+@pytest.mark.parametrize("coord,b,h,w,cin,nout,ngf", [(True, 1, 160, 320, 192, 64, 64), (False, 2, 64, 128, 64, 16, 64)])
+def test_bf16_halo_kernel_eight_and_four_waves_agree(env, coord, b, h, w, cin, nout, ngf):
+    """Plan option BF16_WAVES: the 128x128 tile of conv_halo_bf16_kernel as 4 x 2 waves of 32 pixels x 64 channels (default) or
+    2 x 2 waves of 64 x 64 (r02): the same bf16 operands and fp32 accumulation per output element; only the partition of the
+    LayerNorm sums over waves differs (every wave's share is rounded to one fixed-point unit): isolated bf16 rounding flips of an
+    activation, propagated through 17 layers -- the gates of the halo-vs-tap comparison; either shape is bitwise deterministic.
+    Anything but 4 / 8 is refused."""
+    torch, MSI, nets, onets, _ = env
+    from matryodshka_amd import _native as N
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=43, randomize_affine=True)
+    x = onets.bf16_round(np.random.RandomState(9).uniform(-1, 1, size=(b, h, w, cin)).astype(np.float32))
+    xg = torch.from_numpy(x).cuda().bfloat16()
+    w8 = MSI(weights=weights, coord_net=coord, dtype="bf16")
+    w4 = MSI(weights=weights, coord_net=coord, dtype="bf16")
+    w4.net_options[N.NET_OPT_BF16_WAVES] = 4
+    p8, p4 = w8.run_net(xg, nout, ngf), w4.run_net(xg, nout, ngf)
+    d = (p8 - p4).abs()
+    assert float(d.max()) <= 4e-2 and float(d.mean()) <= 3e-3, (float(d.max()), float(d.mean()))
+    for _ in range(3):
+        assert torch.equal(w8.run_net(xg, nout, ngf), p8)
+        assert torch.equal(w4.run_net(xg, nout, ngf), p4)
+    bad = MSI(weights=weights, coord_net=coord, dtype="bf16")
+    bad.net_options[N.NET_OPT_BF16_WAVES] = 6
+    with pytest.raises(Exception):
+        bad.run_net(xg, nout, ngf)
+
+
 @pytest.mark.parametrize("b,h,w,d,ngf", [(2, 32, 64, 8, 16), (1, 64, 128, 64, 64), (1, 32, 64, 32, 32), (1, 16, 32, 48, 16)])
 def test_bf16_fused_tail_matches_two_step_path(env, b, h, w, d, ngf):
     """msi_net_plan_forward_rgba on a bf16 plan (1x1 head on the fp32 MFMA over the bf16-rounded operands + conv8_2's
