@@ -295,12 +295,13 @@ typedef struct msi_net_plan msi_net_plan;
 #define MSI_NET_OPT_APPLY_AHEAD 7   /* 1: a layer's LayerNorm + ReLU is applied by the first workgroups of its consumer's launch,    */
                                    /* overlapped with that layer's tiles (row counters); 0 (default): one ln_apply launch per layer */
                                    /* -- bit-identical results; measured slower on MI355X (write-through hand-off), see DESIGN.md  */
-#define MSI_NET_OPT_HALO 8          /* default 1.  bit 0: the stride-1 3x3 layers run the halo-patch kernels (conv_halo_kernel fp32,   */
+#define MSI_NET_OPT_HALO 8          /* default 5.  bit 0: the stride-1 3x3 layers run the halo-patch kernels (conv_halo_kernel fp32,   */
                                    /* conv_halo_bf16_kernel: one LDS-stationary halo patch per workgroup and input chunk, the          */
                                    /* producer's LayerNorm applied while staging it) and the bf16 conv-transposes                      */
                                    /* convt_halo_bf16_kernel; bit 1 (measured slower: opt-in): the fp32 SAME conv-transposes run       */
                                    /* convt_halo_kernel (the two classes of one output-row parity per workgroup, either source's       */
-                                   /* LayerNorm applied while staging);                                                                */
+                                   /* LayerNorm applied while staging); bit 2: the fp32 stride-2 3x3 layers run conv_halo_s2_kernel    */
+                                   /* (four parity-plane patches per 32-channel group, the producer's LayerNorm applied while staging);*/
                                    /* 0: tap-DMA kernel everywhere                                                                     */
 #define MSI_NET_OPT_HALO_SKIP 9     /* bit i = layer i (graph order) does NOT take a halo kernel although it qualifies (tuning)          */
 #define MSI_NET_OPT_UNIFORM_SPLIT 10 /* s >= 2: layers with one to two 64x64 tiles per CU cut EVERY tile into s equal K-ranges (tuning; 0 = default split) */

@@ -1591,6 +1591,274 @@ conv_halo_kernel(const ConvParams p) {
 #endif
 }
 
+// ---- halo-patch convolution, stride 2 (fp32; r03) --------------------------------------------------------------------
+// The three stride-2 3x3 layers (conv1_2, conv2_2, conv3_3) were the weakest fp32 layers on the tap kernel (68-77 % of the MFMA
+// peak) and, reading their input through DMA, kept their producers' ln_apply launches alive (conv1_1's is the biggest of the
+// network).  A stride-2 tap (kh, kw) of output pixel (oh, ow) reads input (2 oh + kh - pad, 2 ow + kw - pad): taps of equal
+// (kh, kw) parity read ONE of the four parity planes of the input at unit stride, so per 32-channel group the kernel stages four
+// small patches in turn -- UNIT u = 2 (kh_min) + (kw_min), (4 + 1) x (16 + 1) pixels of plane (kh_min - pad, kw_min - pad) mod 2 --
+// and runs that unit's taps on it exactly like conv_halo_kernel runs its nine (immediate LDS offsets dy, dx in {0, 1}):
+//   unit 0: taps (0,0) (0,2) (2,0) (2,2)   unit 1: (0,1) (2,1)   unit 2: (1,0) (1,2)   unit 3: (1,1)      -- 9 k-steps per group,
+// so the weight ring's stage of a k-step is a literal as before (blob tap-major, row block tap * CH + group).  A unit's patch is
+// requested during the previous unit's first k-step (16-byte slots through registers: the producer's LayerNorm + ReLU applied on
+// the way when APPLY) and stored after its last; four patch swaps per group instead of one, each a fifth of the stride-1 patch.
+// pad = 0 (TF SAME with an even input: CoordNet) or 1 (wrap_pad(1, 1) + VALID: msi_train_net; rows -1 / H are zeros, columns wrap).
+struct HaloGeomS2 {
+  static constexpr int PW = 17, PH = 5, NPX = PW * PH;
+  static constexpr int PIX_BYTES = 144;
+  static constexpr int ROW_PITCH = ((PW * PIX_BYTES + 127) / 256) * 256 + 128;   // (256 n + 128: see HaloGeom)
+  static constexpr int A_BYTES = PH * ROW_PITCH;
+  static constexpr int B_STAGE = 64 * ROW_BYTES;
+  static constexpr int NSTG = 3;
+  static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
+  static constexpr int NLOAD = (NPX * 8 + 255) / 256;
+  static_assert(LDS_BYTES >= EPI_STAGE_BYTES / 2, "the epilogue's staging strips of a 64 x 64 fp32 tile (18 KB)");
+};
+
+template <int APPLY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+conv_halo_s2_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef HaloGeomS2 G;
+  constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
+  constexpr int MT = 1, NT = 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // ---- work decomposition: as conv_halo_kernel (tail split; K-ranges in whole 32-channel groups) ----
+  const int CH = p.cpt0;
+  int t, c0 = 0, c1 = CH, ks = 0, slot = 0;
+  {
+    const int bid = blockIdx.x;
+    if (bid < p.nb_main && p.split0 == 1) {
+      const int q = p.n_main >> 3, r = p.n_main & 7, xcd = bid & 7, local = bid >> 3;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    } else {
+      int sp, r, tbase;
+      unsigned mg;
+      if (bid < p.nb_main) { sp = p.split0; mg = p.mg_sp0; r = bid; tbase = 0; }
+      else { sp = p.split; mg = p.mg_sp; r = bid - p.nb_main; tbase = p.n_main; }
+      const int tl = (int)udiv_magic((unsigned)r, (unsigned)sp, mg);
+      ks = r - tl * sp;
+      t = tbase + tl;
+      c0 = (int)udiv_magic((unsigned)(ks * CH), (unsigned)sp, mg);
+      c1 = (int)udiv_magic((unsigned)((ks + 1) * CH), (unsigned)sp, mg);
+      slot = bid - (p.split0 == 1 ? p.nb_main : 0);
+    }
+  }
+  const bool full = (c0 == 0) & (c1 == CH);
+  int tile_m, tile_n, b;
+  {
+    int r = t;
+    const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
+    tile_m = r - q1 * p.tiles_m; r = q1;
+    const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
+    tile_n = r - q2 * p.tiles_n;
+    b = q2;
+  }
+  const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
+  const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;   // the tile of the OUTPUT grid
+  const int H = p.Hin, W = p.Win, C = p.C0;
+  // the first two weight k-steps (taps (0,0) and (0,2) of group c0) before anything else
+  const int S = p.ksteps;
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)S * p.npad * ROW_BYTES), 0x00020000);
+  const int drow = lane >> 3, dslot = lane & 7;
+  const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + drow) * ROW_BYTES + dslot * 16);
+#define MSI_B_ISSUE(c, tap, st)                                                                                        \
+  {                                                                                                                    \
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * ROW_BYTES;                                         \
+    const int soff_ = ((tap) * CH + (c)) * p.npad * ROW_BYTES;                                                         \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
+  }
+  MSI_B_ISSUE(c0, 0, 0)
+  MSI_B_ISSUE(c0, 2, 1)
+
+  // ---- per-lane patch slots of the four units: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 ----
+  unsigned voff[4][NLOAD], lds_a[NLOAD];
+  bool pok[4][NLOAD];
+  const int cslot = tid & 7;
+  const size_t in_bytes = (size_t)H * W * C * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in_bytes), 0, (int)in_bytes, 0x00020000);
+  v4f araw[NLOAD], g4, be4;
+  // (unit 0 first and its patch of group c0 requested at once: the other units' offsets are worked out under that round trip)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) {
+      const int pp = (tid + 256 * k) >> 3;
+      const int py = pp / PW, px = pp - py * PW;
+      if (u == 0) lds_a[k] = pp < NPX ? (unsigned)(py * G::ROW_PITCH + px * G::PIX_BYTES + cslot * 16) : 0xffffffffu;
+      const int ih = 2 * (oh0 + py) + (u >> 1) - p.pad_t;
+      int iw = 2 * (ow0 + px) + (u & 1) - p.pad_l;
+      if (p.wrap) iw = iw < 0 ? iw + W : (iw >= W ? iw - W : iw);
+      pok[u][k] = pp < NPX && ih >= 0 && ih < H && iw >= 0 && iw < W;
+      voff[u][k] = pok[u][k] ? __umul24((unsigned)(ih * W + iw), (unsigned)(C * 4)) + (unsigned)(cslot * 16) : OOB;
+    }
+    if (u == 0) {
+#pragma unroll
+      for (int k = 0; k < NLOAD; ++k)
+        araw[k] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[0][k], c0 * ROW_BYTES, 0));
+      if (APPLY) {
+        g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + c0 * 32 + cslot * 4);
+        be4 = *reinterpret_cast<const v4f *>(p.ln_beta + c0 * 32 + cslot * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  float inv_f = 1.f, mu_hi = 0.f, mu_lo = 0.f;
+  bool has_pad = false;                                   // wave-uniform: any of the wave's patch pixels (any unit) is padding
+  if (APPLY) {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bad |= (lds_a[k] != 0xffffffffu) && !pok[u][k];
+    has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
+  }
+  v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};   // the group's affine (the lane's four channels): set with unit 0
+  // patch of (group c, unit U) -> registers (+ gamma / beta of the lane's channels with unit 0)
+#define MSI_PATCH_LOAD(c, U)                                                                                           \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[U][k_], (c) * ROW_BYTES, 0)); \
+    if (APPLY && (U) == 0) {                                                                                           \
+      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 32 + cslot * 4);                                          \
+      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 32 + cslot * 4);                                          \
+    }                                                                                                                  \
+  }
+  // registers -> LDS patch, the producer's affine + ReLU applied (ln_apply_kernel's expressions: same bits)
+#define MSI_PATCH_STORE(U)                                                                                             \
+  {                                                                                                                    \
+    if (APPLY && (U) == 0) {                                                                                           \
+      s4 = inv_f * g4;                                                                                                 \
+      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};                          \
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
+      v4f y = araw[k_];                                                                                                \
+      if (APPLY) {                                                                                                     \
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
+        if (has_pad && !pok[U][k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */       \
+      }                                                                                                                \
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = y;                                    \
+    }                                                                                                                  \
+  }
+
+  // ---- MFMA side (as conv_halo_kernel: a wave owns two tile rows x 16 columns x 32 channels) ----
+  const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
+  const unsigned a_base = lds_base + (unsigned)((2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 64);
+  unsigned b_q[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    b_q[q] = lds_base + G::A_BYTES + (wn * 32 + frow) * ROW_BYTES + (((fh * 4 + q) ^ fswz) << 4);
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+
+  // k-step J = 0..8 of the current group: unit, tap and patch offsets are literals
+#define MSI_S2_TAP(J) ((J) == 0 ? 0 : (J) == 1 ? 2 : (J) == 2 ? 6 : (J) == 3 ? 8 : (J) == 4 ? 1 : (J) == 5 ? 7 : (J) == 6 ? 3 : (J) == 7 ? 5 : 4)
+#define MSI_S2_UNIT(J) ((J) < 4 ? 0 : (J) < 6 ? 1 : (J) < 8 ? 2 : 3)
+#define MSI_S2STEP(J)                                                                                                  \
+  {                                                                                                                    \
+    constexpr int TAP_ = MSI_S2_TAP(J), U_ = MSI_S2_UNIT(J), ST_ = (J) % 3;                                            \
+    constexpr int DY_ = (TAP_ / 3) >> 1, DX_ = (TAP_ % 3) >> 1;                                                        \
+    constexpr bool FIRST_ = (J) == 0 || (J) == 4 || (J) == 6 || (J) == 8, LAST_ = (J) == 3 || (J) == 5 || (J) == 7 || (J) == 8; \
+    constexpr int AOFF_ = DY_ * G::ROW_PITCH + DX_ * G::PIX_BYTES;                                                     \
+    const bool more_ = U_ < 3 || c + 1 < c1;               /* a unit follows this one */                               \
+    v4f a_[4], b_[4];                                                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
+      a_[q_] = q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 16>(a_base)                        \
+             : q_ == 2 ? lds_read128<AOFF_ + 32>(a_base) : lds_read128<AOFF_ + 48>(a_base);                            \
+      b_[q_] = lds_read128<ST_ * G::B_STAGE>(b_q[q_]);                                                                 \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
+      if (q_ == 0) wait_lgkm<6>(a_[0], b_[0]);                                                                         \
+      if (q_ == 1) wait_lgkm<4>(a_[1], b_[1]);                                                                         \
+      if (q_ == 2) wait_lgkm<2>(a_[2], b_[2]);                                                                         \
+      if (q_ == 3) wait_lgkm<0>(a_[3], b_[3]);                                                                         \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[0][0], 0, 0, 0);                        \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[0][0], 0, 0, 0);                        \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[0][0], 0, 0, 0);                        \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[0][0], 0, 0, 0);                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if (q_ == 0) {                                                                                                   \
+        if (FIRST_ && more_) {                                                                                         \
+          if (U_ < 3) MSI_PATCH_LOAD(c, (U_ + 1) & 3) else MSI_PATCH_LOAD(c + 1, 0)                                    \
+        }                                                                                                              \
+        /* k-step two ahead: (c, J + 2) or (c + 1, J - 7) */                                                           \
+        if ((J) + 2 < 9) { MSI_B_ISSUE(c, MSI_S2_TAP(((J) + 2) % 9), ((J) + 2) % 3) }                                  \
+        else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, MSI_S2_TAP(((J) + 2) % 9), ((J) + 2) % 3) }                          \
+      }                                                                                                                \
+    }                                                                                                                  \
+    {                                                                                                                  \
+      const bool issued_ = ((J) + 2 < 9) || (c + 1 < c1);                                                              \
+      /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */ \
+      if (FIRST_ && !LAST_ && more_) wait_vmcnt<2 + NLOAD>();                                                          \
+      else if (issued_) wait_vmcnt<2>();                                                                               \
+      else wait_vmcnt<0>();                                                                                            \
+    }                                                                                                                  \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    if (LAST_ && more_) {   /* every wave has read this unit's last tap: swap the patch */                             \
+      MSI_PATCH_STORE((U_ + 1) & 3)                                                                                    \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+      __builtin_amdgcn_s_barrier();                                                                                    \
+    }                                                                                                                  \
+  }
+
+  // ---- prologue: unit 0 of the first group ----
+  int c = c0;   // (unit 0's patch of group c0 is on its way)
+  if (APPLY) {
+    double *s_stat = reinterpret_cast<double *>(smem);
+    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
+    const double mu = s_stat[0];
+    inv_f = (float)s_stat[1];
+    mu_hi = (float)mu;
+    mu_lo = (float)(mu - (double)mu_hi);
+    __syncthreads();
+  }
+  wait_vmcnt<0>();
+  MSI_PATCH_STORE(0)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; c < c1; ++c) {
+    MSI_S2STEP(0) MSI_S2STEP(1) MSI_S2STEP(2) MSI_S2STEP(3) MSI_S2STEP(4) MSI_S2STEP(5) MSI_S2STEP(6) MSI_S2STEP(7) MSI_S2STEP(8)
+  }
+#undef MSI_S2STEP
+#undef MSI_S2_UNIT
+#undef MSI_S2_TAP
+#undef MSI_B_ISSUE
+#undef MSI_PATCH_STORE
+#undef MSI_PATCH_LOAD
+
+  // ---- epilogue: as conv_halo_kernel ----
+  if (!full) {
+    constexpr int SLAB = 64 * 64 * 4;
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)slot * (64 * 64)), 0, SLAB, 0x00020000);
+    if (p.tile_cnt == nullptr) {
+      dump_acc<MT, NT, 0>(acc, rsrc_p, tid);
+      return;
+    }
+    dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
+    const int nsp = t < p.n_main ? p.split0 : p.split;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *s_old = reinterpret_cast<int *>(smem);
+    if (tid == 0)
+      *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_old != nsp - 1) return;
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
+    sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+    __syncthreads();   // (s_old has been read by every thread before the strip below reuses LDS)
+  }
+  emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, smem);
+#endif
+}
+
 // ---- halo-patch kernel for the conv-transpose layers (4x4, stride 2, SAME; fp32) ----------------------------------
 // Output (2 mh + ph, 2 mw + pw) of parity class (ph, pw) reads input rows mh + {0, ph ? +1 : -1} and columns
 // mw + {0, pw ? +1 : -1} (tap_delta).  A workgroup owns a 4 x 16 tile of the INPUT grid x 64 channels for the TWO classes
@@ -3080,6 +3348,7 @@ struct LayerLaunch {
   int fuse_ln;      // head: applies its source's LayerNorm while loading (the source is not normalised in memory)
   int skip_apply;   // this layer's output is consumed raw by the head, or normalised by its consumer's launch: no ln_apply launch
   int halo;         // conv_halo_kernel (fp32) / conv_halo_bf16_kernel instead of conv_igemm_kernel
+  int halo_s2;      // ... conv_halo_s2_kernel: the stride-2 3x3 layers through parity-plane patches (fp32)
   int hbm, hbn;     // bf16 halo tile: 128 x 128 or 256 x 64
   int halo_t;       // convt_halo_kernel (conv-transpose, fp32): the two classes of one output-row parity per workgroup
   int halo_tb;      // convt_halo_bf16_kernel (conv-transpose, bf16): the two classes of one output-row parity per workgroup
@@ -3233,13 +3502,22 @@ int plan_layers(msi_net_plan *pl) {
     }
     // halo-patch kernel (conv_halo_kernel): stride-1 3x3 layers with one source, fp32, whole 4 x 16 tiles and 32-channel chunks
     const bool halo_ok = !((pl->opt[MSI_NET_OPT_HALO_SKIP] >> li) & 1);
-    Q.halo = halo_ok && pl->opt[MSI_NET_OPT_HALO] && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && Q.tile == TILE_64x64 &&
+    Q.halo = halo_ok && (pl->opt[MSI_NET_OPT_HALO] & 1) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && Q.tile == TILE_64x64 &&
              L.kind == MODE_CONV && L.stride == 1 && L.src1 < 0 && L.in_h % 4 == 0 && L.in_w % 16 == 0 && L.c0 % 32 == 0 &&
              (L.rate == 1 || L.rate == 2);
+    // stride-2 halo kernel (conv_halo_s2_kernel; HALO bit 2): the stride-2 3x3 layers, fp32, one source, whole 4 x 16 tiles of the
+    // OUTPUT grid, an even input (TF SAME then pads one row / column at the far side only) or wrap_pad(1, 1) + VALID
+    Q.halo_s2 = halo_ok && (pl->opt[MSI_NET_OPT_HALO] & 4) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && Q.tile == TILE_64x64 &&
+                L.kind == MODE_CONV && L.stride == 2 && L.rate == 1 && L.src1 < 0 && L.in_h % 2 == 0 && L.in_w % 2 == 0 &&
+                L.out_h % 4 == 0 && L.out_w % 16 == 0 && L.c0 % 32 == 0 && p.pad_t == p.pad_l && (p.pad_t == 0 || p.pad_t == 1) &&
+                // (measured at 640 x 320: conv1_2 / conv2_2 gain their producers' ln_apply launches, -22 / -11 us for +4 / +3 us of
+                // kernel time; conv3_3, 400 tiles cut into K-ranges of two groups, loses 11 us to save 6: tap kernel)
+                (long)(L.out_h / 4) * (L.out_w / 16) * (L.cout / 64) * desc->batch >= 3L * pl->num_cus;
+    if (Q.halo_s2) Q.halo = 1;
     int max_split = MAX_SPLIT;
     // bf16 halo-patch kernel (conv_halo_bf16_kernel): the same layers with 64-channel chunks and whole
     // 8 x 16 pixel x 128 channel or 16 x 16 x 64 tiles
-    if (halo_ok && pl->opt[MSI_NET_OPT_HALO] && bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.kind == MODE_CONV && L.stride == 1 && L.src1 < 0 && L.in_w % 16 == 0 &&
+    if (halo_ok && (pl->opt[MSI_NET_OPT_HALO] & 1) && bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.kind == MODE_CONV && L.stride == 1 && L.src1 < 0 && L.in_w % 16 == 0 &&
         L.c0 % 64 == 0 && bigmode != 0) {
       if (L.cout % 128 == 0 && L.in_h % 8 == 0 && (L.rate == 1 || L.rate == 2)) { Q.halo = 1; Q.hbm = 128; Q.hbn = 128; }
       else if (L.cout == 64 && L.in_h % 16 == 0 && L.rate == 1) { Q.halo = 1; Q.hbm = 256; Q.hbn = 64; }
@@ -3264,7 +3542,7 @@ int plan_layers(msi_net_plan *pl) {
       if (Q.halo_tb) { Q.halo = 1; BM = Q.hbm; BN = Q.hbn; max_split = 1; p.nclass = 2; }
     }
     if (Q.halo) {
-      p.halo_tx = L.in_w / 16;
+      p.halo_tx = (Q.halo_s2 ? L.out_w : L.in_w) / 16;
       p.halo_xor = bf16 ? 0 : 8;
       p.mg_htx = p.halo_tx == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)p.halo_tx);
       if (!Q.halo_t && L.cpt0 < max_split) max_split = L.cpt0;      // K-ranges are whole chunks (bf16: whole tiles only)
@@ -3646,7 +3924,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_HEAD_FUSE_LN] = 1;
   pl->opt[MSI_NET_OPT_NUM_CUS] = pl->num_cus;
   pl->opt[MSI_NET_OPT_APPLY_AHEAD] = 0;   // measured r02_h: correct and bit-identical, but 2.69 vs 2.56 ms per network
-  pl->opt[MSI_NET_OPT_HALO] = 1;   // (bit 1, the fp32 conv-transpose halo kernel: measured slower than the tap kernel + ln_apply, see the kernel)
+  pl->opt[MSI_NET_OPT_HALO] = 5;   // bits 0 and 2 (bit 1, the fp32 conv-transpose halo kernel: measured slower than the tap kernel + ln_apply, see the kernel)
   pl->opt[MSI_NET_OPT_F32_TILE] = 0;
   pl->opt[MSI_NET_OPT_F32_TILE_MASK] = 0;
   pl->opt[MSI_NET_OPT_UNIFORM_SPLIT] = 0;
@@ -3670,7 +3948,7 @@ int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value) {
     plan->num_cus = value;
   }
   if (option == MSI_NET_OPT_BIGTILE) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: bigtile %d", value);
-  if (option == MSI_NET_OPT_HALO) MSI_REQUIRE(value >= 0 && value <= 3, "net_plan_set_option: halo %d (bit 0 conv, bit 1 conv-transpose)", value);
+  if (option == MSI_NET_OPT_HALO) MSI_REQUIRE(value >= 0 && value <= 7, "net_plan_set_option: halo %d (bit 0 conv, bit 1 conv-transpose, bit 2 stride-2 conv)", value);
   if (option == MSI_NET_OPT_TAILSPLIT) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: tailsplit %d", value);
   if (option == MSI_NET_OPT_F32_TILE) MSI_REQUIRE(value >= 0 && value <= 2, "net_plan_set_option: f32 tile %d", value);
   if (option == MSI_NET_OPT_BF16_WAVES) MSI_REQUIRE(value == 4 || value == 8, "net_plan_set_option: bf16 waves %d (4 or 8)", value);
@@ -3926,7 +4204,10 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
         p.ln_beta = packed + S.beta_off;
       }
       const dim3 grid(Q.nblocks), block(256);
-      if (L.rate == 1) {
+      if (Q.halo_s2) {
+        if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_kernel<1>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
+        else hipLaunchKernelGGL((conv_halo_s2_kernel<0>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
+      } else if (L.rate == 1) {
         if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_kernel<1, 1>), grid, block, HaloGeom<1>::LDS_BYTES, stream, p);
         else hipLaunchKernelGGL((conv_halo_kernel<1, 0>), grid, block, HaloGeom<1>::LDS_BYTES, stream, p);
       } else {
