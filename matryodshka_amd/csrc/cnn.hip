@@ -1299,8 +1299,11 @@ _Pragma("unroll")                                                               
     const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(p.partial + (size_t)(slot - ks) * (BM * BN)), 0, nsp * SLAB, 0x00020000);
     sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+    __syncthreads();   // (every thread has read s_old before the epilogue's strips reuse LDS)
   }
-  emit_tile<BM, BN, MODE, (BF16 && MODE != MODE_HEAD) ? 1 : 0>(p, acc, tile_m, tile_n, cls, b, tid, cbv, CB_PRE && p.coord_bias != nullptr);
+  // (LDS is free: the k-loop's last barrier is behind; NSTAGE >= 2 stages hold the strips of every instantiation)
+  static_assert((size_t)2 * (BM + BN) * ROW_BYTES >= (size_t)4 * (BM / 64) * 32 * ((BN / 64) * 32 * (BF16 ? 2 : 4) + 16), "staging strips");
+  emit_tile<BM, BN, MODE, (BF16 && MODE != MODE_HEAD) ? 1 : 0>(p, acc, tile_m, tile_n, cls, b, tid, cbv, CB_PRE && p.coord_bias != nullptr, smem);
 #ifdef MSI_CONV_TIMING
   stamp();
 #endif
@@ -1583,8 +1586,9 @@ conv_halo_kernel(const ConvParams p) {
     if (*s_old != nsp - 1) return;
     const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
     sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+    __syncthreads();   // (every thread has read s_old before the epilogue's strips reuse LDS)
   }
-  emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, cbv, p.coord_bias != nullptr);
+  emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, cbv, p.coord_bias != nullptr, smem);
 #ifdef MSI_CONV_TIMING
   stamp();
 #endif
