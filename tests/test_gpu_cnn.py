@@ -226,26 +226,35 @@ def test_fused_head_assembly_is_bit_identical(env, coord, b, h, w, d, ngf):
     assert torch.equal(p2, pred)
 
 
-@pytest.mark.parametrize("halo_opt", [1, 3])
+@pytest.mark.parametrize("halo_opt", [1, 3, 5, 7])
 @pytest.mark.parametrize("coord,b,h,w,cin,nout,ngf", [(True, 1, 160, 320, 96, 32, 64), (False, 2, 32, 64, 32, 8, 32),
-                                                     (True, 2, 16, 48, 64, 16, 32), (True, 1, 320, 640, 192, 64, 64)])
+                                                     (True, 2, 16, 48, 64, 16, 32), (True, 1, 320, 640, 192, 64, 64),
+                                                     (False, 4, 128, 256, 48, 16, 64)])
 def test_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, w, cin, nout, ngf, halo_opt):
     """conv_halo_kernel (plan option HALO, default on: stride-1 3x3 fp32 layers stage one LDS-stationary halo patch per
     input chunk and apply the producer's LayerNorm on the way) against the tap-DMA kernel: same products, chunk-major
     instead of tap-major summation order -> equal to fp32 round-off; bitwise deterministic; K-ranges at chunk boundaries
-    (the first and last shapes split tiles); SAME-zero and wrap padding; rate-2 layers."""
+    (the first and last shapes split tiles); SAME-zero and wrap padding; rate-2 layers.
+    Bit 2 (5 = the default, 7): the stride-2 layers on conv_halo_s2_kernel (parity-plane patches; TF SAME on an even input = one
+    padded row / column at the far side, or wrap_pad(1, 1) + VALID) where the grid is large enough -- their producers conv1_1 /
+    conv2_1 (/ conv3_2) are then never normalised in memory either."""
     torch, MSI, nets, N, onets = env
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=29, randomize_affine=True)
     x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
     halo = MSI(weights=weights, coord_net=coord)
-    halo.net_options[N.NET_OPT_HALO] = halo_opt      # 1: the default; 3: + convt_halo_kernel on the conv-transposes (measured slower: opt-in)
+    halo.net_options[N.NET_OPT_HALO] = halo_opt      # 5: the default; bit 1: + convt_halo_kernel on the conv-transposes (measured slower: opt-in)
     tap = MSI(weights=weights, coord_net=coord)
     tap.net_options[N.NET_OPT_HALO] = 0
     p1, p0 = halo.run_net(x, nout, ngf), tap.run_net(x, nout, ngf)
     plan = halo._plan(b, h, w, cin, nout, ngf)
     raw_layers = [i for i in range(17) if N.lib.msi_net_plan_layer_is_normalized(plan.handle, i) == 0]
     if h % 32 == 0 and w % 128 == 0:                 # every level tiles into 4 x 16 patches:
-        assert len(raw_layers) >= (8 if halo_opt == 1 or not coord else 14), raw_layers   # (3: everything but the stride-2 layers' sources)
+        assert len(raw_layers) >= (8 if not (halo_opt & 2) or not coord else 14), raw_layers   # (bit 1: everything but the stride-2 layers' sources)
+    s2_layers = [i for i, (oh, ow, co) in enumerate([(h // 2, w // 2, 2 * ngf), (h // 4, w // 4, 4 * ngf), (h // 8, w // 8, 8 * ngf)])
+                 if oh % 4 == 0 and ow % 16 == 0 and co % 64 == 0 and (oh // 4) * (ow // 16) * (co // 64) * b >= 3 * 256]
+    if halo_opt & 4:
+        for i in s2_layers:                          # conv1_1 / conv2_1 / conv3_2 feed conv1_2 / conv2_2 / conv3_3 only
+            assert [0, 2, 5][i] in raw_layers, (i, raw_layers)
     assert float((p1 - p0).abs().max()) <= 2e-5
     for _ in range(5):
         assert torch.equal(halo.run_net(x, nout, ngf), p1)
