@@ -286,14 +286,25 @@ __device__ __forceinline__ void ln_atomic_add(long long *dst, double x_scaled, i
 // STEPS: DPP reductions (below), and (r03) 1 / sqrt as v_rsq_f64 + two Newton steps -- 8 dependent fp64 operations, within 2 ulp of
 // the ~50-instruction sqrt + division sequence and far inside the float it is rounded to.  (The 64 shards through two LDS integer
 // atomics instead of the DPP trees: measured, the prologue of conv3_2 went from 9.8 k to 27 k cycles.)
-__device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n, const double *scl, int *status, double *s_stat, int tid) {
+// (ln_shard_load + ln_mean_inv_pre: the same with the lane's shard requested earlier -- at kernel entry, under the index arithmetic)
+struct LnShard { long long w0, w1; };
+__device__ __forceinline__ LnShard ln_shard_load(const long long *sums, int tid) {
+  LnShard r = {0, 0};
+  if (tid < 64) {
+    const long long *s = sums + (size_t)tid * LN_WORDS;
+    r.w0 = s[0]; r.w1 = s[1];
+  }
+  return r;
+}
+template <bool PRE>
+__device__ __forceinline__ void ln_mean_inv_impl(const long long *sums, LnShard pre, double inv_n, const double *scl, int *status, double *s_stat, int tid) {
   static_assert(LN_SHARDS == 64, "one shard per lane of wave 0");
   const double inv_s1 = scl[2], inv_s2 = scl[3];   // (uniform address: scalar loads, issued before the shards')
   if (tid < 64) {
     // the 64 shards as doubles (|shard| < 2^63: rounding at 2^-53 relative, far below the 2^-24 / 2^-16 units) through
     // the DPP reduction: no dependent trips through the LDS crossbar at the head of every consumer workgroup / ln_apply block
     const long long *s = sums + (size_t)tid * LN_WORDS;
-    const double h1 = wave_sum_f64((double)s[0]), h2 = wave_sum_f64((double)s[1]);
+    const double h1 = wave_sum_f64((double)(PRE ? pre.w0 : s[0])), h2 = wave_sum_f64((double)(PRE ? pre.w1 : s[1]));
     if (tid == 0) {
       const double S1 = h1 * inv_s1, S2 = h2 * inv_s2;
       // resolution: every wave's share is rounded to one unit, so the total carries ~0.5 sqrt(waves) units of rounding
@@ -312,6 +323,12 @@ __device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n,
     }
   }
   __syncthreads();
+}
+__device__ __forceinline__ void ln_mean_inv(const long long *sums, double inv_n, const double *scl, int *status, double *s_stat, int tid) {
+  ln_mean_inv_impl<false>(sums, LnShard{0, 0}, inv_n, scl, status, s_stat, tid);
+}
+__device__ __forceinline__ void ln_mean_inv_pre(LnShard pre, double inv_n, const double *scl, int *status, double *s_stat, int tid) {
+  ln_mean_inv_impl<true>(nullptr, pre, inv_n, scl, status, s_stat, tid);
 }
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -550,7 +567,8 @@ __device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&ac
 
 template <int BM, int BN, int MODE, bool INTERIOR, int RAW16, int WR>
 __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc)[BM / (32 * WR)][BN / 64], int tile_m,
-                                               int tile_n, int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre, char *stage) {
+                                               int tile_n, int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre, char *stage,
+                                               float raw_mul_pre) {
   constexpr int MT = BM / (32 * WR), NT = BN / 64;   // WR x 2 waves, 32 MT x 32 NT each
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5;
   const int ph = cls >> 1, pw = cls & 1;
@@ -563,8 +581,10 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
   // (scalar loads at the head of the epilogue: inside the lane-0 branch below they would be vector loads with a memory
   // round trip between the wave reduction and the atomics, at the end of every tile)
   double scl_s1 = 0.0, scl_s2 = 0.0;
-  if (want_stats || RAW16) { scl_s1 = p.ln_scl[0]; scl_s2 = p.ln_scl[1]; }
-  const float raw_mul = RAW16 ? (float)(scl_s1 * (1.0 / 16777216.0)) : 1.f;   // 2^-e
+  // (a whole RAW16 tile needs nothing but 2^-e -- its sums are taken in the scaled unit -- and the caller may have it already)
+  const bool have_pre = INTERIOR && RAW16 && MODE != MODE_HEAD && raw_mul_pre > 0.f;
+  if ((want_stats || RAW16) && !have_pre) { scl_s1 = p.ln_scl[0]; scl_s2 = p.ln_scl[1]; }
+  const float raw_mul = have_pre ? raw_mul_pre : RAW16 ? (float)(scl_s1 * (1.0 / 16777216.0)) : 1.f;   // 2^-e
   constexpr int YSZ = RAW16 ? 2 : 4;                                          // bytes per stored element
   float s1 = 0.f, s2 = 0.f, cnt = 0.f;
   if constexpr (INTERIOR && MODE != MODE_HEAD) {
@@ -677,17 +697,18 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
 
 template <int BM, int BN, int MODE, int RAW16 = 0, int WR = 2>
 __device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / (32 * WR)][BN / 64], int tile_m, int tile_n,
-                                          int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre, char *stage = nullptr) {
+                                          int cls, int b, int tid, const v4f (&cb_pre)[4], bool use_pre, char *stage = nullptr,
+                                          float raw_mul_pre = 0.f) {
   const bool interior = !(MODE == MODE_CONVT && p.wrap != 0) && (tile_m + 1) * BM <= p.Mh * p.Mw &&
                         (tile_n + 1) * BN <= p.Cout && (p.Cout & 3) == 0;
-  if (interior) emit_tile_impl<BM, BN, MODE, true, RAW16, WR>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, stage);
-  else emit_tile_impl<BM, BN, MODE, false, RAW16, WR>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, nullptr);
+  if (interior) emit_tile_impl<BM, BN, MODE, true, RAW16, WR>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, stage, raw_mul_pre);
+  else emit_tile_impl<BM, BN, MODE, false, RAW16, WR>(p, acc, tile_m, tile_n, cls, b, tid, cb_pre, use_pre, nullptr, 0.f);
 }
 template <int BM, int BN, int MODE, int RAW16 = 0, int WR = 2>
 __device__ __forceinline__ void emit_tile(const ConvParams &p, f32x16 (&acc)[BM / (32 * WR)][BN / 64], int tile_m, int tile_n,
-                                          int cls, int b, int tid, char *stage = nullptr) {
+                                          int cls, int b, int tid, char *stage = nullptr, float raw_mul_pre = 0.f) {
   const v4f none[4] = {};
-  emit_tile<BM, BN, MODE, RAW16, WR>(p, acc, tile_m, tile_n, cls, b, tid, none, false, stage);
+  emit_tile<BM, BN, MODE, RAW16, WR>(p, acc, tile_m, tile_n, cls, b, tid, none, false, stage, raw_mul_pre);
 }
 
 // The CoordNet table values of this lane's pixel and 16 channels (64x64 tile, transposed accumulator layout), requested
@@ -2214,6 +2235,11 @@ conv_halo_bf16_kernel(const ConvParams p) {
     tile_n = r - q2 * p.tiles_n;
     b = q2;
   }
+  // (requested here, used after the index arithmetic and the patch requests: the lane's shard of the source's LayerNorm sums, and
+  // the layer's own window exponent for the epilogue -- neither round trip is then waited for where it is needed)
+  LnShard shard = {0, 0};
+  if (APPLY) shard = ln_shard_load(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, tid);
+  const float raw_mul_pre = (float)(p.ln_scl[0] * (1.0 / 16777216.0));   // 2^-e (scalar load)
   const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
   const int oh0 = tyi * G::TH, ow0 = (tile_m - tyi * p.halo_tx) * 16;
   const int H = p.Hin, W = p.Win, C = p.C0;
@@ -2396,7 +2422,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
     // (gamma / beta of the thread's <= 2 channels are requested BEFORE the statistics' round trip, not after it)
     const int ch0 = tid < C ? tid : 0, ch1 = tid + NTHR < C ? tid + NTHR : 0;
     const float g0 = p.ln_gamma[ch0], b0 = p.ln_beta[ch0], g1 = p.ln_gamma[ch1], b1 = p.ln_beta[ch1];
-    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
+    ln_mean_inv_pre(shard, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
     MSI_STAMP(8)
     const double mu = s_stat[0];
     const float inv_f = (float)s_stat[1], mu_hi = (float)mu, mu_lo = (float)(mu - (double)mu_hi);
@@ -2439,7 +2465,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
 #ifdef MSI_CONV_TIMING
   const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
-  emit_tile<BM, BN, MODE_CONV, 1, WR>(p, acc, tile_m, tile_n, 0, b, tid, smem);   // (the k-loop ended with a barrier: LDS is free)
+  emit_tile<BM, BN, MODE_CONV, 1, WR>(p, acc, tile_m, tile_n, 0, b, tid, smem, raw_mul_pre);   // (the k-loop ended with a barrier: LDS is free)
 #ifdef MSI_CONV_TIMING
   if (p.dbg && tid == 0) {
     unsigned long long *o = p.dbg + (size_t)blockIdx.x * 24;
