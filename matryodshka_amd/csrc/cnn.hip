@@ -2477,6 +2477,272 @@ conv_halo_bf16_kernel(const ConvParams p) {
 #endif
 }
 
+// ---- halo-patch kernel, stride 2, bf16 operands (r03) ----------------------------------------------------------------
+// conv_halo_s2_kernel's parity-plane units (four (8 + 1) x (16 + 1)-pixel patches per 64-channel group, 4 + 2 + 2 + 1 taps) with
+// conv_halo_bf16_kernel's machinery: 8 x 16 output pixels x 128 channels per workgroup, NW waves of 32 MT x 64 channels, the patch
+// staged through registers from the bf16 operand copy or (APPLY) from the producer's raw fp16 output with its LayerNorm + ReLU +
+// bf16 rounding on the way (per-channel affine table in LDS), weights through the three-stage DMA ring, whole tiles only.  The
+// bf16 tap kernel ran these three layers at 19-29 % of the peak AND kept the ln_apply launches of conv1_1 / conv2_1 / conv3_2 alive
+// (1.5 GB of HBM round trips per 16 frames).
+struct HaloGeomBS2 {
+  static constexpr int TH = 8;
+  static constexpr int PW = 17, PH = TH + 1, NPX = PW * PH;
+  static constexpr int PIX_BYTES = 144;
+  static constexpr int ROW_PITCH = (PW * PIX_BYTES + 255) / 256 * 256;   // (a multiple of 256: see HaloGeomB)
+  static constexpr int A_BYTES = PH * ROW_PITCH;
+  static constexpr int B_STAGE = 128 * ROW_BYTES;
+  static constexpr int NSTG = 3;
+  static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
+};
+
+template <int APPLY, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2)))
+conv_halo_bf16_s2_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef HaloGeomBS2 G;
+  constexpr int BM = 128, BN = 128;
+  constexpr int NTHR = 64 * NW, WR = NW / 2;                   // NW = 4 or 8 waves in WR x 2: a wave owns 32 MT x 32 NT of the tile
+  constexpr int PW = G::PW, NPX = G::NPX, NLOAD = (NPX * 8 + NTHR - 1) / NTHR, MT = BM / (32 * WR), NT = BN / 64;
+  constexpr int NSTG = G::NSTG, PD = NSTG - 1, BI = BN / (8 * NW);   // BI: weight DMA instructions per wave and k-step (8 rows each)
+  static_assert(BI == 1 || BI == 2 || BI == 4, "weight rows per wave");
+  constexpr int NRAW = NLOAD;                                   // 16-byte patch loads per thread and chunk (bf16 copy, or fp16 raw)
+  constexpr int NPL = NRAW;                                     // VMEM operations of a patch load
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int CH = p.cpt0;                                  // 64-channel chunks of the input
+  int t;
+  {   // XCD x works through the x-th eighth of the tiles (M tiles fastest: neighbours share halo rows and weights in its L2)
+    const int bid = blockIdx.x;
+    const int q = p.ntiles >> 3, r = p.ntiles & 7, xcd = bid & 7, local = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  int tile_m, tile_n, b;
+  {
+    int r = t;
+    const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
+    tile_m = r - q1 * p.tiles_m; r = q1;
+    const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
+    tile_n = r - q2 * p.tiles_n;
+    b = q2;
+  }
+  const float raw_mul_pre = (float)(p.ln_scl[0] * (1.0 / 16777216.0));   // 2^-e (scalar load)
+  const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
+  const int oh0 = tyi * G::TH, ow0 = (tile_m - tyi * p.halo_tx) * 16;
+  const int H = p.Hin, W = p.Win, C = p.C0;
+  constexpr int ESZ = 2;                                  // bytes per source element: the bf16 operand copy, or (APPLY) the producer's fp16 raw output
+
+  // ---- per-lane patch slots: e = tid + 256 k -> patch pixel e / 8, 8-channel slot e % 8 (= tid % 8) ----
+  unsigned voff[4][NLOAD], lds_a[NLOAD];
+  bool pok[4][NLOAD];
+  const int cslot = tid & 7;
+  constexpr unsigned OOB = 0xfffffff0u;
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const int pp = (tid + NTHR * k) >> 3;
+    const int py = pp / PW, px = pp - py * PW;
+    lds_a[k] = pp < NPX ? (unsigned)(py * G::ROW_PITCH + px * G::PIX_BYTES + cslot * 16) : 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // unit u: the parity plane of taps kh = (u >> 1) (+ 2), kw = (u & 1) (+ 2)
+      const int ih = 2 * (oh0 + py) + (u >> 1) - p.pad_t;
+      int iw = 2 * (ow0 + px) + (u & 1) - p.pad_l;
+      if (p.wrap) iw = iw < 0 ? iw + W : (iw >= W ? iw - W : iw);
+      pok[u][k] = pp < NPX && ih >= 0 && ih < H && iw >= 0 && iw < W;
+      voff[u][k] = pok[u][k] ? (unsigned)(ih * W + iw) * (unsigned)(C * ESZ) + (unsigned)(cslot * 8 * ESZ) : OOB;
+    }
+  }
+  const size_t in_bytes = (size_t)H * W * C * ESZ;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in_bytes), 0, (int)(in_bytes < 0xfffffff0u ? in_bytes : 0xfffffff0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)p.ksteps * p.npad * ROW_BYTES), 0x00020000);
+  const int drow = lane >> 3, dslot = lane & 7;
+  const unsigned b_voff = (unsigned)((tile_n * BN + wave * (BN / NW) + drow) * ROW_BYTES + dslot * 16);
+
+  int c_ld = 0;                                           // chunk of the patch held in araw
+  bool has_pad = false;
+  if (APPLY) {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bad |= (lds_a[k] != 0xffffffffu) && !pok[u][k];
+    has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
+  }
+  v4f araw[NRAW];   // (eight bf16 operands, or eight fp16 raw values, per 16-byte slot)
+  float *s_tab = reinterpret_cast<float *>(smem + G::LDS_BYTES);   // APPLY: scale[C] | shift[C] of the source's LayerNorm
+#define MSI_PATCH_LOAD(c, U)                                                                                           \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[U][k_], (c) * 128, 0)); \
+    if (APPLY) c_ld = (c);                                                                                             \
+  }
+#define MSI_PATCH_STORE(U)                                                                                             \
+  {                                                                                                                    \
+    v4f s_[2], t_[2];                                                                                                  \
+    if (APPLY) {   /* the thread's eight channels of chunk c_ld: four ds_read_b128 from the table built in the prologue */ \
+      const float *sp_ = s_tab + c_ld * 64 + cslot * 8;                                                                \
+      s_[0] = *reinterpret_cast<const v4f *>(sp_); s_[1] = *reinterpret_cast<const v4f *>(sp_ + 4);                    \
+      t_[0] = *reinterpret_cast<const v4f *>(sp_ + C); t_[1] = *reinterpret_cast<const v4f *>(sp_ + C + 4);            \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
+      v4f o_;                                                                                                          \
+      if (APPLY) {                                                                                                     \
+        const v4f z_ = {0.f, 0.f, 0.f, 0.f};                                                                           \
+        typedef _Float16 h8_t __attribute__((ext_vector_type(8)));                                                     \
+        const h8_t hx_ = __builtin_bit_cast(h8_t, araw[k_]);   /* eight fp16 raw values x * 2^-e (s_ carries 2^e) */    \
+        const v4f x0_ = {(float)hx_[0], (float)hx_[1], (float)hx_[2], (float)hx_[3]};                                  \
+        const v4f x1_ = {(float)hx_[4], (float)hx_[5], (float)hx_[6], (float)hx_[7]};                                  \
+        v4f y0 = __builtin_elementwise_max(__builtin_elementwise_fma(x0_, s_[0], t_[0]), z_);                          \
+        v4f y1 = __builtin_elementwise_max(__builtin_elementwise_fma(x1_, s_[1], t_[1]), z_);                          \
+        if (has_pad && !pok[U][k_]) { y0 = z_; y1 = z_; }   /* padding is zero AFTER the normalisation */                 \
+        unsigned w0, w1, w2, w3;                                                                                       \
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w0) : "v"(y0.x), "v"(y0.y));                                         \
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1) : "v"(y0.z), "v"(y0.w));                                         \
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2) : "v"(y1.x), "v"(y1.y));                                         \
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w3) : "v"(y1.z), "v"(y1.w));                                         \
+        o_ = __builtin_bit_cast(v4f, u32x4_t{w0, w1, w2, w3});                                                         \
+      } else {                                                                                                         \
+        o_ = araw[k_];                                                                                                 \
+      }                                                                                                                \
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = o_;                                   \
+    }                                                                                                                  \
+  }
+  // weights of k-step (chunk c, tap) -> ring stage st (run-time); the packed blob is tap-major: row block tap * CH + c
+#define MSI_B_ISSUE(c, tap, st)                                                                                        \
+  {                                                                                                                    \
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * (BN / NW) * ROW_BYTES;                                  \
+    const int soff_ = ((tap) * CH + (c)) * p.npad * ROW_BYTES;                                                         \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
+    if (BI >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0); \
+    if (BI == 4) {                                                                                                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 16 * ROW_BYTES, 0);         \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 24 * ROW_BYTES, 0);         \
+    }                                                                                                                  \
+  }
+
+  // ---- MFMA side ----
+  const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
+  const unsigned a_base = lds_base + (unsigned)((wm * (MT * 2) + (frow >> 4)) * G::ROW_PITCH + (frow & 15) * G::PIX_BYTES + fh * 16);
+  unsigned b_q[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    b_q[q] = lds_base + G::A_BYTES + (wn * (NT * 32) + frow) * ROW_BYTES + (((2 * q + fh) ^ fswz) << 4);
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+  // one k-step = tap TAP of the current chunk with the weights in ring stage st.  All 4 (MT + NT) fragments are fetched
+  // first; quarter q waits for its own; the next chunk's patch loads (tap 0) and the DMA of the k-step PD ahead are issued
+  // after the first quarter.  Before the closing barrier the NEXT k-step's weights must have landed: with PD = 2 they
+  // were issued one k-step ago, and only what this k-step issued may still be in flight (in-order return).
+#define MSI_HQ(Q)                                                                                                      \
+  wait_lgkm_frag<(3 - (Q)) * (MT + NT), MT, NT>(fa_[Q], fb_[Q]);                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                                  \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb_[Q][j_]),                    \
+                                                            __builtin_bit_cast(bf16x8, fa_[Q][i_]), acc[i_][j_], 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);
+#define MSI_S2_TAP(J) ((J) == 0 ? 0 : (J) == 1 ? 2 : (J) == 2 ? 6 : (J) == 3 ? 8 : (J) == 4 ? 1 : (J) == 5 ? 7 : (J) == 6 ? 3 : (J) == 7 ? 5 : 4)
+#define MSI_S2_UNIT(J) ((J) < 4 ? 0 : (J) < 6 ? 1 : (J) < 8 ? 2 : 3)
+  // k-step J = 0..8 of the current 64-channel group: unit, tap and patch offsets are literals (conv_halo_s2_kernel's order)
+#define MSI_S2STEP(J)                                                                                                  \
+  {                                                                                                                    \
+    constexpr int TAP_ = MSI_S2_TAP(J), U_ = MSI_S2_UNIT(J);                                                           \
+    constexpr int DY_ = (TAP_ / 3) >> 1, DX_ = (TAP_ % 3) >> 1;                                                        \
+    constexpr bool FIRST_ = (J) == 0 || (J) == 4 || (J) == 6 || (J) == 8, LAST_ = (J) == 3 || (J) == 5 || (J) == 7 || (J) == 8; \
+    constexpr int AOFF_ = DY_ * G::ROW_PITCH + DX_ * G::PIX_BYTES;                                                     \
+    constexpr int AROW_ = 2 * G::ROW_PITCH;   /* next 32-pixel block: two patch rows down */                           \
+    const bool more_ = U_ < 3 || c + 1 < c1;               /* a unit follows this one */                               \
+    v4f fa_[4][MT], fb_[4][NT];                                                                                        \
+    const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
+      const unsigned ba_ = b_q[q_] + bst_;                                                                             \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                                \
+        fa_[q_][i_] = i_ == 0 ? (q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 32>(a_base)      \
+                                : q_ == 2 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base))         \
+                              : (q_ == 0 ? lds_read128<AOFF_ + AROW_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + AROW_ + 32>(a_base) \
+                                : q_ == 2 ? lds_read128<AOFF_ + AROW_ + 64>(a_base) : lds_read128<AOFF_ + AROW_ + 96>(a_base)); \
+      _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                                \
+        fb_[q_][j_] = j_ == 0 ? lds_read128<0>(ba_) : lds_read128<32 * ROW_BYTES>(ba_);                                \
+    }                                                                                                                  \
+    MSI_HQ(0)                                                                                                          \
+    bool issued_;                                                                                                      \
+    {                                                                                                                  \
+      if (FIRST_ && more_) {                                                                                           \
+        if (U_ < 3) MSI_PATCH_LOAD(c, (U_ + 1) & 3) else MSI_PATCH_LOAD(c + 1, 0)                                      \
+      }                                                                                                                \
+      int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                         \
+      issued_ = ((J) + PD < 9) || (c + 1 < c1);                                                                        \
+      if ((J) + PD < 9) { MSI_B_ISSUE(c, MSI_S2_TAP(((J) + PD) % 9), sn_) }                                            \
+      else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, MSI_S2_TAP(((J) + PD) % 9), sn_) }                                     \
+    }                                                                                                                  \
+    MSI_HQ(1) MSI_HQ(2) MSI_HQ(3)                                                                                      \
+    /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */ \
+    if (FIRST_ && !LAST_ && more_) wait_vmcnt<BI + NPL>();                                                             \
+    else if (issued_) wait_vmcnt<BI>();                                                                                \
+    else wait_vmcnt<0>();                                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
+    if (LAST_ && more_) {   /* every wave has read this unit's last tap: swap the patch */                             \
+      MSI_PATCH_STORE((U_ + 1) & 3)                                                                                    \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+      __builtin_amdgcn_s_barrier();                                                                                    \
+    }                                                                                                                  \
+  }
+
+  // ---- prologue: unit 0 of the first group, the first two weight k-steps (taps (0,0), (0,2)) ----
+  static_assert(PD == 2 && MT <= 2, "three-stage weight ring; one or two 32-pixel blocks per wave");
+  const int c0 = 0, c1 = CH;
+  int c = c0, st = 0;
+  MSI_PATCH_LOAD(c0, 0)
+  MSI_B_ISSUE(c0, MSI_S2_TAP(0), 0)
+  MSI_B_ISSUE(c0, MSI_S2_TAP(1), 1)
+  if (APPLY) {
+    // the affine of the source's LayerNorm for every input channel, once per workgroup (as conv_halo_bf16_kernel)
+    double *s_stat = reinterpret_cast<double *>(smem);
+    const int ch0 = tid < C ? tid : 0, ch1 = tid + NTHR < C ? tid + NTHR : 0;
+    const float g0 = p.ln_gamma[ch0], b0 = p.ln_beta[ch0], g1 = p.ln_gamma[ch1], b1 = p.ln_beta[ch1];
+    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
+    const double mu = s_stat[0];
+    const float inv_f = (float)s_stat[1], mu_hi = (float)mu, mu_lo = (float)(mu - (double)mu_hi);
+    const float up_f = (float)(p.ln_scl_src[2] * 16777216.0);   // 2^e of the source layer's window
+    __syncthreads();
+    if (tid < C) {
+      const float su = inv_f * g0;
+      s_tab[C + tid] = __builtin_fmaf(-mu_lo, su, __builtin_fmaf(-mu_hi, su, b0));
+      s_tab[tid] = up_f * su;
+    }
+    if (tid + NTHR < C) {
+      const float su = inv_f * g1;
+      s_tab[C + tid + NTHR] = __builtin_fmaf(-mu_lo, su, __builtin_fmaf(-mu_hi, su, b1));
+      s_tab[tid + NTHR] = up_f * su;
+    }
+    __syncthreads();
+  }
+  wait_vmcnt<0>();
+  MSI_PATCH_STORE(0)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; c < c1; ++c) {
+    MSI_S2STEP(0) MSI_S2STEP(1) MSI_S2STEP(2) MSI_S2STEP(3) MSI_S2STEP(4) MSI_S2STEP(5) MSI_S2STEP(6) MSI_S2STEP(7) MSI_S2STEP(8)
+  }
+#undef MSI_S2STEP
+#undef MSI_S2_UNIT
+#undef MSI_S2_TAP
+#undef MSI_HQ
+#undef MSI_B_ISSUE
+#undef MSI_PATCH_STORE
+#undef MSI_PATCH_LOAD
+  emit_tile<BM, BN, MODE_CONV, 1, WR>(p, acc, tile_m, tile_n, 0, b, tid, smem, raw_mul_pre);   // (the k-loop ended with a barrier: LDS is free)
+#endif
+}
+
 // ---- halo-patch kernel for the conv-transpose layers, bf16 operands ------------------------------------------------
 // The bf16 tap kernel is bound by its L2 -> LDS traffic, and a conv-transpose fetches every input element four times per
 // parity class.  Here a workgroup owns a (BM / 16) x 16 tile of the INPUT grid x BN channels for the TWO classes of one
@@ -3553,6 +3819,12 @@ int plan_layers(msi_net_plan *pl) {
       else if (L.cout == 64 && L.in_h % 16 == 0 && L.rate == 1) { Q.halo = 1; Q.hbm = 256; Q.hbn = 64; }
       if (Q.halo) { BM = Q.hbm; BN = Q.hbn; max_split = 1; }
     }
+    // ... and its stride-2 form (conv_halo_bf16_s2_kernel; HALO bit 2): whole 8 x 16 x 128 tiles of the OUTPUT grid, an even input
+    if (halo_ok && (pl->opt[MSI_NET_OPT_HALO] & 4) && bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] && L.kind == MODE_CONV && L.stride == 2 && L.rate == 1 &&
+        L.src1 < 0 && L.in_h % 2 == 0 && L.in_w % 2 == 0 && L.out_h % 8 == 0 && L.out_w % 16 == 0 && L.c0 % 64 == 0 && L.cout % 128 == 0 &&
+        p.pad_t == p.pad_l && (p.pad_t == 0 || p.pad_t == 1) && bigmode != 0) {
+      Q.halo = 1; Q.halo_s2 = 1; Q.hbm = 128; Q.hbn = 128; BM = 128; BN = 128; max_split = 1;
+    }
     // conv-transpose halo kernel (convt_halo_kernel; HALO bit 1, NOT the default -- measured slower, see the kernel): SAME conv-transposes (CoordNet), fp32, whole
     // 4 x 16 input tiles and 32-channel chunks of both sources; one workgroup per output-row parity (enumerated as two "classes")
     Q.halo_t = halo_ok && (pl->opt[MSI_NET_OPT_HALO] & 2) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] &&
@@ -3692,6 +3964,18 @@ int launch_halo_bf16(const LayerLaunch &Q, const ConvParams &p, hipStream_t stre
   if (rc0) return rc0;
   hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, BN, RATE, APPLY, NW>), dim3(Q.nblocks), dim3(64 * NW), lds, stream, p);
   return msi::check_launch("conv_halo_bf16");
+}
+
+template <int APPLY, int NW>
+int launch_halo_bf16_s2(const LayerLaunch &Q, const ConvParams &p, hipStream_t stream) {
+  constexpr int lds = HaloGeomBS2::LDS_BYTES + (APPLY ? 8 * 512 : 0);
+  static_assert(lds >= EPI_STAGE_BYTES && 2 * lds <= 160 * 1024, "staging strips; two workgroups per CU");
+  if (APPLY && p.C0 > 512) return msi::fail(MSI_E_UNSUPPORTED, "conv_halo_bf16_s2: APPLY with more than 512 input channels");
+  static thread_local unsigned long long done = 0;
+  int rc0 = set_max_lds(reinterpret_cast<const void *>(conv_halo_bf16_s2_kernel<APPLY, NW>), lds, done, "conv_halo_bf16_s2");
+  if (rc0) return rc0;
+  hipLaunchKernelGGL((conv_halo_bf16_s2_kernel<APPLY, NW>), dim3(Q.nblocks), dim3(64 * NW), lds, stream, p);
+  return msi::check_launch("conv_halo_bf16_s2");
 }
 
 template <int BM, int BN, int APPLY>
@@ -4198,6 +4482,10 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
         p.ln_beta = packed + S.beta_off;
       }
       const bool w8 = plan->opt[MSI_NET_OPT_BF16_WAVES] == 8;
+      if (Q.halo_s2) {
+        if (Q.halo_apply) rc = w8 ? launch_halo_bf16_s2<1, 8>(Q, p, stream) : launch_halo_bf16_s2<1, 4>(Q, p, stream);
+        else rc = w8 ? launch_halo_bf16_s2<0, 8>(Q, p, stream) : launch_halo_bf16_s2<0, 4>(Q, p, stream);
+      } else
 #define MSI_HB(BM_, BN_, R_, A_) (w8 ? launch_halo_bf16<BM_, BN_, R_, A_, 8>(Q, p, stream) : launch_halo_bf16<BM_, BN_, R_, A_, 4>(Q, p, stream))
       if (Q.hbm == 128) {
         if (L.rate == 1) rc = Q.halo_apply ? MSI_HB(128, 128, 1, 1) : MSI_HB(128, 128, 1, 0);
