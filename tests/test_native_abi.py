@@ -231,11 +231,16 @@ def test_plan_options_and_raw_layer_bookkeeping(native_lib):
     # HALO_SKIP takes layers out again: conv6_2 (layer 11) back on the tap kernel needs conv6_1 normalised in memory
     h = ctypes.c_void_p()
     assert lib.msi_net_plan_create(desc, ctypes.byref(h)) == 0
-    assert [names[i] for i in range(17) if lib.msi_net_plan_layer_is_normalized(h, i) == 0] == raw_layers(desc, 1)    # the default
+    # bit 2 (r03): the stride-2 layers on conv_halo_s2_kernel where the grid needs no K split -- conv1_2 and conv2_2 at this size
+    # (conv3_3: 400 tiles, tap kernel) -- so conv1_1 and conv2_1 stay raw as well; 5 is the default
+    assert raw_layers(desc, 5) == ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv4_2", "conv6_1", "conv6_2", "conv7_1", "conv8_1", "conv8_2"]
+    assert [names[i] for i in range(17) if lib.msi_net_plan_layer_is_normalized(h, i) == 0] == raw_layers(desc, 5)    # the default
     assert lib.msi_net_plan_set_option(h, N.NET_OPT_HALO_SKIP, 1 << 11) == 0
     assert [names[i] for i in range(17) if lib.msi_net_plan_layer_is_normalized(h, i) == 0] == \
-        ["conv3_1", "conv4_1", "conv4_2", "conv6_2", "conv7_1", "conv8_1", "conv8_2"]
+        ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv4_2", "conv6_2", "conv7_1", "conv8_1", "conv8_2"]
     lib.msi_net_plan_destroy(h)
+    big = nets.make_desc(1, 1024, 2048, 48, 16, 64, True)                 # a larger frame: every stride-2 layer has a large grid
+    assert raw_layers(big, 5) == ["conv1_1", "conv2_1", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv6_1", "conv6_2", "conv7_1", "conv8_1", "conv8_2"]
     # msi_train_net (wrap padding): its conv-transposes normalise over the uncropped output and stay on the tap kernel
     wrap = nets.make_desc(1, 320, 640, 192, 64, 64, False)
     assert raw_layers(wrap, 3) == ["conv3_1", "conv4_1", "conv4_2", "conv6_1", "conv6_2", "conv7_1", "conv8_1", "conv8_2"]
@@ -245,6 +250,8 @@ def test_plan_options_and_raw_layer_bookkeeping(native_lib):
     # conv-transposes read bf16 copies -- the 128x64 one can stage raw sources as well, option BF16_STAGE_RAW bit 1, measured slower)
     bf = nets.make_desc(16, 320, 640, 384, 128, 64, True, dtype="bf16")
     assert raw_layers(bf, 1) == ["conv3_1", "conv4_1", "conv4_2", "conv6_1", "conv6_2", "conv7_1", "conv8_1"] == raw_layers(bf, 3)
+    # + the stride-2 layers on conv_halo_bf16_s2_kernel (bit 2, default): their producers conv1_1, conv2_1, conv3_2
+    assert raw_layers(bf, 5) == ["conv1_1", "conv2_1", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv6_1", "conv6_2", "conv7_1", "conv8_1"]
     # measured-slower experiments are not in the default library: asking for one is an error, not a silent no-op
     h = ctypes.c_void_p()
     assert lib.msi_net_plan_create(desc, ctypes.byref(h)) == 0
@@ -254,7 +261,7 @@ def test_plan_options_and_raw_layer_bookkeeping(native_lib):
     lib.msi_net_plan_destroy(h)
     h = ctypes.c_void_p()
     assert lib.msi_net_plan_create(desc, ctypes.byref(h)) == 0
-    for opt, bad in ((N.NET_OPT_HALO, 4), (N.NET_OPT_BIGTILE, 3), (N.NET_OPT_NUM_CUS, 2), (99, 0)):
+    for opt, bad in ((N.NET_OPT_HALO, 8), (N.NET_OPT_BIGTILE, 3), (N.NET_OPT_NUM_CUS, 2), (N.NET_OPT_BF16_WAVES, 6), (99, 0)):
         assert lib.msi_net_plan_set_option(h, opt, bad) == -1
     assert lib.msi_net_plan_layer_is_normalized(h, 17) == -1 and lib.msi_net_plan_layer_is_normalized(None, 0) == -1
     lib.msi_net_plan_destroy(h)
