@@ -1405,6 +1405,8 @@ conv_halo_kernel(const ConvParams p) {
     tile_n = r - q2 * p.tiles_n;
     b = q2;                                               // (nclass = 1)
   }
+  LnShard shard = {0, 0};   // (the lane's shard of the source's LayerNorm sums: requested here, reduced after the patch requests)
+  if (APPLY) shard = ln_shard_load(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, tid);
   const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
   const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
   const int H = p.Hin, W = p.Win, C = p.C0;
@@ -1547,7 +1549,7 @@ conv_halo_kernel(const ConvParams p) {
   MSI_PATCH_LOAD(c0)                                      // (the weights of k-steps 0 and 1 are on their way already)
   if (APPLY) {   // the sums' round trip rides on the patch's (s_stat sits in the A region: read back before the patch lands)
     double *s_stat = reinterpret_cast<double *>(smem);
-    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
+    ln_mean_inv_pre(shard, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
     const double mu = s_stat[0];
     inv_f = (float)s_stat[1];
     mu_hi = (float)mu;
