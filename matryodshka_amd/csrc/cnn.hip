@@ -2764,6 +2764,9 @@ template <int BM, int BN, int APPLY>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 convt_halo_bf16_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
   typedef HaloGeomB<BM, BN, 1> G;
   constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, MT = BM / 64, NT = BN / 64;
   constexpr int NSTG = G::NSTG, PD = NSTG - 1, BI = BN / 32;
@@ -2992,6 +2995,9 @@ convt_halo_bf16_kernel(const ConvParams p) {
   MSI_PATCH_STORE()
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
   for (; c < c1; ++c) {
     MSI_CTSTEP(0) MSI_CTSTEP(1) MSI_CTSTEP(2) MSI_CTSTEP(3) MSI_CTSTEP(4) MSI_CTSTEP(5) MSI_CTSTEP(6) MSI_CTSTEP(7)
     if (c + 1 < c1) {
@@ -3005,11 +3011,22 @@ convt_halo_bf16_kernel(const ConvParams p) {
 #undef MSI_B_ISSUE
 #undef MSI_PATCH_STORE
 #undef MSI_PATCH_LOAD
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
   for (int pwc = 0; pwc < 2; ++pwc) {   // (LDS is free: the k-loop ended with a barrier)
     emit_tile<BM, BN, MODE_CONVT, 1>(p, acc[pwc], tile_m, tile_n, 2 * ph + pwc, b, tid, smem);
     __builtin_amdgcn_sched_barrier(0);   // one class after the other: interleaved, the two epilogues do not fit the register file
   }
+#ifdef MSI_CONV_TIMING
+  if (p.dbg && tid == 0) {
+    unsigned long long *o = p.dbg + (size_t)blockIdx.x * 24;
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
+    o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+  }
+#endif
 #endif
 }
 
