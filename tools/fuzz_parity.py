@@ -6,7 +6,8 @@ dtype) within the supported set, small enough for the CPU oracle.  Exercises M-t
     python tools/fuzz_parity.py [--n 40] [--seed 0] [--halo]
 
 --halo: shapes that reach the halo-patch kernels (ngf 32 / 64, maps in multiples of 4 x 16 / 8 x 16 / 16 x 16, channel
-counts in multiples of 32 / 64) with a random MSI_NET_OPT_HALO in {0, 1, 3} and a random FIXUP_KERNEL.
+counts in multiples of 32 / 64) with a random MSI_NET_OPT_HALO in {0, 1, 3, 5, 7}, a random FIXUP_KERNEL and a random NUM_CUS
+(8 / 16 CUs in the plan: the stride-2 halo kernels and the K splits are then reached by small grids).
 """
 import argparse
 import os
@@ -47,8 +48,8 @@ for it in range(a.n):
         ngf = int(rng.choice([32, 64]))
         cq = 64 if dtype == "bf16" else 32
         cin = cq * int(rng.randint(1, 4)) if rng.rand() < 0.7 else q * int(rng.randint(1, 13))
-        opts = {N.NET_OPT_HALO: int(rng.choice([0, 1, 1, 3])), N.NET_OPT_FIXUP_KERNEL: int(rng.rand() < 0.3),
-                N.NET_OPT_BIGTILE: int(rng.choice([1, 1, 2]))}
+        opts = {N.NET_OPT_HALO: int(rng.choice([0, 1, 3, 5, 5, 7])), N.NET_OPT_FIXUP_KERNEL: int(rng.rand() < 0.3),
+                N.NET_OPT_BIGTILE: int(rng.choice([1, 1, 2])), N.NET_OPT_NUM_CUS: int(rng.choice([256, 8, 16]))}
     if not coord:          # wrap_pad(x, 2, 2) at 1/8 resolution needs at least two columns / rows (the reference fails below that too)
         h, w = max(h, 16), max(w, 16)
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=int(rng.randint(1 << 30)), randomize_affine=True)
