@@ -303,8 +303,12 @@ __device__ __forceinline__ void ln_mean_inv_impl(const long long *sums, LnShard 
   if (tid < 64) {
     // the 64 shards as doubles (|shard| < 2^63: rounding at 2^-53 relative, far below the 2^-24 / 2^-16 units) through
     // the DPP reduction: no dependent trips through the LDS crossbar at the head of every consumer workgroup / ln_apply block
-    const long long *s = sums + (size_t)tid * LN_WORDS;
-    const double h1 = wave_sum_f64((double)(PRE ? pre.w0 : s[0])), h2 = wave_sum_f64((double)(PRE ? pre.w1 : s[1]));
+    long long w0 = pre.w0, w1 = pre.w1;
+    if constexpr (!PRE) {
+      const long long *s = sums + (size_t)tid * LN_WORDS;
+      w0 = s[0]; w1 = s[1];
+    }
+    const double h1 = wave_sum_f64((double)w0), h2 = wave_sum_f64((double)w1);
     if (tid == 0) {
       const double S1 = h1 * inv_s1, S2 = h2 * inv_s2;
       // resolution: every wave's share is rounded to one unit, so the total carries ~0.5 sqrt(waves) units of rounding
