@@ -3114,7 +3114,7 @@ struct HeadAsmParams {
 // rounded to bf16 (round to nearest even, where ln_apply_kernel<1> rounds it) before it enters the fp32 MFMA with the
 // bf16-rounded weights: the operands of the bf16 head, exact products, fp32 accumulation.
 template <int BF16IN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BF16IN ? 6 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BF16IN ? 6 : 5)))
 head_assemble_kernel(const HeadAsmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
