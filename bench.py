@@ -200,6 +200,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=4,
                     help="extra timed regions of --steps steps after the contract one (reported under `repeats`; the "
                          "headline `value` is always the first region right after the warm-up)")
+    ap.add_argument("--substreams", type=int, default=1,
+                    help="ODS configurations 2 / 3: a step's batch of this rank runs as S sub-batches on S HIP streams (the "
+                         "VALU-bound sweep / tail / render of one sub-batch overlap the MFMA-bound network of another); "
+                         "1 (default) = the whole batch as one batch on one stream.  Reported separately (config.substreams)")
     ap.add_argument("--no-settle", dest="settle", action="store_false",
                     help="skip the untimed settle regions before the contract region (see `settle_regions_ms`)")
     ap.add_argument("--prewarm", type=float, default=None,
@@ -233,6 +237,8 @@ def main():
     affinity = pin_to_gpu_numa_node(local_rank)
     if args.streams > 1 and args.config != 1:
         raise SystemExit("--streams applies to --config 1")
+    if args.substreams > 1 and (args.config not in (2, 3) or args.streams > 1):
+        raise SystemExit("--substreams applies to --config 2 / 3 (ODS batches) without --streams")
 
     from matryodshka_amd import MSI, nets
     from matryodshka_amd import dist as mdist
@@ -260,9 +266,9 @@ def main():
         torch.cuda.synchronize()
         broadcast_ms = (time.perf_counter() - t0) * 1e3
     models = [MSI(weights=weights, coord_net=coord, device=dev, dtype=cfg["dtype"],
-                  input_type="PP" if cfg["kind"] == "pp" else "ODS") for _ in range(max(1, args.streams))]
+                  input_type="PP" if cfg["kind"] == "pp" else "ODS") for _ in range(max(1, args.streams, args.substreams))]
     model = models[0]
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(args.streams - 1)]
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, args.substreams) - 1)]
     planes = model.inv_depths(1.0, 100.0, D)
 
     # synthetic inputs, seeded per global frame index (every rank renders its own frames), resident in HBM
@@ -288,11 +294,17 @@ def main():
     stage_names = ["preprocess", "sweep", "cnn", "assemble", "render", "deprocess"]   # cnn = the convolutions (+ ln_apply);
     # assemble = head + layer assembly (one fused kernel on the fp32 blend_psv path, head launch + K3 otherwise)
 
-    def frame(events=None, model=model, cnn_events=None):
-        """One step of this rank: its B frames as one batch.  `events`: a HIP event at every stage boundary;
-        `cnn_events`: only around the network (the roofline kernel) -- what the timed region records."""
+    def frame(events=None, model=model, cnn_events=None, sl=None):
+        """One step of this rank: its B frames as one batch (sl: a sub-batch of them, --substreams).  `events`: a HIP event at
+        every stage boundary; `cnn_events`: only around the network (the roofline kernel) -- what the timed region records."""
         if B == 0:
             return None
+        if sl is not None:   # (ODS only) contiguous views of the resident inputs
+            src_u8_, ref_u8_, ref_pose_, src_pose_, intr_ = src_u8[sl], ref_u8[sl], ref_pose[sl], src_pose[sl], intr[sl]
+            ref_pose_inv_, tgt_pose_rt_, tgt_pos_ = ref_pose_inv[sl], tgt_pose_rt[sl], tgt_pos[sl]
+        elif cfg["kind"] == "ods":
+            src_u8_, ref_u8_, ref_pose_, src_pose_, intr_ = src_u8, ref_u8, ref_pose, src_pose, intr
+            ref_pose_inv_, tgt_pose_rt_, tgt_pos_ = ref_pose_inv, tgt_pose_rt, tgt_pos
         def mark():
             if events is not None:
                 e = torch.cuda.Event(enable_timing=True)
@@ -305,9 +317,9 @@ def main():
                 cnn_events.append(e)
         mark()
         if cfg["kind"] == "ods":
-            src, ref = model.preprocess_image_pair(src_u8, ref_u8)
+            src, ref = model.preprocess_image_pair(src_u8_, ref_u8_)
             mark()
-            net_input = model.format_network_input(ref, src, ref_pose, src_pose, planes, intr, ref_pose_inv=ref_pose_inv)
+            net_input = model.format_network_input(ref, src, ref_pose_, src_pose_, planes, intr_, ref_pose_inv=ref_pose_inv_)
         else:
             src = model.preprocess_image(pp["src"])
             ref = model.preprocess_image(pp["ref"])
@@ -325,7 +337,7 @@ def main():
             cnn_events.append(mid)
         mark()
         if cfg["kind"] == "ods":
-            rgb, dep = model.msi_render_equirect_view_and_depth(out["rgba_layers"], tgt_pose_rt, tgt_pos, planes, intr)
+            rgb, dep = model.msi_render_equirect_view_and_depth(out["rgba_layers"], tgt_pose_rt_, tgt_pos_, planes, intr_)
             mark()
             rgb8, dep8 = model.deprocess_image_and_depth(rgb, dep)
         else:
@@ -336,7 +348,16 @@ def main():
         mark()
         return rgb, dep, rgb8, dep8, out
 
+    sub_slices = [slice(B * i // args.substreams, B * (i + 1) // args.substreams) for i in range(args.substreams)]
+
     def step(k, cnn_events=None):
+        if args.substreams > 1:                                  # the batch as S sub-batches, one per stream (whole step's work)
+            r = None
+            for i, sl in enumerate(sub_slices):
+                if sl.stop > sl.start:
+                    with torch.cuda.stream(streams[i]):
+                        r = frame(None, models[i], cnn_events=cnn_events if i == 0 else None, sl=sl)
+            return r
         if args.streams == 1:
             return frame(None, cnn_events=cnn_events)
         with torch.cuda.stream(streams[k % args.streams]):      # frame k and k+1 overlap on the device
@@ -466,7 +487,7 @@ def main():
                    "baseline_config_index": args.config, "height": H, "width": W,
                    "num_spheres": D, "ngf": NGF, "frames_per_step": frames_total, "frames_per_step_rank0": B,
                    "parallelism": "frames sharded over %d GPU(s) (dist.shard_frames), no data-path collective" % world,
-                   "streams_per_gpu": args.streams},
+                   "streams_per_gpu": args.streams, "substreams": args.substreams},
         "distributed": {"world_size_env": world, "world_size_process_group": nccl_world, "backend": backend,
                         "frame_ranges_per_rank": ranges,
                         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
