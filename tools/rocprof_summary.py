@@ -49,6 +49,21 @@ def main():
         print("\n# per step (%d steps, %d frame(s) each; launches per step in brackets):" % (steps, batch))
         for r in rows[:12]:
             print("#   %-60s %9.1f us  [%g]" % (short(r[0])[:60], r[2] / 1e3 / steps, round(r[1] / steps, 2)))
+    # device-side gaps between consecutive kernels of the LAST step (end of one launch -> start of the next, same queue)
+    ks = c.execute("select name, start, end from kernels order by start").fetchall()
+    if steps and len(ks) > 4:
+        starts = [i for i, k in enumerate(ks) if "preprocess" in k[0]]
+        # (a step starts with its preprocess launch -- two of them on the PP path -- and ends with the trace)
+        first = starts[-1] if starts else None
+        if first is not None and first > 0 and "preprocess" in ks[first - 1][0]:
+            first -= 1
+        per = len(ks) - first if first is not None else 0
+        if per > 4:
+            last_step = ks[first:]
+            gaps = [max(0, b[1] - a[2]) / 1e3 for a, b in zip(last_step[:-1], last_step[1:])]
+            busy = sum(k[2] - k[1] for k in last_step) / 1e3
+            print("\n# last step: %d launches, %.1f us inside kernels, %.1f us of gaps between consecutive launches (mean %.2f, max %.2f us) "
+                  "-- under the profiler" % (per, busy, sum(gaps), sum(gaps) / len(gaps), max(gaps)))
     conv = c.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, lds_size, vgpr_count, accum_vgpr_count "
                      "from kernels where name like '%conv_igemm%' or name like '%conv_halo%' or name like '%convt_halo%' "
                      "or name like '%conv_s2_%' order by start").fetchall()
