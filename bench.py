@@ -86,6 +86,29 @@ def cnn_flops(h, w, cin, nout, ngf, coord):
     return sum(cnn_layer_flops(h, w, cin, nout, ngf, coord))
 
 
+def conv_flops(h, w, cin, nout, ngf, coord):
+    """2*MACs of the 17 convolutions conv1_1 ... conv8_2 WITHOUT color_pred: the 1x1 head runs inside the fused tail,
+    after the event that closes the roofline interval (300.7 GFLOP at 640x320, D=32, CoordNet)."""
+    return sum(cnn_layer_flops(h, w, cin, nout, ngf, coord)[:-1])
+
+
+def conv_algorithmic_bytes(h, w, cin, ngf, coord, nb, act_bytes=4, w_bytes=4):
+    """HBM bytes one forward of the 17 convolutions has to move at least: every layer reads its input activation(s)
+    once and writes its raw output once (+ the in-place LayerNorm pass where one is launched is NOT counted: it belongs
+    to ln_apply), and the packed weights are read once per forward.  What `roofline.traffic_ratio` divides by."""
+    c = ngf
+    dims = [  # (in pixels scale, cin, out pixels scale, cout, taps)
+        (1, cin, 1, c, 9), (1, c, 4, 2 * c, 9), (4, 2 * c, 4, 2 * c, 9), (4, 2 * c, 16, 4 * c, 9),
+        (16, 4 * c, 16, 4 * c, 9), (16, 4 * c, 16, 4 * c, 9), (16, 4 * c, 64, 8 * c, 9),
+        (64, 8 * c, 64, 8 * c, 9), (64, 8 * c, 64, 8 * c, 9), (64, 8 * c, 64, 8 * c, 9),
+        (64, 16 * c, 16, 4 * c, 16), (16, 4 * c, 16, 4 * c, 9), (16, 4 * c, 16, 4 * c, 9),
+        (16, 8 * c, 4, 2 * c, 16), (4, 2 * c, 4, 2 * c, 9), (4, 4 * c, 1, c, 16), (1, c, 1, c, 9)]
+    act = sum(h * w // si * ci + h * w // so * co for si, ci, so, co, _ in dims) * act_bytes * nb
+    wts = sum(t * ci * co for _, ci, _, co, t in dims) * w_bytes
+    return act + wts
+
+
+
 def csrc_hash():
     """sha256 (first 16 hex digits) over the kernel sources the library is built from -- what a traffic profile is
     stamped with (tools/hbm_traffic.py) and what this run compares it to (the GPU box has no .git)."""
@@ -140,19 +163,6 @@ def geometry_bytes(h, w, d, psv_bytes=4):
     }
 
 
-def pp_inputs(seed, b, n):
-    """data_loader.py:205-226 (input_type PP): fx = cx = W/2, fy = cy = H/2; source shifted along -x by the input
-    offset, target by the target offset."""
-    from tests.util import smooth_noise
-    rng = np.random.RandomState(seed)
-    ref, src = smooth_noise(rng, b, n, n), smooth_noise(rng, b, n, n)
-    K = np.tile(np.array([[n / 2, 0, n / 2], [0, n / 2, n / 2], [0, 0, 1]], np.float32)[None], (b, 1, 1))
-    eye = np.tile(np.eye(4, dtype=np.float32)[None], (b, 1, 1))
-    src_pose = eye.copy(); src_pose[:, 0, 3] = -0.064
-    tgt_pose = eye.copy(); tgt_pose[:, 0, 3] = -0.03; tgt_pose[:, 1, 3] = 0.01
-    return ref, src, K, eye, src_pose, tgt_pose
-
-
 _ORIG_AFFINITY = None
 
 
@@ -190,6 +200,60 @@ def pin_to_gpu_numa_node(device_index):
     return info
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this very command line as N ranks under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1, a free port), hand its streams through
+    (rank 0 prints the one JSON line) and return its exit code.  With fewer than N visible devices RCCL cannot be
+    used (it refuses two ranks on one device): refuse loudly unless MSI_DIST_BACKEND (gloo: functional runs) is set."""
+    import socket
+    import subprocess
+    if "--dist-check" not in sys.argv and not os.environ.get("MSI_DIST_BACKEND") and torch.cuda.device_count() < n:
+        print("bench.py --gpus %d: only %d HIP device(s) visible; one rank per GPU over RCCL needs %d "
+              "(MSI_DIST_BACKEND=gloo lets ranks share a device for a functional run)" % (n, torch.cuda.device_count(), n),
+              file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def dist_check(args, rank, local_rank, world):
+    """--dist-check: what `--gpus N` adds to the one-GPU bench and nothing else (see the flag's help)."""
+    from matryodshka_amd import nets
+    from matryodshka_amd import dist as mdist
+    cfg = CONFIGS[args.config]
+    use_gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count()) if use_gpu else torch.device("cpu")
+    if world > 1:
+        mdist.init_process_group()
+    cin, nout, ngf = 24, 8, 8
+    weights = nets.init_weights(cin, nout, ngf, True, seed=8964) if rank == 0 else None
+    if world > 1:
+        weights = mdist.broadcast_weights(weights, cin, nout, ngf, True, dev, src=0)
+    blob_sum = float(nets.flatten_params(weights, cin, nout, ngf, True).astype(np.float64).sum())
+    lo, hi, total = mdist.step_frames(cfg["total"], cfg["per_rank"], rank, world)
+    if world > 1:
+        mdist.barrier()
+    t = mdist.max_over_ranks(1.0 + rank, dev) if world > 1 else 1.0
+    sums = mdist.gather_floats(blob_sum, dev) if world > 1 else [blob_sum]
+    ranges = mdist.gather_ranges(lo, hi, dev) if world > 1 else [(lo, hi)]
+    if rank == 0:
+        print(json.dumps({"dist_check": True, "n_gpus": world, "config": args.config,
+                          "world_size_process_group": torch.distributed.get_world_size() if world > 1 else 1,
+                          "backend": torch.distributed.get_backend() if world > 1 else None,
+                          "frames_per_step": total, "frame_ranges_per_rank": ranges, "max_over_ranks": t,
+                          "weights_equal_on_all_ranks": len(set(sums)) == 1}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +282,10 @@ def main():
                     help="HIP streams consecutive frames are issued on (1 = strictly one frame at a time, the "
                          "default and the configuration BASELINE quotes; 2 = software-pipeline independent frames, "
                          "each still batch 1, to fill the tile-quantisation tails of the small layers; config 1 only)")
+    ap.add_argument("--dist-check", action="store_true",
+                    help="only the N-rank plumbing of this file: launch, rendezvous, weight broadcast, frame ranges, barrier and "
+                         "max-over-ranks -- no frame loop, no kernels; runs without a GPU on gloo (tests/test_dist_cpu.py) and "
+                         "prints its own one-line JSON (never a benchmark line: no `value`)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.prewarm is None:
@@ -226,10 +294,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))                # `python bench.py --gpus N` typed directly: become N ranks
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         raise SystemExit("--gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dist_check:
+        return dist_check(args, rank, local_rank, world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
     local_rank = local_rank % torch.cuda.device_count()   # (ranks may share a GPU in the gloo functional test)
     torch.cuda.set_device(local_rank)                      # one process per GPU: rank r drives device LOCAL_RANK
@@ -272,7 +342,7 @@ def main():
     planes = model.inv_depths(1.0, 100.0, D)
 
     # synthetic inputs, seeded per global frame index (every rank renders its own frames), resident in HBM
-    from tests.util import make_inputs
+    from matryodshka_amd.synthetic import make_inputs
     g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).contiguous()
     inp = None
     if B > 0 and cfg["kind"] == "ods":
@@ -284,6 +354,7 @@ def main():
         tgt_pose_rt, tgt_pos = g(inp["tgt_pose_rt"]), g(inp["tgt_pos"])
     elif B > 0:
         from matryodshka_amd import poses
+        from matryodshka_amd.synthetic import pp_inputs
         parts = [pp_inputs(8964 + f, 1, H) for f in range(lo, hi)]
         ref, src, K, eye, spose, tpose = (np.concatenate([p[i] for p in parts], axis=0) for i in range(6))
         interp_inv = np.linalg.inv(poses.interpolate_pose(eye, spose).astype(np.float64)).astype(np.float32)   # train.py:118-121
@@ -356,7 +427,7 @@ def main():
             for i, sl in enumerate(sub_slices):
                 if sl.stop > sl.start:
                     with torch.cuda.stream(streams[i]):
-                        r = frame(None, models[i], cnn_events=cnn_events if i == 0 else None, sl=sl)
+                        r = frame(None, models[i], cnn_events=cnn_events, sl=sl)
             return r
         if args.streams == 1:
             return frame(None, cnn_events=cnn_events)
@@ -381,7 +452,11 @@ def main():
         elapsed = time.perf_counter() - t0
         own.append(t_own - t0)
         elapsed = mdist.max_over_ranks(elapsed, dev) if world > 1 else elapsed
-        cnn_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(len(ev) // 2)]
+        # one (start, end) event pair per network forward; --substreams S: S forwards per step, each timed on its own stream --
+        # their SUM is the step's network time (sub-batches overlap with other stages, not with each other's convolutions)
+        per_fwd = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(len(ev) // 2)]
+        nfwd = max(1, sum(1 for sl in sub_slices if sl.stop > sl.start)) if args.substreams > 1 else 1
+        cnn_ms = [sum(per_fwd[i:i + nfwd]) for i in range(0, len(per_fwd) - nfwd + 1, nfwd)]
         return elapsed, cnn_ms, result
 
     # clock / allocator pre-warm (untimed, disclosed as `prewarm_s`): an idle MI355X needs ~0.1 s under load to reach
@@ -459,7 +534,7 @@ def main():
 
     bf16 = cfg["dtype"] == "bf16"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    flops = cnn_flops(H, W, cin, nout, NGF, coord)                 # per frame
+    flops = conv_flops(H, W, cin, nout, NGF, coord)                # per frame: the 17 convolutions the interval contains
     gbytes = geometry_bytes(H, W, D, 2 if bf16 else 4)
     nb = max(B, 1)
     cnn_tflops = flops * nb / (cnn_ms_timed * 1e-3) / 1e12
@@ -472,6 +547,9 @@ def main():
     stages["cnn"].update({"bound": "mfma", "algorithmic_GFLOP": round(flops * nb / 1e9, 1),
                           "achieved_TFLOPps": round(flops * nb / (max(stage_ms["cnn"], 1e-9) * 1e-3) / 1e12, 2)})
     traffic, traffic_src, traffic_stale = cnn_traffic(args.config, coord)
+    conv_bytes = conv_algorithmic_bytes(H, W, cin, NGF, coord, nb, act_bytes=2 if bf16 else 4, w_bytes=2 if bf16 else 4)
+    if args.substreams > 1:   # the per-stage pass runs the whole batch on one stream: not the configuration that was timed
+        stages["note"] = "per-stage pass = whole batch on ONE stream (substreams only changes the timed region)"
 
     unit = "faces/s" if cfg["kind"] == "pp" else "frames/s"
     metric = "novel-view frames/sec, 640x320 ODS->32-sphere MSI infer+render" if args.config == 1 else \
@@ -503,11 +581,15 @@ def main():
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4), "traffic": traffic,
                      "traffic_stale": traffic_stale,
+                     "algorithmic_bytes": conv_bytes,
+                     "traffic_ratio": None if traffic is None else round(traffic / conv_bytes, 3),
                      "traffic_note": None if traffic is None else
                      "HBM bytes per step (%d frame(s)) of the conv launches, %s (separate --pmc FETCH_SIZE / WRITE_SIZE passes, "
                      "gfx950 FETCH correction)%s" % (nb, traffic_src, "; STALE: measured with other kernel sources than this "
                      "run's (csrc_sha %s)" % csrc_hash() if traffic_stale else ""),
-                     "launches_per_frame": 18, "algorithmic_flops_per_launch_set": flops * nb,
+                     "launches_per_frame": 17, "algorithmic_flops_per_launch_set": flops * nb,
+                     "flops_note": "conv1_1 ... conv8_2 only; color_pred (the 1x1 head, %.2f GFLOP per frame) runs in the fused tail "
+                                   "after the closing event and is not counted" % (cnn_layer_flops(H, W, cin, nout, NGF, coord)[-1] / 1e9),
                      "ms_per_forward": round(cnn_ms_timed, 4),
                      "timed": "HIP events around msi_net_plan_forward on the launch stream INSIDE the timed region, mean of "
                               "%d forwards (conv launches + the remaining ln_apply launches: conservative for the conv kernels alone)" % max(len(cnn_ms), 1)},

@@ -74,3 +74,46 @@ def test_two_rank_gloo_broadcast_and_reduce(native_lib):
         assert ranges0 == ranges1 and total0 == total1 == total
         assert sorted(frames0 + frames1) == list(range(total)) and not set(frames0) & set(frames1)
         assert [tuple(r) for r in ranges0] == [(frames0[0], frames0[-1] + 1), (frames1[0], frames1[-1] + 1)]
+
+
+def _run_bench(args, timeout=300):
+    """`python bench.py <args>` exactly as a driver types it: no launcher, no RANK / WORLD_SIZE in the environment."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MSI_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, cwd=root, timeout=timeout,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_itself(native_lib):
+    """`python bench.py --gpus 2` must become two ranks by itself (it used to exit).  --dist-check
+    runs everything `--gpus N` adds to the one-GPU bench -- launch, rendezvous, weight broadcast, frame ranges, barrier,
+    max over ranks -- without the frame loop, so it runs here on gloo without a GPU; the full line is checked on the GPU
+    box by tests/test_gpu_pipeline.py::test_bench_gpus_2_end_to_end_on_one_gpu."""
+    j = _run_bench(["--gpus", "2", "--dist-check", "--config", "3"])
+    assert j["world_size_process_group"] == 2 and j["n_gpus"] == 2 and j["backend"] == "gloo"
+    assert j["frame_ranges_per_rank"] == [[0, 16], [16, 32]] and j["frames_per_step"] == 32
+    assert j["max_over_ranks"] == 2.0 and j["weights_equal_on_all_ranks"] is True
+    j = _run_bench(["--gpus", "2", "--dist-check"])                 # config 1: weak scaling, one frame per rank
+    assert j["frame_ranges_per_rank"] == [[0, 1], [1, 2]] and j["frames_per_step"] == 2
+
+
+def test_bench_refuses_rccl_on_too_few_devices():
+    """Without MSI_DIST_BACKEND the N-rank run is RCCL, one rank per GPU: fewer visible devices is a loud error with
+    exit code 2, never a silent single-rank number."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MSI_DIST_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, cwd=root, timeout=120,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 2 and "HIP device(s) visible" in p.stderr and not p.stdout.strip()

@@ -223,3 +223,19 @@ def test_infer_msi_colour_schemes_match_oracle(scheme, coord):
     rgb = m.msi_render_equirect_view(pred["rgba_layers"], inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
     rgb_o = o.msi_render_equirect_view(pred_o["rgba_layers"], inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
     assert np.abs(rgb.cpu().numpy() - rgb_o).max() <= TOL
+
+
+def test_bench_gpus_2_end_to_end_on_one_gpu():
+    """`python bench.py --gpus 2 --steps 3` as the driver types it (no launcher): bench.py re-runs
+    itself as two ranks; on this one-GPU box they share the device over gloo (RCCL refuses two ranks on one device).
+    The line must be the contract's, from a 2-rank process group, with one frame per rank per step."""
+    from tests.test_dist_cpu import _run_bench
+    j = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm", "0.2", "--repeats", "0", "--no-settle",
+                    "--strong-frames", "2"], timeout=900)
+    assert j["n_gpus"] == 2 and j["distributed"]["world_size_process_group"] == 2 and j["distributed"]["backend"] == "gloo"
+    assert j["distributed"]["frame_ranges_per_rank"] == [[0, 1], [1, 2]] and j["config"]["frames_per_step"] == 2
+    assert j["steps"] == 3 and j["value"] > 0 and abs(j["value"] - 2 * 1e3 / j["ms_per_step"]) <= 0.01 * j["value"]
+    assert j["roofline"]["frac"] > 0 and j["cpu_baseline"] is None and j["scaling"] == "weak"
+    j = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0.2", "--repeats", "0", "--no-settle",
+                    "--config", "3"], timeout=900)
+    assert j["distributed"]["frame_ranges_per_rank"] == [[0, 16], [16, 32]] and j["scaling"] == "strong"

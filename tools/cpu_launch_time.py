@@ -2,7 +2,7 @@ import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from matryodshka_amd import MSI, nets
-from tests.util import make_inputs
+from matryodshka_amd.synthetic import make_inputs
 dev = torch.device("cuda:0")
 H, W, D = 320, 640, 32
 model = MSI(weights=nets.init_weights(6 * D, 2 * D, 64, True), coord_net=True)

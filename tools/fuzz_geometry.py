@@ -16,7 +16,7 @@ import torch
 
 from matryodshka_amd import MSI
 from oracle.msi import MSI as OracleMSI
-from tests.util import make_inputs, random_rgba
+from matryodshka_amd.synthetic import make_inputs, random_rgba
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=30)

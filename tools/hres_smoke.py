@@ -17,7 +17,7 @@ ap.add_argument("--hres_width", type=int, default=4096)
 ap.add_argument("--planes", type=int, default=32)
 a = ap.parse_args()
 from matryodshka_amd import MSI, nets
-from tests.util import make_inputs
+from matryodshka_amd.synthetic import make_inputs
 d = a.planes
 m = MSI(weights=nets.init_weights(6 * d, 2 * d, 64, True), coord_net=True)
 low = make_inputs(1, 1, 320, 640)
