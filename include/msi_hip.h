@@ -53,6 +53,14 @@ extern "C" {
 typedef void *msi_stream_t; /* hipStream_t */
 
 const char *msi_version(void);
+/* ABI version of this header: bumped whenever a struct of this file grows or changes layout, an entry point changes
+ * its signature, or the PACKED weight blob (msi_net_pack_weights_host) changes format.  A caller compares
+ * msi_abi_version() of the library it loaded with the MSI_ABI_VERSION it was compiled against and refuses to run on
+ * a mismatch; packed blobs are not portable across versions (re-pack from the parameter blob).
+ *   3: msi_layer_info.ln_scale_offset; LayerNorm window doubles in the packed blob (round 3)
+ *   4: msi_net_plan_layer_kernel; render status word (msi_render_status_*); sweep volume takes shared poses (round 4) */
+#define MSI_ABI_VERSION 4
+int32_t msi_abi_version(void);
 const char *msi_last_error_string(void);
 /* CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 for a new message): the per-tensor checksum of
  * the TensorFlow checkpoints test.py:191-202 restores (matryodshka_amd/tf_checkpoint.py verifies it on load). */
@@ -320,6 +328,14 @@ size_t msi_net_plan_workspace_bytes(const msi_net_plan *plan);
  * convolution output (0: every consumer applies the LayerNorm itself while loading -- the head, halo-patch layers)?
  * -1: bad arguments.  (Tests / debugging; the frame loop does not need it.) */
 int32_t msi_net_plan_layer_is_normalized(const msi_net_plan *plan, int32_t layer);
+/* Which kernel instantiation the plan launches for `layer` (0 .. MSI_NET_NUM_LAYERS-1), written to name[name_bytes] as
+ * rocprofv3 spells it without the namespace -- e.g. "conv_halo_s2_kernel<1>", "conv_halo_bf16_kernel<128, 128, 1, 1, 8>",
+ * "conv_igemm_kernel<64, 64, 1, 0>" (<BM, BN, MODE 0 conv / 1 conv-transpose / 2 head, BF16>); *nblocks = workgroups of the
+ * launch, *nsplit_tiles = tiles cut into K-ranges (both optional).  The choice depends on batch x tiles against the CU
+ * count, so a parity test at a bench batch asserts with this that the variants it checked are the ones the bench times
+ * (color_pred reports the stand-alone head; msi_net_plan_forward_rgba replaces it by head_assemble_kernel). */
+int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char *name, size_t name_bytes, int32_t *nblocks,
+                                  int32_t *nsplit_tiles);
 /* Health of the LAST forward that ran with `workspace` on `stream` (synchronises the stream: call it after a frame,
  * not inside the frame loop's hot path): MSI_OK, or MSI_E_RANGE with the reason in msi_last_error_string when a
  * LayerNorm sum overflowed its fixed-point window (bit 1 of *status_bits: raw outputs > ~3000x the scale the weights

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsi_hip.so")
 
 MSI_OK = 0
 MSI_NET_NUM_LAYERS = 18
+MSI_ABI_VERSION = 4          # include/msi_hip.h: the version this binding's struct layouts and signatures are written for
 
 
 class MsiError(RuntimeError):
@@ -46,6 +47,7 @@ _I = c_int32
 # name -> (restype, argtypes); must list every function declared in include/msi_hip.h
 SIGNATURES = {
     "msi_version": (c_char_p, []),
+    "msi_abi_version": (c_int32, []),
     "msi_last_error_string": (c_char_p, []),
     "msi_crc32c_host": (ctypes.c_uint32, [_P, c_size_t, ctypes.c_uint32]),
     "msi_trig_table_floats": (c_size_t, [_I, _I]),
@@ -81,6 +83,7 @@ SIGNATURES = {
     "msi_net_plan_set_option": (_I, [_P, _I, _I]),
     "msi_net_plan_workspace_bytes": (c_size_t, [_P]),
     "msi_net_plan_layer_is_normalized": (_I, [_P, _I]),
+    "msi_net_plan_layer_kernel": (_I, [_P, _I, _P, c_size_t, POINTER(c_int32), POINTER(c_int32)]),
     "msi_net_plan_status": (_I, [_P, _P, _P, POINTER(c_int32)]),
     "msi_net_plan_forward": (_I, [_P, _P, _P, _P, _P, c_size_t, _P]),
     "msi_net_plan_forward_rgba": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
@@ -106,6 +109,9 @@ def _load():
             raise ImportError("matryodshka_amd: %s does not export %s" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
+    if lib.msi_abi_version() != MSI_ABI_VERSION:
+        raise ImportError("matryodshka_amd: %s has ABI version %d, this binding is written for %d -- rebuild it "
+                          "(python -m matryodshka_amd.build --force)" % (LIB_PATH, lib.msi_abi_version(), MSI_ABI_VERSION))
     return lib
 
 
@@ -132,6 +138,18 @@ class NetPlan(object):
 
     def workspace_bytes(self):
         return lib.msi_net_plan_workspace_bytes(self.handle)
+
+    def layer_kernel(self, layer):
+        """(kernel instantiation as rocprofv3 spells it, workgroups, tiles cut into K-ranges) of `layer`."""
+        buf = ctypes.create_string_buffer(96)
+        nb, ns = c_int32(0), c_int32(0)
+        check(lib.msi_net_plan_layer_kernel(self.handle, int(layer), ctypes.cast(buf, c_void_p), 96, ctypes.byref(nb), ctypes.byref(ns)),
+              "msi_net_plan_layer_kernel")
+        return buf.value.decode(), int(nb.value), int(ns.value)
+
+    def kernels(self):
+        """[(layer name-less index, kernel, workgroups, split tiles)] for the 18 layers in graph order."""
+        return [self.layer_kernel(i) for i in range(18)]
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None

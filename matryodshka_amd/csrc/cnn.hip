@@ -4315,6 +4315,39 @@ int32_t msi_net_plan_layer_is_normalized(const msi_net_plan *plan, int32_t layer
 static int run_layers(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
                       void *workspace, size_t workspace_bytes, msi_stream_t stream_, int nlayers);
 
+// The kernel instantiation run_layers launches for `layer` (the if-chain below, restated: keep the two in step), spelled
+// as rocprofv3 prints it without the namespace -- so that a parity test can assert WHICH variants a plan at a given batch
+// took (the choice depends on batch x tiles vs CUs) and a profile's kernel table can be matched against tested plans.
+int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char *name, size_t name_bytes, int32_t *nblocks,
+                                  int32_t *nsplit_tiles) {
+  MSI_REQUIRE(plan && name && name_bytes > 0, "net_plan_layer_kernel: null pointer");
+  MSI_REQUIRE(layer >= 0 && layer < MSI_NET_NUM_LAYERS, "net_plan_layer_kernel: bad layer %d", layer);
+  const Layer &L = plan->net.layers[layer];
+  const LayerLaunch &Q = plan->launch[layer];
+  const int bf16 = plan->desc.dtype == MSI_DTYPE_BF16;
+  const char *mode = L.kind == MODE_CONV ? "0" : (L.kind == MODE_CONVT ? "1" : "2");
+  if (Q.halo_tb) {
+    snprintf(name, name_bytes, "convt_halo_bf16_kernel<128, %d, %d>", Q.hbn, Q.p.halo_apply ? 1 : 0);
+  } else if (Q.halo && bf16) {
+    if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_bf16_s2_kernel<%d, 4>", Q.halo_apply ? 1 : 0);
+    else if (Q.hbm == 128) snprintf(name, name_bytes, "conv_halo_bf16_kernel<128, 128, %d, %d, %d>", L.rate, Q.halo_apply ? 1 : 0,
+                                    plan->opt[MSI_NET_OPT_BF16_WAVES] == 8 ? 8 : 4);
+    else snprintf(name, name_bytes, "conv_halo_bf16_kernel<256, 64, 1, %d, 4>", Q.halo_apply ? 1 : 0);
+  } else if (Q.halo_t) {
+    snprintf(name, name_bytes, "convt_halo_kernel");
+  } else if (Q.halo) {
+    if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_s2_kernel<%d>", Q.halo_apply ? 1 : 0);
+    else snprintf(name, name_bytes, "conv_halo_kernel<%d, %d>", L.rate, Q.halo_apply ? 1 : 0);
+  } else {
+    const int bm = Q.tile == TILE_128x128 || Q.tile == TILE_128x64 ? 128 : 64;
+    const int bn = Q.tile == TILE_128x128 || Q.tile == TILE_64x128 ? 128 : 64;
+    snprintf(name, name_bytes, "conv_igemm_kernel<%d, %d, %s, %d>", bm, bn, mode, bf16);
+  }
+  if (nblocks) *nblocks = Q.nblocks + Q.p.n_apply;
+  if (nsplit_tiles) *nsplit_tiles = Q.nfix;
+  return MSI_OK;
+}
+
 int32_t msi_net_plan_status(const msi_net_plan *plan, const void *workspace, msi_stream_t stream_, int32_t *status_bits) {
   MSI_REQUIRE(plan && workspace, "net_plan_status: null pointer");
   hipStream_t stream = msi::as_stream(stream_);

@@ -22,7 +22,9 @@ int fail(int code, const char *fmt, ...) {
 
 extern "C" {
 
-const char *msi_version(void) { return "msi_hip 0.1 (gfx950)"; }
+const char *msi_version(void) { return "msi_hip 0.4 (gfx950)"; }
+
+int32_t msi_abi_version(void) { return MSI_ABI_VERSION; }
 
 const char *msi_last_error_string(void) { return msi::error_buffer(); }
 

@@ -285,3 +285,50 @@ def test_harness_restores_a_hand_assembled_bundle_and_matches_the_oracle(tmp_pat
     _close_png(sample / ("output_depth_%s.png" % tag), o.deprocess_depth_image(o.msi_render_equirect_depth(pred["rgba_layers"], eye, pos, planes, intr))[0])
     assert np.abs(np.load(str(sample / "alphas.npy")) - pred["alphas"]).max() <= 1e-3
     assert np.abs(np.load(str(sample / "blend_weights.npy")) - pred["blend_weights"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("coord", [False, True])
+def test_harness_at_baseline_config0_size_equals_the_oracle(tmp_path, coord):
+    """BASELINE configs[0] at ITS OWN workload: test.py:87-281 on one 640x320 ODS pair, 32 spheres,
+    ngf 64 -- 1280x640 JPEGs on disk -> area resize -> HIP path -> the reference's PNG / NPY files, compared with the CPU
+    oracle on the same decoded + resized images (<= 1 LSB on < 0.1 % of the pixels; blend_weights.npy / alphas.npy 1e-3).
+    coord = False is test.py:52's default network (msi_train_net), True the released ODS models' (msi_coord_train_net)."""
+    import torch
+    from PIL import Image
+    from matryodshka_amd import harness
+    from oracle import nets as onets
+    from oracle.msi import MSI as OracleMSI
+    h, w, d, ngf = 320, 640, 32, 64
+    _write_sample_images(tmp_path / "test_640x320", "apartment_0", 2 * h, 2 * w, 21)
+    cam = tmp_path / "cams.txt"
+    cam.write_text("apartment_0 000 001 002 0.032 0.02 -0.01 0.03\n")
+    weights = onets.init_weights(6 * d, 2 * d, ngf=ngf, coord_net=coord, seed=22, randomize_affine=True)
+    np.savez(str(tmp_path / "w.npz"), **weights)
+    args = ["--cameras_glob", str(cam), "--image_dir", str(tmp_path / "test_640x320"), "--output_root", str(tmp_path / "o"),
+            "--experiment_name", "e", "--weights", str(tmp_path / "w.npz")]       # everything else: the harness' (= test.py's) defaults
+    assert harness.main(args) == 1
+    tag = "apartment_0_000001002"
+    sample = tmp_path / "o" / "e" / tag
+    ref, src = (harness.load_image(str(tmp_path / "test_640x320" / ("apartment_0_pos%s.jpeg" % n)), h, w)[None] for n in ("000", "001"))
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    o = OracleMSI(weights=weights, coord_net=coord)
+    planes = o.inv_depths(1.0, 100.0, d)
+    eye = np.eye(4, dtype=np.float32)[None]
+    intr = np.array([[[0.032, 0, 0], [0, 1, 0], [0, 0, 1]]], np.float32)
+    pos = np.array([[0.02, -0.01, 0.03]], np.float32)
+    pred, psv = o.infer_msi(src, ref, None, None, eye, eye, intr, "blend_psv", d, planes, extra_outputs="blend_weights alphas", ngf=ngf)
+    _close_png(sample / ("output_tgt_%s.png" % tag), o.deprocess_image(o.msi_render_equirect_view(pred["rgba_layers"], eye, pos, planes, intr))[0])
+    _close_png(sample / ("output_depth_%s.png" % tag), o.deprocess_depth_image(o.msi_render_equirect_depth(pred["rgba_layers"], eye, pos, planes, intr))[0])
+    u8 = lambda x: np.clip(x, 0, 255).astype("uint8")          # utils.write_image (utils.py:76-81)
+    for i in (0, d // 2, d - 1):
+        _close_png(sample / ("msi_alpha_%.2d.png" % i), u8(pred["rgba_layers"][0, :, :, i, 3] * 255.0))
+        _close_png(sample / ("msi_rgb_%.2d.png" % i), u8((pred["rgba_layers"][0, :, :, i, :3] + 1.) / 2. * 255))
+        _close_png(sample / ("blend_weight_%.3d.png" % i), u8(pred["blend_weights"][0, :, :, i] * 255.0))
+    for f in ["msi_alpha_%.2d.png" % i for i in range(d)] + ["msi_rgb_%.2d.png" % i for i in range(d)] + \
+             ["src_image_%s.png" % tag, "ref_image_%s.png" % tag, "tgt_image_%s.png" % tag]:
+        assert (sample / f).exists(), f
+    bw, al = np.load(str(sample / "blend_weights.npy")), np.load(str(sample / "alphas.npy"))
+    assert bw.shape == al.shape == (1, h, w, d)
+    e_bw, e_al = np.abs(bw - pred["blend_weights"]).max(), np.abs(al - pred["alphas"]).max()
+    print("configs[0] size, coord=%s: blend_weights %.2e alphas %.2e" % (coord, e_bw, e_al))
+    assert e_bw <= 1e-3 and e_al <= 1e-3
