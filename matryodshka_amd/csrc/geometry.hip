@@ -341,36 +341,59 @@ __device__ __forceinline__ void ods_tail(const OdsQuad &q, float order, const Pi
   }
 }
 
-// resample (sampling.py:135-197) of one RGB texel; `img` = buffer descriptor of one sample's [H,W,3] image
+// resample (sampling.py:135-197) of one RGB texel; `img` = buffer descriptor of one sample's [H,W,3] image.
+// The four corners as BYTE offsets (pixel offset x 12, 24-bit multiply) + area weights: everything of a sample that does
+// not depend on the image -- kept in registers while the frames of a batch that share (pose, baseline) are gathered.
 typedef unsigned u32x3_g __attribute__((ext_vector_type(3)));
 typedef float f32x3_g __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ void gather3(__amdgpu_buffer_rsrc_t img, int width, int height, float u, float v, float *out) {
+struct TapsB {
+  unsigned oa, ob, oc, od;
+  float wa, wb, wc, wd;
+};
+__device__ __forceinline__ TapsB make_taps_bytes(float u, float v, int width, int height) {
   const TapsR t = make_taps_ranged(u, v, width, height);
-  const f32x3_g a = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, __umul24(t.oa, 12u), 0, 0));
-  const f32x3_g b = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, __umul24(t.ob, 12u), 0, 0));
-  const f32x3_g c = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, __umul24(t.oc, 12u), 0, 0));
-  const f32x3_g d = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, __umul24(t.od, 12u), 0, 0));
+  TapsB r;
+  r.oa = __umul24(t.oa, 12u); r.ob = __umul24(t.ob, 12u); r.oc = __umul24(t.oc, 12u); r.od = __umul24(t.od, 12u);
+  r.wa = t.wa; r.wb = t.wb; r.wc = t.wc; r.wd = t.wd;
+  return r;
+}
+__device__ __forceinline__ float blend4(const TapsB &t, float a, float b, float c, float d) {
+  return ((t.wa * a + t.wb * b) + t.wc * c) + t.wd * d;   // tf.add_n order (sampling.py:187-190)
+}
+__device__ __forceinline__ void gather3(__amdgpu_buffer_rsrc_t img, const TapsB &t, float *out) {
+  const f32x3_g a = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, t.oa, 0, 0));
+  const f32x3_g b = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, t.ob, 0, 0));
+  const f32x3_g c = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, t.oc, 0, 0));
+  const f32x3_g d = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, t.od, 0, 0));
   out[0] = blend4(t, a.x, b.x, c.x, d.x);
   out[1] = blend4(t, a.y, b.y, c.y, d.y);
   out[2] = blend4(t, a.z, b.z, c.z, d.z);
 }
 
-// One work item = (pixel, NS consecutive depths); depth is the fastest index so a wavefront's 64
-// lanes write 64 x NS consecutive 12-byte texels of the NHWC volume.  The source image (2.4 MB) stays L2-resident.
+// One work item = (pixel, NS consecutive depths) for up to `bchunk` frames of the batch; depth is the fastest index so a
+// wavefront's 64 lanes write 64 x NS consecutive 12-byte texels of the NHWC volume.  The source images (2.4 MB) stay L2-resident.
 // OutT = float, or unsigned short = bf16 bits (the bf16 network input of BASELINE configs[2]).
 // NS = samples (consecutive depths of one pixel) per thread: with two, the per-pixel work (trigonometry,
 // index arithmetic) is shared and hipcc pairs the independent multiplies / adds of the two samples into
-// v_pk_mul_f32 / v_pk_add_f32 (IEEE, same roundings as the scalar forms) -- this kernel is VALU-bound.
+// v_pk_mul_f32 / v_pk_add_f32 (IEEE, same roundings as the scalar forms).
 // NSRC = 1: one source (image0, pose0, order) -> channels [coff, coff + 3D).
 // NSRC = 2: the whole double volume of format_network_input (msi.py:1124-1129): source 0 with order +1 into
 // channels [0, 3D), source 1 with order -1 into [3D, 6D); the quadratic is shared when the two poses are equal.
+// BATCH LOOP (round 4): the sample position (u, v), its four corners and weights depend on (pixel, depth, pose, baseline)
+// only -- not on the image.  The reference recomputes them per batch element (projector.py:129-170 runs per sample); on
+// the test path every frame has the identity pose and the camera file's baseline (data_loader.py:146-160), so a thread
+// keeps the corners of its samples in registers (TapsB: ~230 of the ~276 VALU per sample) and walks the frames
+// [blockIdx.z * bchunk, + bchunk): per frame a wave-uniform comparison of the 24 pose entries + baseline with those the
+// held corners were computed from (scalar loads, scalar branch) decides between "gather with the held corners" and
+// "recompute" -- the same arithmetic either way, so the volume is bit-identical to the frame-at-a-time form.
 template <typename OutT, int NS, int NSRC>
 __global__ void __launch_bounds__(256)
 ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ image1, const float *__restrict__ pose0,
                  const float *__restrict__ pose1, const float *__restrict__ intrinsics, const float *__restrict__ depths,
                  const float *__restrict__ trig, int batch, int height, int width, int nd,
-                 float order, OutT *__restrict__ psv, int channels, int coff, PixConsts K, unsigned ng_magic, int coalesce) {
-  // grid = (ceil(W*(D/NS) / 256), H, B): 32-bit index math only (64-bit div/mod are emulated in ~100
+                 float order, OutT *__restrict__ psv, int channels, int coff, PixConsts K, unsigned ng_magic, int coalesce,
+                 int bchunk) {
+  // grid = (ceil(W*(D/NS) / 256), H, ceil(B / bchunk)): 32-bit index math only (64-bit div/mod are emulated in ~100
   // VALU instructions each and used to dominate this kernel)
   const int ng = nd / NS;                       // depth groups per pixel (nd % NS == 0, checked on the host)
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -378,77 +401,104 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
   unsigned jq = __umulhi((unsigned)idx, ng_magic);   // idx / ng by multiply-high (+ one correction), see cnn.hip udiv_magic
   if ((unsigned)idx - jq * (unsigned)ng >= (unsigned)ng) ++jq;
   const int j = (int)jq, d0 = (idx - j * ng) * NS;
-  const int i = blockIdx.y, b = blockIdx.z;
-  const long p = ((long)b * height + i) * width + j;
+  const int i = blockIdx.y;
+  const int b_lo = blockIdx.z * bchunk, b_hi = min(batch, b_lo + bchunk);
 
   const float cs = trig[j], ss = trig[width + j];
   const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
-  const float *P0 = pose0 + (size_t)b * 16;
-  const float *P1 = NSRC == 2 ? pose1 + (size_t)b * 16 : P0;
-  const float r = intrinsics[(size_t)b * 9];
   const int img_bytes = height * width * 12;
-  const __amdgpu_buffer_rsrc_t img0 = __builtin_amdgcn_make_buffer_rsrc((void *)(image0 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t img1 = NSRC == 2 ? __builtin_amdgcn_make_buffer_rsrc((void *)(image1 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000) : img0;
   const float csct = cs * ct, ssct = ss * ct;
-  bool same = NSRC == 2;                         // wave-uniform (scalar loads)
-  if (NSRC == 2) {
+  float depth[NS];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) same = same && (P0[k] == P1[k]);
-  }
-  float out[NSRC][NS][3];
+  for (int q = 0; q < NS; ++q) depth[q] = depths[d0 + q];
+
+  // lane -> (pixel of the wave, depth group) for the whole-pixel store path
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned plq = __umulhi((unsigned)lane, ng_magic);      // lane / ng by multiply-high (+ one correction), like idx / ng above
+  if ((unsigned)lane - plq * (unsigned)ng >= (unsigned)ng) ++plq;
+  const int pl = (int)plq, dg = lane - pl * ng;
+  constexpr int WAVE_ELEMS = 384 * NS;
+  __shared__ __attribute__((aligned(16))) OutT s_out[4][WAVE_ELEMS];
+
+  TapsB taps[NSRC][NS];
+  int held = -1;                                  // frame the corners in `taps` were computed for (wave-uniform)
+  for (int b = b_lo; b < b_hi; ++b) {
+    const float *P0 = pose0 + (size_t)b * 16;
+    const float *P1 = NSRC == 2 ? pose1 + (size_t)b * 16 : P0;
+    const float r = intrinsics[(size_t)b * 9];
+    bool reuse = held >= 0;                       // wave-uniform: scalar loads, scalar compares
+    if (reuse) {
+      const float *H0 = pose0 + (size_t)held * 16;
+      const float *H1 = NSRC == 2 ? pose1 + (size_t)held * 16 : H0;
+      reuse = r == intrinsics[(size_t)held * 9];
 #pragma unroll
-  for (int q = 0; q < NS; ++q) {
-    const float depth = depths[d0 + q];
-    float u, v;
-    const OdsQuad q0 = ods_quad(P0, r, depth, csct, st, ssct);
-    ods_tail(q0, NSRC == 2 ? 1.0f : order, K, u, v);
-    gather3(img0, width, height, u, v, out[0][q]);
-    if (NSRC == 2) {
-      if (same) {
-        ods_tail(q0, -1.0f, K, u, v);
-      } else {
-        const OdsQuad q1 = ods_quad(P1, r, depth, csct, st, ssct);
-        ods_tail(q1, -1.0f, K, u, v);
-      }
-      gather3(img1, width, height, u, v, out[NSRC - 1][q]);
+      for (int k = 0; k < 12; ++k) reuse = reuse && (P0[k] == H0[k]) && (NSRC == 1 || P1[k] == H1[k]);
     }
-  }
-  if (NSRC == 2 && coalesce) {
-    // Whole-pixel stores: with both sources in one thread a wavefront owns 64 / ng complete pixels = 384 NS
-    // CONTIGUOUS elements of the NHWC volume.  They are exchanged through a wave-private LDS strip and leave as
-    // 16-byte-per-lane stores (3 fully coalesced instructions per wave instead of 12 strided dword stores per lane,
-    // which kept the store path -- not the VALU -- the limiter of this kernel).  No block barrier: LDS operations of
-    // one wave are performed in order.
-    constexpr int WAVE_ELEMS = 384 * NS;
-    __shared__ __attribute__((aligned(16))) OutT s_out[4][WAVE_ELEMS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned plq = __umulhi((unsigned)lane, ng_magic);      // lane / ng by multiply-high (+ one correction), like idx / ng above
-    if ((unsigned)lane - plq * (unsigned)ng >= (unsigned)ng) ++plq;
-    const int pl = (int)plq, dg = lane - pl * ng;
-    OutT *w = s_out[wave];
+    if (!reuse) {
+      bool same = NSRC == 2;                      // both sources share the quadratic when their poses are equal
+      if (NSRC == 2) {
 #pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx)
+        for (int k = 0; k < 12; ++k) same = same && (P0[k] == P1[k]);
+      }
 #pragma unroll
-      for (int q = 0; q < NS; ++q)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) store_elem(w, (size_t)(pl * 6 * nd + sidx * 3 * nd + (dg * NS + q) * 3 + c), out[sidx][q][c]);
-    __builtin_amdgcn_wave_barrier();
-    const size_t first = (size_t)(p - pl) * channels;      // element offset of the wave's first pixel (lane 0's pixel)
-    const uint4 *src = reinterpret_cast<const uint4 *>(w);
-    uint4 *dst = reinterpret_cast<uint4 *>(psv + first);
-    constexpr int NV = WAVE_ELEMS * (int)sizeof(OutT) / 16;
-#pragma unroll
-    for (int k = lane; k < NV; k += 64) dst[k] = src[k];
-    return;
-  }
-#pragma unroll
-  for (int sidx = 0; sidx < NSRC; ++sidx) {
-    const size_t o = (size_t)p * channels + (NSRC == 2 ? sidx * 3 * nd : coff) + d0 * 3;
+      for (int q = 0; q < NS; ++q) {
+        float u, v;
+        const OdsQuad q0 = ods_quad(P0, r, depth[q], csct, st, ssct);
+        ods_tail(q0, NSRC == 2 ? 1.0f : order, K, u, v);
+        taps[0][q] = make_taps_bytes(u, v, width, height);
+        if (NSRC == 2) {
+          if (same) {
+            ods_tail(q0, -1.0f, K, u, v);
+          } else {
+            const OdsQuad q1 = ods_quad(P1, r, depth[q], csct, st, ssct);
+            ods_tail(q1, -1.0f, K, u, v);
+          }
+          taps[NSRC - 1][q] = make_taps_bytes(u, v, width, height);
+        }
+      }
+      held = b;
+    }
+    const __amdgpu_buffer_rsrc_t img0 = __builtin_amdgcn_make_buffer_rsrc((void *)(image0 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t img1 = NSRC == 2 ? __builtin_amdgcn_make_buffer_rsrc((void *)(image1 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000) : img0;
+    float out[NSRC][NS][3];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-      store_elem(psv, o + q * 3 + 0, out[sidx][q][0]);
-      store_elem(psv, o + q * 3 + 1, out[sidx][q][1]);
-      store_elem(psv, o + q * 3 + 2, out[sidx][q][2]);
+      gather3(img0, taps[0][q], out[0][q]);
+      if (NSRC == 2) gather3(img1, taps[NSRC - 1][q], out[NSRC - 1][q]);
+    }
+    const long p = ((long)b * height + i) * width + j;
+    if (NSRC == 2 && coalesce) {
+      // Whole-pixel stores: with both sources in one thread a wavefront owns 64 / ng complete pixels = 384 NS
+      // CONTIGUOUS elements of the NHWC volume.  They are exchanged through a wave-private LDS strip and leave as
+      // 16-byte-per-lane stores (3 fully coalesced instructions per wave instead of 12 strided dword stores per lane,
+      // which kept the store path -- not the VALU -- the limiter of this kernel).  No block barrier: LDS operations of
+      // one wave are performed in order (the next frame's strip writes follow this frame's strip reads).
+      OutT *w = s_out[wave];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) store_elem(w, (size_t)(pl * 6 * nd + sidx * 3 * nd + (dg * NS + q) * 3 + c), out[sidx][q][c]);
+      __builtin_amdgcn_wave_barrier();
+      const size_t first = (size_t)(p - pl) * channels;      // element offset of the wave's first pixel (lane 0's pixel)
+      const uint4 *src = reinterpret_cast<const uint4 *>(w);
+      uint4 *dst = reinterpret_cast<uint4 *>(psv + first);
+      constexpr int NV = WAVE_ELEMS * (int)sizeof(OutT) / 16;
+#pragma unroll
+      for (int k = lane; k < NV; k += 64) dst[k] = src[k];
+      continue;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < NSRC; ++sidx) {
+      const size_t o = (size_t)p * channels + (NSRC == 2 ? sidx * 3 * nd : coff) + d0 * 3;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        store_elem(psv, o + q * 3 + 0, out[sidx][q][0]);
+        store_elem(psv, o + q * 3 + 1, out[sidx][q][1]);
+        store_elem(psv, o + q * 3 + 2, out[sidx][q][2]);
+      }
     }
   }
 }
@@ -1090,6 +1140,9 @@ int msi_compose_poses_f32(const float *lhs, const float *rhs, float *out, int32_
 #ifndef MSI_SWEEP_NS_DEFAULT
 #define MSI_SWEEP_NS_DEFAULT 2
 #endif
+#ifndef MSI_SWEEP_BCHUNK
+#define MSI_SWEEP_BCHUNK 16
+#endif
 static int sweep_common(const float *image, const float *image1, const float *pose, const float *pose1,
                         const float *intrinsics,
                         const float *depths, const float *trig, int32_t batch,
@@ -1109,13 +1162,16 @@ static int sweep_common(const float *image, const float *image1, const float *po
   // NS depths per thread (bit-identical results for every NS; -DMSI_SWEEP_NS_DEFAULT=1/2/4 at build time)
   int ns = MSI_SWEEP_NS_DEFAULT;
   while (num_depths % ns != 0) ns >>= 1;
-  const dim3 grid((unsigned)(((long)width * (num_depths / ns) + 255) / 256), height, batch);
+  // frames per thread (see the kernel's BATCH LOOP): up to MSI_SWEEP_BCHUNK consecutive frames share a thread's sample
+  // corners when their poses / baselines agree; chunks keep grid.z >= 1 and every chunk but the last full
+  const int bchunk = batch < MSI_SWEEP_BCHUNK ? batch : MSI_SWEEP_BCHUNK;
+  const dim3 grid((unsigned)(((long)width * (num_depths / ns) + 255) / 256), height, (batch + bchunk - 1) / bchunk);
 #define MSI_LAUNCH_SWEEP(T, NS_, NSRC_)                                                                          \
   hipLaunchKernelGGL((ods_sweep_kernel<T, NS_, NSRC_>), grid, dim3(256), 0, msi::as_stream(stream), image, image1, \
                      pose, pose1, intrinsics, depths, trig, batch, height, width, num_depths, (float)order,      \
                      static_cast<T *>(psv), psv_channels, channel_offset, make_consts(height, width),           \
                      (num_depths / NS_) == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)(num_depths / NS_)),  \
-                     (pair && 64 % (num_depths / NS_) == 0 && ((long)width * (num_depths / NS_)) % 64 == 0) ? 1 : 0)
+                     (pair && 64 % (num_depths / NS_) == 0 && ((long)width * (num_depths / NS_)) % 64 == 0) ? 1 : 0, bchunk)
 #define MSI_LAUNCH_SWEEP_N(T, NSRC_)                                                                     \
   { if (ns == 4) MSI_LAUNCH_SWEEP(T, 4, NSRC_); else if (ns == 2) MSI_LAUNCH_SWEEP(T, 2, NSRC_); else MSI_LAUNCH_SWEEP(T, 1, NSRC_); }
 #define MSI_LAUNCH_SWEEP_T(T) { if (pair) MSI_LAUNCH_SWEEP_N(T, 2) else MSI_LAUNCH_SWEEP_N(T, 1) }

@@ -41,7 +41,7 @@ def run(seed, b, h, w, d, ngf, coord):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="alias of --configs config1")
-    ap.add_argument("--configs", nargs="*", default=[], choices=["config1", "wrap", "config2", "config3", "config4"],
+    ap.add_argument("--configs", nargs="*", default=[], choices=["config1", "wrap", "config2", "config3", "config4", "hres4k"],
                     help="full-size dense stratified fixtures: config1 = BASELINE configs[1] (640x320x32, CoordNet), wrap = the "
                          "same frame through msi_train_net (test.py:52's default network), config2 / 3 / 4 = BASELINE "
                          "configs[2..4] (minutes of CPU each)")
@@ -57,7 +57,7 @@ def main():
     todo = list(a.configs) + (["config1"] if a.full and "config1" not in a.configs else [])
     for name in todo:
         {"config1": full_config1, "wrap": full_wrap, "config2": full_config2, "config3": full_config3,
-         "config4": full_config4}[name]()
+         "config4": full_config4, "hres4k": full_hres4k}[name]()
 
 
 # ---- full-size fixtures: dense stratified samples ------------------------------------------------------------------
@@ -203,6 +203,42 @@ def full_config3():
     np.savez_compressed(os.path.join(HERE, "full_config3_1280x640x32_samples.npz"),
                         cfg=np.array(sorted(cfg.items()), dtype=object), **samples)
     print("wrote config3 samples")
+
+
+def full_hres4k():
+    """SURVEY 8f-3 / the reference's DEFAULT high-res size (loader.py:34-35: 4096 x 2048; test.py:283-394): network at
+    640x320 (the config1 frame), blend weights / alphas upsampled (align_corners) and the layers re-assembled from the
+    4096x2048 sweep volume and rendered, plane by plane as the reference's host loop does (oracle.MSI.render_hres;
+    ~15 min of numpy).  Dense stratified samples of hres_rgb / hres_depth + the pixels with disc < 0 on the far / near
+    plane at the high resolution."""
+    import time
+    from oracle import geometry as G
+    cfg = dict(seed=8969, b=1, h=2048, w=4096, d=32, ngf=64, coord=True, low_seed=8964, low_h=320, low_w=640)
+    t0 = time.time()
+    low_inp, low = run(cfg["low_seed"], 1, cfg["low_h"], cfg["low_w"], cfg["d"], cfg["ngf"], True)
+    print("low-res pass %.0f s" % (time.time() - t0), flush=True)
+    hres = make_inputs(cfg["seed"], 1, cfg["h"], cfg["w"])
+    o = OracleMSI(coord_net=True)
+    planes = o.inv_depths(1.0, 100.0, cfg["d"])
+    # invalid pixels of both sweeps on the far / near plane (identity poses: format_network_input's curr_pose = I)
+    S, T = G.lat_long_grid((cfg["h"], cfg["w"]))
+    bad = np.zeros((cfg["h"], cfg["w"]), dtype=bool)
+    for order in (1, -1):
+        for dpt in (planes[0], planes[-1]):
+            pts = G.apply_pose(G.backproject_spherical(S, T, np.asarray([dpt], np.float32)), np.eye(4, dtype=np.float32))
+            _, _, v = G.project_ods(pts, order, low_inp["intrinsics"][0, 0, 0], cfg["w"], cfg["h"])
+            bad |= ~v.reshape(cfg["h"], cfg["w"])
+    extra = np.flatnonzero(bad.reshape(-1))
+    print("invalid far / near pixels at 4096x2048: %d (%.0f s)" % (extra.size, time.time() - t0), flush=True)
+    hrgb, hdep = o.render_hres(low["blend_weights"], low["alphas"], hres["ref_image"], hres["src_image"], low_inp["ref_pose"],
+                               low_inp["src_pose"], low_inp["tgt_pose_rt"], low_inp["tgt_pos"], planes, low_inp["intrinsics"])
+    print("render_hres %.0f s" % (time.time() - t0), flush=True)
+    s = dense_samples(dict(hres_rgb=hrgb, hres_depth=hdep), ("hres_rgb", "hres_depth"), extra, 9)
+    s["extra_pixels"] = extra.astype(np.int32)
+    s["sample_seed"] = np.int64(9)
+    np.savez_compressed(os.path.join(HERE, "full_hres_4096x2048x32_samples.npz"),
+                        cfg=np.array(sorted(cfg.items()), dtype=object), **s)
+    print("wrote hres4k samples", {k: v.shape for k, v in s.items() if hasattr(v, "shape")})
 
 
 def pp_inputs(seed, b, n):

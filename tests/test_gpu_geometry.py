@@ -329,6 +329,52 @@ def test_sweep_volume_equals_two_single_source_sweeps(gpu, same_pose, bf16, d):
         assert np.abs(_np(both) - want).max() <= TOL
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("b,d", [(7, 8), (19, 8), (5, 6)])     # 19 > the 16-frame chunk of a thread; d = 6: strided store path
+def test_sweep_batch_loop_reuses_corners_only_between_equal_frames(gpu, b, d, bf16):
+    """Round 4: a thread keeps the sample corners of its (pixel, depths) and walks the frames of the batch, recomputing
+    them only when a frame's (ref pose, src pose, baseline) differ from the frame they were computed for (wave-uniform
+    compare).  One batch mixing runs of equal frames, a changed src pose, a changed ref pose, a changed baseline and a
+    return to the first setting must equal -- bit for bit -- every frame swept ALONE (batch 1: nothing to reuse), and
+    the oracle within 1e-3."""
+    torch, m, o = gpu
+    from matryodshka_amd import _native as N
+    h, w = 24, 48
+    inp = make_inputs(41, b, h, w)
+    ref = m.preprocess_image(torch.from_numpy(inp["ref_image"]))
+    src = m.preprocess_image(torch.from_numpy(inp["src_image"]))
+    p0 = np.tile(np.eye(4, dtype=np.float32)[None], (b, 1, 1))
+    p1 = p0.copy()
+    intr = inp["intrinsics"].copy()
+    p1[2, 0, 3] = 0.01                         # frame 2: src pose differs (frames 0, 1 equal; 3 returns to the first setting)
+    if b > 4:
+        p0[4, 1, 3] = -0.02                    # frame 4: ref pose differs
+    if b > 5:
+        intr[5:7, 0, 0] = 0.05                 # frames 5, 6: another baseline, equal to each other
+    if b > 17:
+        p1[17, 2, 3] = 0.015                   # second chunk of 16: frame 16 starts it, 17 differs, 18 equals 16
+    t0, t1, ti = torch.from_numpy(p0).cuda(), torch.from_numpy(p1).cuda(), torch.from_numpy(intr).cuda()
+    depths = torch.tensor(m.inv_depths(1.0, 100.0, d), dtype=torch.float32).cuda()
+    trig = m._trig(h, w)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    whole = torch.zeros((b, h, w, 6 * d), dtype=dt, device="cuda")
+    alone = torch.zeros_like(whole)
+    N.check(N.lib.msi_ods_sweep_volume(ref.data_ptr(), src.data_ptr(), t0.data_ptr(), t1.data_ptr(), ti.data_ptr(),
+                                       depths.data_ptr(), trig.data_ptr(), b, h, w, d, whole.data_ptr(), int(bf16), None), "volume")
+    for k in range(b):
+        N.check(N.lib.msi_ods_sweep_volume(ref[k:k + 1].data_ptr(), src[k:k + 1].data_ptr(), t0[k:k + 1].data_ptr(), t1[k:k + 1].data_ptr(),
+                                           ti[k:k + 1].data_ptr(), depths.data_ptr(), trig.data_ptr(), 1, h, w, d,
+                                           alone[k:k + 1].data_ptr(), int(bf16), None), "volume of one frame")
+    torch.cuda.synchronize()
+    assert torch.equal(whole, alone)
+    assert not torch.equal(whole[1], whole[2]) and not torch.equal(whole[0], whole[1])       # (different images / poses)
+    if not bf16:
+        G = __import__("oracle.geometry", fromlist=["x"])
+        want = np.concatenate([G.ods_sphere_sweep(o.preprocess_image(img), order, m.inv_depths(1.0, 100.0, d), pose, intr)
+                               for img, pose, order in ((inp["ref_image"], p0, 1), (inp["src_image"], p1, -1))], axis=3)
+        assert np.abs(_np(whole) - want).max() <= TOL
+
+
 def test_pair_launches_equal_single_ones(gpu):
     """preprocess / deprocess of the two images of a frame in one launch: same bits as the single-image entry points."""
     torch, m, o = gpu
