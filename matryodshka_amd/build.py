@@ -17,7 +17,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE
 # (source, extra flags).  geometry.hip must not contract a*b+c into fma: see its header.
 SOURCES = [
     ("common.cpp", ["-x", "hip"]),
-    ("geometry.hip", ["-ffp-contract=off"]),
+    ("geometry.hip", ["-ffp-contract=off"] + os.environ.get("MSI_GEO_DEFINES", "").split()),   # e.g. MSI_GEO_DEFINES="-DMSI_SWEEP_WAVES=5" (tuning)
     ("cnn.hip", os.environ.get("MSI_CNN_DEFINES", "").split()),   # e.g. MSI_CNN_DEFINES="-DMSI_NSTAGE=2" (tuning)
 ]
 

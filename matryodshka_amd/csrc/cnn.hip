@@ -3098,7 +3098,7 @@ struct HeadAsmParams {
   float *bw_out, *al_out;    // optional [B,H,W,D]
   float *pred_out;           // optional [B,H,W,2D] (tanh output)
   int C0, ksteps, npad, nd, hw;
-  int lg;                    // layers per workgroup: D / gridDim.y (a multiple of 4, <= HA_LG)
+  int lg, ng;                // layers per workgroup (a multiple of 4, <= HA_LG) and layer groups: D = lg * ng
   unsigned mg_vpp, mg_nchunk, mg_hw;   // udiv_magic multipliers of the 16-byte vectors per pixel of the sweep-volume tile, of the
                              // 16-byte chunks per pixel of the activation tile, of H * W (run-time integer divisions are ~25 VALU each)
   long npix_total;
@@ -3120,7 +3120,16 @@ head_assemble_kernel(const HeadAsmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BN = 64;                                        // >= 2 lg local output columns
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nd = p.nd, lg = p.lg, g = blockIdx.y;
+  // 1-D grid.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2): id -> XCD id & 7, slot id >> 3.  The ng
+  // layer groups of a pixel tile take CONSECUTIVE slots of ONE XCD, so what they share -- the 32 x C0 activations and the
+  // 128-byte lines their 192-byte colour runs straddle (1.43x the algorithmic read bytes when group 1 ran a whole grid
+  // later, r03_g_hbm_traffic_config2) -- is fetched from HBM once and hit in that XCD's L2 the second time.
+  const int nd = p.nd, lg = p.lg, ng = p.ng;
+  const unsigned slot = blockIdx.x >> 3;
+  const unsigned tsl = ng == 1 ? slot : slot / (unsigned)ng;
+  const int g = (int)(slot - tsl * (unsigned)ng);
+  const long tile = (long)tsl * 8 + (blockIdx.x & 7u);
+  if (tile * HA_TP >= p.npix_total) return;                    // (grid rounded up to 8 ng workgroups)
   const int c_psv = 6 * nd, c_pred = 2 * nd;                    // global row lengths
   const int l_cpsv = 6 * lg, l_cpred = 2 * lg;                  // local ones
   const int s_psv = l_cpsv + 1, s_pred = l_cpred + 1;           // odd row strides (see assemble_kernel)
@@ -3143,7 +3152,7 @@ head_assemble_kernel(const HeadAsmParams p) {
   // local output column -> global one (in float4 groups: lg % 4 == 0)
   auto gcol = [&](int n) __attribute__((always_inline)) -> int { return n < lg ? g * lg + n : nd + g * lg + (n - lg); };
 
-  const long p0 = (long)blockIdx.x * HA_TP;
+  const long p0 = tile * HA_TP;
   const int b = (int)udiv_magic((unsigned)p0, (unsigned)p.hw, p.mg_hw);   // (H * W is a multiple of 32: a tile never straddles samples; B * H * W < 2^32, host-checked)
   // 1. every global load of the workgroup goes out first and is parked in registers: the sweep-volume tile, the raw
   //    activations (C0 <= 64: at most two float4 per thread), the weight rows -- ONE memory round trip per workgroup
@@ -3152,8 +3161,8 @@ head_assemble_kernel(const HeadAsmParams p) {
   constexpr int PSV_VEC = BF16IN ? 8 : 4;                       // elements per 16-byte vector
   constexpr int ESZ = BF16IN ? 2 : 4;
   // runs of the global row this group needs: the whole row (one group), or its foreground and background colours
-  const int nrun = gridDim.y == 1 ? 1 : 2;
-  const int run_len = gridDim.y == 1 ? c_psv : 3 * lg;          // elements; a multiple of PSV_VEC (host-checked)
+  const int nrun = ng == 1 ? 1 : 2;
+  const int run_len = ng == 1 ? c_psv : 3 * lg;          // elements; a multiple of PSV_VEC (host-checked)
   const int vpr = run_len / PSV_VEC, vpp = nrun * vpr;          // vectors per run / per pixel
   const int nv_psv = HA_TP * vpp;
   float4 q[PSV_PER_THREAD];
@@ -3163,7 +3172,7 @@ head_assemble_kernel(const HeadAsmParams p) {
     for (int k = 0; k < PSV_PER_THREAD; ++k) {
       const int v = tid + 256 * k;
       if (v < nv_psv) {
-        if (gridDim.y == 1) {   // the whole tile is contiguous: no index arithmetic in front of the loads
+        if (ng == 1) {   // the whole tile is contiguous: no index arithmetic in front of the loads
           q[k] = reinterpret_cast<const float4 *>(gp)[v];
         } else {
           const int px = (int)udiv_magic((unsigned)v, (unsigned)vpp, p.mg_vpp), w = v - px * vpp;
@@ -3180,9 +3189,9 @@ head_assemble_kernel(const HeadAsmParams p) {
     // a bf16 plan keeps conv8_2's raw output as fp16 of x * 2^-e (the affine of ln_finish_kernel carries 2^e): thread t loads
     // the 16 bytes that hold its two chunks e = 2 t, 2 t + 1 (eight channels) -- one 16-byte load per thread, as in the fp32 form
     typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-    const int e = 2 * tid, r = (int)udiv_magic((unsigned)e, (unsigned)nchunk, p.mg_nchunk), c = (e - r * nchunk) * 4;
+    const int r = tid >> 3, c = (tid & 7) * 8;   // 32 pixels x 8 slots of 8 channels (C0 <= 64)
     araw[0] = araw[1] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (e < HA_TP * nchunk && c < p.C0) {   // (C0 % 8 == 0 in a bf16 plan: both chunks are in range together)
+    if (c < p.C0) {   // (C0 % 8 == 0 in a bf16 plan)
       const h8_t h = *reinterpret_cast<const h8_t *>(reinterpret_cast<const _Float16 *>(p.x) + (size_t)(p0 + r) * p.C0 + c);
       araw[0] = v4f{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
       araw[1] = v4f{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
@@ -3198,21 +3207,23 @@ head_assemble_kernel(const HeadAsmParams p) {
   }
   const int nb = p.ksteps * BN * 8;
   v4f braw[B_PER_THREAD];
-  v4f wfrag[2][4];                                              // BF16IN, waves 0 / 1: the weight fragments of the lane's output column
+  v4f wfrag[4];                                                 // BF16IN, waves 0 / 1: the weight fragments of the lane's output column
   if (BF16IN) {
+    // round 4: the head of a bf16 plan runs on v_mfma_f32_32x32x16_bf16 over the packed bf16 rows of color_pred themselves
+    // (64 channels per 128-byte row: one k-step for C0 <= 64; MFMA q takes chunk 2 q + half, as in the conv kernels) --
+    // the same operands as before (the fp32 MFMA ran on fp32-format copies of these bf16 values), exact products, fp32
+    // accumulation, another summation order; 4 MFMAs of 8 passes instead of 32 of 16 per wave and tile
     if (wave < 2) {
       const int frow = lane & 31, fh = lane >> 5;
       const int nloc = wave * 32 + frow;
       const int gn = gcol(nloc < l_cpred ? nloc : 0);
       const int fswz = (gn >> 1) & 7;                           // (a packed row's slots are swizzled by its GLOBAL row)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          wfrag[ks][qq] = v4f{0.f, 0.f, 0.f, 0.f};
-          if (ks < p.ksteps && nloc < l_cpred)
-            wfrag[ks][qq] = *reinterpret_cast<const v4f *>(p.wpk + ((size_t)ks * p.npad + gn) * (ROW_BYTES / 4) + (((fh * 4 + qq) ^ fswz) << 2));
-        }
+      for (int qq = 0; qq < 4; ++qq) {
+        wfrag[qq] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (nloc < l_cpred)
+          wfrag[qq] = *reinterpret_cast<const v4f *>(p.wpk + (size_t)gn * (ROW_BYTES / 4) + (((2 * qq + fh) ^ fswz) << 2));
+      }
     }
   } else {
 #pragma unroll
@@ -3232,9 +3243,28 @@ head_assemble_kernel(const HeadAsmParams p) {
   // 3. A: 32 pixels x (ksteps * 32) channels, LayerNorm + ReLU applied (the stand-alone head's expression), zero beyond
   //    C0; the 16-byte slot s of row r holds data chunk s ^ ((r >> 1) & 7) (the conv kernel's LDS image).  B: the group's
   //    rows of every k-step of the packed blob as they are (pre-swizzled by their GLOBAL row)
+  if (BF16IN) {
+    // thread t holds channels 8 (t & 7) .. + 7 of pixel t >> 3: LayerNorm + ReLU, two values per v_cvt_pk_bf16_f32 (round to
+    // nearest even, where ln_apply_kernel<1> rounds), one 16-byte slot of the pixel's 128-byte row (64 channels)
+    const int r = tid >> 3, ch = tid & 7, c = ch * 8;
+    unsigned pk[4] = {0u, 0u, 0u, 0u};
+    if (c < p.C0) {                                             // C0 % 8 == 0 in a bf16 plan
+      float y[8];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const v4f s4 = *reinterpret_cast<const v4f *>(s_aff + c + 4 * k), t4 = *reinterpret_cast<const v4f *>(s_aff + p.C0 + c + 4 * k);
+        y[4 * k] = fmaxf(araw[k].x * s4.x + t4.x, 0.f); y[4 * k + 1] = fmaxf(araw[k].y * s4.y + t4.y, 0.f);
+        y[4 * k + 2] = fmaxf(araw[k].z * s4.z + t4.z, 0.f); y[4 * k + 3] = fmaxf(araw[k].w * s4.w + t4.w, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[k]) : "v"(y[2 * k]), "v"(y[2 * k + 1]));
+    }
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<v4u_t *>(sA + r * ROW_BYTES + ((ch ^ ((r >> 1) & 7)) << 4)) = v4u_t{pk[0], pk[1], pk[2], pk[3]};
+  } else
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int e = BF16IN ? 2 * tid + k : tid + 256 * k;   // (the chunk araw[k] holds: see the loads above)
+    const int e = tid + 256 * k;                          // (the chunk araw[k] holds: see the loads above)
     if (e < HA_TP * nchunk) {
       const int r = (int)udiv_magic((unsigned)e, (unsigned)nchunk, p.mg_nchunk), ch = e - r * nchunk;
       const int c = ch * 4;
@@ -3243,13 +3273,6 @@ head_assemble_kernel(const HeadAsmParams p) {
         const v4f s4 = *reinterpret_cast<const v4f *>(s_aff + c), t4 = *reinterpret_cast<const v4f *>(s_aff + p.C0 + c);
         y.x = fmaxf(araw[k].x * s4.x + t4.x, 0.f); y.y = fmaxf(araw[k].y * s4.y + t4.y, 0.f);
         y.z = fmaxf(araw[k].z * s4.z + t4.z, 0.f); y.w = fmaxf(araw[k].w * s4.w + t4.w, 0.f);
-        if (BF16IN) {
-          auto rne = [](float f) __attribute__((always_inline)) -> float {
-            const unsigned u = __builtin_bit_cast(unsigned, f);
-            return __builtin_bit_cast(float, (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
-          };
-          y.x = rne(y.x); y.y = rne(y.y); y.z = rne(y.z); y.w = rne(y.w);
-        }
       }
       const int ks = ch >> 3, chunk = ch & 7;
       *reinterpret_cast<v4f *>(sA + (ks * HA_TP + r) * ROW_BYTES + ((chunk ^ ((r >> 1) & 7)) << 4)) = y;
@@ -3272,12 +3295,19 @@ head_assemble_kernel(const HeadAsmParams p) {
     const int frow = lane & 31, fh = lane >> 5;
     const int fswz_a = (frow >> 1) & 7;
     const int fswz_b = (gcol(wave * 32 + frow < l_cpred ? wave * 32 + frow : 0) >> 1) & 7;   // B rows keep the swizzle of their global row
+    if (BF16IN) {
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const v4f a = *reinterpret_cast<const v4f *>(sA + frow * ROW_BYTES + (((2 * qq + fh) ^ fswz_a) << 4));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag[qq]), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+      }
+    } else
     for (int ks = 0; ks < p.ksteps; ++ks) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const v4f a = *reinterpret_cast<const v4f *>(sA + (ks * HA_TP + frow) * ROW_BYTES + (((fh * 4 + qq) ^ fswz_a) << 4));
-        const v4f w = BF16IN ? (ks == 0 ? wfrag[0][qq] : wfrag[1][qq])
-                             : *reinterpret_cast<const v4f *>(sB + (ks * BN + wave * 32 + frow) * ROW_BYTES + (((fh * 4 + qq) ^ fswz_b) << 4));
+        const v4f w = *reinterpret_cast<const v4f *>(sB + (ks * BN + wave * 32 + frow) * ROW_BYTES + (((fh * 4 + qq) ^ fswz_b) << 4));
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a.z, acc, 0, 0, 0);
@@ -4399,7 +4429,7 @@ int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, con
   const Layer &S = net.layers[H.src0];
   HeadAsmParams q;
   q.x = reinterpret_cast<const float *>(ws + S.raw_off);
-  q.wpk = packed + (bf16 ? net.head_f32_off : H.packed_off);
+  q.wpk = packed + H.packed_off;   // (bf16 plans: the packed bf16 rows themselves -- the fp32-format copy at head_f32_off is unused since r04)
   q.bias = packed + H.gamma_off;
   float *aff = reinterpret_cast<float *>(ws + S.aff_off);
   hipLaunchKernelGGL(ln_finish_kernel, dim3(desc->batch), dim3(256), 0, stream,
@@ -4414,10 +4444,11 @@ int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, con
   q.bw_out = blend_weights;
   q.al_out = alphas;
   q.pred_out = pred;
-  q.C0 = H.c0; q.ksteps = bf16 ? net.head_f32_ksteps : H.ksteps; q.npad = bf16 ? net.head_f32_npad : H.npad;
+  q.C0 = H.c0; q.ksteps = H.ksteps; q.npad = H.npad;   // (bf16: one k-step of 64 channels)
   q.nd = nd; q.hw = desc->height * desc->width;
   q.npix_total = (long)desc->batch * q.hw;
   q.lg = nd / ng;
+  q.ng = ng;
   {
     auto magic = [](unsigned d) { return d == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / d); };
     const int vec = bf16 ? 8 : 4;                                  // elements per 16-byte vector of the sweep volume
@@ -4435,7 +4466,9 @@ int msi_net_plan_forward_rgba(const msi_net_plan *plan, const float *packed, con
     if (r_bytes < (size_t)HA_TP * (3 * q.lg + 1) * sizeof(unsigned)) r_bytes = (size_t)HA_TP * (3 * q.lg + 1) * sizeof(unsigned);
   }
   const size_t lds = 2 * 64 * 4 + 64 + ((r_bytes + 15) & ~(size_t)15) + (size_t)HA_TP * (2 * q.lg + 1) * sizeof(float);
-  const dim3 grid((unsigned)(q.npix_total / HA_TP), (unsigned)ng);
+  const long ntile = q.npix_total / HA_TP;
+  if (((ntile + 7) / 8) * 8 * ng >= (1L << 31)) return msi::fail(MSI_E_UNSUPPORTED, "net_forward_rgba: too many pixel tiles for one launch");
+  const dim3 grid((unsigned)(((ntile + 7) / 8) * 8 * ng));     // (see the kernel: XCD x takes tiles x, x + 8, ...; the layer groups of a tile are neighbours there)
   if (bf16) hipLaunchKernelGGL(head_assemble_kernel<1>, grid, dim3(256), lds, stream, q);
   else hipLaunchKernelGGL(head_assemble_kernel<0>, grid, dim3(256), lds, stream, q);
   return msi::check_launch("head_assemble");

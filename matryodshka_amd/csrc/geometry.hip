@@ -384,10 +384,15 @@ __device__ __forceinline__ void gather3(__amdgpu_buffer_rsrc_t img, const TapsB 
 // the test path every frame has the identity pose and the camera file's baseline (data_loader.py:146-160), so a thread
 // keeps the corners of its samples in registers (TapsB: ~230 of the ~276 VALU per sample) and walks the frames
 // [blockIdx.z * bchunk, + bchunk): per frame a wave-uniform comparison of the 24 pose entries + baseline with those the
-// held corners were computed from (scalar loads, scalar branch) decides between "gather with the held corners" and
+// previous frame's (bit patterns; scalar loads, scalar branch) decides between "gather with the held corners" and
 // "recompute" -- the same arithmetic either way, so the volume is bit-identical to the frame-at-a-time form.
-template <typename OutT, int NS, int NSRC>
-__global__ void __launch_bounds__(256)
+// LOOP = 0: one frame per thread (grid.z = batch, nothing to reuse: the compiler interleaves the corner arithmetic with
+// the gathers and needs 88 instead of 119 registers -- five waves per SIMD; 61 vs 70 us at batch 1).
+#ifndef MSI_SWEEP_WAVES
+#define MSI_SWEEP_WAVES 4
+#endif
+template <typename OutT, int NS, int NSRC, int LOOP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LOOP ? MSI_SWEEP_WAVES : 1, 8)))
 ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ image1, const float *__restrict__ pose0,
                  const float *__restrict__ pose1, const float *__restrict__ intrinsics, const float *__restrict__ depths,
                  const float *__restrict__ trig, int batch, int height, int width, int nd,
@@ -402,7 +407,7 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
   if ((unsigned)idx - jq * (unsigned)ng >= (unsigned)ng) ++jq;
   const int j = (int)jq, d0 = (idx - j * ng) * NS;
   const int i = blockIdx.y;
-  const int b_lo = blockIdx.z * bchunk, b_hi = min(batch, b_lo + bchunk);
+  const int b_lo = LOOP ? blockIdx.z * bchunk : blockIdx.z, b_hi = LOOP ? min(batch, b_lo + bchunk) : b_lo + 1;
 
   const float cs = trig[j], ss = trig[width + j];
   const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
@@ -420,21 +425,31 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
   constexpr int WAVE_ELEMS = 384 * NS;
   __shared__ __attribute__((aligned(16))) OutT s_out[4][WAVE_ELEMS];
 
+  // bit k of eqmask: frame b_lo + k has bit for bit the poses and the baseline of frame b_lo + k - 1 (wave-uniform: scalar
+  // loads and integer compares, all issued before the frame loop so that no frame waits on them)
+  unsigned eqmask = 0;
+  if (LOOP) {
+    const unsigned *U0 = reinterpret_cast<const unsigned *>(pose0), *U1 = reinterpret_cast<const unsigned *>(NSRC == 2 ? pose1 : pose0);
+    const unsigned *UI = reinterpret_cast<const unsigned *>(intrinsics);
+    for (int b = b_lo + 1; b < b_hi; ++b) {
+      bool eq = UI[(size_t)b * 9] == UI[(size_t)(b - 1) * 9];
+#pragma unroll
+      for (int k = 0; k < 12; ++k)
+        eq = eq && (U0[(size_t)b * 16 + k] == U0[(size_t)(b - 1) * 16 + k]) && (NSRC == 1 || U1[(size_t)b * 16 + k] == U1[(size_t)(b - 1) * 16 + k]);
+      eqmask |= (eq ? 1u : 0u) << (b - b_lo);
+    }
+    eqmask = __builtin_amdgcn_readfirstlane(eqmask);
+  }
   TapsB taps[NSRC][NS];
-  int held = -1;                                  // frame the corners in `taps` were computed for (wave-uniform)
   for (int b = b_lo; b < b_hi; ++b) {
     const float *P0 = pose0 + (size_t)b * 16;
     const float *P1 = NSRC == 2 ? pose1 + (size_t)b * 16 : P0;
-    const float r = intrinsics[(size_t)b * 9];
-    bool reuse = held >= 0;                       // wave-uniform: scalar loads, scalar compares
-    if (reuse) {
-      const float *H0 = pose0 + (size_t)held * 16;
-      const float *H1 = NSRC == 2 ? pose1 + (size_t)held * 16 : H0;
-      reuse = r == intrinsics[(size_t)held * 9];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) reuse = reuse && (P0[k] == H0[k]) && (NSRC == 1 || P1[k] == H1[k]);
-    }
+    const bool reuse = (eqmask >> (b - b_lo)) & 1u;   // the corners in `taps` were computed for an identical frame
+    const __amdgpu_buffer_rsrc_t img0 = __builtin_amdgcn_make_buffer_rsrc((void *)(image0 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t img1 = NSRC == 2 ? __builtin_amdgcn_make_buffer_rsrc((void *)(image1 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000) : img0;
+    float out[NSRC][NS][3];
     if (!reuse) {
+      const float r = intrinsics[(size_t)b * 9];
       bool same = NSRC == 2;                      // both sources share the quadratic when their poses are equal
       if (NSRC == 2) {
 #pragma unroll
@@ -446,6 +461,7 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
         const OdsQuad q0 = ods_quad(P0, r, depth[q], csct, st, ssct);
         ods_tail(q0, NSRC == 2 ? 1.0f : order, K, u, v);
         taps[0][q] = make_taps_bytes(u, v, width, height);
+        if (!LOOP) gather3(img0, taps[0][q], out[0][q]);      // (one frame per thread: request each sample as soon as its corners exist)
         if (NSRC == 2) {
           if (same) {
             ods_tail(q0, -1.0f, K, u, v);
@@ -454,17 +470,16 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
             ods_tail(q1, -1.0f, K, u, v);
           }
           taps[NSRC - 1][q] = make_taps_bytes(u, v, width, height);
+          if (!LOOP) gather3(img1, taps[NSRC - 1][q], out[NSRC - 1][q]);
         }
       }
-      held = b;
     }
-    const __amdgpu_buffer_rsrc_t img0 = __builtin_amdgcn_make_buffer_rsrc((void *)(image0 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t img1 = NSRC == 2 ? __builtin_amdgcn_make_buffer_rsrc((void *)(image1 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000) : img0;
-    float out[NSRC][NS][3];
+    if (LOOP) {
 #pragma unroll
-    for (int q = 0; q < NS; ++q) {
-      gather3(img0, taps[0][q], out[0][q]);
-      if (NSRC == 2) gather3(img1, taps[NSRC - 1][q], out[NSRC - 1][q]);
+      for (int q = 0; q < NS; ++q) {
+        gather3(img0, taps[0][q], out[0][q]);
+        if (NSRC == 2) gather3(img1, taps[NSRC - 1][q], out[NSRC - 1][q]);
+      }
     }
     const long p = ((long)b * height + i) * width + j;
     if (NSRC == 2 && coalesce) {
@@ -476,11 +491,27 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
       OutT *w = s_out[wave];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int sidx = 0; sidx < 2; ++sidx)
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const int e0 = pl * 6 * nd + sidx * 3 * nd + dg * NS * 3;     // a lane's 3 NS values per source are contiguous
+        if constexpr (sizeof(OutT) == 2 && NS % 2 == 0) {
+          // bf16, two values per instruction (v_cvt_pk_bf16_f32: round to nearest even, what f32_to_bf16 computes for the
+          // finite values stored here) and dword LDS stores (e0 is even): 12 integer-rounding sequences + 12 ds_write_b16 per
+          // lane and frame were a third of the per-frame instruction stream once the corners are reused
+          unsigned *wd = reinterpret_cast<unsigned *>(w + e0);
+          const float *v = &out[sidx][0][0];
 #pragma unroll
-        for (int q = 0; q < NS; ++q)
+          for (int k = 0; k < 3 * NS / 2; ++k) {
+            unsigned pk;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(v[2 * k]), "v"(v[2 * k + 1]));
+            wd[k] = pk;
+          }
+        } else {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) store_elem(w, (size_t)(pl * 6 * nd + sidx * 3 * nd + (dg * NS + q) * 3 + c), out[sidx][q][c]);
+          for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) store_elem(w, (size_t)(e0 + q * 3 + c), out[sidx][q][c]);
+        }
+      }
       __builtin_amdgcn_wave_barrier();
       const size_t first = (size_t)(p - pl) * channels;      // element offset of the wave's first pixel (lane 0's pixel)
       const uint4 *src = reinterpret_cast<const uint4 *>(w);
@@ -1166,17 +1197,19 @@ static int sweep_common(const float *image, const float *image1, const float *po
   // corners when their poses / baselines agree; chunks keep grid.z >= 1 and every chunk but the last full
   const int bchunk = batch < MSI_SWEEP_BCHUNK ? batch : MSI_SWEEP_BCHUNK;
   const dim3 grid((unsigned)(((long)width * (num_depths / ns) + 255) / 256), height, (batch + bchunk - 1) / bchunk);
-#define MSI_LAUNCH_SWEEP(T, NS_, NSRC_)                                                                          \
-  hipLaunchKernelGGL((ods_sweep_kernel<T, NS_, NSRC_>), grid, dim3(256), 0, msi::as_stream(stream), image, image1, \
+#define MSI_LAUNCH_SWEEP(T, NS_, NSRC_, LOOP_)                                                                          \
+  hipLaunchKernelGGL((ods_sweep_kernel<T, NS_, NSRC_, LOOP_>), grid, dim3(256), 0, msi::as_stream(stream), image, image1, \
                      pose, pose1, intrinsics, depths, trig, batch, height, width, num_depths, (float)order,      \
                      static_cast<T *>(psv), psv_channels, channel_offset, make_consts(height, width),           \
                      (num_depths / NS_) == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)(num_depths / NS_)),  \
                      (pair && 64 % (num_depths / NS_) == 0 && ((long)width * (num_depths / NS_)) % 64 == 0) ? 1 : 0, bchunk)
-#define MSI_LAUNCH_SWEEP_N(T, NSRC_)                                                                     \
-  { if (ns == 4) MSI_LAUNCH_SWEEP(T, 4, NSRC_); else if (ns == 2) MSI_LAUNCH_SWEEP(T, 2, NSRC_); else MSI_LAUNCH_SWEEP(T, 1, NSRC_); }
-#define MSI_LAUNCH_SWEEP_T(T) { if (pair) MSI_LAUNCH_SWEEP_N(T, 2) else MSI_LAUNCH_SWEEP_N(T, 1) }
+#define MSI_LAUNCH_SWEEP_N(T, NSRC_, LOOP_)                                                              \
+  { if (ns == 4) MSI_LAUNCH_SWEEP(T, 4, NSRC_, LOOP_); else if (ns == 2) MSI_LAUNCH_SWEEP(T, 2, NSRC_, LOOP_); else MSI_LAUNCH_SWEEP(T, 1, NSRC_, LOOP_); }
+#define MSI_LAUNCH_SWEEP_L(T, NSRC_) { if (bchunk > 1) MSI_LAUNCH_SWEEP_N(T, NSRC_, 1) else MSI_LAUNCH_SWEEP_N(T, NSRC_, 0) }
+#define MSI_LAUNCH_SWEEP_T(T) { if (pair) MSI_LAUNCH_SWEEP_L(T, 2) else MSI_LAUNCH_SWEEP_L(T, 1) }
   if (psv_bf16) MSI_LAUNCH_SWEEP_T(unsigned short) else MSI_LAUNCH_SWEEP_T(float)
 #undef MSI_LAUNCH_SWEEP_T
+#undef MSI_LAUNCH_SWEEP_L
 #undef MSI_LAUNCH_SWEEP_N
 #undef MSI_LAUNCH_SWEEP
   return msi::check_launch("ods_sphere_sweep");
