@@ -181,17 +181,24 @@ int msi_assemble_rgba_scaled_f32(const float *psv, const float *weights_alphas, 
  * (projector.py:246-265) and/or pj.over_composite_depth (:225-244), fused in one
  * pass: neither the pixel coordinates nor the warped layers are materialised,
  * and RGB + depth share the warp.  out_rgb / out_depth may be NULL (not both).
- *   tgt_pose_rt [B,4,4], tgt_pos [B,3], depths [D] (far -> near). */
+ *   tgt_pose_rt [B,4,4], tgt_pos [B,3], depths [D] (far -> near).
+ * status_device (all four render entry points; may be NULL): one int32 in DEVICE memory the kernel ORs
+ * MSI_RENDER_STATUS_ORIGIN_OUTSIDE into when a sample's ray origin (pose @ tgt_pos, or the ODS viewing circle) is not
+ * strictly inside every sphere it is intersected with.  There spherical.py:316-318 takes the square root of a negative
+ * number and the int cast of the NaN pixel coordinate is undefined; the kernel clamps the discriminant (finite pixels,
+ * not reference-defined) and reports it here instead of failing silently.  The caller zeroes the word and reads it back
+ * when it wants to know (the MSI class checks host-side inputs before the launch and device-side ones through this). */
+#define MSI_RENDER_STATUS_ORIGIN_OUTSIDE 1
 int msi_render_equirect_f32(const float *rgba_native, const float *tgt_pose_rt,
                             const float *tgt_pos, const float *depths, const float *trig,
                             int32_t batch, int32_t height, int32_t width, int32_t num_planes,
-                            float *out_rgb, float *out_depth, msi_stream_t stream);
+                            float *out_rgb, float *out_depth, int32_t *status_device, msi_stream_t stream);
 /* MSI.msi_render_equirect_view_single (msi.py:431-452): the warped, un-composited
  * layers, out_layers [D,B,H,W,4]. */
 int msi_project_layers_f32(const float *rgba_native, const float *tgt_pose_rt,
                            const float *tgt_pos, const float *depths, const float *trig,
                            int32_t batch, int32_t height, int32_t width, int32_t num_planes,
-                           float *out_layers, msi_stream_t stream);
+                           float *out_layers, int32_t *status_device, msi_stream_t stream);
 
 /* MSI.msi_render_ods_view (msi.py:502-525): pj.projective_forward_ods (projector.py:100-127) =
  * spherical.intersect_ods (spherical.py:328-365; eye rays tangent to the viewing circle of radius
@@ -200,7 +207,7 @@ int msi_project_layers_f32(const float *rgba_native, const float *tgt_pose_rt,
 int msi_render_ods_f32(const float *rgba_native, const float *pose, const float *intrinsics,
                        const float *depths, const float *trig, int32_t batch, int32_t height,
                        int32_t width, int32_t num_planes, int32_t order, float *out_rgb,
-                       msi_stream_t stream);
+                       int32_t *status_device, msi_stream_t stream);
 /* MSI.msi_render_perspective_view (msi.py:475-500): pj.projective_forward_sphere_to_perspective
  * (projector.py:64-98) = spherical.intersect_perspective (spherical.py:367-401; hard-coded
  * 0.1/0.05 intrinsics) -> resample -> over_composite.  `pose` [B,4,4] is the crop rotation the
@@ -208,7 +215,7 @@ int msi_render_ods_f32(const float *rgba_native, const float *pose, const float 
 int msi_render_perspective_f32(const float *rgba_native, const float *pose, const float *tgt_pos,
                                const float *depths, int32_t batch, int32_t height, int32_t width,
                                int32_t num_planes, int32_t tgt_height, int32_t tgt_width, float *out_rgb,
-                               msi_stream_t stream);
+                               int32_t *status_device, msi_stream_t stream);
 
 /* ---- PP (perspective cube-face) path, BASELINE configs[4] ------------------------------------
  * pj.perspective_plane_sweep (projector.py:221-223): sweep_one with spherical.uv_grid (:46-48),

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsi_hip.so")
 
 MSI_OK = 0
 MSI_NET_NUM_LAYERS = 18
+RENDER_STATUS_ORIGIN_OUTSIDE = 1
 MSI_ABI_VERSION = 4          # include/msi_hip.h: the version this binding's struct layouts and signatures are written for
 
 
@@ -67,10 +68,10 @@ SIGNATURES = {
     "msi_assemble_rgba_color_f32": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msi_resize_bilinear_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msi_assemble_rgba_scaled_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "msi_render_equirect_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
-    "msi_project_layers_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
-    "msi_render_ods_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
-    "msi_render_perspective_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "msi_render_equirect_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "msi_project_layers_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "msi_render_ods_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "msi_render_perspective_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "msi_perspective_plane_sweep_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "msi_mpi_render_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "msi_net_layer_info": (_I, [POINTER(NetDesc), _I, POINTER(LayerInfo)]),

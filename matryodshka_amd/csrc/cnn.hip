@@ -3126,7 +3126,7 @@ head_assemble_kernel(const HeadAsmParams p) {
   // later, r03_g_hbm_traffic_config2) -- is fetched from HBM once and hit in that XCD's L2 the second time.
   const int nd = p.nd, lg = p.lg, ng = p.ng;
   const unsigned slot = blockIdx.x >> 3;
-  const unsigned tsl = ng == 1 ? slot : slot / (unsigned)ng;
+  const unsigned tsl = ng == 1 ? slot : (ng == 2 ? slot >> 1 : slot / (unsigned)ng);   // (D <= 64: one or two groups)
   const int g = (int)(slot - tsl * (unsigned)ng);
   const long tile = (long)tsl * 8 + (blockIdx.x & 7u);
   if (tile * HA_TP >= p.npix_total) return;                    // (grid rounded up to 8 ng workgroups)

@@ -170,6 +170,45 @@ __device__ __forceinline__ float t_atan2(float y, float x) {
 #endif
 }
 
+// atan on [-1, 1] (the polynomial of t_atan2 without its range reduction) and the two angles of a point (x, y, z) with
+// horizontal distance h = sqrt(x^2 + z^2) and norm R through half-angle forms, tan(a / 2) = sin a / (1 + cos a):
+//   atan2(y, h) = 2 atan(y / (h + R))                       (|phi| <= pi/2: the argument is in [-1, 1] as it is)
+//   atan2(z, x) = 2 atan(z / (h + x))            for x >= 0,
+//               = copysign(pi, z) - 2 atan(z / (h - x))  for x < 0   (both arguments in [-1, 1])
+// -- no min / max / swap range reduction, no quadrant fix-ups, one shared square root: ~14 instead of ~30 instructions
+// per angle in the render kernel, which is bound by its VALU stream.  Same 1.3e-7 rad polynomial (doubled: 2.6e-7 rad =
+// 3e-5 px at W = 640); atan2(+-0, +-0) = +-0 like libm's for (+0, +0).  Render kernel only: its chain has no data-dependent
+// reference branch and its inputs are finite (no NaN propagation needed).
+__device__ __forceinline__ float t_atan_unit(float a) {
+  const float s = a * a;
+  float p = -0.0040545277297496796f;
+  p = __builtin_fmaf(p, s, 0.021862812340259552f);
+  p = __builtin_fmaf(p, s, -0.05591211095452309f);
+  p = __builtin_fmaf(p, s, 0.09642180800437927f);
+  p = __builtin_fmaf(p, s, -0.13908623158931732f);
+  p = __builtin_fmaf(p, s, 0.19946564733982086f);
+  p = __builtin_fmaf(p, s, -0.33329859375953674f);
+  p = __builtin_fmaf(p, s, 0.9999993443489075f);
+  return p * a;
+}
+
+__device__ __forceinline__ void t_angles(float x, float y, float z, float R, float &theta_neg, float &phi) {
+#if defined(MSI_RENDER_OLD_ANGLES)   // (A/B: the r03 form, two range-reduced atan2)
+  theta_neg = -t_atan2(z, x);
+  phi = t_atan2(y, t_sqrt(x * x + z * z));
+#elif MSI_FAST_TAIL
+  const float h = __builtin_amdgcn_sqrtf(x * x + z * z);
+  const float den = fmaxf(h + fabsf(x), 1.17549435e-38f);               // (x = z = 0: 0 / tiny = 0)
+  const float a2 = 2.0f * t_atan_unit(z * __builtin_amdgcn_rcpf(den));
+  const float th = __builtin_signbitf(x) ? __builtin_copysignf(3.14159265358979324f, z) - a2 : a2;
+  theta_neg = -th;
+  phi = 2.0f * t_atan_unit(y * __builtin_amdgcn_rcpf(h + R));
+#else
+  theta_neg = -atan2f(z, x);
+  phi = atan2f(y, sqrtf(x * x + z * z));
+#endif
+}
+
 // ------------------------------------------------------------------------ K5
 __global__ void preprocess_u8_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
                                      size_t n) {
@@ -362,9 +401,15 @@ __device__ __forceinline__ float blend4(const TapsB &t, float a, float b, float 
 }
 __device__ __forceinline__ void gather3(__amdgpu_buffer_rsrc_t img, const TapsB &t, float *out) {
   const f32x3_g a = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, t.oa, 0, 0));
+#ifdef MSI_SWEEP_ABLATE_TAPS   // timing experiment only (wrong volume): two of the four corner loads
+  const f32x3_g b = a;
+  const f32x3_g c = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, t.oc, 0, 0));
+  const f32x3_g d = c;
+#else
   const f32x3_g b = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, t.ob, 0, 0));
   const f32x3_g c = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, t.oc, 0, 0));
   const f32x3_g d = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, t.od, 0, 0));
+#endif
   out[0] = blend4(t, a.x, b.x, c.x, d.x);
   out[1] = blend4(t, a.y, b.y, c.y, d.y);
   out[2] = blend4(t, a.z, b.z, c.z, d.z);
@@ -707,7 +752,7 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
               const float *__restrict__ tgt_pos, const float *__restrict__ intrinsics,
               const float *__restrict__ depths, const float *__restrict__ trig, int batch, int height,
               int width, int nd, float *__restrict__ out_rgb, float *__restrict__ out_depth,
-              float4 *__restrict__ out_layers, PixConsts K, RayParams R, DepthFrac F) {
+              float4 *__restrict__ out_layers, PixConsts K, RayParams R, DepthFrac F, int *__restrict__ status) {
   // block = 64 pixels of one target row x RENDER_SEGS layer segments: a pixel's D layers are split over RENDER_SEGS
   // threads (same lane, different waves), each compositing its contiguous range of layers from transparent black,
   //   C <- rgb a + C (1-a),   T <- T (1-a),
@@ -774,30 +819,39 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
   const float cc = (cx * cx + cy * cy) + cz * cz;
   const float qb2 = qb * qb;
   const float fa = 4.0f * qa, ta = 2.0f * qa;
+  const float inv_ta = __builtin_amdgcn_rcpf(ta);
 
   const size_t hw = (size_t)height * width;             // source layer size
   const int layer_bytes = (int)(hw * 16);                // (H * W < 2^24, checked on the host)
   const size_t ohw = (size_t)R.out_h * R.out_w;          // target size
   const size_t pix = (size_t)i * R.out_w + j;
   float o0 = 0.f, o1 = 0.f, o2 = 0.f, od = 0.f, tr = 1.f;
+  float qc_max = -1.0f;                                  // max over this thread's layers of |origin|^2 - radius^2 (>= 0: origin not inside that sphere)
   const int d_lo = (seg * nd) / RENDER_SEGS, d_hi = ((seg + 1) * nd) / RENDER_SEGS;
 
 #pragma unroll 4
   for (int d = d_lo; d < d_hi; ++d) {
     const float radius = depths[d];
     const float qc = cc - radius * radius;
+    qc_max = fmaxf(qc_max, qc);
     const float disc = qb2 - fa * qc;
     // disc >= 0 whenever the ray origin is inside the sphere (the documented domain; the host-side guard of the MSI class
     // enforces it for host inputs).  Outside it the reference takes sqrt of a negative number and casts NaN to int
     // (undefined); the clamp keeps device-side inputs finite and changes nothing inside the domain.
     // (no branch of the reference depends on these values: the whole chain is continuous -> 1-ulp primitives)
+#if MSI_FAST_TAIL
+    const float num = t_sqrt(fmaxf(disc, 0.0f)) - qb;           // t = num / ta with the pixel's 1 / ta (one correction step: <= 1 ulp)
+    const float tq = num * inv_ta;
+    const float t = __builtin_fmaf(__builtin_fmaf(-tq, ta, num), inv_ta, tq);
+#else
     const float t = t_div(-qb + t_sqrt(fmaxf(disc, 0.0f)), ta);
+#endif
     const float x = cx + t * rx;
     const float y = cy + t * ry;
     const float z = cz + t * rz;
-    // project_spherical (spherical.py:243-246) + theta_phi_to_pixels (:54-68)
-    const float theta = -t_atan2(z, x);
-    const float phi = t_atan2(y, t_sqrt(x * x + z * z));
+    // project_spherical (spherical.py:243-246) + theta_phi_to_pixels (:54-68); the point lies on the layer's sphere: |P| = radius
+    float theta, phi;
+    t_angles(x, y, z, radius, theta, phi);
 #if MSI_FAST_TAIL
     const float u = ((theta + K.pi) - K.pi_over_w) * K.u_scale;
     const float v = ((phi + K.half_pi) - K.half_pi_over_h) * K.v_scale;
@@ -806,14 +860,27 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
     const float v = (((phi + K.half_pi) - K.half_pi_over_h) / K.v_den) * K.hm1;
 #endif
 
+#ifdef MSI_RENDER_ABLATE_MATH   // timing experiment only (wrong pixels): identity warp, no per-layer angle math
+    const TapsR tp4 = make_taps_ranged((float)j + 0.3f + 0.001f * radius, (float)i + 0.3f, width, height);
+    (void)u; (void)v;
+#else
     const TapsR tp4 = make_taps_ranged(u, v, width, height);
+#endif
     // one descriptor per layer (scalar work): 32-bit texel offsets also for stacks beyond 2 GiB
     const __amdgpu_buffer_rsrc_t L = __builtin_amdgcn_make_buffer_rsrc((void *)(rgba + ((size_t)b * nd + d) * hw), 0, layer_bytes, 0x00020000);
     typedef unsigned u32x4_g __attribute__((ext_vector_type(4)));
     const float4 A = __builtin_bit_cast(float4, (u32x4_g)__builtin_amdgcn_raw_buffer_load_b128(L, tp4.oa << 4, 0, 0));
+#if defined(MSI_RENDER_ABLATE_TAPS) && MSI_RENDER_ABLATE_TAPS == 3   // timing experiments only (wrong pixels): one / two of the four corner loads
+    const float4 Bv = A, C = A, Dv = A;
+#elif defined(MSI_RENDER_ABLATE_TAPS)
+    const float4 Bv = A;
+    const float4 C = __builtin_bit_cast(float4, (u32x4_g)__builtin_amdgcn_raw_buffer_load_b128(L, tp4.oc << 4, 0, 0));
+    const float4 Dv = C;
+#else
     const float4 Bv = __builtin_bit_cast(float4, (u32x4_g)__builtin_amdgcn_raw_buffer_load_b128(L, tp4.ob << 4, 0, 0));
     const float4 C = __builtin_bit_cast(float4, (u32x4_g)__builtin_amdgcn_raw_buffer_load_b128(L, tp4.oc << 4, 0, 0));
     const float4 Dv = __builtin_bit_cast(float4, (u32x4_g)__builtin_amdgcn_raw_buffer_load_b128(L, tp4.od << 4, 0, 0));
+#endif
     const float al = blend4(tp4, A.w, Bv.w, C.w, Dv.w);
     if (MODE & RENDER_LAYERS) {
       float4 o;
@@ -846,6 +913,10 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
     }
     tr = tr * (1.0f - al);
   }
+  // the ray origin of this sample is not inside every sphere it was intersected with: outside the reference's domain
+  // (spherical.py:316-318 takes the square root of a negative number there); the clamp above kept the pixels finite, the
+  // status word says so (one lane per wave; the origin is a property of the sample, so all lanes agree)
+  if (status != nullptr && threadIdx.x == 0 && !(qc_max < 0.0f)) atomicOr(status, MSI_RENDER_STATUS_ORIGIN_OUTSIDE);
   if (MODE & RENDER_LAYERS) return;            // (nothing to combine)
   s_part[seg][threadIdx.x][0] = o0; s_part[seg][threadIdx.x][1] = o1; s_part[seg][threadIdx.x][2] = o2;
   s_part[seg][threadIdx.x][3] = od; s_part[seg][threadIdx.x][4] = tr;
@@ -1322,7 +1393,7 @@ int msi_resize_bilinear_f32(const float *in, float *out, int32_t batch, int32_t 
 static int render_common(int mode, int ray, const float *rgba_native, const float *pose, const float *tgt_pos,
                          const float *intrinsics, const float *depths, const float *trig, int32_t batch,
                          int32_t height, int32_t width, int32_t num_planes, RayParams R, float *out_rgb,
-                         float *out_depth, float *out_layers, msi_stream_t stream) {
+                         float *out_depth, float *out_layers, int32_t *status, msi_stream_t stream) {
   MSI_REQUIRE(rgba_native && pose && depths, "render: null pointer");
   MSI_REQUIRE(batch >= 0 && height > 0 && width > 0 && num_planes > 0 && R.out_h > 0 && R.out_w > 0,
               "render: bad dims");
@@ -1339,7 +1410,7 @@ static int render_common(int mode, int ray, const float *rgba_native, const floa
   for (int d = 0; d < DEPTH_FRAC_MAX; ++d) F.f[d] = d < num_planes ? (float)((double)d / (double)num_planes) : 0.0f;
 #define MSI_LAUNCH_RENDER(M, RY)                                                                       \
   hipLaunchKernelGGL((render_kernel<M, RY>), grid, block, 0, s, src, pose, tgt_pos, intrinsics, depths, \
-                     trig, batch, height, width, num_planes, out_rgb, out_depth, lay, K, R, F)
+                     trig, batch, height, width, num_planes, out_rgb, out_depth, lay, K, R, F, status)
   if (ray == RAY_EQUIRECT) {
     switch (mode) {
       case RENDER_RGB: MSI_LAUNCH_RENDER(RENDER_RGB, RAY_EQUIRECT); break;
@@ -1367,21 +1438,21 @@ static RayParams same_size(int32_t height, int32_t width) {
 int msi_render_equirect_f32(const float *rgba_native, const float *tgt_pose_rt,
                             const float *tgt_pos, const float *depths, const float *trig,
                             int32_t batch, int32_t height, int32_t width, int32_t num_planes,
-                            float *out_rgb, float *out_depth, msi_stream_t stream) {
+                            float *out_rgb, float *out_depth, int32_t *status_device, msi_stream_t stream) {
   MSI_REQUIRE(out_rgb || out_depth, "render_equirect: both outputs are NULL");
   MSI_REQUIRE(tgt_pos && trig, "render_equirect: null pointer");
   const int mode = (out_rgb ? RENDER_RGB : 0) | (out_depth ? RENDER_DEPTH : 0);
   return render_common(mode, RAY_EQUIRECT, rgba_native, tgt_pose_rt, tgt_pos, nullptr, depths, trig, batch, height,
-                       width, num_planes, same_size(height, width), out_rgb, out_depth, nullptr, stream);
+                       width, num_planes, same_size(height, width), out_rgb, out_depth, nullptr, status_device, stream);
 }
 
 int msi_project_layers_f32(const float *rgba_native, const float *tgt_pose_rt,
                            const float *tgt_pos, const float *depths, const float *trig,
                            int32_t batch, int32_t height, int32_t width, int32_t num_planes,
-                           float *out_layers, msi_stream_t stream) {
+                           float *out_layers, int32_t *status_device, msi_stream_t stream) {
   MSI_REQUIRE(out_layers && tgt_pos && trig, "project_layers: null pointer");
   return render_common(RENDER_LAYERS, RAY_EQUIRECT, rgba_native, tgt_pose_rt, tgt_pos, nullptr, depths, trig, batch,
-                       height, width, num_planes, same_size(height, width), nullptr, nullptr, out_layers, stream);
+                       height, width, num_planes, same_size(height, width), nullptr, nullptr, out_layers, status_device, stream);
 }
 
 int msi_perspective_plane_sweep_f32(const float *image, const float *pose, const float *intrinsics,
@@ -1422,20 +1493,20 @@ int msi_mpi_render_f32(const float *rgba_native, const float *tgt_pose, const fl
 
 int msi_render_ods_f32(const float *rgba_native, const float *pose, const float *intrinsics,
                        const float *depths, const float *trig, int32_t batch, int32_t height,
-                       int32_t width, int32_t num_planes, int32_t order, float *out_rgb,
+                       int32_t width, int32_t num_planes, int32_t order, float *out_rgb, int32_t *status_device,
                        msi_stream_t stream) {
   MSI_REQUIRE(out_rgb && intrinsics && trig, "render_ods: null pointer");
   MSI_REQUIRE(order == 1 || order == -1, "render_ods: order must be +1 or -1");
   RayParams R = same_size(height, width);
   R.order = (float)order;
   return render_common(RENDER_RGB, RAY_ODS, rgba_native, pose, nullptr, intrinsics, depths, trig, batch, height,
-                       width, num_planes, R, out_rgb, nullptr, nullptr, stream);
+                       width, num_planes, R, out_rgb, nullptr, nullptr, status_device, stream);
 }
 
 int msi_render_perspective_f32(const float *rgba_native, const float *pose, const float *tgt_pos,
                                const float *depths, int32_t batch, int32_t height, int32_t width,
                                int32_t num_planes, int32_t tgt_height, int32_t tgt_width, float *out_rgb,
-                               msi_stream_t stream) {
+                               int32_t *status_device, msi_stream_t stream) {
   MSI_REQUIRE(out_rgb && tgt_pos, "render_perspective: null pointer");
   MSI_REQUIRE(tgt_height > 1 && tgt_width > 1, "render_perspective: bad target size");
   RayParams R = same_size(tgt_height, tgt_width);
@@ -1445,7 +1516,7 @@ int msi_render_perspective_f32(const float *rgba_native, const float *pose, cons
   R.s0 = s0; R.sstep = (s1 - s0) / (float)(tgt_width - 1);
   R.t0 = t0; R.tstep = (t1 - t0) / (float)(tgt_height - 1);
   return render_common(RENDER_RGB, RAY_PERSPECTIVE, rgba_native, pose, tgt_pos, nullptr, depths, nullptr, batch,
-                       height, width, num_planes, R, out_rgb, nullptr, nullptr, stream);
+                       height, width, num_planes, R, out_rgb, nullptr, nullptr, status_device, stream);
 }
 
 }  // extern "C"

@@ -109,11 +109,13 @@ def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_o
     pos = np.asarray(tgt_pos, dtype=np.float32)[None]
     outs, net_input = model.infer_msi(src, ref, None, None, eye, eye, intr, which_color_pred, num_planes, planes,
                                       extra_outputs="blend_weights alphas psv", ngf=ngf)
+    model.network_status()           # (after EVERY forward: the status word is reset by the next one -- ADVICE r03)
     jouts = None
     if jitter_pose is not None:      # test.py:141-147: second inference with the sweep rotated by jitter_pose^-1
         jinv = np.linalg.inv(np.asarray(jitter_pose, dtype=np.float64)).astype(np.float32)
         jouts, _ = model.infer_msi(src, ref, None, None, eye, eye, intr, which_color_pred, num_planes, planes,
                                    extra_outputs="blend_weights alphas psv", ngf=ngf, jitter_pose_inv=jinv)
+        model.network_status()
     os.makedirs(output_dir, exist_ok=True)
     if "tgt_image" in test_outputs:
         rgb, dep = model.msi_render_equirect_view_and_depth(outs["rgba_layers"], eye, pos, planes, intr)
@@ -247,6 +249,9 @@ def main(argv=None):
     ap.add_argument("--test_outputs", default="rgba_layers_src_image_ref_image_tgt_image_blend_weights_alphas",
                     help="test.py:79-82")
     ap.add_argument("--num_runs", type=int, default=-1)
+    ap.add_argument("--strict", action="store_true",
+                    help="abort at the first sample whose LayerNorm statistics leave the kernels' fixed-point window or whose target "
+                         "position lies outside the innermost sphere (default: write UNRELIABLE.txt next to its files and go on)")
     args = ap.parse_args(argv)
     if args.num_psv_planes != args.num_msi_planes:
         raise SystemExit("--num_psv_planes must equal --num_msi_planes (msi.py:138 indexes the source volume with num_msi_planes)")
@@ -254,6 +259,8 @@ def main(argv=None):
         raise SystemExit("--test_type high_res is the ODS path (test.py:283-394)")
 
     from . import MSI, nets
+    from ._native import MsiError
+    failed = []
     d = args.num_msi_planes
     coord = args.coord_net
     nout = {"blend_psv": 2 * d, "blend_bg": 2 * d + 3, "blend_bg_psv": 3 * d + 3, "alpha_only": d}[args.which_color_pred]
@@ -286,17 +293,29 @@ def main(argv=None):
             if n == 0:
                 with open(os.path.join(exp_dir, "step.txt"), "w") as f:
                     f.write("%d" % args.step)
-            if args.input_type == "PP":
-                run_sample_pp(model, images, cam[0], cam[1], planes, d, args.ngf, args.test_outputs, out_dir, dirname,
-                              which_color_pred=args.which_color_pred)
-            else:
-                jitter = None
-                if jitter_rng is not None:
-                    from . import poses
-                    jitter = poses.random_rotation(args.rot_factor, args.tr_factor, jitter_rng)
-                run_sample(model, images, cam[0], cam[1:4], planes, d, args.ngf, args.test_outputs, out_dir, dirname,
-                           which_color_pred=args.which_color_pred, jitter_pose=jitter)
-            model.network_status()           # raises if a LayerNorm statistic left the range the kernels resolve
+            try:
+                if args.input_type == "PP":
+                    run_sample_pp(model, images, cam[0], cam[1], planes, d, args.ngf, args.test_outputs, out_dir, dirname,
+                                  which_color_pred=args.which_color_pred)
+                    model.network_status()   # raises if a LayerNorm statistic left the range the kernels resolve
+                else:
+                    jitter = None
+                    if jitter_rng is not None:
+                        from . import poses
+                        jitter = poses.random_rotation(args.rot_factor, args.tr_factor, jitter_rng)
+                    run_sample(model, images, cam[0], cam[1:4], planes, d, args.ngf, args.test_outputs, out_dir, dirname,
+                               which_color_pred=args.which_color_pred, jitter_pose=jitter)
+                model.render_status()        # raises if a render's ray origin was outside the innermost sphere
+            except (MsiError, ValueError) as e:
+                # a sample whose statistics leave the LayerNorm window (a heuristic built from the weights) or whose target lies
+                # outside the innermost sphere must not stop the remaining samples: its files are on disk but
+                # flagged; --strict restores the abort
+                if args.strict:
+                    raise
+                failed.append(dirname)
+                print("WARNING: sample %s is outside the range the kernels resolve: %s" % (dirname, e))
+                with open(os.path.join(out_dir, "UNRELIABLE.txt"), "w") as f:
+                    f.write(str(e) + "\n")
             n += 1
     if "high_res" in args.test_type:
         for scene, ids, cam in samples:
@@ -305,7 +324,7 @@ def main(argv=None):
             dirname = sample_dirname(scene, ids, args.test_type, args.prefix)
             run_hres_sample(model, hres, cam[0], cam[1:4], planes, os.path.join(exp_dir, dirname), dirname)
             n += "high_res_only" in args.test_type
-    print("processed %d samples" % n)
+    print("processed %d samples%s" % (n, " (%d flagged UNRELIABLE: %s)" % (len(failed), ", ".join(failed)) if failed else ""))
     return n
 
 

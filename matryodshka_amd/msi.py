@@ -82,6 +82,7 @@ class MSI(object):
         self.net_options = {}     # msi_net_plan_set_option key -> value, applied to plans created from now on (tests)
         self._trig_cache = {}     # (H, W) -> device tensor
         self._planes_cache = {}   # tuple(planes) -> device tensor
+        self._render_status = torch.zeros(1, dtype=torch.int32, device=self.device)   # msi_render_*'s status_device word
         if weights is not None:
             self.load_weights(weights)
 
@@ -165,6 +166,19 @@ class MSI(object):
         bits = N.c_int32(0)
         N.check(N.lib.msi_net_plan_status(plan.handle, ws.data_ptr(), self._stream(), N.ctypes.byref(bits)), "msi_net_plan_status")
         return int(bits.value)
+
+    def render_status(self):
+        """Status word of the renders since the last call (include/msi_hip.h: MSI_RENDER_STATUS_*): raises ValueError when a
+        ray origin -- handed over in DEVICE memory, where the host-side guard cannot look without a sync -- was not inside
+        the innermost sphere (the kernel clamped the discriminant: finite pixels, not reference-defined).  Synchronises the
+        stream -- call it after a frame, not inside a timed loop -- and resets the word.  Returns 0."""
+        bits = int(self._render_status.item())
+        if bits:
+            self._render_status.zero_()
+        if bits & N.RENDER_STATUS_ORIGIN_OUTSIDE:
+            raise ValueError("a render's ray origin (pose @ tgt_pos) was not inside the innermost sphere: the reference takes "
+                             "sqrt of a negative number there (spherical.py:316-318); the pixels of that call are not defined")
+        return bits
 
     def _plan(self, batch, height, width, in_channels, num_outputs, ngf):
         self._net(batch, height, width, in_channels, num_outputs, ngf)
@@ -405,7 +419,8 @@ class MSI(object):
         (spherical.py:286-288 / :390-392) and taken through the FULL 4x4 pose, translation included (spherical.py:303-310)
         -- must lie inside the innermost sphere, or intersect_sphere takes the square root of a negative number
         (spherical.py:316-318) and the int cast of the NaN pixel coordinate is undefined.  Skipped when either input
-        lives on the device (render_kernel clamps a negative discriminant to zero, so the result is finite, not reference-defined)."""
+        lives on the device: render_kernel clamps a negative discriminant to zero (finite, not reference-defined) and ORs
+        MSI_RENDER_STATUS_ORIGIN_OUTSIDE into the model's status word -- render_status() reports it."""
         if any(torch.is_tensor(t) and t.is_cuda for t in (tgt_pos, pose, planes)):
             return
         tp = np.asarray(torch.as_tensor(tgt_pos), dtype=np.float64).reshape(-1, 3)
@@ -457,7 +472,8 @@ class MSI(object):
         dep = torch.empty((b, h, w, 3), dtype=torch.float32, device=self.device) if want_depth else None
         N.check(N.lib.msi_render_equirect_f32(native.data_ptr(), pose.data_ptr(), pos.data_ptr(),
                                               depths.data_ptr(), trig.data_ptr(), b, h, w, d,
-                                              _ptr(rgb), _ptr(dep), self._stream()), "msi_render_equirect_f32")
+                                              _ptr(rgb), _ptr(dep), self._render_status.data_ptr(), self._stream()),
+                "msi_render_equirect_f32")
         return rgb, dep
 
     def msi_render_equirect_view_single(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics):
@@ -466,7 +482,7 @@ class MSI(object):
         out = torch.empty((d, b, h, w, 4), dtype=torch.float32, device=self.device)
         N.check(N.lib.msi_project_layers_f32(native.data_ptr(), pose.data_ptr(), pos.data_ptr(),
                                              depths.data_ptr(), trig.data_ptr(), b, h, w, d,
-                                             out.data_ptr(), self._stream()), "msi_project_layers_f32")
+                                             out.data_ptr(), self._render_status.data_ptr(), self._stream()), "msi_project_layers_f32")
         return out
 
     def msi_render_equirect_depth_single(self, rgba_layers, tgt_pose_rt, tgt_pos, planes, intrinsics):
@@ -492,7 +508,7 @@ class MSI(object):
         out = torch.empty((b, h, w, 3), dtype=torch.float32, device=self.device)
         N.check(N.lib.msi_render_ods_f32(native.data_ptr(), pose.data_ptr(), intr.data_ptr(), depths.data_ptr(),
                                          self._trig(h, w).data_ptr(), b, h, w, d, int(order), out.data_ptr(),
-                                         self._stream()), "msi_render_ods_f32")
+                                         self._render_status.data_ptr(), self._stream()), "msi_render_ods_f32")
         return out
 
     # ------------------------------------------------------------------ msi.py:475-500
@@ -524,7 +540,8 @@ class MSI(object):
             raise ValueError("len(planes) != number of layers")
         out = torch.empty((b, psp_height, psp_width, 3), dtype=torch.float32, device=self.device)
         N.check(N.lib.msi_render_perspective_f32(native.data_ptr(), pose.data_ptr(), pos.data_ptr(), depths.data_ptr(),
-                                                 b, h, w, d, psp_height, psp_width, out.data_ptr(), self._stream()),
+                                                 b, h, w, d, psp_height, psp_width, out.data_ptr(),
+                                                 self._render_status.data_ptr(), self._stream()),
                 "msi_render_perspective_f32")
         return out
 

@@ -286,8 +286,19 @@ def test_domain_guard_uses_the_full_pose(gpu):
         m.msi_render_equirect_view(rgba, pose, pos, planes, None)
     with pytest.raises(ValueError):
         m.msi_render_perspective_view(rgba, pose, np.array([[0.0, 0.0, 1.2]], np.float32), planes, None, psp_height=8, psp_width=8)
+    assert m.render_status() == 0                              # (nothing launched so far: the host guard raised first)
     out = m.msi_render_equirect_view(rgba, torch.from_numpy(pose).cuda(), torch.from_numpy(pos).cuda(), planes, None)
     assert bool(torch.isfinite(out).all())
+    with pytest.raises(ValueError):                            # device-side inputs: the kernel clamps AND says so (status word)
+        m.render_status()
+    assert m.render_status() == 0                              # (the word is reset by the report)
+    ok = pose.copy(); ok[0, 0, 3] = 0.5                        # inside the innermost sphere (radius 1): no bit
+    m.msi_render_equirect_view(rgba, torch.from_numpy(ok).cuda(), torch.from_numpy(pos).cuda(), planes, None)
+    m.msi_render_equirect_view_single(rgba, torch.from_numpy(ok).cuda(), torch.from_numpy(pos).cuda(), planes, None)
+    assert m.render_status() == 0
+    m.msi_render_equirect_view_single(rgba, torch.from_numpy(pose).cuda(), torch.from_numpy(pos).cuda(), planes, None)
+    with pytest.raises(ValueError):
+        m.render_status()
     same = m.msi_render_equirect_depth_single(rgba, np.eye(4, dtype=np.float32)[None], pos, planes, None)
     assert torch.equal(same, m.msi_render_equirect_view_single(rgba, np.eye(4, dtype=np.float32)[None], pos, planes, None))
 

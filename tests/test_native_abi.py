@@ -52,7 +52,7 @@ def test_bad_arguments_return_codes(native_lib):
     assert b"bad arguments" in lib.msi_last_error_string()
     assert lib.msi_ods_sphere_sweep_f32(None, None, None, None, None, 1, 8, 8, 4, 1, None, 24, 0, None) == -1
     assert lib.msi_compose_poses_f32(None, None, None, 1, None) == -1
-    assert lib.msi_render_equirect_f32(None, None, None, None, None, 1, 8, 8, 4, None, None, None) == -1
+    assert lib.msi_render_equirect_f32(None, None, None, None, None, 1, 8, 8, 4, None, None, None, None) == -1
     assert lib.msi_assemble_rgba_f32(None, None, None, None, None, 1, 8, 8, 4, None) == -1
     from matryodshka_amd import nets
     bad = nets.make_desc(1, 30, 64, 24, 8, 16, True)        # height not a multiple of 8
