@@ -190,3 +190,19 @@ def test_kat10_wrap_convT_layernorm_runs_before_the_crop():
     assert np.abs(acts["conv6_1"][0] - expect).max() < 2e-5
     assert np.abs(ln_relu(full[5:-5, 5:-5]) - expect).max() > 1e-3    # crop-then-normalise is NOT what the reference does
     assert np.all(full[:4] == 0) and np.all(full[-4:] == 0) and np.any(full[4] != 0) and np.any(full[-5] != 0)
+
+
+def test_reference_function_bodies_agree_with_the_oracle():
+    """oracle/crosscheck_reference.py: the reference's own geometry / nets / msi function bodies, executed over a numpy
+    stand-in for tensorflow, are bit-identical to the oracle's restatement (build container only: /root/reference does not
+    exist on the GPU box and is never read by a -m gpu test, smoke() or bench.py)."""
+    import os
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.isdir("/root/reference/geometry"):
+        pytest.skip("no reference checkout here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "oracle", "crosscheck_reference.py")], cwd=root, timeout=600,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0 and "MISMATCH" not in p.stdout and p.stdout.count("bit-identical") >= 50, p.stdout[-3000:]
