@@ -346,7 +346,8 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
 /* Health of the LAST forward that ran with `workspace` on `stream` (synchronises the stream: call it after a frame,
  * not inside the frame loop's hot path): MSI_OK, or MSI_E_RANGE with the reason in msi_last_error_string when a
  * LayerNorm sum overflowed its fixed-point window (bit 1 of *status_bits: raw outputs > ~3000x the scale the weights
- * predict, or non-finite input) or a variance fell below its resolution (bit 2: < ~1e-3 of that scale, or a constant
+ * predict, or non-finite input; bf16 plans also set it when a raw output may have left the range of the fp16 it is
+ * stored in -- some |x 2^-e - pivot| of a wave's 1 024 values above 32 752, i.e. > ~1000x that scale) or a variance fell below its resolution (bit 2: < ~1e-3 of that scale, or a constant
  * layer); bit 0: an apply-ahead wait timed out.  status_bits may be NULL.  The word is reset by the next forward. */
 #define MSI_NET_STATUS_APPLY_AHEAD_TIMEOUT 1
 #define MSI_NET_STATUS_LN_OVERFLOW 2

@@ -561,6 +561,10 @@ __device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&ac
     if (lane == 0 && !(MSI_EPI_ABLATE & 2)) {
       const double P = (double)pv_s, n = (double)(MT * NT * 16 * 64), a = (double)s1;
       const double u1 = RAW16 ? 16777216.0 : scl_s1, u2 = RAW16 ? 65536.0 : scl_s2;
+      // RAW16: the tile was just stored as fp16 of y = x 2^-e, which is +-inf beyond 65504.  s2 = sum (y - pivot)^2 over the wave
+      // bounds every |y - pivot|: above 32752^2 a stored value MAY have left the fp16 range (or the layer is > 1000 x the scale
+      // its weights predict) -- reported like a LayerNorm sum that left its window (no silent inf -> NaN pixels)
+      if (RAW16 && !(s2 <= 1.0727e9f)) __hip_atomic_fetch_or(p.status, STATUS_LN_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * LN_WORDS;   // (any spread will do)
       ln_atomic_add(dst, (n * P + a) * u1, p.status);
       ln_atomic_add(dst + 1, ((double)s2 + 2.0 * P * a + n * P * P) * u2, p.status);
@@ -693,6 +697,8 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
     if (lane == 0 && wcnt > 0.f && !(MSI_EPI_ABLATE & 2)) {
       const double P = (double)pivot, n = (double)wcnt, a = (double)s1;
       long long *dst = p.sums + ((size_t)b * LN_SHARDS + ((blockIdx.x * 4 + wave) & (LN_SHARDS - 1))) * LN_WORDS;   // (any spread will do)
+      // (RAW16, see emit_whole_tile: here the sums are in x, the stored value is x raw_mul)
+      if (RAW16 && !(s2 * raw_mul * raw_mul <= 1.0727e9f)) __hip_atomic_fetch_or(p.status, STATUS_LN_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ln_atomic_add(dst, (n * P + a) * scl_s1, p.status);
       ln_atomic_add(dst + 1, ((double)s2 + 2.0 * P * a + n * P * P) * scl_s2, p.status);
     }

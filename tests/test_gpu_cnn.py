@@ -353,3 +353,24 @@ def test_status_reports_statistics_outside_the_fixed_point_window(env):
         m.network_status()
     m.run_net(x, nout, ngf)
     assert m.network_status() == 0
+
+
+def test_bf16_plan_reports_raw_outputs_beyond_the_fp16_range(env):
+    """a bf16 plan stores raw outputs as fp16 of x * 2^-e; an input 2^12 times the [-1, 1] volume puts conv1_1's
+    stored values near / beyond 65504 -- inside the fixed-point window of the sums (~3000 x 2^e x sqrt-of-count headroom), so
+    only the fp16-range check can say it.  The forward must report MSI_E_RANGE; in-range forwards stay clean."""
+    torch, MSI, nets, N, onets = env
+    b, h, w, cin, nout, ngf = 1, 32, 64, 48, 16, 16
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=False, seed=44, randomize_affine=True)
+    m = MSI(weights=weights, coord_net=False, dtype="bf16")
+    x = (torch.rand((b, h, w, cin), device="cuda") * 2 - 1)
+    m.run_net(x.bfloat16(), nout, ngf)
+    assert m.network_status() == 0
+    m.run_net((x * 8.0).bfloat16(), nout, ngf)                  # a gain of 8 is far inside every range
+    assert m.network_status() == 0
+    m.run_net((x * 2.0 ** 12).bfloat16(), nout, ngf)
+    with pytest.raises(N.MsiError) as ei:
+        m.network_status()
+    assert "LayerNorm" in str(ei.value)
+    m.run_net(x.bfloat16(), nout, ngf)
+    assert m.network_status() == 0
