@@ -275,6 +275,10 @@ def main():
                          "configurations, whose first second under load contains a slow transient: 19 vs 11.4 ms per step at config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--no-coord-net", action="store_true", help="msi_train_net instead of msi_coord_train_net")
+    ap.add_argument("--arithmetic", default=None, choices=["native", "split3"],
+                    help="fp32 configurations: how the stride-1 3x3 layers multiply -- native = v_mfma_f32_32x32x2_f32; split3 = 3-way bf16 "
+                         "split of both operands, SIX products on the bf16 MFMA, fp32 accumulation (fp32-grade: dropped terms < 2^-26 of a "
+                         "product; plan option F32_SPLIT3).  Default: the library's default plan.  Reported as config.arithmetic")
     ap.add_argument("--strong-frames", type=int, default=8,
                     help="config 1: after the contract region, also time a FIXED batch of this many frames sharded over the "
                          "ranks (strong-scaling reading of the same path, reported under `strong_scaling`; 0 = skip)")
@@ -338,6 +342,12 @@ def main():
     models = [MSI(weights=weights, coord_net=coord, device=dev, dtype=cfg["dtype"],
                   input_type="PP" if cfg["kind"] == "pp" else "ODS") for _ in range(max(1, args.streams, args.substreams))]
     model = models[0]
+    from matryodshka_amd import _native as _N
+    if args.arithmetic is not None:
+        if cfg["dtype"] != "f32":
+            raise SystemExit("--arithmetic applies to the fp32 configurations")
+        for mm in models:
+            mm.net_options[_N.NET_OPT_F32_SPLIT3] = 0x3ffff if args.arithmetic == "split3" else 0
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, args.substreams) - 1)]
     planes = model.inv_depths(1.0, 100.0, D)
 
@@ -552,6 +562,14 @@ def main():
         stages["note"] = "per-stage pass = whole batch on ONE stream (substreams only changes the timed region)"
 
     unit = "faces/s" if cfg["kind"] == "pp" else "frames/s"
+    arithmetic = None
+    if B > 0:
+        plan = model._plan(B, H, W, cin, nout, NGF)
+        kern = [plan.layer_kernel(i)[0] for i in range(17)]
+        nx3 = sum(k.startswith("conv_halo_x3_kernel") for k in kern)
+        arithmetic = ("bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16)" if bf16 else
+                      "fp32: %d of 17 convolutions as a 3-way bf16 split with 6 products on the bf16 MFMA (fp32 accumulate, fp32-grade), "
+                      "%d on the native fp32 MFMA" % (nx3, 17 - nx3) if nx3 else "native fp32 MFMA (v_mfma_f32_32x32x2_f32)")
     metric = "novel-view frames/sec, 640x320 ODS->32-sphere MSI infer+render" if args.config == 1 else \
         "novel-view %s, %dx%d %s->%d-%s infer+render" % (unit.replace("/s", "/sec"), W, H, "PP face" if cfg["kind"] == "pp" else "ODS",
                                                         D, "plane MPI" if cfg["kind"] == "pp" else "sphere MSI")
@@ -565,7 +583,8 @@ def main():
                    "baseline_config_index": args.config, "height": H, "width": W,
                    "num_spheres": D, "ngf": NGF, "frames_per_step": frames_total, "frames_per_step_rank0": B,
                    "parallelism": "frames sharded over %d GPU(s) (dist.shard_frames), no data-path collective" % world,
-                   "streams_per_gpu": args.streams, "substreams": args.substreams},
+                   "streams_per_gpu": args.streams, "substreams": args.substreams,
+                   "arithmetic": arithmetic},
         "distributed": {"world_size_env": world, "world_size_process_group": nccl_world, "backend": backend,
                         "frame_ranges_per_rank": ranges,
                         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],

@@ -326,7 +326,11 @@ typedef struct msi_net_plan msi_net_plan;
 #define MSI_NET_OPT_BF16_WAVES 13 /* waves per workgroup of the bf16 halo-patch conv kernel's 128x128 tile: 8 (default; 4 x 2 waves of 32 pixels x 64 channels: */
                                   /* four waves per SIMD with two workgroups per CU, so that a workgroup's prologue / epilogue has neighbours to hide behind) */
                                   /* or 4 (r02 shape).  The 256x64 tile always runs four (eight measured slower) */
-#define MSI_NET_OPT_COUNT 14
+#define MSI_NET_OPT_F32_SPLIT3 14 /* fp32 plans, bit i = layer i (graph order): a stride-1 halo-patch 3x3 layer computes its fp32 convolution as a 3-way */
+                                  /* bf16 split of both operands with SIX products (h.h, h.m, m.h, h.l, l.h, m.m; exact products, fp32 accumulation; */
+                                  /* dropped terms <= 2^-26 of a product: fp32-grade, NOT the 3-product TF32-grade split) on the 16x faster bf16 MFMA */
+                                  /* (conv_halo_x3_kernel).  0 (default) = native fp32 MFMA everywhere */
+#define MSI_NET_OPT_COUNT 15
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
 int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);

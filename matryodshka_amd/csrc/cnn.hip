@@ -102,6 +102,7 @@ struct ConvParams {
   // element-typed buffers (fp32, or bf16 in the BF16 instantiation) are addressed in bytes
   const char *x0, *x1;       // NHWC sources, already normalised (x1 = second half of a skip concat)
   const char *wpk;           // packed weights [nclass][ksteps][npad][128 B], slots pre-swizzled
+  const char *wpk_x3;        // conv_halo_x3_kernel: [tap][chunk][plane][npad][64 B] bf16 parts of the fp32 weights (see HaloGeomX3)
   const float *coord_bias;   // CoordNet: contribution of the |sin(lat)| channel, [Mh][COORD_CLASSES][cb_stride] fp32, or null
   int cb_stride;
   const double *ln_scl;      // fixed-point scales of THIS layer's LayerNorm sums {S1, S2, 1 / S1, 1 / S2} (packed blob)
@@ -1549,6 +1550,313 @@ conv_halo_kernel(const ConvParams p) {
       const bool issued_ = ((TAP) + 2 < 9) || (c + 1 < c1);                                                            \
       if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<2 + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight */ \
       else if (issued_) wait_vmcnt<2>();                                                                               \
+      else wait_vmcnt<0>();                                                                                            \
+    }                                                                                                                  \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+  }
+
+  // ---- prologue: first patch, first two weight k-steps ----
+  int c = c0;
+  MSI_PATCH_LOAD(c0)                                      // (the weights of k-steps 0 and 1 are on their way already)
+  if (APPLY) {   // the sums' round trip rides on the patch's (s_stat sits in the A region: read back before the patch lands)
+    double *s_stat = reinterpret_cast<double *>(smem);
+    ln_mean_inv_pre(shard, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
+    const double mu = s_stat[0];
+    inv_f = (float)s_stat[1];
+    mu_hi = (float)mu;
+    mu_lo = (float)(mu - (double)mu_hi);
+    __syncthreads();
+  }
+  wait_vmcnt<0>();
+  MSI_PATCH_STORE()
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
+  for (; c < c1; ++c) {
+    MSI_HTAP(0) MSI_HTAP(1) MSI_HTAP(2) MSI_HTAP(3) MSI_HTAP(4) MSI_HTAP(5) MSI_HTAP(6) MSI_HTAP(7) MSI_HTAP(8)
+    if (c + 1 < c1) {   // every wave has read the last tap of this chunk (closing barrier of tap 8): swap the patch
+      MSI_PATCH_STORE()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+#undef MSI_HTAP
+#undef MSI_B_ISSUE
+#undef MSI_PATCH_STORE
+#undef MSI_PATCH_LOAD
+
+  // ---- epilogue: as conv_igemm_kernel ----
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if (p.dbg && tid == 0) {
+      unsigned long long *o = p.dbg + (size_t)blockIdx.x * 24;
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
+      o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+      o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+    }
+  };
+#endif
+  if (!full) {
+    constexpr int SLAB = 64 * 64 * 4;
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)slot * (64 * 64)), 0, SLAB, 0x00020000);
+    if (p.tile_cnt == nullptr) {
+      dump_acc<MT, NT, 0>(acc, rsrc_p, tid);
+#ifdef MSI_CONV_TIMING
+      stamp();
+#endif
+      return;
+    }
+    dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
+    const int nsp = t < p.n_main ? p.split0 : p.split;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *s_old = reinterpret_cast<int *>(smem);
+    if (tid == 0)
+      *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_old != nsp - 1) return;
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
+    sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+    __syncthreads();   // (every thread has read s_old before the epilogue's strips reuse LDS)
+  }
+  emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, cbv, p.coord_bias != nullptr, smem);
+#ifdef MSI_CONV_TIMING
+  stamp();
+#endif
+#endif
+}
+
+// ---- halo-patch convolution, fp32 through a 3-way bf16 split with six products (round 4; plan option F32_SPLIT3) ----------------
+// the native fp32 MFMA (v_mfma_f32_32x32x2_f32, 256 flop per cycle and SIMD) is at 0.82 of its peak and the
+// rest is per-visit overhead.  The bf16 MFMA is 16 x faster; an fp32 operand x is EXACTLY h + m + l + (|rest| <= 2^-25 |x|) with bf16
+// parts h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round to nearest even; both differences are exact in fp32), so
+//     x w  =  h.h + h.m + m.h + h.l + l.h + m.m  +  (m.l + l.m + l.l + rest terms: <= 2^-26 |x w|, below fp32's own product rounding)
+// -- six v_mfma_f32_32x32x16_bf16 (exact products, fp32 accumulation of 16 terms each) per 16 channels: 192 instead of 512 matrix
+// cycles.  NOT the 2-way / 3-product split (that is TF32-grade and narrower than the reference's fp32).  The activations stay
+// fp32 in memory: the patch is staged through registers as in conv_halo_kernel (the producer's LayerNorm applied on the
+// way) and split there -- three v_cvt_pk_bf16_f32 pairs and two exact subtractions per float4 -- into three 64-byte planes per
+// pixel (pixel stride 208 B: 13 x 16, odd, so the fragment reads stay conflict-free with the row pitch / column rotation of
+// HaloGeom).  The weights are split on the host at pack time (x3 block of the packed blob).  Everything around the k-loop --
+// work decomposition, tail split, in-launch hand-off, epilogue, LayerNorm sums -- is conv_halo_kernel's.
+// Numerics: oracle emulation of this arithmetic against the fp32 oracle at the configs[1] frame: pred 3.0e-6, rgba 1.9e-6,
+// rgb 1.0e-6 max-abs (profiles/r04_split3_numerics.txt: the native fp32 path's own summation-order error is 4.5e-6 on pred).
+template <int RATE>
+struct HaloGeomX3 {
+  static constexpr int PW = 16 + 2 * RATE, PH = 4 + 2 * RATE, NPX = PW * PH;
+  static constexpr int PIX_BYTES = 208;                   // 3 planes x 32 bf16 + 16
+  static constexpr int ROW_PITCH = ((PW * PIX_BYTES + 127) / 256) * 256 + 128;
+  static constexpr int A_BYTES = PH * ROW_PITCH;
+  static constexpr int B_ROW = 64;                        // 32 bf16 channels of one output row and plane
+  static constexpr int B_PLANE = 64 * B_ROW, B_STAGE = 3 * B_PLANE;
+  static constexpr int NSTG = 3;
+  static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
+  static constexpr int NLOAD = (NPX * 8 + 255) / 256;
+};
+template <int N>
+__device__ __forceinline__ void wait_lgkm6(v4f &a, v4f &b, v4f &c, v4f &d, v4f &e, v4f &f) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N) : "memory");
+}
+
+template <int RATE, int APPLY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+conv_halo_x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef HaloGeomX3<RATE> G;
+  constexpr int R = RATE, PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
+  constexpr int MT = 1, NT = 1;
+#ifdef MSI_CONV_TIMING
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // ---- work decomposition: as conv_igemm_kernel (tail split), K-ranges in whole chunks ----
+  const int CH = p.cpt0;                                  // 32-channel chunks of the input
+  int t, c0 = 0, c1 = CH, ks = 0, slot = 0;
+  {
+    const int bid = blockIdx.x;
+    if (bid < p.nb_main && p.split0 == 1) {
+      const int q = p.n_main >> 3, r = p.n_main & 7, xcd = bid & 7, local = bid >> 3;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    } else {
+      int sp, r, tbase;
+      unsigned mg;
+      if (bid < p.nb_main) { sp = p.split0; mg = p.mg_sp0; r = bid; tbase = 0; }
+      else { sp = p.split; mg = p.mg_sp; r = bid - p.nb_main; tbase = p.n_main; }
+      const int tl = (int)udiv_magic((unsigned)r, (unsigned)sp, mg);
+      ks = r - tl * sp;
+      t = tbase + tl;
+      c0 = (int)udiv_magic((unsigned)(ks * CH), (unsigned)sp, mg);
+      c1 = (int)udiv_magic((unsigned)((ks + 1) * CH), (unsigned)sp, mg);
+      slot = bid - (p.split0 == 1 ? p.nb_main : 0);
+    }
+  }
+  const bool full = (c0 == 0) & (c1 == CH);
+  int tile_m, tile_n, b;
+  {
+    int r = t;
+    const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
+    tile_m = r - q1 * p.tiles_m; r = q1;
+    const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
+    tile_n = r - q2 * p.tiles_n;
+    b = q2;                                               // (nclass = 1)
+  }
+  LnShard shard = {0, 0};   // (the lane's shard of the source's LayerNorm sums: requested here, reduced after the patch requests)
+  if (APPLY) shard = ln_shard_load(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, tid);
+  const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
+  const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
+  const int H = p.Hin, W = p.Win, C = p.C0;
+  v4f cbv[4];
+  load_coord_bias(p, tile_m, tile_n, tid, cbv);           // in flight during the prologue and the k-loop
+  // the first two weight k-steps go out before the patch addresses are worked out (they depend on tile_n and the wave only)
+  const int S = p.ksteps;                                 // 9 CH
+  // x3 block of the packed blob: [tap][chunk][plane h | m | l][npad rows][64 B = 32 bf16 channels], 16-byte slots swizzled by
+  // (row >> 2) & 3.  A wave's DMA instruction moves 16 rows x 64 B = 1 KB of one plane: three instructions per k-step
+  const int plane_bytes = p.npad * G::B_ROW;
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)S * 3 * plane_bytes), 0x00020000);
+  const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + (lane >> 2)) * G::B_ROW + (lane & 3) * 16);
+#define MSI_B_ISSUE(c, tap, st)                                                                                        \
+  {                                                                                                                    \
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;                                          \
+    const int soff_ = ((tap) * CH + (c)) * 3 * plane_bytes;                                                            \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
+  }
+  MSI_B_ISSUE(c0, 0, 0)
+  MSI_B_ISSUE(c0, 1, 1)
+
+  // ---- per-lane patch elements: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 (= tid % 8) ----
+  unsigned voff[NLOAD], lds_a[NLOAD];
+  bool pok[NLOAD];
+  const int cslot = tid & 7;
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const int pp = (tid + 256 * k) >> 3;
+    const int py = pp / PW, px = pp - py * PW;
+    const int ih = oh0 - R + py;
+    int iw = ow0 - R + px;
+    if (p.wrap) iw = iw < 0 ? iw + W : (iw >= W ? iw - W : iw);   // msi_train_net: wrap along W, zeros along H
+    pok[k] = pp < NPX && ih >= 0 && ih < H && iw >= 0 && iw < W;
+    voff[k] = pok[k] ? __umul24((unsigned)(ih * W + iw), (unsigned)(C * 4)) + (unsigned)(cslot * 16) : OOB;
+    lds_a[k] = pp < NPX ? (unsigned)(py * G::ROW_PITCH + px * G::PIX_BYTES + cslot * 8) : 0xffffffffu;
+  }
+  const size_t in_bytes = (size_t)H * W * C * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in_bytes), 0, (int)in_bytes, 0x00020000);
+
+  // producer's LayerNorm: mean / inv once per workgroup; the per-channel affine per chunk (the lane's four channels)
+  float inv_f = 1.f, mu_hi = 0.f, mu_lo = 0.f;
+  bool has_pad = false;                                   // wave-uniform: any of the wave's patch pixels is padding
+  if (APPLY) {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) bad |= (lds_a[k] != 0xffffffffu) && !pok[k];
+    has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
+  }
+  v4f araw[NLOAD], g4, be4;
+  // patch of chunk c -> registers (+ gamma / beta of the lane's channels)
+#define MSI_PATCH_LOAD(c)                                                                                              \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], (c) * ROW_BYTES, 0)); \
+    if (APPLY) {                                                                                                       \
+      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 32 + cslot * 4);                                          \
+      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 32 + cslot * 4);                                          \
+    }                                                                                                                  \
+  }
+  // registers -> LDS patch, the producer's affine + ReLU applied (ln_apply_kernel's expressions: same bits)
+#define MSI_PATCH_STORE()                                                                                              \
+  {                                                                                                                    \
+    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};                                                          \
+    if (APPLY) {   /* scale = inv * gamma; shift = beta - mean * scale with the mean as hi + lo floats: fp32 ops only */ \
+      s4 = inv_f * g4;                                                                                                 \
+      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};                          \
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
+      v4f y = araw[k_];                                                                                                \
+      if (APPLY) {                                                                                                     \
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
+        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */          \
+      }                                                                                                                \
+      /* y = h + m + l, bf16 parts (round to nearest even; y - h and (y - h) - m are exact in fp32) */                  \
+      unsigned h0, h1, m0, m1, l0, l1;                                                                                 \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h0) : "v"(y.x), "v"(y.y));                                             \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h1) : "v"(y.z), "v"(y.w));                                             \
+      v4f r = y - v4f{__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h0 & 0xffff0000u),               \
+                      __builtin_bit_cast(float, h1 << 16), __builtin_bit_cast(float, h1 & 0xffff0000u)};              \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m0) : "v"(r.x), "v"(r.y));                                             \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m1) : "v"(r.z), "v"(r.w));                                             \
+      r = r - v4f{__builtin_bit_cast(float, m0 << 16), __builtin_bit_cast(float, m0 & 0xffff0000u),                    \
+                  __builtin_bit_cast(float, m1 << 16), __builtin_bit_cast(float, m1 & 0xffff0000u)};                  \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l0) : "v"(r.x), "v"(r.y));                                             \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l1) : "v"(r.z), "v"(r.w));                                             \
+      if (lds_a[k_] != 0xffffffffu) {                                                                                  \
+        typedef unsigned u2x_t __attribute__((ext_vector_type(2)));                                                    \
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_]) = u2x_t{h0, h1};                                                  \
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 64) = u2x_t{m0, m1};                                             \
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 128) = u2x_t{l0, l1};                                            \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }
+  // ---- MFMA side ----
+  const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
+  // A: plane P, K16-step s of the lane's pixel at + P * 64 + s * 32 (fh * 16 in the base); B: row wn * 32 + frow of plane P
+  // at + P * B_PLANE, slot (2 s + fh) ^ ((row >> 2) & 3)
+  const unsigned a_base = lds_base + (unsigned)((2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
+  unsigned b_s[2];
+  (void)fswz;
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+    b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+
+  // one k-step = tap TAP of the current chunk, weights in ring stage TAP % 3; the DMA of the k-step two ahead is issued
+  // after the first MFMA quarter; before the closing barrier the NEXT k-step's weights must have landed: every VMEM
+  // operation issued before them (the next chunk's patch loads, issued in tap 0) completes first (in-order return)
+#define MSI_HTAP(TAP)                                                                                                  \
+  {                                                                                                                    \
+    constexpr int KH_ = (TAP) / 3, KW_ = (TAP) % 3, ST_ = (TAP) % 3;                                                   \
+    constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;                                             \
+    v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
+      ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);                                \
+      bh_[s_] = lds_read128<ST_ * G::B_STAGE>(b_s[s_]);                                                                \
+      am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);                           \
+      bm_[s_] = lds_read128<ST_ * G::B_STAGE + G::B_PLANE>(b_s[s_]);                                                   \
+      al_[s_] = s_ == 0 ? lds_read128<AOFF_ + 128>(a_base) : lds_read128<AOFF_ + 160>(a_base);                         \
+      bl_[s_] = lds_read128<ST_ * G::B_STAGE + 2 * G::B_PLANE>(b_s[s_]);                                               \
+    }                                                                                                                  \
+    /* six products per K16 step, small terms first: m.m, l.h, h.l, m.h, h.m, h.h (weights = the MFMA's row operand) */  \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
+      if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                      \
+      else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                              \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0); \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, al_[s_]), acc[0][0], 0, 0, 0); \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0); \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if (s_ == 0) {                                                                                                   \
+        if ((TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                            \
+        /* k-step two ahead: (c, TAP + 2) or (c + 1, TAP - 7) */                                                       \
+        if ((TAP) + 2 < 9) { MSI_B_ISSUE(c, (TAP) + 2, ((TAP) + 2) % 3) }                                              \
+        else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) - 7, ((TAP) + 2) % 3) }                                        \
+      }                                                                                                                \
+    }                                                                                                                  \
+    {                                                                                                                  \
+      const bool issued_ = ((TAP) + 2 < 9) || (c + 1 < c1);                                                            \
+      if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<3 + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight */ \
+      else if (issued_) wait_vmcnt<3>();                                                                               \
       else wait_vmcnt<0>();                                                                                            \
     }                                                                                                                  \
     __builtin_amdgcn_s_barrier();                                                                                      \
@@ -3513,6 +3821,7 @@ struct Layer {
   size_t packed_w_floats;
   size_t gamma_off, beta_off, coord_off;  // floats inside the packed blob
   size_t lnscl_off;                       // floats inside the packed blob: LN_SCL_DOUBLES doubles (8-byte aligned)
+  size_t x3_off;                          // floats inside the packed blob: the 3-way bf16 split of the weights (conv_halo_x3_kernel), 0 = none
   size_t raw_off, aff_off;                // bytes inside the workspace
   size_t act_off;                         // bf16 path: normalised bf16 activation (the next layer's operand)
   size_t sums_off;                        // LayerNorm sums [B][LN_SHARDS][LN_WORDS] int64
@@ -3636,6 +3945,12 @@ int build_net(const msi_net_desc *d, int num_cus, Net &net) {
     L.coord_off = L.lnscl_off + 2 * LN_SCL_DOUBLES;
     koff = L.coord_off + (L.has_coord ? (size_t)L.out_h * COORD_CLASSES * round_up(L.cout, 4) : 0);
     koff = round_up(koff, 64);
+    // fp32 plans: the stride-1 one-source 3x3 layers also carry their weights as three bf16 planes (plan option F32_SPLIT3):
+    // [tap][chunk of 32 channels][plane][npad rows][64 B]
+    if (!bf16 && s.kind == MODE_CONV && s.stride == 1 && s.src1 < 0 && L.c0 % 32 == 0) {
+      L.x3_off = koff;
+      koff = round_up(koff + (size_t)9 * (L.c0 / 32) * 3 * L.npad * 16, 64);
+    }
     // workspace
     if (s.kind != MODE_HEAD) {
       L.raw_off = woff;
@@ -3704,6 +4019,7 @@ struct LayerLaunch {
   int skip_apply;   // this layer's output is consumed raw by the head, or normalised by its consumer's launch: no ln_apply launch
   int halo;         // conv_halo_kernel (fp32) / conv_halo_bf16_kernel instead of conv_igemm_kernel
   int halo_s2;      // ... conv_halo_s2_kernel: the stride-2 3x3 layers through parity-plane patches (fp32)
+  int halo_x3;      // ... conv_halo_x3_kernel: fp32 through the 3-way bf16 split with six products (plan option F32_SPLIT3)
   int hbm, hbn;     // bf16 halo tile: 128 x 128 or 256 x 64
   int halo_t;       // convt_halo_kernel (conv-transpose, fp32): the two classes of one output-row parity per workgroup
   int halo_tb;      // convt_halo_bf16_kernel (conv-transpose, bf16): the two classes of one output-row parity per workgroup
@@ -3869,6 +4185,7 @@ int plan_layers(msi_net_plan *pl) {
                 // kernel time; conv3_3, 400 tiles cut into K-ranges of two groups, loses 11 us to save 6: tap kernel)
                 (long)(L.out_h / 4) * (L.out_w / 16) * (L.cout / 64) * desc->batch >= 3L * pl->num_cus;
     if (Q.halo_s2) Q.halo = 1;
+    Q.halo_x3 = Q.halo && !Q.halo_s2 && L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1);
     int max_split = MAX_SPLIT;
     // bf16 halo-patch kernel (conv_halo_bf16_kernel): the same layers with 64-channel chunks and whole
     // 8 x 16 pixel x 128 channel or 16 x 16 x 64 tiles
@@ -4205,6 +4522,37 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
                                           ldexp(1.0, -(LN_S1_BITS - e)), ldexp(1.0, -(LN_S2_BITS - 2 * e))};
       memcpy(packed + L.lnscl_off, scl, sizeof(scl));
     }
+    if (L.x3_off) {
+      // x = h + m + l, bf16 parts by round-to-nearest-even of the successive (exact) remainders; slot j (channels 8 j .. 8 j + 7 of
+      // the chunk) of row n is stored at slot j ^ ((n >> 2) & 3) of the row's 64 bytes (HaloGeomX3: conflict-free fragment reads)
+      auto bf16_rne = [](float v) -> uint16_t {
+        uint32_t u;
+        memcpy(&u, &v, 4);
+        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+      };
+      auto widen = [](uint16_t h) -> float {
+        const uint32_t u = (uint32_t)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+      };
+      const int ch = L.c0 / 32;
+      char *base = reinterpret_cast<char *>(packed + L.x3_off);
+      for (int tap = 0; tap < 9; ++tap)
+        for (int c = 0; c < ch; ++c)
+          for (int n = 0; n < L.cout; ++n)
+            for (int kk = 0; kk < 32; ++kk) {
+              const float v = w[((size_t)tap * cin_w + c * 32 + kk) * L.cout + n];
+              uint16_t part[3];
+              part[0] = bf16_rne(v);
+              const float r1 = v - widen(part[0]);
+              part[1] = bf16_rne(r1);
+              part[2] = bf16_rne(r1 - widen(part[1]));
+              const int slot = (kk >> 3) ^ ((n >> 2) & 3);
+              for (int pl = 0; pl < 3; ++pl)
+                memcpy(base + ((((size_t)tap * ch + c) * 3 + pl) * L.npad + n) * 64 + slot * 16 + (kk & 7) * 2, &part[pl], 2);
+            }
+    }
     if (L.kind == MODE_HEAD) {
       memcpy(packed + L.gamma_off, w + wf, L.cout * sizeof(float));  // biases
     } else {
@@ -4303,6 +4651,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_UNIFORM_SPLIT] = 0;
   pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD] = 0;
   pl->opt[MSI_NET_OPT_BF16_WAVES] = 8;
+  pl->opt[MSI_NET_OPT_F32_SPLIT3] = 0;
   pl->opt[MSI_NET_OPT_BF16_STAGE_RAW] = 1;   // (bit 1, conv8_1 staging its raw sources: measured 50 us per 16 frames SLOWER -- ~180 VALU per chunk
                                                // against 2 048 matrix cycles of the 128 x 64 tile; bit 0, conv8_2: 130 us faster.  Three interleaved repeats)
   int rc = plan_layers(pl);
@@ -4373,6 +4722,7 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
     snprintf(name, name_bytes, "convt_halo_kernel");
   } else if (Q.halo) {
     if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_s2_kernel<%d>", Q.halo_apply ? 1 : 0);
+    else if (Q.halo_x3) snprintf(name, name_bytes, "conv_halo_x3_kernel<%d, %d>", L.rate, Q.halo_apply ? 1 : 0);
     else snprintf(name, name_bytes, "conv_halo_kernel<%d, %d>", L.rate, Q.halo_apply ? 1 : 0);
   } else {
     const int bm = Q.tile == TILE_128x128 || Q.tile == TILE_128x64 ? 128 : 64;
@@ -4620,6 +4970,19 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       if (Q.halo_s2) {
         if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_kernel<1>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
         else hipLaunchKernelGGL((conv_halo_s2_kernel<0>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
+      } else if (Q.halo_x3) {
+        p.wpk_x3 = reinterpret_cast<const char *>(packed + L.x3_off);
+        static thread_local unsigned long long done2 = 0;       // (rate 2: 69.8 KB of LDS)
+        if (L.rate == 1) {
+          if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_x3_kernel<1, 1>), grid, block, HaloGeomX3<1>::LDS_BYTES, stream, p);
+          else hipLaunchKernelGGL((conv_halo_x3_kernel<1, 0>), grid, block, HaloGeomX3<1>::LDS_BYTES, stream, p);
+        } else {
+          int rc0 = set_max_lds(Q.halo_apply ? reinterpret_cast<const void *>(conv_halo_x3_kernel<2, 1>) : reinterpret_cast<const void *>(conv_halo_x3_kernel<2, 0>),
+                                HaloGeomX3<2>::LDS_BYTES, done2, "conv_halo_x3");
+          if (rc0) return rc0;
+          if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_x3_kernel<2, 1>), grid, block, HaloGeomX3<2>::LDS_BYTES, stream, p);
+          else hipLaunchKernelGGL((conv_halo_x3_kernel<2, 0>), grid, block, HaloGeomX3<2>::LDS_BYTES, stream, p);
+        }
       } else if (L.rate == 1) {
         if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_kernel<1, 1>), grid, block, HaloGeom<1>::LDS_BYTES, stream, p);
         else hipLaunchKernelGGL((conv_halo_kernel<1, 0>), grid, block, HaloGeom<1>::LDS_BYTES, stream, p);

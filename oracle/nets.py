@@ -145,7 +145,25 @@ def bf16_round(t):
     return t.bfloat16().float()
 
 
-def forward(weights, net_input, coord_net=True, return_activations=False, bf16=False):
+def split3(t):
+    """x = h + m + l with bf16 parts (8 + 8 + 8 significand bits): the operand format of the 6-product study below."""
+    h = t.bfloat16().float()
+    r = t - h
+    m = r.bfloat16().float()
+    return h, m, (r - m).bfloat16().float()
+
+
+def conv_split3(fn, x, w):
+    """STUDY ONLY (tools/split3_study.py; not a product path): fp32 convolution emulated by six bf16 x bf16
+    products with fp32 accumulation -- h.h + h.m + m.h + h.l + l.h + m.m (the dropped m.l, l.m, l.l terms are <= 2^-24 of the
+    leading one).  Each term is an fp32 torch convolution of bf16-representable operands (exact products, fp32 sums), the
+    terms are added smallest first."""
+    xh, xm, xl = split3(x)
+    wh, wm, wl = split3(w)
+    return ((fn(xm, wm) + fn(xl, wh)) + fn(xh, wl)) + ((fn(xm, wh) + fn(xh, wm)) + fn(xh, wh))
+
+
+def forward(weights, net_input, coord_net=True, return_activations=False, bf16=False, split3_products=False):
     """msi_coord_train_net (nets.py:471-515) / msi_train_net (:387-450).
     net_input: np [B,H,W,Cin] fp32.  Returns np [B,H,W,num_outputs] fp32.
 
@@ -176,7 +194,10 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
             x = TF.pad(x, (pl, pr, pt, pb))
         else:
             x = wrap_pad(x, rate, rate)
-        y = TF.conv2d(x, w, stride=stride, dilation=rate)
+        if split3_products:
+            y = conv_split3(lambda a, b_: TF.conv2d(a, b_, stride=stride, dilation=rate), x, w)
+        else:
+            y = TF.conv2d(x, w, stride=stride, dilation=rate)
         acts[name + "/raw"] = y
         y = rnd(ln(name, y))
         acts[name] = y
@@ -185,7 +206,10 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
     def convT(name, x):
         w = rnd(_convT_w(weights[name + "/weights"]))
         if coord_net:
-            y = TF.conv_transpose2d(x, w, stride=2, padding=1)
+            if split3_products:
+                y = conv_split3(lambda a, b_: TF.conv_transpose2d(a, b_, stride=2, padding=1), x, w)
+            else:
+                y = TF.conv_transpose2d(x, w, stride=2, padding=1)
             acts[name + "/raw"] = y
             y = rnd(ln(name, y))
         else:
@@ -220,7 +244,10 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
         c82 = conv("conv8_2", c81)
         w = rnd(_conv_w(weights["color_pred/weights"]))
         b = torch.from_numpy(weights["color_pred/biases"])
-        pred = torch.tanh(TF.conv2d(c82, w, bias=b))
+        if split3_products:
+            pred = torch.tanh(conv_split3(lambda a, b_: TF.conv2d(a, b_), c82, w) + b.view(1, -1, 1, 1))
+        else:
+            pred = torch.tanh(TF.conv2d(c82, w, bias=b))
     out = np.ascontiguousarray(pred.permute(0, 2, 3, 1).numpy())
     if return_activations:
         res = {k: np.ascontiguousarray(v.permute(0, 2, 3, 1).numpy()) for k, v in acts.items()}

@@ -1,0 +1,81 @@
+"""Plan option F32_SPLIT3 (round 4): the stride-1 halo-patch layers of an fp32 plan compute their convolution as a 3-way bf16 split
+of both operands with SIX products on the bf16 MFMA (conv_halo_x3_kernel): fp32-grade arithmetic -- the dropped terms are below
+2^-26 of a product -- so every gate of the native fp32 path applies unchanged: layers within 2e-4 of their scale, the tanh output
+within 1e-3, the full-size fixtures within 1e-3, bitwise determinism, the fix-up launch equal to the in-launch hand-off."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_cnn import _run, env  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+ALL = 0x3ffff
+
+
+@pytest.mark.parametrize("coord", [True, False])
+@pytest.mark.parametrize("b,h,w,cin,nout,ngf", [(1, 32, 64, 96, 32, 32), (2, 16, 48, 32, 8, 32), (1, 64, 128, 192, 64, 64)])
+def test_split3_layers_match_the_oracle(env, coord, b, h, w, cin, nout, ngf):
+    torch, MSI, nets, N, onets = env
+    pred, ref, raws, acts = _run(env, b, h, w, cin, nout, ngf, coord, seed=3, options={N.NET_OPT_F32_SPLIT3: ALL})
+    native, _, raws_n, _ = _run(env, b, h, w, cin, nout, ngf, coord, seed=3)
+    m = MSI(weights=onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=3, randomize_affine=True), coord_net=coord)
+    m.net_options[N.NET_OPT_F32_SPLIT3] = ALL
+    kern = [m._plan(b, h, w, cin, nout, ngf).layer_kernel(i)[0] for i in range(17)]
+    assert sum(k.startswith("conv_halo_x3_kernel") for k in kern) >= (8 if w % 64 == 0 else 2), kern      # (the split path really ran)
+    worst = 0.0
+    for name, raw in raws.items():
+        o = acts[name]
+        err = np.abs(raw - o).max() / (np.abs(o).max() + 1e-12)
+        worst = max(worst, err)
+        assert err < 2e-4, "%s: relative max err %g" % (name, err)
+    e_split, e_native = np.abs(pred - ref).max(), np.abs(native - ref).max()
+    print("split3 vs oracle %.2e | native fp32 vs oracle %.2e | split3 vs native %.2e | worst layer %.2e" % (
+        e_split, e_native, np.abs(pred - native).max(), worst))
+    assert e_split <= 1e-3 and e_split <= 2 * e_native + 2e-6
+
+
+def test_split3_is_deterministic_and_fixup_launch_agrees(env):
+    torch, MSI, nets, N, onets = env
+    b, h, w, cin, nout, ngf = 1, 160, 320, 96, 32, 64          # 40 x 80 deepest layers: tiles cut into K-ranges
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=9, randomize_affine=True)
+    x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
+    m = MSI(weights=weights, coord_net=True)
+    m.net_options[N.NET_OPT_F32_SPLIT3] = ALL
+    first = m.run_net(x, nout, ngf).clone()
+    for _ in range(10):
+        assert torch.equal(m.run_net(x, nout, ngf), first)
+    assert m.network_status() == 0
+    plan = m._plan(b, h, w, cin, nout, ngf)
+    assert any(plan.layer_kernel(i)[2] > 0 and plan.layer_kernel(i)[0].startswith("conv_halo_x3") for i in range(17))
+    f = MSI(weights=weights, coord_net=True)
+    f.net_options[N.NET_OPT_F32_SPLIT3] = ALL
+    f.net_options[N.NET_OPT_FIXUP_KERNEL] = 1
+    assert torch.equal(f.run_net(x, nout, ngf), first)
+
+
+@pytest.mark.parametrize("fixture", ["full_640x320x32_samples.npz", "full_640x320x32_wrap_samples.npz"])
+def test_split3_full_size_fixtures(fixture):
+    """The configs[1] frame (CoordNet) and the reference's default network (wrap padding) at 640x320x32, ngf 64, through
+    the split path: the same dense oracle samples and the same 1e-3 gate as the native path; max-abs reported beside it."""
+    import torch
+    from matryodshka_amd import MSI, _native as N
+    from matryodshka_amd.synthetic import make_inputs
+    from oracle import nets as onets
+    from tests.test_golden import _fixture, _check_dense
+    z, cfg = _fixture(fixture)
+    d, ngf, coord, seed = int(cfg["d"]), int(cfg["ngf"]), bool(cfg["coord"]), int(cfg["seed"])
+    inp = make_inputs(seed, int(cfg["b"]), int(cfg["h"]), int(cfg["w"]))
+    weights = onets.init_weights(6 * d, 2 * d, ngf=ngf, coord_net=coord, seed=seed, randomize_affine=True)
+    errs = {}
+    for tag, opt in (("native", 0), ("split3", ALL)):
+        m = MSI(weights=weights, coord_net=coord)
+        m.net_options[N.NET_OPT_F32_SPLIT3] = opt
+        planes = m.inv_depths(1.0, 100.0, d)
+        pred, net_input = m.infer_msi(torch.from_numpy(inp["src_image"]), torch.from_numpy(inp["ref_image"]), None, None,
+                                      inp["ref_pose"], inp["src_pose"], inp["intrinsics"], "blend_psv", d, planes, ngf=ngf)
+        rgb, dep = m.msi_render_equirect_view_and_depth(pred["rgba_layers"], inp["tgt_pose_rt"], inp["tgt_pos"], planes, inp["intrinsics"])
+        assert m.network_status() == 0
+        got = dict(rgba_layers=pred["rgba_layers"].cpu().numpy(), rgb=rgb.cpu().numpy(), depth=dep.cpu().numpy())
+        errs[tag] = _check_dense(z, got, ("rgba_layers", "rgb", "depth"), 1e-3)
+    print(fixture, {t: {k: "%.2e" % v[0] for k, v in e.items()} for t, e in errs.items()})
+    for k in ("rgba_layers", "rgb", "depth"):
+        assert errs["split3"][k][0] <= 2 * errs["native"][k][0] + 1e-5, (k, errs["split3"][k], errs["native"][k])

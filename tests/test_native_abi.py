@@ -183,6 +183,28 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
                     assert np.allclose(tab[mh, cc, :info.cout], exp, rtol=1e-6, atol=1e-7), (name, mh, cc)
             off += tab.size
         off = -(-off // 64) * 64
+        # fp32 plans: the x3 block of a stride-1 one-source 3x3 layer (plan option F32_SPLIT3): [tap][chunk of 32][plane h | m | l]
+        # [npad][64 B]; h = bf16(w), m = bf16(w - h), l = bf16(w - h - m); 16-byte slot j of row n stored at j ^ ((n >> 2) & 3)
+        if dtype == "f32" and info.kind == 0 and info.stride == 1 and c1 == 0 and c0 % 32 == 0:
+            ch = c0 // 32
+            blk = packed[off:off + 9 * ch * 3 * npad * 16].view(np.uint16).reshape(9, ch, 3, npad, 32)
+            for _ in range(40):
+                tap, c, n = rng.randint(9), rng.randint(ch), rng.randint(info.cout)
+                want = wt[tap // 3, tap % 3, c * 32:(c + 1) * 32, n].astype(np.float32)
+                parts = []
+                for pl in range(3):
+                    row = blk[tap, c, pl, n].reshape(4, 8)
+                    un = np.empty_like(row)
+                    for j in range(4):
+                        un[j ^ ((n >> 2) & 3)] = row[j]
+                    parts.append((un.reshape(32).astype(np.uint32) << 16).view(np.float32))
+                h = onets.bf16_round(want)
+                m = onets.bf16_round(want - h)
+                l = onets.bf16_round(want - h - m)
+                assert np.array_equal(parts[0], h) and np.array_equal(parts[1], m) and np.array_equal(parts[2], l), (name, tap, c, n)
+                assert np.abs((parts[0].astype(np.float64) + parts[1] + parts[2]) - want).max() <= 2.0 ** -24 * np.abs(want).max()
+            assert not blk[:, :, :, info.cout:, :].any()
+            off = -(-(off + blk.size // 2) // 64) * 64
     if dtype == "bf16":
         # bf16 plans end with the head's bf16-ROUNDED weights once more as fp32 rows (32 channels per 128-byte row, rows
         # padded to 64, slots swizzled like every fp32 row): the fused tail runs the 1x1 head on the fp32 MFMA
