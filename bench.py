@@ -548,6 +548,14 @@ def main():
     gbytes = geometry_bytes(H, W, D, 2 if bf16 else 4)
     nb = max(B, 1)
     cnn_tflops = flops * nb / (cnn_ms_timed * 1e-3) / 1e12
+    # the peak the convolutions are priced against: per layer the dense MFMA peak of the instruction it runs on -- bf16 plans
+    # 2 500 TFLOP/s; fp32 layers 157.3 on v_mfma_f32_32x32x2_f32, or 2 500 / 6 = 416.7 fp32-equivalent TFLOP/s where the plan
+    # runs the six-product 3-way bf16 split (conv_halo_x3_kernel) -- blended by the layers' flops: peak = flops / sum(flops_l / peak_l)
+    layer_fl = cnn_layer_flops(H, W, cin, nout, NGF, coord)[:-1]
+    if B > 0 and not bf16:
+        kplan = model._plan(B, H, W, cin, nout, NGF)
+        layer_peak = [PEAK_BF16_MFMA_TFLOPS / 6.0 if "_x3_kernel" in kplan.layer_kernel(i)[0] else PEAK_FP32_MFMA_TFLOPS for i in range(17)]
+        peak = sum(layer_fl) / sum(f / pk for f, pk in zip(layer_fl, layer_peak))
     stages = {k: {"ms": round(v, 4)} for k, v in stage_ms.items()}
     for k in ("sweep", "assemble", "render"):
         if stage_ms[k] > 0:
@@ -596,8 +604,9 @@ def main():
         "repeats": {"ms_per_step": [round(r / args.steps * 1e3, 4) for r in [elapsed] + repeats],
                     "median_ms_per_step": round(float(np.median([elapsed] + repeats)) / args.steps * 1e3, 4),
                     "note": "region 0 is the contract region `value` / `ms_per_step` are computed from"},
-        "roofline": {"kernel": "conv_halo_kernel + conv_igemm_kernel (the 3x3 / 4x4 conv launches of one forward, %s MFMA implicit GEMM)" % ("bf16" if bf16 else "fp32"),
-                     "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": peak,
+        "roofline": {"kernel": "conv_halo*_kernel + conv_igemm_kernel (the 3x3 / 4x4 conv launches of one forward, %s implicit GEMM)" % ("bf16 MFMA" if bf16 else "fp32: " + str(arithmetic)),
+                     "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": round(peak, 2),
+                     "peak_note": "dense MFMA peak of the instruction each layer runs on, blended by the layers' flops (fp32 MFMA 157.3; six-product bf16 split 2500 / 6 = 416.7 fp32-equivalent; bf16 2500 TFLOP/s)",
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4), "traffic": traffic,
                      "traffic_stale": traffic_stale,
                      "algorithmic_bytes": conv_bytes,

@@ -329,7 +329,7 @@ typedef struct msi_net_plan msi_net_plan;
 #define MSI_NET_OPT_F32_SPLIT3 14 /* fp32 plans, bit i = layer i (graph order): a stride-1 halo-patch 3x3 layer computes its fp32 convolution as a 3-way */
                                   /* bf16 split of both operands with SIX products (h.h, h.m, m.h, h.l, l.h, m.m; exact products, fp32 accumulation; */
                                   /* dropped terms <= 2^-26 of a product: fp32-grade, NOT the 3-product TF32-grade split) on the 16x faster bf16 MFMA */
-                                  /* (conv_halo_x3_kernel).  0 (default) = native fp32 MFMA everywhere */
+                                  /* (conv_halo_x3_kernel).  Default 0x3ffff (every layer that qualifies); 0 = native fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere */
 #define MSI_NET_OPT_COUNT 15
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);

@@ -1643,6 +1643,9 @@ conv_halo_kernel(const ConvParams p) {
 // work decomposition, tail split, in-launch hand-off, epilogue, LayerNorm sums -- is conv_halo_kernel's.
 // Numerics: oracle emulation of this arithmetic against the fp32 oracle at the configs[1] frame: pred 3.0e-6, rgba 1.9e-6,
 // rgb 1.0e-6 max-abs (profiles/r04_split3_numerics.txt: the native fp32 path's own summation-order error is 4.5e-6 on pred).
+#ifndef MSI_X3_ABLATE   // timing experiments only (wrong results): 1 no weight DMA, 4 no per-tap barrier, 8 no fragment reads, 16 no MFMAs, 32 no patch swap
+#define MSI_X3_ABLATE 0
+#endif
 template <int RATE>
 struct HaloGeomX3 {
   static constexpr int PW = 16 + 2 * RATE, PH = 4 + 2 * RATE, NPX = PW * PH;
@@ -1720,7 +1723,7 @@ conv_halo_x3_kernel(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)S * 3 * plane_bytes), 0x00020000);
   const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + (lane >> 2)) * G::B_ROW + (lane & 3) * 16);
 #define MSI_B_ISSUE(c, tap, st)                                                                                        \
-  {                                                                                                                    \
+  if (!(MSI_X3_ABLATE & 1)) {                                                                                          \
     char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;                                          \
     const int soff_ = ((tap) * CH + (c)) * 3 * plane_bytes;                                                            \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
@@ -1827,6 +1830,7 @@ conv_halo_x3_kernel(const ConvParams p) {
     constexpr int KH_ = (TAP) / 3, KW_ = (TAP) % 3, ST_ = (TAP) % 3;                                                   \
     constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;                                             \
     v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
+    if (!(MSI_X3_ABLATE & 8))                                                                                         \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
       ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);                                \
       bh_[s_] = lds_read128<ST_ * G::B_STAGE>(b_s[s_]);                                                                \
@@ -1839,12 +1843,14 @@ conv_halo_x3_kernel(const ConvParams p) {
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
       if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                      \
       else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                              \
+      if (!(MSI_X3_ABLATE & 16)) {                                                                                     \
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0); \
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, al_[s_]), acc[0][0], 0, 0, 0); \
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0); \
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
+      }                                                                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                                               \
       if (s_ == 0) {                                                                                                   \
         if ((TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                            \
@@ -1859,7 +1865,7 @@ conv_halo_x3_kernel(const ConvParams p) {
       else if (issued_) wait_vmcnt<3>();                                                                               \
       else wait_vmcnt<0>();                                                                                            \
     }                                                                                                                  \
-    __builtin_amdgcn_s_barrier();                                                                                      \
+    if (!(MSI_X3_ABLATE & 4)) __builtin_amdgcn_s_barrier();                                                            \
   }
 
   // ---- prologue: first patch, first two weight k-steps ----
@@ -1883,7 +1889,7 @@ conv_halo_x3_kernel(const ConvParams p) {
 #endif
   for (; c < c1; ++c) {
     MSI_HTAP(0) MSI_HTAP(1) MSI_HTAP(2) MSI_HTAP(3) MSI_HTAP(4) MSI_HTAP(5) MSI_HTAP(6) MSI_HTAP(7) MSI_HTAP(8)
-    if (c + 1 < c1) {   // every wave has read the last tap of this chunk (closing barrier of tap 8): swap the patch
+    if (c + 1 < c1 && !(MSI_X3_ABLATE & 32)) {   // every wave has read the last tap of this chunk (closing barrier of tap 8): swap the patch
       MSI_PATCH_STORE()
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -2144,6 +2150,285 @@ conv_halo_s2_kernel(const ConvParams p) {
       /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */ \
       if (FIRST_ && !LAST_ && more_) wait_vmcnt<2 + NLOAD>();                                                          \
       else if (issued_) wait_vmcnt<2>();                                                                               \
+      else wait_vmcnt<0>();                                                                                            \
+    }                                                                                                                  \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    if (LAST_ && more_) {   /* every wave has read this unit's last tap: swap the patch */                             \
+      MSI_PATCH_STORE((U_ + 1) & 3)                                                                                    \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+      __builtin_amdgcn_s_barrier();                                                                                    \
+    }                                                                                                                  \
+  }
+
+  // ---- prologue: unit 0 of the first group ----
+  int c = c0;   // (unit 0's patch of group c0 is on its way)
+  if (APPLY) {
+    double *s_stat = reinterpret_cast<double *>(smem);
+    ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
+    const double mu = s_stat[0];
+    inv_f = (float)s_stat[1];
+    mu_hi = (float)mu;
+    mu_lo = (float)(mu - (double)mu_hi);
+    __syncthreads();
+  }
+  wait_vmcnt<0>();
+  MSI_PATCH_STORE(0)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; c < c1; ++c) {
+    MSI_S2STEP(0) MSI_S2STEP(1) MSI_S2STEP(2) MSI_S2STEP(3) MSI_S2STEP(4) MSI_S2STEP(5) MSI_S2STEP(6) MSI_S2STEP(7) MSI_S2STEP(8)
+  }
+#undef MSI_S2STEP
+#undef MSI_S2_UNIT
+#undef MSI_S2_TAP
+#undef MSI_B_ISSUE
+#undef MSI_PATCH_STORE
+#undef MSI_PATCH_LOAD
+
+  // ---- epilogue: as conv_halo_kernel ----
+  if (!full) {
+    constexpr int SLAB = 64 * 64 * 4;
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)slot * (64 * 64)), 0, SLAB, 0x00020000);
+    if (p.tile_cnt == nullptr) {
+      dump_acc<MT, NT, 0>(acc, rsrc_p, tid);
+      return;
+    }
+    dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
+    const int nsp = t < p.n_main ? p.split0 : p.split;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *s_old = reinterpret_cast<int *>(smem);
+    if (tid == 0)
+      *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_old != nsp - 1) return;
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
+    sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+    __syncthreads();   // (s_old has been read by every thread before the strip below reuses LDS)
+  }
+  emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, smem);
+#endif
+}
+
+// ---- the stride-2 halo-patch kernel through the six-product bf16 split (conv_halo_s2_kernel x conv_halo_x3_kernel; r04) ----------
+struct HaloGeomS2X3 {
+  static constexpr int PW = 17, PH = 5, NPX = PW * PH;
+  static constexpr int PIX_BYTES = 208;
+  static constexpr int ROW_PITCH = ((PW * PIX_BYTES + 127) / 256) * 256 + 128;
+  static constexpr int A_BYTES = PH * ROW_PITCH;
+  static constexpr int B_ROW = 64, B_PLANE = 64 * B_ROW, B_STAGE = 3 * B_PLANE;
+  static constexpr int NSTG = 3;
+  static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
+  static constexpr int NLOAD = (NPX * 8 + 255) / 256;
+};
+
+template <int APPLY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+conv_halo_s2_x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef HaloGeomS2X3 G;
+  constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
+  constexpr int MT = 1, NT = 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // ---- work decomposition: as conv_halo_kernel (tail split; K-ranges in whole 32-channel groups) ----
+  const int CH = p.cpt0;
+  int t, c0 = 0, c1 = CH, ks = 0, slot = 0;
+  {
+    const int bid = blockIdx.x;
+    if (bid < p.nb_main && p.split0 == 1) {
+      const int q = p.n_main >> 3, r = p.n_main & 7, xcd = bid & 7, local = bid >> 3;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    } else {
+      int sp, r, tbase;
+      unsigned mg;
+      if (bid < p.nb_main) { sp = p.split0; mg = p.mg_sp0; r = bid; tbase = 0; }
+      else { sp = p.split; mg = p.mg_sp; r = bid - p.nb_main; tbase = p.n_main; }
+      const int tl = (int)udiv_magic((unsigned)r, (unsigned)sp, mg);
+      ks = r - tl * sp;
+      t = tbase + tl;
+      c0 = (int)udiv_magic((unsigned)(ks * CH), (unsigned)sp, mg);
+      c1 = (int)udiv_magic((unsigned)((ks + 1) * CH), (unsigned)sp, mg);
+      slot = bid - (p.split0 == 1 ? p.nb_main : 0);
+    }
+  }
+  const bool full = (c0 == 0) & (c1 == CH);
+  int tile_m, tile_n, b;
+  {
+    int r = t;
+    const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
+    tile_m = r - q1 * p.tiles_m; r = q1;
+    const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
+    tile_n = r - q2 * p.tiles_n;
+    b = q2;
+  }
+  const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
+  const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;   // the tile of the OUTPUT grid
+  const int H = p.Hin, W = p.Win, C = p.C0;
+  // the first two weight k-steps (taps (0,0) and (0,2) of group c0) before anything else
+  const int S = p.ksteps;
+  // (weights: the x3 block of the packed blob, three 64-byte-row planes per k-step -- see conv_halo_x3_kernel)
+  const int plane_bytes = p.npad * G::B_ROW;
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)S * 3 * plane_bytes), 0x00020000);
+  const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + (lane >> 2)) * G::B_ROW + (lane & 3) * 16);
+#define MSI_B_ISSUE(c, tap, st)                                                                                        \
+  {                                                                                                                    \
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;                                          \
+    const int soff_ = ((tap) * CH + (c)) * 3 * plane_bytes;                                                            \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
+  }
+  MSI_B_ISSUE(c0, 0, 0)
+  MSI_B_ISSUE(c0, 2, 1)
+
+  // ---- per-lane patch slots of the four units: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 ----
+  unsigned voff[4][NLOAD], lds_a[NLOAD];
+  bool pok[4][NLOAD];
+  const int cslot = tid & 7;
+  const size_t in_bytes = (size_t)H * W * C * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in_bytes), 0, (int)in_bytes, 0x00020000);
+  v4f araw[NLOAD], g4, be4;
+  // (unit 0 first and its patch of group c0 requested at once: the other units' offsets are worked out under that round trip)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) {
+      const int pp = (tid + 256 * k) >> 3;
+      const int py = pp / PW, px = pp - py * PW;
+      if (u == 0) lds_a[k] = pp < NPX ? (unsigned)(py * G::ROW_PITCH + px * G::PIX_BYTES + cslot * 8) : 0xffffffffu;
+      const int ih = 2 * (oh0 + py) + (u >> 1) - p.pad_t;
+      int iw = 2 * (ow0 + px) + (u & 1) - p.pad_l;
+      if (p.wrap) iw = iw < 0 ? iw + W : (iw >= W ? iw - W : iw);
+      pok[u][k] = pp < NPX && ih >= 0 && ih < H && iw >= 0 && iw < W;
+      voff[u][k] = pok[u][k] ? __umul24((unsigned)(ih * W + iw), (unsigned)(C * 4)) + (unsigned)(cslot * 16) : OOB;
+    }
+    if (u == 0) {
+#pragma unroll
+      for (int k = 0; k < NLOAD; ++k)
+        araw[k] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[0][k], c0 * ROW_BYTES, 0));
+      if (APPLY) {
+        g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + c0 * 32 + cslot * 4);
+        be4 = *reinterpret_cast<const v4f *>(p.ln_beta + c0 * 32 + cslot * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  float inv_f = 1.f, mu_hi = 0.f, mu_lo = 0.f;
+  bool has_pad = false;                                   // wave-uniform: any of the wave's patch pixels (any unit) is padding
+  if (APPLY) {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bad |= (lds_a[k] != 0xffffffffu) && !pok[u][k];
+    has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
+  }
+  v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};   // the group's affine (the lane's four channels): set with unit 0
+  // patch of (group c, unit U) -> registers (+ gamma / beta of the lane's channels with unit 0)
+#define MSI_PATCH_LOAD(c, U)                                                                                           \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[U][k_], (c) * ROW_BYTES, 0)); \
+    if (APPLY && (U) == 0) {                                                                                           \
+      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 32 + cslot * 4);                                          \
+      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 32 + cslot * 4);                                          \
+    }                                                                                                                  \
+  }
+  // registers -> LDS patch, the producer's affine + ReLU applied (ln_apply_kernel's expressions: same bits)
+#define MSI_PATCH_STORE(U)                                                                                             \
+  {                                                                                                                    \
+    if (APPLY && (U) == 0) {                                                                                           \
+      s4 = inv_f * g4;                                                                                                 \
+      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};                          \
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
+      v4f y = araw[k_];                                                                                                \
+      if (APPLY) {                                                                                                     \
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
+        if (has_pad && !pok[U][k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */       \
+      }                                                                                                                \
+      unsigned h0, h1, m0, m1, l0, l1;   /* y = h + m + l, bf16 parts (see conv_halo_x3_kernel) */                       \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h0) : "v"(y.x), "v"(y.y));                                             \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h1) : "v"(y.z), "v"(y.w));                                             \
+      v4f r = y - v4f{__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h0 & 0xffff0000u),               \
+                      __builtin_bit_cast(float, h1 << 16), __builtin_bit_cast(float, h1 & 0xffff0000u)};              \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m0) : "v"(r.x), "v"(r.y));                                             \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m1) : "v"(r.z), "v"(r.w));                                             \
+      r = r - v4f{__builtin_bit_cast(float, m0 << 16), __builtin_bit_cast(float, m0 & 0xffff0000u),                    \
+                  __builtin_bit_cast(float, m1 << 16), __builtin_bit_cast(float, m1 & 0xffff0000u)};                  \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l0) : "v"(r.x), "v"(r.y));                                             \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l1) : "v"(r.z), "v"(r.w));                                             \
+      if (lds_a[k_] != 0xffffffffu) {                                                                                  \
+        typedef unsigned u2x_t __attribute__((ext_vector_type(2)));                                                    \
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_]) = u2x_t{h0, h1};                                                  \
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 64) = u2x_t{m0, m1};                                             \
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 128) = u2x_t{l0, l1};                                            \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }
+
+  // ---- MFMA side (as conv_halo_kernel: a wave owns two tile rows x 16 columns x 32 channels) ----
+  const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
+  const unsigned a_base = lds_base + (unsigned)((2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
+  unsigned b_s[2];
+  (void)fswz;
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+    b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+
+  // k-step J = 0..8 of the current group: unit, tap and patch offsets are literals
+#define MSI_S2_TAP(J) ((J) == 0 ? 0 : (J) == 1 ? 2 : (J) == 2 ? 6 : (J) == 3 ? 8 : (J) == 4 ? 1 : (J) == 5 ? 7 : (J) == 6 ? 3 : (J) == 7 ? 5 : 4)
+#define MSI_S2_UNIT(J) ((J) < 4 ? 0 : (J) < 6 ? 1 : (J) < 8 ? 2 : 3)
+#define MSI_S2STEP(J)                                                                                                  \
+  {                                                                                                                    \
+    constexpr int TAP_ = MSI_S2_TAP(J), U_ = MSI_S2_UNIT(J), ST_ = (J) % 3;                                            \
+    constexpr int DY_ = (TAP_ / 3) >> 1, DX_ = (TAP_ % 3) >> 1;                                                        \
+    constexpr bool FIRST_ = (J) == 0 || (J) == 4 || (J) == 6 || (J) == 8, LAST_ = (J) == 3 || (J) == 5 || (J) == 7 || (J) == 8; \
+    constexpr int AOFF_ = DY_ * G::ROW_PITCH + DX_ * G::PIX_BYTES;                                                     \
+    const bool more_ = U_ < 3 || c + 1 < c1;               /* a unit follows this one */                               \
+    v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
+      ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);                                \
+      bh_[s_] = lds_read128<ST_ * G::B_STAGE>(b_s[s_]);                                                                \
+      am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);                           \
+      bm_[s_] = lds_read128<ST_ * G::B_STAGE + G::B_PLANE>(b_s[s_]);                                                   \
+      al_[s_] = s_ == 0 ? lds_read128<AOFF_ + 128>(a_base) : lds_read128<AOFF_ + 160>(a_base);                         \
+      bl_[s_] = lds_read128<ST_ * G::B_STAGE + 2 * G::B_PLANE>(b_s[s_]);                                               \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
+      if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                      \
+      else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                              \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0); \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, al_[s_]), acc[0][0], 0, 0, 0); \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0); \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if (s_ == 0) {                                                                                                   \
+        if (FIRST_ && more_) {                                                                                         \
+          if (U_ < 3) MSI_PATCH_LOAD(c, (U_ + 1) & 3) else MSI_PATCH_LOAD(c + 1, 0)                                    \
+        }                                                                                                              \
+        /* k-step two ahead: (c, J + 2) or (c + 1, J - 7) */                                                           \
+        if ((J) + 2 < 9) { MSI_B_ISSUE(c, MSI_S2_TAP(((J) + 2) % 9), ((J) + 2) % 3) }                                  \
+        else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, MSI_S2_TAP(((J) + 2) % 9), ((J) + 2) % 3) }                          \
+      }                                                                                                                \
+    }                                                                                                                  \
+    {                                                                                                                  \
+      const bool issued_ = ((J) + 2 < 9) || (c + 1 < c1);                                                              \
+      /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */ \
+      if (FIRST_ && !LAST_ && more_) wait_vmcnt<3 + NLOAD>();                                                          \
+      else if (issued_) wait_vmcnt<3>();                                                                               \
       else wait_vmcnt<0>();                                                                                            \
     }                                                                                                                  \
     __builtin_amdgcn_s_barrier();                                                                                      \
@@ -3947,7 +4232,7 @@ int build_net(const msi_net_desc *d, int num_cus, Net &net) {
     koff = round_up(koff, 64);
     // fp32 plans: the stride-1 one-source 3x3 layers also carry their weights as three bf16 planes (plan option F32_SPLIT3):
     // [tap][chunk of 32 channels][plane][npad rows][64 B]
-    if (!bf16 && s.kind == MODE_CONV && s.stride == 1 && s.src1 < 0 && L.c0 % 32 == 0) {
+    if (!bf16 && s.kind == MODE_CONV && s.src1 < 0 && L.c0 % 32 == 0) {
       L.x3_off = koff;
       koff = round_up(koff + (size_t)9 * (L.c0 / 32) * 3 * L.npad * 16, 64);
     }
@@ -4183,9 +4468,11 @@ int plan_layers(msi_net_plan *pl) {
                 L.out_h % 4 == 0 && L.out_w % 16 == 0 && L.c0 % 32 == 0 && p.pad_t == p.pad_l && (p.pad_t == 0 || p.pad_t == 1) &&
                 // (measured at 640 x 320: conv1_2 / conv2_2 gain their producers' ln_apply launches, -22 / -11 us for +4 / +3 us of
                 // kernel time; conv3_3, 400 tiles cut into K-ranges of two groups, loses 11 us to save 6: tap kernel)
-                (long)(L.out_h / 4) * (L.out_w / 16) * (L.cout / 64) * desc->batch >= 3L * pl->num_cus;
+                ((long)(L.out_h / 4) * (L.out_w / 16) * (L.cout / 64) * desc->batch >= 3L * pl->num_cus ||
+                 // (r04: through the six-product split the halo form wins on conv3_3's 400 tiles as well: 76 -> 5x us)
+                 (L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1) && !(pl->opt[MSI_NET_OPT_HALO_SKIP] >> 20 & 1)));
     if (Q.halo_s2) Q.halo = 1;
-    Q.halo_x3 = Q.halo && !Q.halo_s2 && L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1);
+    Q.halo_x3 = Q.halo && !bf16 && L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1);
     int max_split = MAX_SPLIT;
     // bf16 halo-patch kernel (conv_halo_bf16_kernel): the same layers with 64-channel chunks and whole
     // 8 x 16 pixel x 128 channel or 16 x 16 x 64 tiles
@@ -4651,7 +4938,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_UNIFORM_SPLIT] = 0;
   pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD] = 0;
   pl->opt[MSI_NET_OPT_BF16_WAVES] = 8;
-  pl->opt[MSI_NET_OPT_F32_SPLIT3] = 0;
+  pl->opt[MSI_NET_OPT_F32_SPLIT3] = 0x3ffff;   // every layer that has the kernel (r04: same error against the oracle as the native path, 1.35-1.45 x faster per layer)
   pl->opt[MSI_NET_OPT_BF16_STAGE_RAW] = 1;   // (bit 1, conv8_1 staging its raw sources: measured 50 us per 16 frames SLOWER -- ~180 VALU per chunk
                                                // against 2 048 matrix cycles of the 128 x 64 tile; bit 0, conv8_2: 130 us faster.  Three interleaved repeats)
   int rc = plan_layers(pl);
@@ -4721,7 +5008,8 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
   } else if (Q.halo_t) {
     snprintf(name, name_bytes, "convt_halo_kernel");
   } else if (Q.halo) {
-    if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_s2_kernel<%d>", Q.halo_apply ? 1 : 0);
+    if (Q.halo_s2 && Q.halo_x3) snprintf(name, name_bytes, "conv_halo_s2_x3_kernel<%d>", Q.halo_apply ? 1 : 0);
+    else if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_s2_kernel<%d>", Q.halo_apply ? 1 : 0);
     else if (Q.halo_x3) snprintf(name, name_bytes, "conv_halo_x3_kernel<%d, %d>", L.rate, Q.halo_apply ? 1 : 0);
     else snprintf(name, name_bytes, "conv_halo_kernel<%d, %d>", L.rate, Q.halo_apply ? 1 : 0);
   } else {
@@ -4967,7 +5255,11 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
         p.ln_beta = packed + S.beta_off;
       }
       const dim3 grid(Q.nblocks), block(256);
-      if (Q.halo_s2) {
+      if (Q.halo_s2 && Q.halo_x3) {
+        p.wpk_x3 = reinterpret_cast<const char *>(packed + L.x3_off);
+        if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_x3_kernel<1>), grid, block, HaloGeomS2X3::LDS_BYTES, stream, p);
+        else hipLaunchKernelGGL((conv_halo_s2_x3_kernel<0>), grid, block, HaloGeomS2X3::LDS_BYTES, stream, p);
+      } else if (Q.halo_s2) {
         if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_kernel<1>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
         else hipLaunchKernelGGL((conv_halo_s2_kernel<0>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
       } else if (Q.halo_x3) {

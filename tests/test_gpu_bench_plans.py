@@ -19,11 +19,12 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = 1e-3
 
 # graph order conv1_1 ... conv8_2 (the head runs inside head_assemble_kernel on the blend_psv path)
-F32_BIG_GRID = ["conv_halo_kernel<1, 0>", "conv_halo_s2_kernel<1>", "conv_halo_kernel<1, 0>", "conv_halo_s2_kernel<1>",
-                "conv_halo_kernel<1, 0>", "conv_halo_kernel<1, 1>", "conv_halo_s2_kernel<1>", "conv_halo_kernel<2, 0>",
-                "conv_halo_kernel<2, 1>", "conv_halo_kernel<2, 1>", "conv_igemm_kernel<64, 64, 1, 0>", "conv_halo_kernel<1, 1>",
-                "conv_halo_kernel<1, 1>", "conv_igemm_kernel<64, 64, 1, 0>", "conv_halo_kernel<1, 1>",
-                "conv_igemm_kernel<64, 64, 1, 0>", "conv_halo_kernel<1, 1>"]
+# (r04: the stride-1 halo layers of an fp32 plan run the six-product bf16 split by default -- conv_halo_x3_kernel)
+F32_BIG_GRID = ["conv_halo_x3_kernel<1, 0>", "conv_halo_s2_x3_kernel<1>", "conv_halo_x3_kernel<1, 0>", "conv_halo_s2_x3_kernel<1>",
+                "conv_halo_x3_kernel<1, 0>", "conv_halo_x3_kernel<1, 1>", "conv_halo_s2_x3_kernel<1>", "conv_halo_x3_kernel<2, 0>",
+                "conv_halo_x3_kernel<2, 1>", "conv_halo_x3_kernel<2, 1>", "conv_igemm_kernel<64, 64, 1, 0>", "conv_halo_x3_kernel<1, 1>",
+                "conv_halo_x3_kernel<1, 1>", "conv_igemm_kernel<64, 64, 1, 0>", "conv_halo_x3_kernel<1, 1>",
+                "conv_igemm_kernel<64, 64, 1, 0>", "conv_halo_x3_kernel<1, 1>"]
 BF16_CONFIG2 = ["conv_halo_bf16_kernel<256, 64, 1, 0, 4>", "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>", "conv_halo_bf16_kernel<128, 128, 1, 1, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 2, 0, 8>", "conv_halo_bf16_kernel<128, 128, 2, 1, 8>",
@@ -122,7 +123,8 @@ def test_config3_bench_batches_every_frame(batch):
 @pytest.mark.parametrize("batch", [64, 8])
 def test_config4_bench_batches_every_face(batch):
     """bench.py --config 4: PP cube faces 256x256, 32 planes, fp32; 64 faces on one GPU, 8 = a rank's shard on 8 GPUs.
-    At these batches conv2_2 / conv3_3 take conv_halo_s2_kernel; in the b = 2 fixture test they take the tap kernel."""
+    (With the native arithmetic -- plan option F32_SPLIT3 = 0 -- conv3_3 takes conv_halo_s2_kernel at these batches and the tap
+    kernel in the b = 2 fixture test; the default six-product plan runs the halo form at every batch.)"""
     import torch
     from matryodshka_amd import MSI, poses
     from oracle import nets as onets
@@ -142,21 +144,25 @@ def test_config4_bench_batches_every_face(batch):
     assert m.network_status() == 0
     kern = _plan_kernels(m, batch, n, n, d)
     assert [k[0] for k in kern] == F32_BIG_GRID, kern
-    two = [k[0] for k in _plan_kernels(m, 2, n, n, d)]
-    assert two[3] == two[6] == "conv_igemm_kernel<64, 64, 0, 0>"          # (the plan the b = 2 fixture test runs)
+    native = MSI(weights=weights, coord_net=True, input_type="PP")      # (the native-arithmetic plan still switches kernels with the batch)
+    native.net_options[__import__("matryodshka_amd")._native.NET_OPT_F32_SPLIT3] = 0
+    assert [k[0] for k in _plan_kernels(native, 2, n, n, d)][6] == "conv_igemm_kernel<64, 64, 0, 0>"
+    assert [k[0] for k in _plan_kernels(native, batch, n, n, d)][6] == "conv_halo_s2_kernel<1>"
     got = dict(psv=net_input, rgba_layers=pred["rgba_layers"], rgb=rgb)
     rep = {k: _check_every_frame(z, k, got[k], bfix, TOL) for k in ("psv", "rgba_layers", "rgb")}
     print("config4 b=%d (max, mean, samples per group, faces):" % batch, rep)
 
 
 def test_config1_plan_is_the_profiled_one():
-    """configs[1] (batch 1): the plan of profiles/*_config1_kernel_stats.txt -- conv3_3 on the tap kernel (400 tiles cut into
-    K-ranges), the other stride-2 layers on the halo kernel, split tiles handed off inside the launch.  Parity at this
-    shape: tests/test_golden.py::test_gpu_matches_full_size_samples."""
+    """configs[1] (batch 1): the plan of profiles/r04_*_config1_kernel_stats.txt -- fourteen 3x3 layers through the six-product
+    bf16 split (conv_halo_x3_kernel / conv_halo_s2_x3_kernel), the conv-transposes on the native fp32 tap kernel, split tiles
+    handed off inside the launch; with F32_SPLIT3 = 0 the r03 plan (conv3_3 on the tap kernel).  Parity at this shape:
+    tests/test_golden.py::test_gpu_matches_full_size_samples, tests/test_gpu_split3.py."""
     from matryodshka_amd import _native as N, nets
     plan = N.NetPlan(nets.make_desc(1, 320, 640, 192, 64, 64, True, "f32"))
     k = [plan.layer_kernel(i) for i in range(18)]
-    want = list(F32_BIG_GRID)
-    want[6] = "conv_igemm_kernel<64, 64, 0, 0>"
-    assert [x[0] for x in k[:17]] == want and k[17][0] == "conv_igemm_kernel<64, 64, 2, 0>", k
+    assert [x[0] for x in k[:17]] == F32_BIG_GRID and k[17][0] == "conv_igemm_kernel<64, 64, 2, 0>", k
     assert [x[2] for x in k[:17]] == [128, 64, 64, 32, 32, 32, 400, 400, 400, 400, 32, 32, 32, 64, 64, 128, 128]
+    plan.set_option(N.NET_OPT_F32_SPLIT3, 0)
+    k = [plan.layer_kernel(i)[0] for i in range(17)]
+    assert k[6] == "conv_igemm_kernel<64, 64, 0, 0>" and k[0] == "conv_halo_kernel<1, 0>" and k[1] == "conv_halo_s2_kernel<1>", k

@@ -185,7 +185,7 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
         off = -(-off // 64) * 64
         # fp32 plans: the x3 block of a stride-1 one-source 3x3 layer (plan option F32_SPLIT3): [tap][chunk of 32][plane h | m | l]
         # [npad][64 B]; h = bf16(w), m = bf16(w - h), l = bf16(w - h - m); 16-byte slot j of row n stored at j ^ ((n >> 2) & 3)
-        if dtype == "f32" and info.kind == 0 and info.stride == 1 and c1 == 0 and c0 % 32 == 0:
+        if dtype == "f32" and info.kind == 0 and c1 == 0 and c0 % 32 == 0:
             ch = c0 // 32
             blk = packed[off:off + 9 * ch * 3 * npad * 16].view(np.uint16).reshape(9, ch, 3, npad, 32)
             for _ in range(40):

@@ -1,14 +1,14 @@
 #!/bin/bash
-# tools/variants_ktime.sh CONFIG "PAT1|PAT2" [ROUNDS] (on the GPU box): average duration (rocprofv3 --kernel-trace) of the kernels whose name
+# tools/variants_ktime.sh CONFIG "PAT1|PAT2" [ROUNDS] ["extra bench args"] (on the GPU box): average duration (rocprofv3 --kernel-trace) of the kernels whose name
 # matches one of the |-separated substrings, with every tools/_variants/libmsi_*.so installed in turn, ROUNDS interleaved rounds.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-CFG=${1:-1}; PATS=${2:-ods_sweep}; ROUNDS=${3:-2}
+CFG=${1:-1}; PATS=${2:-ods_sweep}; ROUNDS=${3:-2}; EXTRA=${4:-}
 cp matryodshka_amd/libmsi_hip.so /tmp/libmsi_saved.so
 for r in $(seq $ROUNDS); do
   for v in tools/_variants/libmsi_*.so; do
     cp "$v" matryodshka_amd/libmsi_hip.so
-    rm -rf /tmp/vkt; rocprofv3 --kernel-trace -d /tmp/vkt -o t -- python bench.py --config $CFG --steps 10 --warmup 3 --repeats 0 --no-cpu-baseline --prewarm 0.5 --strong-frames 0 --no-settle > /tmp/vkt.json 2>/dev/null
+    rm -rf /tmp/vkt; rocprofv3 --kernel-trace -d /tmp/vkt -o t -- python bench.py --config $CFG $EXTRA --steps 10 --warmup 3 --repeats 0 --no-cpu-baseline --prewarm 0.5 --strong-frames 0 --no-settle > /tmp/vkt.json 2>/dev/null
     python - "$v" "$PATS" "$r" <<'PY'
 import sqlite3, glob, sys, json
 v, pats, r = sys.argv[1], sys.argv[2].split("|"), sys.argv[3]
