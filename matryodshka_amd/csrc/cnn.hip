@@ -2774,6 +2774,295 @@ convt_halo_kernel(const ConvParams p) {
 #endif
 }
 
+// ---- the conv-transpose halo kernel through the six-product bf16 split (convt_halo_kernel x conv_halo_x3_kernel; r04) ----------
+// At native fp32 the two-class halo form lost to the tap kernel (above): the tap kernel's k-loop has no VALU and five workgroups
+// per CU.  The tap kernel cannot split its operands (both arrive by DMA), this one stages the patch through registers anyway:
+// with 192 instead of 512 matrix cycles per 16 channels it wins (conv8_1 197 -> ... us, see profiles/r04_*), and its sources
+// need no ln_apply launch.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+convt_halo_x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef HaloGeomX3<1> G;
+  constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, NSTG = G::NSTG, PD = NSTG - 1;
+  static_assert(NSTG == 3 && PD == 2, "prefetch distance two");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int CH = p.cpt0 + p.cpt1;                         // 32-channel chunks of both sources
+  int t, c0 = 0, c1 = CH, ks = 0, slot = 0;
+  {
+    const int bid = blockIdx.x;
+    if (bid < p.nb_main && p.split0 == 1) {
+      const int q = p.n_main >> 3, r = p.n_main & 7, xcd = bid & 7, local = bid >> 3;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    } else {
+      int sp, r, tbase;
+      unsigned mg;
+      if (bid < p.nb_main) { sp = p.split0; mg = p.mg_sp0; r = bid; tbase = 0; }
+      else { sp = p.split; mg = p.mg_sp; r = bid - p.nb_main; tbase = p.n_main; }
+      const int tl = (int)udiv_magic((unsigned)r, (unsigned)sp, mg);
+      ks = r - tl * sp;
+      t = tbase + tl;
+      c0 = (int)udiv_magic((unsigned)(ks * CH), (unsigned)sp, mg);
+      c1 = (int)udiv_magic((unsigned)((ks + 1) * CH), (unsigned)sp, mg);
+      slot = bid - (p.split0 == 1 ? p.nb_main : 0);
+    }
+  }
+  const bool full = (c0 == 0) & (c1 == CH);
+  int ph, tile_m, tile_n, b;
+  {   // row parity fastest (p.nclass = 2 here), then M tiles, N tiles, samples
+    int r = t;
+    ph = r & 1; r >>= 1;
+    const int q1 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_m, p.mg_tm);
+    tile_m = r - q1 * p.tiles_m; r = q1;
+    const int q2 = (int)udiv_magic((unsigned)r, (unsigned)p.tiles_n, p.mg_tn);
+    tile_n = r - q2 * p.tiles_n;
+    b = q2;
+  }
+  const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
+  const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
+  const int H = p.Hin, W = p.Win;
+
+  // the first two weight k-steps (class pw = 0, taps 0 and 1 of chunk c0) go out before the patch addresses are worked out
+  const int S = p.ksteps;                                 // k-steps per class: 4 CH
+  // (weights: the x3 block, [class][tap * CH + c][plane h | m | l][npad][64 B] -- see conv_halo_x3_kernel)
+  const int plane_bytes = p.npad * G::B_ROW;
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)4 * S * 3 * plane_bytes), 0x00020000);
+  const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + (lane >> 2)) * G::B_ROW + (lane & 3) * 16);
+#define MSI_B_ISSUE(cls, tap, c, st)                                                                                   \
+  {                                                                                                                    \
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;                                          \
+    const int soff_ = ((cls) * S + (tap) * CH + (c)) * 3 * plane_bytes;                                                \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
+  }
+  MSI_B_ISSUE(2 * ph, 0, c0, 0)
+  MSI_B_ISSUE(2 * ph, 1, c0, 1)
+
+  // ---- per-lane patch elements (as conv_halo_kernel; the byte offset depends on the source's channel count) ----
+  unsigned pixi[NLOAD], lds_a[NLOAD];
+  bool pok[NLOAD];
+  const int cslot = tid & 7;
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const int pp = (tid + 256 * k) >> 3;
+    const int py = pp / PW, px = pp - py * PW;
+    const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
+    pok[k] = pp < NPX && ih >= 0 && ih < H && iw >= 0 && iw < W;   // SAME: zeros outside
+    pixi[k] = (unsigned)(ih * W + iw);
+    lds_a[k] = pp < NPX ? (unsigned)(py * G::ROW_PITCH + px * G::PIX_BYTES + cslot * 8) : 0xffffffffu;
+  }
+  const size_t in0 = (size_t)H * W * p.C0 * 4, in1 = (size_t)H * W * p.C1 * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in0), 0, (int)in0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x1 + (size_t)b * in1), 0, (int)(in1 ? in1 : 16), 0x00020000);
+
+  // LayerNorm of the raw sources: mean as hi + lo floats and 1 / sigma per source
+  float inv_f[2] = {1.f, 1.f}, mu_hi[2] = {0.f, 0.f}, mu_lo[2] = {0.f, 0.f};
+  bool has_pad = false;
+  {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) bad |= (lds_a[k] != 0xffffffffu) && !pok[k];
+    has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
+  }
+  v4f araw[NLOAD], g4, be4;
+  int src_ld = 0;                                         // source of the patch held in araw
+  // patch of chunk c -> registers (+ gamma / beta of the lane's channels when that source is raw)
+#define MSI_PATCH_LOAD(c)                                                                                              \
+  {                                                                                                                    \
+    const int s_ = (c) >= p.cpt0 ? 1 : 0, cc_ = s_ ? (c) - p.cpt0 : (c);                                               \
+    const unsigned cb_ = (unsigned)((s_ ? p.C1 : p.C0) * 4);                                                           \
+    src_ld = s_;                                                                                                       \
+    if (s_ == 0) {                                                                                                     \
+      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
+            rsrc_a0, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));           \
+    } else {                                                                                                           \
+      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
+            rsrc_a1, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));           \
+    }                                                                                                                  \
+    const float *gp_ = (s_ ? p.ln_gamma1 : p.ln_gamma), *bp_ = (s_ ? p.ln_beta1 : p.ln_beta);                          \
+    if ((p.halo_apply >> s_) & 1) {                                                                                    \
+      g4 = *reinterpret_cast<const v4f *>(gp_ + cc_ * 32 + cslot * 4);                                                 \
+      be4 = *reinterpret_cast<const v4f *>(bp_ + cc_ * 32 + cslot * 4);                                                \
+    } else {   /* (same number of VMEM operations on both paths: the vmcnt arithmetic of the k-steps counts them) */   \
+      g4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16);                                                         \
+      be4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16 + 128);                                                  \
+    }                                                                                                                  \
+  }
+#define MSI_PATCH_STORE()                                                                                              \
+  {                                                                                                                    \
+    const bool ap_ = (p.halo_apply >> src_ld) & 1;                                                                     \
+    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};                                                          \
+    if (ap_) {                                                                                                         \
+      const float ih_ = src_ld ? inv_f[1] : inv_f[0], mh_ = src_ld ? mu_hi[1] : mu_hi[0], ml_ = src_ld ? mu_lo[1] : mu_lo[0]; \
+      s4 = ih_ * g4;                                                                                                   \
+      const v4f nh = {-mh_, -mh_, -mh_, -mh_}, nl = {-ml_, -ml_, -ml_, -ml_};                                          \
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
+      v4f y = araw[k_];                                                                                                \
+      if (ap_) {                                                                                                       \
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
+        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};                                                          \
+      }                                                                                                                \
+      unsigned h0, h1, m0, m1, l0, l1;   /* y = h + m + l, bf16 parts (see conv_halo_x3_kernel) */                       \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h0) : "v"(y.x), "v"(y.y));                                             \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h1) : "v"(y.z), "v"(y.w));                                             \
+      v4f r = y - v4f{__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h0 & 0xffff0000u),               \
+                      __builtin_bit_cast(float, h1 << 16), __builtin_bit_cast(float, h1 & 0xffff0000u)};              \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m0) : "v"(r.x), "v"(r.y));                                             \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m1) : "v"(r.z), "v"(r.w));                                             \
+      r = r - v4f{__builtin_bit_cast(float, m0 << 16), __builtin_bit_cast(float, m0 & 0xffff0000u),                    \
+                  __builtin_bit_cast(float, m1 << 16), __builtin_bit_cast(float, m1 & 0xffff0000u)};                  \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l0) : "v"(r.x), "v"(r.y));                                             \
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l1) : "v"(r.z), "v"(r.w));                                             \
+      if (lds_a[k_] != 0xffffffffu) {                                                                                  \
+        typedef unsigned u2x_t __attribute__((ext_vector_type(2)));                                                    \
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_]) = u2x_t{h0, h1};                                                  \
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 64) = u2x_t{m0, m1};                                             \
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 128) = u2x_t{l0, l1};                                            \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }
+
+  // ---- MFMA side ----
+  const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
+  // fragment base of tap row th = 0 (patch row 1 + local row) and of th = 1 (one row up for ph = 0, one down for ph = 1)
+  const unsigned a_base0 = lds_base + (unsigned)((1 + 2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
+  const unsigned a_base1 = ph ? a_base0 + G::ROW_PITCH : a_base0 - G::ROW_PITCH;
+  unsigned b_s[2];
+  (void)fswz;
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+    b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  f32x16 acc[2][1][1];
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cl][0][0][r] = 0.f;
+
+  // k-step J of the chunk = class pw = J / 4, tap (th, tw) = ((J / 2) & 1, J & 1), weights in ring stage st (run-time).
+  // The DMA of the k-step PD = 2 ahead and (J == 0) the next chunk's patch loads are issued after the first MFMA quarter;
+  // before the closing barrier the NEXT k-step's weights must have landed: they were issued one k-step ago, so only what
+  // THIS k-step issued (2 DMA, + the patch loads of J == 0) may still be in flight (in-order return).
+  constexpr int NPL = NLOAD + 2;                          // VMEM operations of a patch load
+#define MSI_CTSTEP(J)                                                                                                  \
+  {                                                                                                                    \
+    constexpr int PWC_ = (J) >> 2, TH_ = ((J) >> 1) & 1, TW_ = (J) & 1;                                                \
+    constexpr int COFF_ = (1 + (PWC_ ? TW_ : -TW_)) * G::PIX_BYTES;   /* column of the tap: immediate */                \
+    const unsigned ab_ = TH_ ? a_base1 : a_base0;                                                                      \
+    v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
+    const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
+      ah_[s_] = s_ == 0 ? lds_read128<COFF_>(ab_) : lds_read128<COFF_ + 32>(ab_);                                      \
+      bh_[s_] = lds_read128<0>(b_s[s_] + bst_);                                                                        \
+      am_[s_] = s_ == 0 ? lds_read128<COFF_ + 64>(ab_) : lds_read128<COFF_ + 96>(ab_);                                 \
+      bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);                                                               \
+      al_[s_] = s_ == 0 ? lds_read128<COFF_ + 128>(ab_) : lds_read128<COFF_ + 160>(ab_);                               \
+      bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);                                                           \
+    }                                                                                                                  \
+    bool issued_ = false;                                                                                              \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
+      if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                      \
+      else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                              \
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[PWC_][0][0], 0, 0, 0); \
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, al_[s_]), acc[PWC_][0][0], 0, 0, 0); \
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[PWC_][0][0], 0, 0, 0); \
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[PWC_][0][0], 0, 0, 0); \
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[PWC_][0][0], 0, 0, 0); \
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[PWC_][0][0], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if (s_ == 0) {                                                                                                   \
+        if ((J) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                              \
+        int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                       \
+        constexpr int JN_ = ((J) + PD) & 7;                                                                            \
+        if ((J) + PD < 8) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c, sn_) }                        \
+        else if (c + 1 < c1) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_) }                 \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if ((J) == 0 && c + 1 < c1) wait_vmcnt<3 + NPL>();                                                                 \
+    else if (issued_) wait_vmcnt<3>();                                                                                 \
+    else wait_vmcnt<0>();                                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
+  }
+
+  // ---- prologue: first patch (the first two weight k-steps are on their way), the sources' LayerNorm statistics ----
+  int c = c0, st = 0;
+  MSI_PATCH_LOAD(c0)
+  if (p.halo_apply) {
+    double *s_stat = reinterpret_cast<double *>(smem);
+    if (p.halo_apply & 1) {
+      ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
+      const double mu = s_stat[0];
+      inv_f[0] = (float)s_stat[1]; mu_hi[0] = (float)mu; mu_lo[0] = (float)(mu - (double)mu_hi[0]);
+      __syncthreads();
+    }
+    if (p.halo_apply & 2) {
+      ln_mean_inv(p.ln_sums1 + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n1, p.ln_scl_src1, p.status, s_stat, tid);
+      const double mu = s_stat[0];
+      inv_f[1] = (float)s_stat[1]; mu_hi[1] = (float)mu; mu_lo[1] = (float)(mu - (double)mu_hi[1]);
+      __syncthreads();
+    }
+  }
+  wait_vmcnt<0>();
+  MSI_PATCH_STORE()
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; c < c1; ++c) {
+    MSI_CTSTEP(0) MSI_CTSTEP(1) MSI_CTSTEP(2) MSI_CTSTEP(3) MSI_CTSTEP(4) MSI_CTSTEP(5) MSI_CTSTEP(6) MSI_CTSTEP(7)
+    if (c + 1 < c1) {
+      MSI_PATCH_STORE()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+#undef MSI_CTSTEP
+#undef MSI_B_ISSUE
+#undef MSI_PATCH_STORE
+#undef MSI_PATCH_LOAD
+
+  // ---- epilogue: two class tiles ----
+  if (!full) {
+    constexpr int SLAB = 64 * 64 * 4;
+    if (p.tile_cnt == nullptr) {                          // separate fix-up launch (conv_fixup_kernel, class = blockIdx.y)
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl) {
+        const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 2 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
+        dump_acc<1, 1, 0>(acc[cl], rsrc_p, tid);
+      }
+      return;
+    }
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 2 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
+      dump_acc<1, 1, 16>(acc[cl], rsrc_p, tid);
+    }
+    const int nsp = t < p.n_main ? p.split0 : p.split;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *s_old = reinterpret_cast<int *>(smem);
+    if (tid == 0)
+      *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_old != nsp - 1) return;
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)(slot - ks) * 2 + cl) * (64 * 64)), 0, nsp * 2 * SLAB, 0x00020000);
+      sum_slabs<1, 1, 16>(acc[cl], rsrc_t, nsp, 2 * SLAB, tid);
+    }
+  }
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl) emit_tile<64, 64, MODE_CONVT>(p, acc[cl], tile_m, tile_n, 2 * ph + cl, b, tid);
+#endif
+}
+
 // ---- halo-patch kernel, bf16 operands ----------------------------------------------------------------------------
 // Same idea as conv_halo_kernel at the shapes the 16x faster bf16 MFMA needs: at 4 MFMAs per wave and k-step the
 // 64x64 tile cannot be fed (the tap kernel's bf16 instantiations are bound by their L2 -> LDS traffic: 32 KB per k-step
@@ -4232,9 +4521,10 @@ int build_net(const msi_net_desc *d, int num_cus, Net &net) {
     koff = round_up(koff, 64);
     // fp32 plans: the stride-1 one-source 3x3 layers also carry their weights as three bf16 planes (plan option F32_SPLIT3):
     // [tap][chunk of 32 channels][plane][npad rows][64 B]
-    if (!bf16 && s.kind == MODE_CONV && s.src1 < 0 && L.c0 % 32 == 0) {
+    if (!bf16 && ((s.kind == MODE_CONV && s.src1 < 0 && L.c0 % 32 == 0) ||
+                  (s.kind == MODE_CONVT && !L.wrapt && L.c0 % 32 == 0 && L.c1 % 32 == 0))) {
       L.x3_off = koff;
-      koff = round_up(koff + (size_t)9 * (L.c0 / 32) * 3 * L.npad * 16, 64);
+      koff = round_up(koff + (size_t)L.nclass * L.ksteps * 3 * L.npad * 16, 64);
     }
     // workspace
     if (s.kind != MODE_HEAD) {
@@ -4490,11 +4780,13 @@ int plan_layers(msi_net_plan *pl) {
     }
     // conv-transpose halo kernel (convt_halo_kernel; HALO bit 1, NOT the default -- measured slower, see the kernel): SAME conv-transposes (CoordNet), fp32, whole
     // 4 x 16 input tiles and 32-channel chunks of both sources; one workgroup per output-row parity (enumerated as two "classes")
-    Q.halo_t = halo_ok && (pl->opt[MSI_NET_OPT_HALO] & 2) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] &&
+    const bool x3_on = !bf16 && L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1);
+    Q.halo_t = halo_ok && ((pl->opt[MSI_NET_OPT_HALO] & 2) || x3_on) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] &&
                Q.tile == TILE_64x64 && L.kind == MODE_CONVT && !L.wrapt && L.in_h % 4 == 0 && L.in_w % 16 == 0 &&
                L.c0 % 32 == 0 && L.c1 % 32 == 0;
     if (Q.halo_t) {
       Q.halo = 1;
+      Q.halo_x3 = x3_on;
       p.nclass = 2;                                      // tiles are enumerated per (ph, tile_m, tile_n, sample): a workgroup owns pw = 0, 1
       if (L.cpt0 + L.cpt1 < max_split) max_split = L.cpt0 + L.cpt1;
     }
@@ -4531,7 +4823,7 @@ int plan_layers(msi_net_plan *pl) {
     Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
     if (Q.halo_t && (size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * 2 * BM * BN * sizeof(float) > net.partial_bytes) {
       // two slabs per K-range do not fit the partial-accumulator workspace -> the tap kernel
-      Q.halo_t = 0; Q.halo = 0;
+      Q.halo_t = 0; Q.halo = 0; Q.halo_x3 = 0;
       p.halo_tx = 0; p.halo_xor = 0; p.nclass = L.nclass;
       plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], MAX_SPLIT, &Q.nblocks, &Q.nfix);
       Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
@@ -4810,8 +5102,10 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
       memcpy(packed + L.lnscl_off, scl, sizeof(scl));
     }
     if (L.x3_off) {
-      // x = h + m + l, bf16 parts by round-to-nearest-even of the successive (exact) remainders; slot j (channels 8 j .. 8 j + 7 of
-      // the chunk) of row n is stored at slot j ^ ((n >> 2) & 3) of the row's 64 bytes (HaloGeomX3: conflict-free fragment reads)
+      // x3 block (conv_halo_x3_kernel and its stride-2 / conv-transpose forms): the k-steps of the loop above, each as three planes
+      // of 64-byte rows -- [class][k-step][plane h | m | l][npad][32 bf16] -- with w = h + m + l, bf16 parts by round-to-nearest-even
+      // of the successive (exact) remainders; 16-byte slot j (channels 8 j .. 8 j + 7 of the chunk) of row n is stored at slot
+      // j ^ ((n >> 2) & 3) (HaloGeomX3: conflict-free fragment reads)
       auto bf16_rne = [](float v) -> uint16_t {
         uint32_t u;
         memcpy(&u, &v, 4);
@@ -4823,13 +5117,25 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
         memcpy(&f, &u, 4);
         return f;
       };
-      const int ch = L.c0 / 32;
       char *base = reinterpret_cast<char *>(packed + L.x3_off);
-      for (int tap = 0; tap < 9; ++tap)
-        for (int c = 0; c < ch; ++c)
+      for (int cls = 0; cls < L.nclass; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+        for (int s = 0; s < L.ksteps; ++s) {
+          const int tap = s / cpt, within = s % cpt;
+          const int src = within < L.cpt0 ? 0 : 1;
+          const int chunk = src ? within - L.cpt0 : within;
+          const int cbase = src ? L.c0 : 0;
           for (int n = 0; n < L.cout; ++n)
             for (int kk = 0; kk < 32; ++kk) {
-              const float v = w[((size_t)tap * cin_w + c * 32 + kk) * L.cout + n];
+              const int c = cbase + chunk * 32 + kk;
+              float v;
+              if (L.kind == MODE_CONV) {
+                v = w[((size_t)tap * cin_w + c) * L.cout + n];
+              } else {   // MODE_CONVT, SAME (the halo form is not built for msi_train_net's VALID transposes)
+                const int th = tap >> 1, tw = tap & 1;
+                const int kh = ph == 0 ? 1 + 2 * th : 2 - 2 * th, kw = pw == 0 ? 1 + 2 * tw : 2 - 2 * tw;
+                v = w[(((size_t)kh * 4 + kw) * L.cout + n) * L.cin + c];
+              }
               uint16_t part[3];
               part[0] = bf16_rne(v);
               const float r1 = v - widen(part[0]);
@@ -4837,8 +5143,10 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
               part[2] = bf16_rne(r1 - widen(part[1]));
               const int slot = (kk >> 3) ^ ((n >> 2) & 3);
               for (int pl = 0; pl < 3; ++pl)
-                memcpy(base + ((((size_t)tap * ch + c) * 3 + pl) * L.npad + n) * 64 + slot * 16 + (kk & 7) * 2, &part[pl], 2);
+                memcpy(base + ((((size_t)cls * L.ksteps + s) * 3 + pl) * L.npad + n) * 64 + slot * 16 + (kk & 7) * 2, &part[pl], 2);
             }
+        }
+      }
     }
     if (L.kind == MODE_HEAD) {
       memcpy(packed + L.gamma_off, w + wf, L.cout * sizeof(float));  // biases
@@ -5006,7 +5314,7 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
                                     plan->opt[MSI_NET_OPT_BF16_WAVES] == 8 ? 8 : 4);
     else snprintf(name, name_bytes, "conv_halo_bf16_kernel<256, 64, 1, %d, 4>", Q.halo_apply ? 1 : 0);
   } else if (Q.halo_t) {
-    snprintf(name, name_bytes, "convt_halo_kernel");
+    snprintf(name, name_bytes, Q.halo_x3 ? "convt_halo_x3_kernel" : "convt_halo_kernel");
   } else if (Q.halo) {
     if (Q.halo_s2 && Q.halo_x3) snprintf(name, name_bytes, "conv_halo_s2_x3_kernel<%d>", Q.halo_apply ? 1 : 0);
     else if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_s2_kernel<%d>", Q.halo_apply ? 1 : 0);
@@ -5241,7 +5549,12 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
         p.ln_gamma1 = packed + S.gamma_off;
         p.ln_beta1 = packed + S.beta_off;
       }
-      hipLaunchKernelGGL(convt_halo_kernel, dim3(Q.nblocks), dim3(256), ConvtHaloGeom::LDS_BYTES, stream, p);
+      if (Q.halo_x3) {
+        p.wpk_x3 = reinterpret_cast<const char *>(packed + L.x3_off);
+        hipLaunchKernelGGL(convt_halo_x3_kernel, dim3(Q.nblocks), dim3(256), HaloGeomX3<1>::LDS_BYTES, stream, p);
+      } else {
+        hipLaunchKernelGGL(convt_halo_kernel, dim3(Q.nblocks), dim3(256), ConvtHaloGeom::LDS_BYTES, stream, p);
+      }
       rc = msi::check_launch("convt_halo");
       if (!rc && Q.nfix > 0 && p.tile_cnt == nullptr) {
         hipLaunchKernelGGL((conv_fixup_kernel<64, 64, MODE_CONVT>), dim3(Q.nfix, 2), dim3(256), 0, stream, p);

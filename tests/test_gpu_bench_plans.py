@@ -20,11 +20,11 @@ TOL = 1e-3
 
 # graph order conv1_1 ... conv8_2 (the head runs inside head_assemble_kernel on the blend_psv path)
 # (r04: the stride-1 halo layers of an fp32 plan run the six-product bf16 split by default -- conv_halo_x3_kernel)
-F32_BIG_GRID = ["conv_halo_x3_kernel<1, 0>", "conv_halo_s2_x3_kernel<1>", "conv_halo_x3_kernel<1, 0>", "conv_halo_s2_x3_kernel<1>",
-                "conv_halo_x3_kernel<1, 0>", "conv_halo_x3_kernel<1, 1>", "conv_halo_s2_x3_kernel<1>", "conv_halo_x3_kernel<2, 0>",
-                "conv_halo_x3_kernel<2, 1>", "conv_halo_x3_kernel<2, 1>", "conv_igemm_kernel<64, 64, 1, 0>", "conv_halo_x3_kernel<1, 1>",
-                "conv_halo_x3_kernel<1, 1>", "conv_igemm_kernel<64, 64, 1, 0>", "conv_halo_x3_kernel<1, 1>",
-                "conv_igemm_kernel<64, 64, 1, 0>", "conv_halo_x3_kernel<1, 1>"]
+F32_BIG_GRID = ["conv_halo_x3_kernel<1, 0>", "conv_halo_s2_x3_kernel<1>", "conv_halo_x3_kernel<1, 1>", "conv_halo_s2_x3_kernel<1>",
+                "conv_halo_x3_kernel<1, 1>", "conv_halo_x3_kernel<1, 1>", "conv_halo_s2_x3_kernel<1>", "conv_halo_x3_kernel<2, 1>",
+                "conv_halo_x3_kernel<2, 1>", "conv_halo_x3_kernel<2, 1>", "convt_halo_x3_kernel", "conv_halo_x3_kernel<1, 1>",
+                "conv_halo_x3_kernel<1, 1>", "convt_halo_x3_kernel", "conv_halo_x3_kernel<1, 1>",
+                "convt_halo_x3_kernel", "conv_halo_x3_kernel<1, 1>"]
 BF16_CONFIG2 = ["conv_halo_bf16_kernel<256, 64, 1, 0, 4>", "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>", "conv_halo_bf16_kernel<128, 128, 1, 1, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 2, 0, 8>", "conv_halo_bf16_kernel<128, 128, 2, 1, 8>",
@@ -155,14 +155,14 @@ def test_config4_bench_batches_every_face(batch):
 
 def test_config1_plan_is_the_profiled_one():
     """configs[1] (batch 1): the plan of profiles/r04_*_config1_kernel_stats.txt -- fourteen 3x3 layers through the six-product
-    bf16 split (conv_halo_x3_kernel / conv_halo_s2_x3_kernel), the conv-transposes on the native fp32 tap kernel, split tiles
+    bf16 split (conv_halo_x3_kernel / conv_halo_s2_x3_kernel) and the conv-transposes on convt_halo_x3_kernel, split tiles
     handed off inside the launch; with F32_SPLIT3 = 0 the r03 plan (conv3_3 on the tap kernel).  Parity at this shape:
     tests/test_golden.py::test_gpu_matches_full_size_samples, tests/test_gpu_split3.py."""
     from matryodshka_amd import _native as N, nets
     plan = N.NetPlan(nets.make_desc(1, 320, 640, 192, 64, 64, True, "f32"))
     k = [plan.layer_kernel(i) for i in range(18)]
     assert [x[0] for x in k[:17]] == F32_BIG_GRID and k[17][0] == "conv_igemm_kernel<64, 64, 2, 0>", k
-    assert [x[2] for x in k[:17]] == [128, 64, 64, 32, 32, 32, 400, 400, 400, 400, 32, 32, 32, 64, 64, 128, 128]
+    assert [x[2] for x in k[:17]] == [128, 64, 64, 32, 32, 32, 400, 400, 400, 400, 400, 32, 32, 32, 64, 64, 128], k
     plan.set_option(N.NET_OPT_F32_SPLIT3, 0)
     k = [plan.layer_kernel(i)[0] for i in range(17)]
-    assert k[6] == "conv_igemm_kernel<64, 64, 0, 0>" and k[0] == "conv_halo_kernel<1, 0>" and k[1] == "conv_halo_s2_kernel<1>", k
+    assert k[6] == "conv_igemm_kernel<64, 64, 0, 0>" and k[0] == "conv_halo_kernel<1, 0>" and k[1] == "conv_halo_s2_kernel<1>" and k[10] == "conv_igemm_kernel<64, 64, 1, 0>", k

@@ -183,17 +183,27 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
                     assert np.allclose(tab[mh, cc, :info.cout], exp, rtol=1e-6, atol=1e-7), (name, mh, cc)
             off += tab.size
         off = -(-off // 64) * 64
-        # fp32 plans: the x3 block of a stride-1 one-source 3x3 layer (plan option F32_SPLIT3): [tap][chunk of 32][plane h | m | l]
-        # [npad][64 B]; h = bf16(w), m = bf16(w - h), l = bf16(w - h - m); 16-byte slot j of row n stored at j ^ ((n >> 2) & 3)
-        if dtype == "f32" and info.kind == 0 and c1 == 0 and c0 % 32 == 0:
-            ch = c0 // 32
-            blk = packed[off:off + 9 * ch * 3 * npad * 16].view(np.uint16).reshape(9, ch, 3, npad, 32)
+        # fp32 plans: the x3 block (plan option F32_SPLIT3) of a one-source 3x3 layer or a SAME conv-transpose whose sources are whole
+        # 32-channel chunks: the same k-steps as above, each as three planes of 64-byte rows -- [class][k-step][plane h | m | l][npad][32 bf16];
+        # h = bf16(w), m = bf16(w - h), l = bf16(w - h - m); 16-byte slot j of row n stored at j ^ ((n >> 2) & 3)
+        if dtype == "f32" and ((info.kind == 0 and c1 == 0 and c0 % 32 == 0) or (info.kind == 1 and same_pad and c0 % 32 == 0 and c1 % 32 == 0)):
+            blk = packed[off:off + ncls * ksteps * 3 * npad * 16].view(np.uint16).reshape(ncls, ksteps, 3, npad, 32)
             for _ in range(40):
-                tap, c, n = rng.randint(9), rng.randint(ch), rng.randint(info.cout)
-                want = wt[tap // 3, tap % 3, c * 32:(c + 1) * 32, n].astype(np.float32)
+                cls, s_, n = rng.randint(ncls), rng.randint(ksteps), rng.randint(info.cout)
+                tap, within = divmod(s_, cpt0 + cpt1)
+                src, chunk = (0, within) if within < cpt0 else (1, within - cpt0)
+                cb = (0 if src == 0 else c0) + chunk * 32
+                if info.kind == 0:
+                    want = wt[tap // 3, tap % 3, cb:cb + 32, n].astype(np.float32)
+                else:
+                    ph, pw = cls >> 1, cls & 1
+                    th, tw = tap >> 1, tap & 1
+                    kh = 1 + 2 * th if ph == 0 else 2 - 2 * th
+                    kw = 1 + 2 * tw if pw == 0 else 2 - 2 * tw
+                    want = wt[kh, kw, n, cb:cb + 32].astype(np.float32)
                 parts = []
                 for pl in range(3):
-                    row = blk[tap, c, pl, n].reshape(4, 8)
+                    row = blk[cls, s_, pl, n].reshape(4, 8)
                     un = np.empty_like(row)
                     for j in range(4):
                         un[j ^ ((n >> 2) & 3)] = row[j]
@@ -201,7 +211,7 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
                 h = onets.bf16_round(want)
                 m = onets.bf16_round(want - h)
                 l = onets.bf16_round(want - h - m)
-                assert np.array_equal(parts[0], h) and np.array_equal(parts[1], m) and np.array_equal(parts[2], l), (name, tap, c, n)
+                assert np.array_equal(parts[0], h) and np.array_equal(parts[1], m) and np.array_equal(parts[2], l), (name, cls, s_, n)
                 assert np.abs((parts[0].astype(np.float64) + parts[1] + parts[2]) - want).max() <= 2.0 ** -24 * np.abs(want).max()
             assert not blk[:, :, :, info.cout:, :].any()
             off = -(-(off + blk.size // 2) // 64) * 64
@@ -232,10 +242,12 @@ def test_plan_options_and_raw_layer_bookkeeping(native_lib):
     lib = native_lib.lib
     names = nets.LAYER_NAMES
 
-    def raw_layers(desc, halo):
+    def raw_layers(desc, halo, split3=0):
+        """(split3 = 0: the native fp32 arithmetic, whose conv-transposes and small stride-2 grids stay on the tap kernel)"""
         h = ctypes.c_void_p()
         assert lib.msi_net_plan_create(desc, ctypes.byref(h)) == 0
         try:
+            assert lib.msi_net_plan_set_option(h, N.NET_OPT_F32_SPLIT3, split3) == 0
             assert lib.msi_net_plan_set_option(h, N.NET_OPT_HALO, halo) == 0
             return [names[i] for i in range(17) if lib.msi_net_plan_layer_is_normalized(h, i) == 0]
         finally:
@@ -256,7 +268,12 @@ def test_plan_options_and_raw_layer_bookkeeping(native_lib):
     # bit 2 (r03): the stride-2 layers on conv_halo_s2_kernel where the grid needs no K split -- conv1_2 and conv2_2 at this size
     # (conv3_3: 400 tiles, tap kernel) -- so conv1_1 and conv2_1 stay raw as well; 5 is the default
     assert raw_layers(desc, 5) == ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv4_2", "conv6_1", "conv6_2", "conv7_1", "conv8_1", "conv8_2"]
-    assert [names[i] for i in range(17) if lib.msi_net_plan_layer_is_normalized(h, i) == 0] == raw_layers(desc, 5)    # the default
+    # the DEFAULT plan (r04): every 3x3 layer and every SAME conv-transpose stages its patch through registers for the six-product
+    # bf16 split (conv_halo_x3_kernel, conv_halo_s2_x3_kernel, convt_halo_x3_kernel): no producer is normalised in memory -- no
+    # ln_apply launch at all at configs[1]
+    assert [names[i] for i in range(17) if lib.msi_net_plan_layer_is_normalized(h, i) == 0] == names[:17] == raw_layers(desc, 5, 0x3ffff)
+    assert lib.msi_net_plan_set_option(h, N.NET_OPT_F32_SPLIT3, 0) == 0
+    assert [names[i] for i in range(17) if lib.msi_net_plan_layer_is_normalized(h, i) == 0] == raw_layers(desc, 5)
     assert lib.msi_net_plan_set_option(h, N.NET_OPT_HALO_SKIP, 1 << 11) == 0
     assert [names[i] for i in range(17) if lib.msi_net_plan_layer_is_normalized(h, i) == 0] == \
         ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv4_2", "conv6_2", "conv7_1", "conv8_1", "conv8_2"]
