@@ -1643,10 +1643,18 @@ conv_halo_kernel(const ConvParams p) {
 // work decomposition, tail split, in-launch hand-off, epilogue, LayerNorm sums -- is conv_halo_kernel's.
 // Numerics: oracle emulation of this arithmetic against the fp32 oracle at the configs[1] frame: pred 3.0e-6, rgba 1.9e-6,
 // rgb 1.0e-6 max-abs (profiles/r04_split3_numerics.txt: the native fp32 path's own summation-order error is 4.5e-6 on pred).
+#ifndef MSI_X3_EARLY_DMA
+#define MSI_X3_EARLY_DMA 0
+#endif
+#ifndef MSI_X3_NSTG   // weight ring of conv_halo_x3_kernel: 0 = by rate -- two stages at rate 1 (47.8 KB of LDS: three workgroups per CU;
+                      // measured 84.7 -> 81.2 us per layer against three stages / two workgroups) and three at rate 2 (two workgroups either
+                      // way: 92.5 vs 99.7 us); 2 / 3 force it (tuning)
+#define MSI_X3_NSTG 0
+#endif
 #ifndef MSI_X3_ABLATE   // timing experiments only (wrong results): 1 no weight DMA, 4 no per-tap barrier, 8 no fragment reads, 16 no MFMAs, 32 no patch swap
 #define MSI_X3_ABLATE 0
 #endif
-template <int RATE>
+template <int RATE, int NS = (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3))>
 struct HaloGeomX3 {
   static constexpr int PW = 16 + 2 * RATE, PH = 4 + 2 * RATE, NPX = PW * PH;
   static constexpr int PIX_BYTES = 208;                   // 3 planes x 32 bf16 + 16
@@ -1654,7 +1662,7 @@ struct HaloGeomX3 {
   static constexpr int A_BYTES = PH * ROW_PITCH;
   static constexpr int B_ROW = 64;                        // 32 bf16 channels of one output row and plane
   static constexpr int B_PLANE = 64 * B_ROW, B_STAGE = 3 * B_PLANE;
-  static constexpr int NSTG = 3;
+  static constexpr int NSTG = NS;
   static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
   static constexpr int NLOAD = (NPX * 8 + 255) / 256;
 };
@@ -1731,7 +1739,7 @@ conv_halo_x3_kernel(const ConvParams p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
   }
   MSI_B_ISSUE(c0, 0, 0)
-  MSI_B_ISSUE(c0, 1, 1)
+  if (G::NSTG == 3) MSI_B_ISSUE(c0, 1, 1)
 
   // ---- per-lane patch elements: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 (= tid % 8) ----
   unsigned voff[NLOAD], lds_a[NLOAD];
@@ -1827,17 +1835,25 @@ conv_halo_x3_kernel(const ConvParams p) {
   // operation issued before them (the next chunk's patch loads, issued in tap 0) completes first (in-order return)
 #define MSI_HTAP(TAP)                                                                                                  \
   {                                                                                                                    \
-    constexpr int KH_ = (TAP) / 3, KW_ = (TAP) % 3, ST_ = (TAP) % 3;                                                   \
+    constexpr int KH_ = (TAP) / 3, KW_ = (TAP) % 3;                                                                    \
+    /* ring stage of this k-step: three stages -> TAP % 3 (a literal); two stages -> (TAP + chunk parity) & 1 (run-time scalar) */ \
+    const unsigned bst_ = (unsigned)(G::NSTG == 3 ? (TAP) % 3 : (((TAP) ^ cpar) & 1)) * G::B_STAGE;                     \
     constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;                                             \
     v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
+    if (MSI_X3_EARLY_DMA || G::NSTG == 2) {   /* the k-step NSTG - 1 ahead: its ring stage was last read in the previous k-step (closing barrier passed) */ \
+      constexpr int PD_ = G::NSTG - 1;                                                                                 \
+      const int stn_ = G::NSTG == 3 ? ((TAP) + 2) % 3 : ((((TAP) ^ cpar) & 1) ^ 1);   /* (two stages: the other one) */  \
+      if ((TAP) + PD_ < 9) { MSI_B_ISSUE(c, (TAP) + PD_, stn_) }                                                       \
+      else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) + PD_ - 9, stn_) }                                               \
+    }                                                                                                                  \
     if (!(MSI_X3_ABLATE & 8))                                                                                         \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
       ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);                                \
-      bh_[s_] = lds_read128<ST_ * G::B_STAGE>(b_s[s_]);                                                                \
+      bh_[s_] = lds_read128<0>(b_s[s_] + bst_);                                                                \
       am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);                           \
-      bm_[s_] = lds_read128<ST_ * G::B_STAGE + G::B_PLANE>(b_s[s_]);                                                   \
+      bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);                                                   \
       al_[s_] = s_ == 0 ? lds_read128<AOFF_ + 128>(a_base) : lds_read128<AOFF_ + 160>(a_base);                         \
-      bl_[s_] = lds_read128<ST_ * G::B_STAGE + 2 * G::B_PLANE>(b_s[s_]);                                               \
+      bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);                                               \
     }                                                                                                                  \
     /* six products per K16 step, small terms first: m.m, l.h, h.l, m.h, h.m, h.h (weights = the MFMA's row operand) */  \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
@@ -1855,13 +1871,18 @@ conv_halo_x3_kernel(const ConvParams p) {
       if (s_ == 0) {                                                                                                   \
         if ((TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                            \
         /* k-step two ahead: (c, TAP + 2) or (c + 1, TAP - 7) */                                                       \
+        if (!MSI_X3_EARLY_DMA && G::NSTG == 3) {                                                                       \
         if ((TAP) + 2 < 9) { MSI_B_ISSUE(c, (TAP) + 2, ((TAP) + 2) % 3) }                                              \
         else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) - 7, ((TAP) + 2) % 3) }                                        \
+        }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
     {                                                                                                                  \
       const bool issued_ = ((TAP) + 2 < 9) || (c + 1 < c1);                                                            \
-      if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<3 + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight */ \
+      if (G::NSTG == 2) {                                                                                              \
+        if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<NLOAD + (APPLY ? 2 : 0)>();   /* (the patch loads were issued after the DMA) */ \
+        else wait_vmcnt<0>();                                                                                          \
+      } else if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<3 + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight (either order) */ \
       else if (issued_) wait_vmcnt<3>();                                                                               \
       else wait_vmcnt<0>();                                                                                            \
     }                                                                                                                  \
@@ -1888,6 +1909,7 @@ conv_halo_x3_kernel(const ConvParams p) {
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
   for (; c < c1; ++c) {
+    const int cpar = (c - c0) & 1;   // (two-stage ring: nine k-steps per chunk flip the stage parity)
     MSI_HTAP(0) MSI_HTAP(1) MSI_HTAP(2) MSI_HTAP(3) MSI_HTAP(4) MSI_HTAP(5) MSI_HTAP(6) MSI_HTAP(7) MSI_HTAP(8)
     if (c + 1 < c1 && !(MSI_X3_ABLATE & 32)) {   // every wave has read the last tap of this chunk (closing barrier of tap 8): swap the patch
       MSI_PATCH_STORE()
@@ -2782,7 +2804,7 @@ convt_halo_kernel(const ConvParams p) {
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 convt_halo_x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  typedef HaloGeomX3<1> G;
+  typedef HaloGeomX3<1, 3> G;
   constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, NSTG = G::NSTG, PD = NSTG - 1;
   static_assert(NSTG == 3 && PD == 2, "prefetch distance two");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -5551,7 +5573,8 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       }
       if (Q.halo_x3) {
         p.wpk_x3 = reinterpret_cast<const char *>(packed + L.x3_off);
-        hipLaunchKernelGGL(convt_halo_x3_kernel, dim3(Q.nblocks), dim3(256), HaloGeomX3<1>::LDS_BYTES, stream, p);
+        constexpr int lds_ct = HaloGeomX3<1, 3>::LDS_BYTES;
+        hipLaunchKernelGGL(convt_halo_x3_kernel, dim3(Q.nblocks), dim3(256), lds_ct, stream, p);
       } else {
         hipLaunchKernelGGL(convt_halo_kernel, dim3(Q.nblocks), dim3(256), ConvtHaloGeom::LDS_BYTES, stream, p);
       }
