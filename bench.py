@@ -574,7 +574,7 @@ def main():
     if B > 0:
         plan = model._plan(B, H, W, cin, nout, NGF)
         kern = [plan.layer_kernel(i)[0] for i in range(17)]
-        nx3 = sum(k.startswith("conv_halo_x3_kernel") for k in kern)
+        nx3 = sum("_x3_kernel" in k for k in kern)
         arithmetic = ("bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16)" if bf16 else
                       "fp32: %d of 17 convolutions as a 3-way bf16 split with 6 products on the bf16 MFMA (fp32 accumulate, fp32-grade), "
                       "%d on the native fp32 MFMA" % (nx3, 17 - nx3) if nx3 else "native fp32 MFMA (v_mfma_f32_32x32x2_f32)")
