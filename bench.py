@@ -86,6 +86,21 @@ def cnn_flops(h, w, cin, nout, ngf, coord):
     return sum(cnn_layer_flops(h, w, cin, nout, ngf, coord))
 
 
+def is_f16_split(kernel_name):
+    """A plan kernel name (NetPlan.layer_kernel) of the fp16 three-product form: the x3 kernels' last template argument is the
+    number of operand planes (2 = fp16 h | m', 3 = bf16 h | m | l)."""
+    return "_x3_kernel" in kernel_name and kernel_name.rstrip(">").endswith(", 2")
+
+
+def split_peak(kernel_name):
+    """Dense MFMA peak (fp32-equivalent TFLOP/s) of the instruction a plan's layer runs on."""
+    if is_f16_split(kernel_name):
+        return PEAK_BF16_MFMA_TFLOPS / 3.0
+    if "_x3_kernel" in kernel_name:
+        return PEAK_BF16_MFMA_TFLOPS / 6.0
+    return PEAK_FP32_MFMA_TFLOPS
+
+
 def conv_flops(h, w, cin, nout, ngf, coord):
     """2*MACs of the 17 convolutions conv1_1 ... conv8_2 WITHOUT color_pred: the 1x1 head runs inside the fused tail,
     after the event that closes the roofline interval (300.7 GFLOP at 640x320, D=32, CoordNet)."""
@@ -275,10 +290,12 @@ def main():
                          "configurations, whose first second under load contains a slow transient: 19 vs 11.4 ms per step at config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--no-coord-net", action="store_true", help="msi_train_net instead of msi_coord_train_net")
-    ap.add_argument("--arithmetic", default=None, choices=["native", "split3"],
+    ap.add_argument("--arithmetic", default=None, choices=["native", "split3", "split_f16"],
                     help="fp32 configurations: how the stride-1 3x3 layers multiply -- native = v_mfma_f32_32x32x2_f32; split3 = 3-way bf16 "
                          "split of both operands, SIX products on the bf16 MFMA, fp32 accumulation (fp32-grade: dropped terms < 2^-26 of a "
-                         "product; plan option F32_SPLIT3).  Default: the library's default plan.  Reported as config.arithmetic")
+                         "product; plan option F32_SPLIT3); split_f16 = 2-way fp16 split (22 significand bits), THREE products on the fp16 MFMA "
+                         "(plan option F32_SPLIT_F16; operands limited to the fp16 range, flagged in the status word).  Default: the library's "
+                         "default plan.  Reported as config.arithmetic")
     ap.add_argument("--strong-frames", type=int, default=8,
                     help="config 1: after the contract region, also time a FIXED batch of this many frames sharded over the "
                          "ranks (strong-scaling reading of the same path, reported under `strong_scaling`; 0 = skip)")
@@ -347,7 +364,8 @@ def main():
         if cfg["dtype"] != "f32":
             raise SystemExit("--arithmetic applies to the fp32 configurations")
         for mm in models:
-            mm.net_options[_N.NET_OPT_F32_SPLIT3] = 0x3ffff if args.arithmetic == "split3" else 0
+            mm.net_options[_N.NET_OPT_F32_SPLIT3] = 0 if args.arithmetic == "native" else 0x3ffff
+            mm.net_options[_N.NET_OPT_F32_SPLIT_F16] = 0x3ffff if args.arithmetic == "split_f16" else 0
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, args.substreams) - 1)]
     planes = model.inv_depths(1.0, 100.0, D)
 
@@ -554,7 +572,7 @@ def main():
     layer_fl = cnn_layer_flops(H, W, cin, nout, NGF, coord)[:-1]
     if B > 0 and not bf16:
         kplan = model._plan(B, H, W, cin, nout, NGF)
-        layer_peak = [PEAK_BF16_MFMA_TFLOPS / 6.0 if "_x3_kernel" in kplan.layer_kernel(i)[0] else PEAK_FP32_MFMA_TFLOPS for i in range(17)]
+        layer_peak = [split_peak(kplan.layer_kernel(i)[0]) for i in range(17)]
         peak = sum(layer_fl) / sum(f / pk for f, pk in zip(layer_fl, layer_peak))
     stages = {k: {"ms": round(v, 4)} for k, v in stage_ms.items()}
     for k in ("sweep", "assemble", "render"):
@@ -574,10 +592,12 @@ def main():
     if B > 0:
         plan = model._plan(B, H, W, cin, nout, NGF)
         kern = [plan.layer_kernel(i)[0] for i in range(17)]
-        nx3 = sum("_x3_kernel" in k for k in kern)
+        nx2 = sum(is_f16_split(k) for k in kern)
+        nx3 = sum("_x3_kernel" in k for k in kern) - nx2
         arithmetic = ("bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16)" if bf16 else
-                      "fp32: %d of 17 convolutions as a 3-way bf16 split with 6 products on the bf16 MFMA (fp32 accumulate, fp32-grade), "
-                      "%d on the native fp32 MFMA" % (nx3, 17 - nx3) if nx3 else "native fp32 MFMA (v_mfma_f32_32x32x2_f32)")
+                      "fp32: %d of 17 convolutions as a 2-way fp16 split with 3 products on the fp16 MFMA (22-bit operands), %d as a 3-way bf16 split "
+                      "with 6 products on the bf16 MFMA (both fp32 accumulate, fp32-grade), %d on the native fp32 MFMA" % (nx2, nx3, 17 - nx2 - nx3)
+                      if nx2 + nx3 else "native fp32 MFMA (v_mfma_f32_32x32x2_f32)")
     metric = "novel-view frames/sec, 640x320 ODS->32-sphere MSI infer+render" if args.config == 1 else \
         "novel-view %s, %dx%d %s->%d-%s infer+render" % (unit.replace("/s", "/sec"), W, H, "PP face" if cfg["kind"] == "pp" else "ODS",
                                                         D, "plane MPI" if cfg["kind"] == "pp" else "sphere MSI")
@@ -606,7 +626,7 @@ def main():
                     "note": "region 0 is the contract region `value` / `ms_per_step` are computed from"},
         "roofline": {"kernel": "conv_halo*_kernel + conv_igemm_kernel (the 3x3 / 4x4 conv launches of one forward, %s implicit GEMM)" % ("bf16 MFMA" if bf16 else "fp32: " + str(arithmetic)),
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": round(peak, 2),
-                     "peak_note": "dense MFMA peak of the instruction each layer runs on, blended by the layers' flops (fp32 MFMA 157.3; six-product bf16 split 2500 / 6 = 416.7 fp32-equivalent; bf16 2500 TFLOP/s)",
+                     "peak_note": "dense MFMA peak of the instruction each layer runs on, blended by the layers' flops (fp32 MFMA 157.3; six-product bf16 split 2500 / 6 = 416.7, three-product fp16 split 2500 / 3 = 833.3 fp32-equivalent; bf16 2500 TFLOP/s)",
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4), "traffic": traffic,
                      "traffic_stale": traffic_stale,
                      "algorithmic_bytes": conv_bytes,

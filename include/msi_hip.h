@@ -59,7 +59,7 @@ const char *msi_version(void);
  * a mismatch; packed blobs are not portable across versions (re-pack from the parameter blob).
  *   3: msi_layer_info.ln_scale_offset; LayerNorm window doubles in the packed blob (round 3)
  *   4: msi_net_plan_layer_kernel; render status word (msi_render_status_*); sweep volume takes shared poses (round 4) */
-#define MSI_ABI_VERSION 4
+#define MSI_ABI_VERSION 5
 int32_t msi_abi_version(void);
 const char *msi_last_error_string(void);
 /* CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 for a new message): the per-tensor checksum of
@@ -330,7 +330,11 @@ typedef struct msi_net_plan msi_net_plan;
                                   /* bf16 split of both operands with SIX products (h.h, h.m, m.h, h.l, l.h, m.m; exact products, fp32 accumulation; */
                                   /* dropped terms <= 2^-26 of a product: fp32-grade, NOT the 3-product TF32-grade split) on the 16x faster bf16 MFMA */
                                   /* (conv_halo_x3_kernel).  Default 0x3ffff (every layer that qualifies); 0 = native fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere */
-#define MSI_NET_OPT_COUNT 15
+#define MSI_NET_OPT_F32_SPLIT_F16 15 /* fp32 plans, bit i = layer i: a layer that runs the split (F32_SPLIT3) uses its fp16 form -- x = h + m' 2^-11 with fp16 */
+                                     /* parts (22 significand bits), THREE products h.h + (h.m' + m'.h) 2^-11, fp32 accumulation: half the matrix work of the */
+                                     /* six-product bf16 form at the same measured error (profiles/r04_split_f16_numerics.txt), but the operands must lie in */
+                                     /* the fp16 RANGE: |x| > 65504 (weights or normalised activations) poisons the layer and sets MSI_NET_STATUS_F16_SPLIT_RANGE */
+#define MSI_NET_OPT_COUNT 16
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
 int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);
@@ -356,6 +360,7 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
 #define MSI_NET_STATUS_APPLY_AHEAD_TIMEOUT 1
 #define MSI_NET_STATUS_LN_OVERFLOW 2
 #define MSI_NET_STATUS_LN_UNDERFLOW 4
+#define MSI_NET_STATUS_F16_SPLIT_RANGE 8 /* an operand of a layer on the fp16 split (F32_SPLIT_F16) exceeded 65504: rerun with that option 0 */
 int32_t msi_net_plan_status(const msi_net_plan *plan, const void *workspace, msi_stream_t stream, int32_t *status_bits);
 /* net_input [B,H,W,in_channels] (fp32, or bf16 when desc.dtype = MSI_DTYPE_BF16) -> pred [B,H,W,num_outputs] fp32. */
 int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,

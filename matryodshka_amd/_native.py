@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmsi_hip.so")
 MSI_OK = 0
 MSI_NET_NUM_LAYERS = 18
 RENDER_STATUS_ORIGIN_OUTSIDE = 1
-MSI_ABI_VERSION = 4          # include/msi_hip.h: the version this binding's struct layouts and signatures are written for
+MSI_ABI_VERSION = 5          # include/msi_hip.h: the version this binding's struct layouts and signatures are written for
 
 
 class MsiError(RuntimeError):
@@ -32,6 +32,8 @@ MSI_DTYPE_F32, MSI_DTYPE_BF16 = 0, 1
 NET_OPT_FIXUP_KERNEL, NET_OPT_TAILSPLIT, NET_OPT_BIGTILE, NET_OPT_HEAD_FUSE_LN, NET_OPT_NUM_CUS = 0, 1, 2, 3, 4
 NET_OPT_F32_TILE, NET_OPT_F32_TILE_MASK, NET_OPT_APPLY_AHEAD, NET_OPT_HALO, NET_OPT_HALO_SKIP = 5, 6, 7, 8, 9
 NET_OPT_UNIFORM_SPLIT, NET_OPT_BF16_STAGE_RAW, NET_OPT_SPLIT_OVERHEAD, NET_OPT_BF16_WAVES, NET_OPT_F32_SPLIT3 = 10, 11, 12, 13, 14
+NET_OPT_F32_SPLIT_F16 = 15
+NET_STATUS_F16_SPLIT_RANGE = 8
 
 
 class LayerInfo(Structure):

@@ -92,7 +92,7 @@ constexpr int LN_SHARDS = 64, LN_WORDS = 2;
 constexpr int LN_S1_BITS = 24, LN_S2_BITS = 16;   // S1 = 2^(24 - e), S2 = 2^(16 - 2 e)
 constexpr int LN_SCL_DOUBLES = 4;                 // per layer in the packed blob: S1, S2, 1 / S1, 1 / S2
 constexpr double LN_UNDERFLOW_UNITS_SQ = 1e12;    // (1e6 units)^2 per contributing wave, see ln_mean_inv
-enum { STATUS_APPLY_AHEAD_TIMEOUT = 1, STATUS_LN_OVERFLOW = 2, STATUS_LN_UNDERFLOW = 4 };
+enum { STATUS_APPLY_AHEAD_TIMEOUT = 1, STATUS_LN_OVERFLOW = 2, STATUS_LN_UNDERFLOW = 4, STATUS_F16_SPLIT_RANGE = 8 };
 constexpr int AP_FLAG_STRIDE = 16;  // ints between two row counters of the apply-ahead hand-off: one counter per 64-byte line
 constexpr int HEAD_MAX_C = 256;   // the head's fused LayerNorm keeps scale | shift of its source in LDS
 
@@ -1654,28 +1654,37 @@ conv_halo_kernel(const ConvParams p) {
 #ifndef MSI_X3_ABLATE   // timing experiments only (wrong results): 1 no weight DMA, 4 no per-tap barrier, 8 no fragment reads, 16 no MFMAs, 32 no patch swap
 #define MSI_X3_ABLATE 0
 #endif
-template <int RATE, int NS = (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3))>
+// NPL = 3: x = h + m + l in bf16, six products (F32_SPLIT3).  NPL = 2: x = h + m' 2^-11 in fp16, three products h.h + (h.m' + m'.h) 2^-11
+// (F32_SPLIT_F16: 22 significand bits per operand, operands limited to the fp16 RANGE -- the patch store flags |x| > 65504 in the status word)
+template <int RATE, int NS = (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3)), int NPL = 3>
 struct HaloGeomX3 {
   static constexpr int PW = 16 + 2 * RATE, PH = 4 + 2 * RATE, NPX = PW * PH;
-  static constexpr int PIX_BYTES = 208;                   // 3 planes x 32 bf16 + 16
+  static constexpr int PIX_BYTES = NPL * 64 + 16;         // NPL planes x 32 two-byte parts + 16 (13 or 9 sixteen-byte slots: odd)
   static constexpr int ROW_PITCH = ((PW * PIX_BYTES + 127) / 256) * 256 + 128;
   static constexpr int A_BYTES = PH * ROW_PITCH;
   static constexpr int B_ROW = 64;                        // 32 bf16 channels of one output row and plane
-  static constexpr int B_PLANE = 64 * B_ROW, B_STAGE = 3 * B_PLANE;
+  static constexpr int B_PLANE = 64 * B_ROW, B_STAGE = NPL * B_PLANE;
   static constexpr int NSTG = NS;
   static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
   static constexpr int NLOAD = (NPX * 8 + 255) / 256;
 };
 template <int N>
+__device__ __forceinline__ void wait_lgkm4(v4f &a, v4f &b, v4f &c, v4f &d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void wait_lgkm6(v4f &a, v4f &b, v4f &c, v4f &d, v4f &e, v4f &f) {
   asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N) : "memory");
 }
 
-template <int RATE, int APPLY>
+#ifndef MSI_X2_NSTG   // weight ring of the fp16 form (half the matrix work per tap: the DMA latency budget of a two-stage ring is one SHORT tap)
+#define MSI_X2_NSTG 3
+#endif
+template <int RATE, int APPLY, int NPL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 conv_halo_x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  typedef HaloGeomX3<RATE> G;
+  typedef HaloGeomX3<RATE, (NPL == 2 ? MSI_X2_NSTG : (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3))), NPL> G;
   constexpr int R = RATE, PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
   constexpr int MT = 1, NT = 1;
 #ifdef MSI_CONV_TIMING
@@ -1728,15 +1737,15 @@ conv_halo_x3_kernel(const ConvParams p) {
   // x3 block of the packed blob: [tap][chunk][plane h | m | l][npad rows][64 B = 32 bf16 channels], 16-byte slots swizzled by
   // (row >> 2) & 3.  A wave's DMA instruction moves 16 rows x 64 B = 1 KB of one plane: three instructions per k-step
   const int plane_bytes = p.npad * G::B_ROW;
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)S * 3 * plane_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)S * NPL * plane_bytes), 0x00020000);
   const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + (lane >> 2)) * G::B_ROW + (lane & 3) * 16);
 #define MSI_B_ISSUE(c, tap, st)                                                                                        \
   if (!(MSI_X3_ABLATE & 1)) {                                                                                          \
     char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;                                          \
-    const int soff_ = ((tap) * CH + (c)) * 3 * plane_bytes;                                                            \
+    const int soff_ = ((tap) * CH + (c)) * NPL * plane_bytes;                                                          \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0); \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
+    if (NPL == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
   }
   MSI_B_ISSUE(c0, 0, 0)
   if (G::NSTG == 3) MSI_B_ISSUE(c0, 1, 1)
@@ -1769,6 +1778,7 @@ conv_halo_x3_kernel(const ConvParams p) {
     has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
   }
   v4f araw[NLOAD], g4, be4;
+  float amax_ = 0.f;   // (NPL == 2: the largest operand magnitude this lane stored -- the fp16 range check)
   // patch of chunk c -> registers (+ gamma / beta of the lane's channels)
 #define MSI_PATCH_LOAD(c)                                                                                              \
   {                                                                                                                    \
@@ -1794,6 +1804,18 @@ conv_halo_x3_kernel(const ConvParams p) {
         y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
         if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */          \
       }                                                                                                                \
+      if (NPL == 2) {   /* y = h + m' 2^-11, fp16 parts (round to nearest even; y - h is exact in fp32) */                 \
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));                                                     \
+        typedef unsigned u2x_t __attribute__((ext_vector_type(2)));                                                    \
+        amax_ = __builtin_fmaxf(amax_, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(y.x), __builtin_fabsf(y.y)), __builtin_fmaxf(__builtin_fabsf(y.z), __builtin_fabsf(y.w)))); \
+        const h2_t ha = {(_Float16)y.x, (_Float16)y.y}, hb = {(_Float16)y.z, (_Float16)y.w};                          \
+        const h2_t ma = {(_Float16)((y.x - (float)ha.x) * 2048.f), (_Float16)((y.y - (float)ha.y) * 2048.f)};          \
+        const h2_t mb = {(_Float16)((y.z - (float)hb.x) * 2048.f), (_Float16)((y.w - (float)hb.y) * 2048.f)};          \
+        if (lds_a[k_] != 0xffffffffu) {                                                                                \
+          *reinterpret_cast<u2x_t *>(smem + lds_a[k_]) = u2x_t{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)}; \
+          *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 64) = u2x_t{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)}; \
+        }                                                                                                              \
+      } else {                                                                                                         \
       /* y = h + m + l, bf16 parts (round to nearest even; y - h and (y - h) - m are exact in fp32) */                  \
       unsigned h0, h1, m0, m1, l0, l1;                                                                                 \
       asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h0) : "v"(y.x), "v"(y.y));                                             \
@@ -1813,6 +1835,7 @@ conv_halo_x3_kernel(const ConvParams p) {
         *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 128) = u2x_t{l0, l1};                                            \
       }                                                                                                                \
     }                                                                                                                  \
+    }                                                                                                                  \
   }
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
@@ -1826,9 +1849,10 @@ conv_halo_x3_kernel(const ConvParams p) {
   for (int s_ = 0; s_ < 2; ++s_)
     b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-  f32x16 acc[1][1];
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  f32x16 acc[1][1], acc_lo;   // (NPL == 2: acc = h.h, acc_lo = (h.m' + m'.h), folded as acc + acc_lo 2^-11 after the loop)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = acc_lo[r] = 0.f;
 
   // one k-step = tap TAP of the current chunk, weights in ring stage TAP % 3; the DMA of the k-step two ahead is issued
   // after the first MFMA quarter; before the closing barrier the NEXT k-step's weights must have landed: every VMEM
@@ -1846,6 +1870,29 @@ conv_halo_x3_kernel(const ConvParams p) {
       if ((TAP) + PD_ < 9) { MSI_B_ISSUE(c, (TAP) + PD_, stn_) }                                                       \
       else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) + PD_ - 9, stn_) }                                               \
     }                                                                                                                  \
+    if (NPL == 2) {                                                                                                    \
+      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                               \
+        ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);                              \
+        bh_[s_] = lds_read128<0>(b_s[s_] + bst_);                                                                      \
+        am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);                         \
+        bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);                                                             \
+      }                                                                                                                \
+      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                               \
+        if (s_ == 0) wait_lgkm4<4>(ah_[0], bh_[0], am_[0], bm_[0]);                                                    \
+        else wait_lgkm4<0>(ah_[1], bh_[1], am_[1], bm_[1]);                                                            \
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bm_[s_]), __builtin_bit_cast(f16x8, ah_[s_]), acc_lo, 0, 0, 0); \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh_[s_]), __builtin_bit_cast(f16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh_[s_]), __builtin_bit_cast(f16x8, am_[s_]), acc_lo, 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (s_ == 0) {                                                                                                 \
+          if ((TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                          \
+          if (!MSI_X3_EARLY_DMA && G::NSTG == 3) {                                                                     \
+            if ((TAP) + 2 < 9) { MSI_B_ISSUE(c, (TAP) + 2, ((TAP) + 2) % 3) }                                          \
+            else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) - 7, ((TAP) + 2) % 3) }                                    \
+          }                                                                                                            \
+        }                                                                                                              \
+      }                                                                                                                \
+    } else {                                                                                                           \
     if (!(MSI_X3_ABLATE & 8))                                                                                         \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
       ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);                                \
@@ -1877,13 +1924,14 @@ conv_halo_x3_kernel(const ConvParams p) {
         }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
+    }                                                                                                                  \
     {                                                                                                                  \
       const bool issued_ = ((TAP) + 2 < 9) || (c + 1 < c1);                                                            \
       if (G::NSTG == 2) {                                                                                              \
         if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<NLOAD + (APPLY ? 2 : 0)>();   /* (the patch loads were issued after the DMA) */ \
         else wait_vmcnt<0>();                                                                                          \
-      } else if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<3 + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight (either order) */ \
-      else if (issued_) wait_vmcnt<3>();                                                                               \
+      } else if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<NPL + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight (either order) */ \
+      else if (issued_) wait_vmcnt<NPL>();                                                                             \
       else wait_vmcnt<0>();                                                                                            \
     }                                                                                                                  \
     if (!(MSI_X3_ABLATE & 4)) __builtin_amdgcn_s_barrier();                                                            \
@@ -1921,6 +1969,12 @@ conv_halo_x3_kernel(const ConvParams p) {
 #undef MSI_B_ISSUE
 #undef MSI_PATCH_STORE
 #undef MSI_PATCH_LOAD
+  if (NPL == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_fmaf(acc_lo[r], 1.f / 2048.f, acc[0][0][r]);
+    // an operand beyond the fp16 range became inf (h) and NaN (m'): the layer's output is garbage -- say so
+    if (__builtin_amdgcn_ballot_w64(!(amax_ <= 65504.f)) != 0 && lane == 0) atomicOr(p.status, STATUS_F16_SPLIT_RANGE);
+  }
 
   // ---- epilogue: as conv_igemm_kernel ----
 #ifdef MSI_CONV_TIMING
@@ -4418,6 +4472,7 @@ struct Layer {
   size_t gamma_off, beta_off, coord_off;  // floats inside the packed blob
   size_t lnscl_off;                       // floats inside the packed blob: LN_SCL_DOUBLES doubles (8-byte aligned)
   size_t x3_off;                          // floats inside the packed blob: the 3-way bf16 split of the weights (conv_halo_x3_kernel), 0 = none
+  size_t x2_off;                          // ... the 2-way fp16 split (h, m' = (w - h) 2^11: plan option F32_SPLIT_F16), 0 = none
   size_t raw_off, aff_off;                // bytes inside the workspace
   size_t act_off;                         // bf16 path: normalised bf16 activation (the next layer's operand)
   size_t sums_off;                        // LayerNorm sums [B][LN_SHARDS][LN_WORDS] int64
@@ -4547,6 +4602,8 @@ int build_net(const msi_net_desc *d, int num_cus, Net &net) {
                   (s.kind == MODE_CONVT && !L.wrapt && L.c0 % 32 == 0 && L.c1 % 32 == 0))) {
       L.x3_off = koff;
       koff = round_up(koff + (size_t)L.nclass * L.ksteps * 3 * L.npad * 16, 64);
+      L.x2_off = koff;   // the same rows as two fp16 planes
+      koff = round_up(koff + (size_t)L.nclass * L.ksteps * 2 * L.npad * 16, 64);
     }
     // workspace
     if (s.kind != MODE_HEAD) {
@@ -4617,6 +4674,7 @@ struct LayerLaunch {
   int halo;         // conv_halo_kernel (fp32) / conv_halo_bf16_kernel instead of conv_igemm_kernel
   int halo_s2;      // ... conv_halo_s2_kernel: the stride-2 3x3 layers through parity-plane patches (fp32)
   int halo_x3;      // ... conv_halo_x3_kernel: fp32 through the 3-way bf16 split with six products (plan option F32_SPLIT3)
+  int halo_x2;      // ... its fp16 form: 2-way split, three products (plan option F32_SPLIT_F16; needs halo_x3)
   int hbm, hbn;     // bf16 halo tile: 128 x 128 or 256 x 64
   int halo_t;       // convt_halo_kernel (conv-transpose, fp32): the two classes of one output-row parity per workgroup
   int halo_tb;      // convt_halo_bf16_kernel (conv-transpose, bf16): the two classes of one output-row parity per workgroup
@@ -4785,6 +4843,7 @@ int plan_layers(msi_net_plan *pl) {
                  (L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1) && !(pl->opt[MSI_NET_OPT_HALO_SKIP] >> 20 & 1)));
     if (Q.halo_s2) Q.halo = 1;
     Q.halo_x3 = Q.halo && !bf16 && L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1);
+    Q.halo_x2 = Q.halo_x3 && !Q.halo_s2 && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
     int max_split = MAX_SPLIT;
     // bf16 halo-patch kernel (conv_halo_bf16_kernel): the same layers with 64-channel chunks and whole
     // 8 x 16 pixel x 128 channel or 16 x 16 x 64 tiles
@@ -4845,7 +4904,7 @@ int plan_layers(msi_net_plan *pl) {
     Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
     if (Q.halo_t && (size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * 2 * BM * BN * sizeof(float) > net.partial_bytes) {
       // two slabs per K-range do not fit the partial-accumulator workspace -> the tap kernel
-      Q.halo_t = 0; Q.halo = 0; Q.halo_x3 = 0;
+      Q.halo_t = 0; Q.halo = 0; Q.halo_x3 = 0; Q.halo_x2 = 0;
       p.halo_tx = 0; p.halo_xor = 0; p.nclass = L.nclass;
       plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], MAX_SPLIT, &Q.nblocks, &Q.nfix);
       Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
@@ -5166,6 +5225,13 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
               const int slot = (kk >> 3) ^ ((n >> 2) & 3);
               for (int pl = 0; pl < 3; ++pl)
                 memcpy(base + ((((size_t)cls * L.ksteps + s) * 3 + pl) * L.npad + n) * 64 + slot * 16 + (kk & 7) * 2, &part[pl], 2);
+              // x2 block: w = h + m' 2^-11 with fp16 parts (round to nearest even; w - h is exact, m' keeps 11 of its bits:
+              // 22 significand bits in all).  |w| > 65504 packs as inf and poisons the layer (LN_OVERFLOW in the status word)
+              const _Float16 hh = (_Float16)v;
+              const _Float16 hm = (_Float16)((v - (float)hh) * 2048.f);
+              char *base2 = reinterpret_cast<char *>(packed + L.x2_off);
+              memcpy(base2 + ((((size_t)cls * L.ksteps + s) * 2 + 0) * L.npad + n) * 64 + slot * 16 + (kk & 7) * 2, &hh, 2);
+              memcpy(base2 + ((((size_t)cls * L.ksteps + s) * 2 + 1) * L.npad + n) * 64 + slot * 16 + (kk & 7) * 2, &hm, 2);
             }
         }
       }
@@ -5268,6 +5334,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_UNIFORM_SPLIT] = 0;
   pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD] = 0;
   pl->opt[MSI_NET_OPT_BF16_WAVES] = 8;
+  pl->opt[MSI_NET_OPT_F32_SPLIT_F16] = 0;
   pl->opt[MSI_NET_OPT_F32_SPLIT3] = 0x3ffff;   // every layer that has the kernel (r04: same error against the oracle as the native path, 1.35-1.45 x faster per layer)
   pl->opt[MSI_NET_OPT_BF16_STAGE_RAW] = 1;   // (bit 1, conv8_1 staging its raw sources: measured 50 us per 16 frames SLOWER -- ~180 VALU per chunk
                                                // against 2 048 matrix cycles of the 128 x 64 tile; bit 0, conv8_2: 130 us faster.  Three interleaved repeats)
@@ -5340,7 +5407,7 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
   } else if (Q.halo) {
     if (Q.halo_s2 && Q.halo_x3) snprintf(name, name_bytes, "conv_halo_s2_x3_kernel<%d>", Q.halo_apply ? 1 : 0);
     else if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_s2_kernel<%d>", Q.halo_apply ? 1 : 0);
-    else if (Q.halo_x3) snprintf(name, name_bytes, "conv_halo_x3_kernel<%d, %d>", L.rate, Q.halo_apply ? 1 : 0);
+    else if (Q.halo_x3) snprintf(name, name_bytes, "conv_halo_x3_kernel<%d, %d, %d>", L.rate, Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);
     else snprintf(name, name_bytes, "conv_halo_kernel<%d, %d>", L.rate, Q.halo_apply ? 1 : 0);
   } else {
     const int bm = Q.tile == TILE_128x128 || Q.tile == TILE_128x64 ? 128 : 64;
@@ -5361,7 +5428,8 @@ int32_t msi_net_plan_status(const msi_net_plan *plan, const void *workspace, msi
   if (e != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_plan_status: %s", hipGetErrorString(e));
   if (status_bits) *status_bits = word;
   if (word == 0) return MSI_OK;
-  return msi::fail(MSI_E_RANGE, "net_plan_status: 0x%x:%s%s%s", word,
+  return msi::fail(MSI_E_RANGE, "net_plan_status: 0x%x:%s%s%s%s", word,
+                   (word & STATUS_F16_SPLIT_RANGE) ? " an operand of a layer on the fp16 split exceeded the fp16 range (|x| > 65504): set MSI_NET_OPT_F32_SPLIT_F16 = 0" : "",
                    (word & STATUS_LN_OVERFLOW) ? " a LayerNorm sum left its fixed-point window (raw convolution output far above the scale the weights predict: non-finite or mis-scaled input?)" : "",
                    (word & STATUS_LN_UNDERFLOW) ? " a LayerNorm variance is below the resolution of its fixed-point window (raw convolution output far below the scale the weights predict, or constant)" : "",
                    (word & STATUS_APPLY_AHEAD_TIMEOUT) ? " an apply-ahead wait timed out" : "");
@@ -5599,18 +5667,29 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
         if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_kernel<1>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
         else hipLaunchKernelGGL((conv_halo_s2_kernel<0>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
       } else if (Q.halo_x3) {
-        p.wpk_x3 = reinterpret_cast<const char *>(packed + L.x3_off);
-        static thread_local unsigned long long done2 = 0;       // (rate 2: 69.8 KB of LDS)
-        if (L.rate == 1) {
-          if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_x3_kernel<1, 1>), grid, block, HaloGeomX3<1>::LDS_BYTES, stream, p);
-          else hipLaunchKernelGGL((conv_halo_x3_kernel<1, 0>), grid, block, HaloGeomX3<1>::LDS_BYTES, stream, p);
-        } else {
-          int rc0 = set_max_lds(Q.halo_apply ? reinterpret_cast<const void *>(conv_halo_x3_kernel<2, 1>) : reinterpret_cast<const void *>(conv_halo_x3_kernel<2, 0>),
-                                HaloGeomX3<2>::LDS_BYTES, done2, "conv_halo_x3");
-          if (rc0) return rc0;
-          if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_x3_kernel<2, 1>), grid, block, HaloGeomX3<2>::LDS_BYTES, stream, p);
-          else hipLaunchKernelGGL((conv_halo_x3_kernel<2, 0>), grid, block, HaloGeomX3<2>::LDS_BYTES, stream, p);
+        p.wpk_x3 = reinterpret_cast<const char *>(packed + (Q.halo_x2 ? L.x2_off : L.x3_off));
+        static thread_local unsigned long long done2[8] = {0};       // (above 64 KB of LDS the launch needs the attribute)
+#define MSI_X3_LAUNCH(R, A, N)                                                                                         \
+  {                                                                                                                    \
+    typedef HaloGeomX3<R, (N == 2 ? MSI_X2_NSTG : (MSI_X3_NSTG ? MSI_X3_NSTG : (R == 1 ? 2 : 3))), N> G_;              \
+    if (G_::LDS_BYTES > 65536) {                                                                                       \
+      int rc0 = set_max_lds(reinterpret_cast<const void *>(conv_halo_x3_kernel<R, A, N>), G_::LDS_BYTES, done2[(R - 1) * 4 + A * 2 + (N - 2)], "conv_halo_x3"); \
+      if (rc0) return rc0;                                                                                             \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((conv_halo_x3_kernel<R, A, N>), grid, block, G_::LDS_BYTES, stream, p);                          \
+  }
+        const int sel = (L.rate == 1 ? 0 : 4) + (Q.halo_apply ? 2 : 0) + (Q.halo_x2 ? 0 : 1);
+        switch (sel) {
+          case 0: MSI_X3_LAUNCH(1, 0, 2) break;
+          case 1: MSI_X3_LAUNCH(1, 0, 3) break;
+          case 2: MSI_X3_LAUNCH(1, 1, 2) break;
+          case 3: MSI_X3_LAUNCH(1, 1, 3) break;
+          case 4: MSI_X3_LAUNCH(2, 0, 2) break;
+          case 5: MSI_X3_LAUNCH(2, 0, 3) break;
+          case 6: MSI_X3_LAUNCH(2, 1, 2) break;
+          default: MSI_X3_LAUNCH(2, 1, 3) break;
         }
+#undef MSI_X3_LAUNCH
       } else if (L.rate == 1) {
         if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_kernel<1, 1>), grid, block, HaloGeom<1>::LDS_BYTES, stream, p);
         else hipLaunchKernelGGL((conv_halo_kernel<1, 0>), grid, block, HaloGeom<1>::LDS_BYTES, stream, p);

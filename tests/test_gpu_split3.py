@@ -9,18 +9,24 @@ from tests.test_gpu_cnn import _run, env  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 ALL = 0x3ffff
+# the two split arithmetics: six bf16 products (F32_SPLIT_F16 = 0) and three fp16 products of 22-bit operands (F32_SPLIT_F16 = ALL)
+ARITH = [pytest.param(0, id="bf16x6"), pytest.param(ALL, id="f16x3")]
 
 
+@pytest.mark.parametrize("f16", ARITH)
 @pytest.mark.parametrize("coord", [True, False])
 @pytest.mark.parametrize("b,h,w,cin,nout,ngf", [(1, 32, 64, 96, 32, 32), (2, 16, 48, 32, 8, 32), (1, 64, 128, 192, 64, 64)])
-def test_split3_layers_match_the_oracle(env, coord, b, h, w, cin, nout, ngf):
+def test_split3_layers_match_the_oracle(env, coord, b, h, w, cin, nout, ngf, f16):
     torch, MSI, nets, N, onets = env
-    pred, ref, raws, acts = _run(env, b, h, w, cin, nout, ngf, coord, seed=3, options={N.NET_OPT_F32_SPLIT3: ALL})
+    pred, ref, raws, acts = _run(env, b, h, w, cin, nout, ngf, coord, seed=3, options={N.NET_OPT_F32_SPLIT3: ALL, N.NET_OPT_F32_SPLIT_F16: f16})
     native, _, raws_n, _ = _run(env, b, h, w, cin, nout, ngf, coord, seed=3, options={N.NET_OPT_F32_SPLIT3: 0})
     m = MSI(weights=onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=3, randomize_affine=True), coord_net=coord)
     m.net_options[N.NET_OPT_F32_SPLIT3] = ALL
+    m.net_options[N.NET_OPT_F32_SPLIT_F16] = f16
     kern = [m._plan(b, h, w, cin, nout, ngf).layer_kernel(i)[0] for i in range(17)]
     assert sum("_x3_kernel" in k for k in kern) >= (8 if w % 64 == 0 else 2), kern      # (the split path really ran)
+    if f16:
+        assert sum(k.endswith(", 2>") for k in kern) >= (5 if w % 64 == 0 else 1), kern  # (... in its fp16 form)
     worst = 0.0
     for name, raw in raws.items():
         o = acts[name]
@@ -33,13 +39,15 @@ def test_split3_layers_match_the_oracle(env, coord, b, h, w, cin, nout, ngf):
     assert e_split <= 1e-3 and e_split <= 2 * e_native + 2e-6
 
 
-def test_split3_is_deterministic_and_fixup_launch_agrees(env):
+@pytest.mark.parametrize("f16", ARITH)
+def test_split3_is_deterministic_and_fixup_launch_agrees(env, f16):
     torch, MSI, nets, N, onets = env
     b, h, w, cin, nout, ngf = 1, 160, 320, 96, 32, 64          # 40 x 80 deepest layers: tiles cut into K-ranges
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=9, randomize_affine=True)
     x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
     m = MSI(weights=weights, coord_net=True)
     m.net_options[N.NET_OPT_F32_SPLIT3] = ALL
+    m.net_options[N.NET_OPT_F32_SPLIT_F16] = f16
     first = m.run_net(x, nout, ngf).clone()
     for _ in range(10):
         assert torch.equal(m.run_net(x, nout, ngf), first)
@@ -48,6 +56,7 @@ def test_split3_is_deterministic_and_fixup_launch_agrees(env):
     assert any(plan.layer_kernel(i)[2] > 0 and "_x3_kernel" in plan.layer_kernel(i)[0] for i in range(17))
     f = MSI(weights=weights, coord_net=True)
     f.net_options[N.NET_OPT_F32_SPLIT3] = ALL
+    f.net_options[N.NET_OPT_F32_SPLIT_F16] = f16
     f.net_options[N.NET_OPT_FIXUP_KERNEL] = 1
     assert torch.equal(f.run_net(x, nout, ngf), first)
 
@@ -66,9 +75,10 @@ def test_split3_full_size_fixtures(fixture):
     inp = make_inputs(seed, int(cfg["b"]), int(cfg["h"]), int(cfg["w"]))
     weights = onets.init_weights(6 * d, 2 * d, ngf=ngf, coord_net=coord, seed=seed, randomize_affine=True)
     errs = {}
-    for tag, opt in (("native", 0), ("split3", ALL)):
+    for tag, opt, f16 in (("native", 0, 0), ("split3", ALL, 0), ("split_f16", ALL, ALL)):
         m = MSI(weights=weights, coord_net=coord)
         m.net_options[N.NET_OPT_F32_SPLIT3] = opt
+        m.net_options[N.NET_OPT_F32_SPLIT_F16] = f16
         planes = m.inv_depths(1.0, 100.0, d)
         pred, net_input = m.infer_msi(torch.from_numpy(inp["src_image"]), torch.from_numpy(inp["ref_image"]), None, None,
                                       inp["ref_pose"], inp["src_pose"], inp["intrinsics"], "blend_psv", d, planes, ngf=ngf)
@@ -78,4 +88,27 @@ def test_split3_full_size_fixtures(fixture):
         errs[tag] = _check_dense(z, got, ("rgba_layers", "rgb", "depth"), 1e-3)
     print(fixture, {t: {k: "%.2e" % v[0] for k, v in e.items()} for t, e in errs.items()})
     for k in ("rgba_layers", "rgb", "depth"):
-        assert errs["split3"][k][0] <= 2 * errs["native"][k][0] + 1e-5, (k, errs["split3"][k], errs["native"][k])
+        for tag in ("split3", "split_f16"):
+            assert errs[tag][k][0] <= 2 * errs["native"][k][0] + 1e-5, (tag, k, errs[tag][k], errs["native"][k])
+
+
+def test_split_f16_flags_operands_beyond_the_fp16_range(env):
+    """The fp16 form needs |operand| <= 65504: an input beyond that poisons the layer (h = inf) -- and says so in the status word
+    (MSI_NET_STATUS_F16_SPLIT_RANGE); the six-product bf16 form (fp32's exponent range) digests the same input silently and correctly."""
+    torch, MSI, nets, N, onets = env
+    b, h, w, cin, nout, ngf = 1, 32, 64, 96, 32, 32
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=5, randomize_affine=True)
+    x = torch.rand((b, h, w, cin), device="cuda") * 2 - 1
+    x[0, 7, 9, 3] = 7.0e4
+    m = MSI(weights=weights, coord_net=True)
+    m.net_options[N.NET_OPT_F32_SPLIT3] = ALL
+    m.net_options[N.NET_OPT_F32_SPLIT_F16] = ALL
+    m.run_net(x, nout, ngf)
+    with pytest.raises(N.MsiError) as ei:
+        m.network_status()
+    assert "fp16 range" in str(ei.value)
+    m6 = MSI(weights=weights, coord_net=True)
+    m6.net_options[N.NET_OPT_F32_SPLIT3] = ALL
+    m6.net_options[N.NET_OPT_F32_SPLIT_F16] = 0
+    y6 = m6.run_net(x, nout, ngf)
+    assert bool(torch.isfinite(y6).all())

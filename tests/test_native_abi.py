@@ -215,6 +215,35 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
                 assert np.abs((parts[0].astype(np.float64) + parts[1] + parts[2]) - want).max() <= 2.0 ** -24 * np.abs(want).max()
             assert not blk[:, :, :, info.cout:, :].any()
             off = -(-(off + blk.size // 2) // 64) * 64
+            # ... followed by the x2 block (plan option F32_SPLIT_F16): the same rows as TWO fp16 planes, h = fp16(w) and
+            # m' = fp16((w - h) 2^11) -- w = h + m' 2^-11 to 22 significand bits
+            blk2 = packed[off:off + ncls * ksteps * 2 * npad * 16].view(np.float16).reshape(ncls, ksteps, 2, npad, 32)
+            for _ in range(40):
+                cls, s_, n = rng.randint(ncls), rng.randint(ksteps), rng.randint(info.cout)
+                tap, within = divmod(s_, cpt0 + cpt1)
+                src, chunk = (0, within) if within < cpt0 else (1, within - cpt0)
+                cb = (0 if src == 0 else c0) + chunk * 32
+                if info.kind == 0:
+                    want = wt[tap // 3, tap % 3, cb:cb + 32, n].astype(np.float32)
+                else:
+                    ph, pw = cls >> 1, cls & 1
+                    th, tw = tap >> 1, tap & 1
+                    kh = 1 + 2 * th if ph == 0 else 2 - 2 * th
+                    kw = 1 + 2 * tw if pw == 0 else 2 - 2 * tw
+                    want = wt[kh, kw, n, cb:cb + 32].astype(np.float32)
+                parts = []
+                for pl in range(2):
+                    row = blk2[cls, s_, pl, n].reshape(4, 8)
+                    un = np.empty_like(row)
+                    for j in range(4):
+                        un[j ^ ((n >> 2) & 3)] = row[j]
+                    parts.append(un.reshape(32))
+                h = want.astype(np.float16)
+                m = ((want - h.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+                assert np.array_equal(parts[0], h) and np.array_equal(parts[1], m), (name, cls, s_, n)
+                assert np.abs(parts[0].astype(np.float64) + parts[1].astype(np.float64) / 2048.0 - want).max() <= 2.0 ** -21 * np.abs(want).max()
+            assert not blk2[:, :, :, info.cout:, :].any()
+            off = -(-(off + blk2.size // 2) // 64) * 64
     if dtype == "bf16":
         # bf16 plans end with the head's bf16-ROUNDED weights once more as fp32 rows (32 channels per 128-byte row, rows
         # padded to 64, slots swizzled like every fp32 row): the fused tail runs the 1x1 head on the fp32 MFMA
