@@ -332,8 +332,9 @@ typedef struct msi_net_plan msi_net_plan;
                                   /* (conv_halo_x3_kernel).  Default 0x3ffff (every layer that qualifies); 0 = native fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere */
 #define MSI_NET_OPT_F32_SPLIT_F16 15 /* fp32 plans, bit i = layer i: a layer that runs the split (F32_SPLIT3) uses its fp16 form -- x = h + m' 2^-11 with fp16 */
                                      /* parts (22 significand bits), THREE products h.h + (h.m' + m'.h) 2^-11, fp32 accumulation: half the matrix work of the */
-                                     /* six-product bf16 form at the same measured error (profiles/r04_split_f16_numerics.txt), but the operands must lie in */
-                                     /* the fp16 RANGE: |x| > 65504 (weights or normalised activations) poisons the layer and sets MSI_NET_STATUS_F16_SPLIT_RANGE */
+                                     /* six-product bf16 form at the same measured error (profiles/r04_split_numerics.txt), but the operands must lie in */
+                                     /* the fp16 RANGE: |x| > 65504 (weights or normalised activations) poisons the layer and sets MSI_NET_STATUS_F16_SPLIT_RANGE. */
+                                     /* Default 0x3ffff; 0 = the six-product bf16 form (fp32's exponent range) */
 #define MSI_NET_OPT_COUNT 16
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);

@@ -2286,23 +2286,89 @@ conv_halo_s2_kernel(const ConvParams p) {
 #endif
 }
 
+
+// ---- shared pieces of the split kernels' stride-2 / conv-transpose forms (NP = 3: bf16 h | m | l, six products; NP = 2: fp16 h | m', three) ----
+template <int NP>
+__device__ __forceinline__ void split_store(char *smem, unsigned off, v4f y, float &amax) {
+  typedef unsigned u2x_t __attribute__((ext_vector_type(2)));
+  if (NP == 2) {   // y = h + m' 2^-11, fp16 parts (round to nearest even; y - h is exact in fp32)
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(y.x), __builtin_fabsf(y.y)), __builtin_fmaxf(__builtin_fabsf(y.z), __builtin_fabsf(y.w))));
+    const h2_t ha = {(_Float16)y.x, (_Float16)y.y}, hb = {(_Float16)y.z, (_Float16)y.w};
+    const h2_t ma = {(_Float16)((y.x - (float)ha.x) * 2048.f), (_Float16)((y.y - (float)ha.y) * 2048.f)};
+    const h2_t mb = {(_Float16)((y.z - (float)hb.x) * 2048.f), (_Float16)((y.w - (float)hb.y) * 2048.f)};
+    if (off != 0xffffffffu) {
+      *reinterpret_cast<u2x_t *>(smem + off) = u2x_t{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+      *reinterpret_cast<u2x_t *>(smem + off + 64) = u2x_t{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+    }
+  } else {         // y = h + m + l, bf16 parts (see conv_halo_x3_kernel)
+    unsigned h0, h1, m0, m1, l0, l1;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h0) : "v"(y.x), "v"(y.y));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h1) : "v"(y.z), "v"(y.w));
+    v4f r = y - v4f{__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h0 & 0xffff0000u),
+                    __builtin_bit_cast(float, h1 << 16), __builtin_bit_cast(float, h1 & 0xffff0000u)};
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m0) : "v"(r.x), "v"(r.y));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m1) : "v"(r.z), "v"(r.w));
+    r = r - v4f{__builtin_bit_cast(float, m0 << 16), __builtin_bit_cast(float, m0 & 0xffff0000u),
+                __builtin_bit_cast(float, m1 << 16), __builtin_bit_cast(float, m1 & 0xffff0000u)};
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l0) : "v"(r.x), "v"(r.y));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l1) : "v"(r.z), "v"(r.w));
+    if (off != 0xffffffffu) {
+      *reinterpret_cast<u2x_t *>(smem + off) = u2x_t{h0, h1};
+      *reinterpret_cast<u2x_t *>(smem + off + 64) = u2x_t{m0, m1};
+      *reinterpret_cast<u2x_t *>(smem + off + 128) = u2x_t{l0, l1};
+    }
+  }
+}
+// the products of one K16 step (weights = the MFMA's row operand), small terms first; NP = 2: lo collects h.m' + m'.h
+template <int NP>
+__device__ __forceinline__ void split_mfma(f32x16 &acc, f32x16 &lo, const v4f &ah, const v4f &am, const v4f &al, const v4f &bh, const v4f &bm, const v4f &bl) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  if (NP == 2) {
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bm), __builtin_bit_cast(f16x8, ah), lo, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh), __builtin_bit_cast(f16x8, ah), acc, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh), __builtin_bit_cast(f16x8, am), lo, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm), __builtin_bit_cast(bf16x8, am), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh), __builtin_bit_cast(bf16x8, al), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl), __builtin_bit_cast(bf16x8, ah), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh), __builtin_bit_cast(bf16x8, am), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm), __builtin_bit_cast(bf16x8, ah), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh), __builtin_bit_cast(bf16x8, ah), acc, 0, 0, 0);
+  }
+}
+// NP = 2, after the k-loop: acc += lo 2^-11; an operand beyond the fp16 range (h = inf, m' = NaN) is reported
+template <int NP>
+__device__ __forceinline__ void split_finish(f32x16 &acc, const f32x16 &lo, float amax, int lane, int *status) {
+  if (NP == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(lo[r], 1.f / 2048.f, acc[r]);
+    if (__builtin_amdgcn_ballot_w64(!(amax <= 65504.f)) != 0 && lane == 0) atomicOr(status, STATUS_F16_SPLIT_RANGE);
+  }
+}
+
 // ---- the stride-2 halo-patch kernel through the six-product bf16 split (conv_halo_s2_kernel x conv_halo_x3_kernel; r04) ----------
+template <int NP>
 struct HaloGeomS2X3 {
   static constexpr int PW = 17, PH = 5, NPX = PW * PH;
-  static constexpr int PIX_BYTES = 208;
+  static constexpr int PIX_BYTES = NP * 64 + 16;
   static constexpr int ROW_PITCH = ((PW * PIX_BYTES + 127) / 256) * 256 + 128;
   static constexpr int A_BYTES = PH * ROW_PITCH;
-  static constexpr int B_ROW = 64, B_PLANE = 64 * B_ROW, B_STAGE = 3 * B_PLANE;
+  static constexpr int B_ROW = 64, B_PLANE = 64 * B_ROW, B_STAGE = NP * B_PLANE;
   static constexpr int NSTG = 3;
   static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
   static constexpr int NLOAD = (NPX * 8 + 255) / 256;
 };
 
-template <int APPLY>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+#ifndef MSI_S2X_WAVES
+#define MSI_S2X_WAVES 3
+#endif
+template <int APPLY, int NP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? MSI_S2X_WAVES : 2)))
 conv_halo_s2_x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  typedef HaloGeomS2X3 G;
+  typedef HaloGeomS2X3<NP> G;
   constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
   constexpr int MT = 1, NT = 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2347,15 +2413,15 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
   const int S = p.ksteps;
   // (weights: the x3 block of the packed blob, three 64-byte-row planes per k-step -- see conv_halo_x3_kernel)
   const int plane_bytes = p.npad * G::B_ROW;
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)S * 3 * plane_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)S * NP * plane_bytes), 0x00020000);
   const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + (lane >> 2)) * G::B_ROW + (lane & 3) * 16);
 #define MSI_B_ISSUE(c, tap, st)                                                                                        \
   {                                                                                                                    \
     char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;                                          \
-    const int soff_ = ((tap) * CH + (c)) * 3 * plane_bytes;                                                            \
+    const int soff_ = ((tap) * CH + (c)) * NP * plane_bytes;                                                           \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0); \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
+    if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
   }
   MSI_B_ISSUE(c0, 0, 0)
   MSI_B_ISSUE(c0, 2, 1)
@@ -2367,6 +2433,7 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
   const size_t in_bytes = (size_t)H * W * C * 4;
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in_bytes), 0, (int)in_bytes, 0x00020000);
   v4f araw[NLOAD], g4, be4;
+  float amax_ = 0.f;
   // (unit 0 first and its patch of group c0 requested at once: the other units' offsets are worked out under that round trip)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -2428,23 +2495,7 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
         y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
         if (has_pad && !pok[U][k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */       \
       }                                                                                                                \
-      unsigned h0, h1, m0, m1, l0, l1;   /* y = h + m + l, bf16 parts (see conv_halo_x3_kernel) */                       \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h0) : "v"(y.x), "v"(y.y));                                             \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h1) : "v"(y.z), "v"(y.w));                                             \
-      v4f r = y - v4f{__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h0 & 0xffff0000u),               \
-                      __builtin_bit_cast(float, h1 << 16), __builtin_bit_cast(float, h1 & 0xffff0000u)};              \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m0) : "v"(r.x), "v"(r.y));                                             \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m1) : "v"(r.z), "v"(r.w));                                             \
-      r = r - v4f{__builtin_bit_cast(float, m0 << 16), __builtin_bit_cast(float, m0 & 0xffff0000u),                    \
-                  __builtin_bit_cast(float, m1 << 16), __builtin_bit_cast(float, m1 & 0xffff0000u)};                  \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l0) : "v"(r.x), "v"(r.y));                                             \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l1) : "v"(r.z), "v"(r.w));                                             \
-      if (lds_a[k_] != 0xffffffffu) {                                                                                  \
-        typedef unsigned u2x_t __attribute__((ext_vector_type(2)));                                                    \
-        *reinterpret_cast<u2x_t *>(smem + lds_a[k_]) = u2x_t{h0, h1};                                                  \
-        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 64) = u2x_t{m0, m1};                                             \
-        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 128) = u2x_t{l0, l1};                                            \
-      }                                                                                                                \
+      split_store<NP>(smem, lds_a[k_], y, amax_);                                                                      \
     }                                                                                                                  \
   }
 
@@ -2458,9 +2509,9 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
   for (int s_ = 0; s_ < 2; ++s_)
     b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-  f32x16 acc[1][1];
+  f32x16 acc[1][1], acc_lo;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = acc_lo[r] = 0.f;
 
   // k-step J = 0..8 of the current group: unit, tap and patch offsets are literals
 #define MSI_S2_TAP(J) ((J) == 0 ? 0 : (J) == 1 ? 2 : (J) == 2 ? 6 : (J) == 3 ? 8 : (J) == 4 ? 1 : (J) == 5 ? 7 : (J) == 6 ? 3 : (J) == 7 ? 5 : 4)
@@ -2478,18 +2529,20 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
       bh_[s_] = lds_read128<ST_ * G::B_STAGE>(b_s[s_]);                                                                \
       am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);                           \
       bm_[s_] = lds_read128<ST_ * G::B_STAGE + G::B_PLANE>(b_s[s_]);                                                   \
-      al_[s_] = s_ == 0 ? lds_read128<AOFF_ + 128>(a_base) : lds_read128<AOFF_ + 160>(a_base);                         \
-      bl_[s_] = lds_read128<ST_ * G::B_STAGE + 2 * G::B_PLANE>(b_s[s_]);                                               \
+      if (NP == 3) {                                                                                                   \
+        al_[s_] = s_ == 0 ? lds_read128<AOFF_ + 128>(a_base) : lds_read128<AOFF_ + 160>(a_base);                       \
+        bl_[s_] = lds_read128<ST_ * G::B_STAGE + 2 * G::B_PLANE>(b_s[s_]);                                             \
+      } else { al_[s_] = ah_[s_]; bl_[s_] = bh_[s_]; }                                                                 \
     }                                                                                                                  \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
-      if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                      \
-      else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                              \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0); \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, al_[s_]), acc[0][0], 0, 0, 0); \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0); \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
+      if (NP == 3) {                                                                                                   \
+        if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                    \
+        else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                            \
+      } else {                                                                                                         \
+        if (s_ == 0) wait_lgkm4<4>(ah_[0], bh_[0], am_[0], bm_[0]);                                                    \
+        else wait_lgkm4<0>(ah_[1], bh_[1], am_[1], bm_[1]);                                                            \
+      }                                                                                                                \
+      split_mfma<NP>(acc[0][0], acc_lo, ah_[s_], am_[s_], al_[s_], bh_[s_], bm_[s_], bl_[s_]);                         \
       __builtin_amdgcn_sched_barrier(0);                                                                               \
       if (s_ == 0) {                                                                                                   \
         if (FIRST_ && more_) {                                                                                         \
@@ -2503,8 +2556,8 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
     {                                                                                                                  \
       const bool issued_ = ((J) + 2 < 9) || (c + 1 < c1);                                                              \
       /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */ \
-      if (FIRST_ && !LAST_ && more_) wait_vmcnt<3 + NLOAD>();                                                          \
-      else if (issued_) wait_vmcnt<3>();                                                                               \
+      if (FIRST_ && !LAST_ && more_) wait_vmcnt<NP + NLOAD>();                                                          \
+      else if (issued_) wait_vmcnt<NP>();                                                                              \
       else wait_vmcnt<0>();                                                                                            \
     }                                                                                                                  \
     __builtin_amdgcn_s_barrier();                                                                                      \
@@ -2539,6 +2592,7 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
 #undef MSI_B_ISSUE
 #undef MSI_PATCH_STORE
 #undef MSI_PATCH_LOAD
+  split_finish<NP>(acc[0][0], acc_lo, amax_, lane, p.status);
 
   // ---- epilogue: as conv_halo_kernel ----
   if (!full) {
@@ -2855,10 +2909,11 @@ convt_halo_kernel(const ConvParams p) {
 // per CU.  The tap kernel cannot split its operands (both arrive by DMA), this one stages the patch through registers anyway:
 // with 192 instead of 512 matrix cycles per 16 channels it wins (conv8_1 197 -> ... us, see profiles/r04_*), and its sources
 // need no ln_apply launch.
+template <int NP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 convt_halo_x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  typedef HaloGeomX3<1, 3> G;
+  typedef HaloGeomX3<1, 3, NP> G;
   constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, NSTG = G::NSTG, PD = NSTG - 1;
   static_assert(NSTG == 3 && PD == 2, "prefetch distance two");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2904,15 +2959,15 @@ convt_halo_x3_kernel(const ConvParams p) {
   const int S = p.ksteps;                                 // k-steps per class: 4 CH
   // (weights: the x3 block, [class][tap * CH + c][plane h | m | l][npad][64 B] -- see conv_halo_x3_kernel)
   const int plane_bytes = p.npad * G::B_ROW;
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)4 * S * 3 * plane_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)4 * S * NP * plane_bytes), 0x00020000);
   const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + (lane >> 2)) * G::B_ROW + (lane & 3) * 16);
 #define MSI_B_ISSUE(cls, tap, c, st)                                                                                   \
   {                                                                                                                    \
     char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;                                          \
-    const int soff_ = ((cls) * S + (tap) * CH + (c)) * 3 * plane_bytes;                                                \
+    const int soff_ = ((cls) * S + (tap) * CH + (c)) * NP * plane_bytes;                                               \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0); \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
+    if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
   }
   MSI_B_ISSUE(2 * ph, 0, c0, 0)
   MSI_B_ISSUE(2 * ph, 1, c0, 1)
@@ -2944,6 +2999,7 @@ convt_halo_x3_kernel(const ConvParams p) {
     has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
   }
   v4f araw[NLOAD], g4, be4;
+  float amax_ = 0.f;
   int src_ld = 0;                                         // source of the patch held in araw
   // patch of chunk c -> registers (+ gamma / beta of the lane's channels when that source is raw)
 #define MSI_PATCH_LOAD(c)                                                                                              \
@@ -2985,23 +3041,7 @@ convt_halo_x3_kernel(const ConvParams p) {
         y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
         if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};                                                          \
       }                                                                                                                \
-      unsigned h0, h1, m0, m1, l0, l1;   /* y = h + m + l, bf16 parts (see conv_halo_x3_kernel) */                       \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h0) : "v"(y.x), "v"(y.y));                                             \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h1) : "v"(y.z), "v"(y.w));                                             \
-      v4f r = y - v4f{__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h0 & 0xffff0000u),               \
-                      __builtin_bit_cast(float, h1 << 16), __builtin_bit_cast(float, h1 & 0xffff0000u)};              \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m0) : "v"(r.x), "v"(r.y));                                             \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m1) : "v"(r.z), "v"(r.w));                                             \
-      r = r - v4f{__builtin_bit_cast(float, m0 << 16), __builtin_bit_cast(float, m0 & 0xffff0000u),                    \
-                  __builtin_bit_cast(float, m1 << 16), __builtin_bit_cast(float, m1 & 0xffff0000u)};                  \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l0) : "v"(r.x), "v"(r.y));                                             \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l1) : "v"(r.z), "v"(r.w));                                             \
-      if (lds_a[k_] != 0xffffffffu) {                                                                                  \
-        typedef unsigned u2x_t __attribute__((ext_vector_type(2)));                                                    \
-        *reinterpret_cast<u2x_t *>(smem + lds_a[k_]) = u2x_t{h0, h1};                                                  \
-        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 64) = u2x_t{m0, m1};                                             \
-        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 128) = u2x_t{l0, l1};                                            \
-      }                                                                                                                \
+      split_store<NP>(smem, lds_a[k_], y, amax_);                                                                      \
     }                                                                                                                  \
   }
 
@@ -3017,17 +3057,17 @@ convt_halo_x3_kernel(const ConvParams p) {
   for (int s_ = 0; s_ < 2; ++s_)
     b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-  f32x16 acc[2][1][1];
+  f32x16 acc[2][1][1], acc_lo[2];
 #pragma unroll
   for (int cl = 0; cl < 2; ++cl)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[cl][0][0][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[cl][0][0][r] = acc_lo[cl][r] = 0.f;
 
   // k-step J of the chunk = class pw = J / 4, tap (th, tw) = ((J / 2) & 1, J & 1), weights in ring stage st (run-time).
   // The DMA of the k-step PD = 2 ahead and (J == 0) the next chunk's patch loads are issued after the first MFMA quarter;
   // before the closing barrier the NEXT k-step's weights must have landed: they were issued one k-step ago, so only what
   // THIS k-step issued (2 DMA, + the patch loads of J == 0) may still be in flight (in-order return).
-  constexpr int NPL = NLOAD + 2;                          // VMEM operations of a patch load
+  constexpr int NPLD = NLOAD + 2;                         // VMEM operations of a patch load
 #define MSI_CTSTEP(J)                                                                                                  \
   {                                                                                                                    \
     constexpr int PWC_ = (J) >> 2, TH_ = ((J) >> 1) & 1, TW_ = (J) & 1;                                                \
@@ -3040,19 +3080,21 @@ convt_halo_x3_kernel(const ConvParams p) {
       bh_[s_] = lds_read128<0>(b_s[s_] + bst_);                                                                        \
       am_[s_] = s_ == 0 ? lds_read128<COFF_ + 64>(ab_) : lds_read128<COFF_ + 96>(ab_);                                 \
       bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);                                                               \
-      al_[s_] = s_ == 0 ? lds_read128<COFF_ + 128>(ab_) : lds_read128<COFF_ + 160>(ab_);                               \
-      bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);                                                           \
+      if (NP == 3) {                                                                                                   \
+        al_[s_] = s_ == 0 ? lds_read128<COFF_ + 128>(ab_) : lds_read128<COFF_ + 160>(ab_);                             \
+        bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);                                                         \
+      } else { al_[s_] = ah_[s_]; bl_[s_] = bh_[s_]; }                                                                 \
     }                                                                                                                  \
     bool issued_ = false;                                                                                              \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
-      if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                      \
-      else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                              \
-      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[PWC_][0][0], 0, 0, 0); \
-      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, al_[s_]), acc[PWC_][0][0], 0, 0, 0); \
-      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[PWC_][0][0], 0, 0, 0); \
-      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[PWC_][0][0], 0, 0, 0); \
-      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[PWC_][0][0], 0, 0, 0); \
-      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[PWC_][0][0], 0, 0, 0); \
+      if (NP == 3) {                                                                                                   \
+        if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                    \
+        else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                            \
+      } else {                                                                                                         \
+        if (s_ == 0) wait_lgkm4<4>(ah_[0], bh_[0], am_[0], bm_[0]);                                                    \
+        else wait_lgkm4<0>(ah_[1], bh_[1], am_[1], bm_[1]);                                                            \
+      }                                                                                                                \
+      split_mfma<NP>(acc[PWC_][0][0], acc_lo[PWC_], ah_[s_], am_[s_], al_[s_], bh_[s_], bm_[s_], bl_[s_]);             \
       __builtin_amdgcn_sched_barrier(0);                                                                               \
       if (s_ == 0) {                                                                                                   \
         if ((J) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                              \
@@ -3062,8 +3104,8 @@ convt_halo_x3_kernel(const ConvParams p) {
         else if (c + 1 < c1) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_) }                 \
       }                                                                                                                \
     }                                                                                                                  \
-    if ((J) == 0 && c + 1 < c1) wait_vmcnt<3 + NPL>();                                                                 \
-    else if (issued_) wait_vmcnt<3>();                                                                                 \
+    if ((J) == 0 && c + 1 < c1) wait_vmcnt<NP + NPLD>();                                                                 \
+    else if (issued_) wait_vmcnt<NP>();                                                                                \
     else wait_vmcnt<0>();                                                                                              \
     __builtin_amdgcn_s_barrier();                                                                                      \
     st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
@@ -3103,6 +3145,8 @@ convt_halo_x3_kernel(const ConvParams p) {
 #undef MSI_B_ISSUE
 #undef MSI_PATCH_STORE
 #undef MSI_PATCH_LOAD
+  split_finish<NP>(acc[0][0][0], acc_lo[0], amax_, lane, p.status);
+  split_finish<NP>(acc[1][0][0], acc_lo[1], amax_, lane, p.status);
 
   // ---- epilogue: two class tiles ----
   if (!full) {
@@ -4843,7 +4887,7 @@ int plan_layers(msi_net_plan *pl) {
                  (L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1) && !(pl->opt[MSI_NET_OPT_HALO_SKIP] >> 20 & 1)));
     if (Q.halo_s2) Q.halo = 1;
     Q.halo_x3 = Q.halo && !bf16 && L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1);
-    Q.halo_x2 = Q.halo_x3 && !Q.halo_s2 && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
+    Q.halo_x2 = Q.halo_x3 && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
     int max_split = MAX_SPLIT;
     // bf16 halo-patch kernel (conv_halo_bf16_kernel): the same layers with 64-channel chunks and whole
     // 8 x 16 pixel x 128 channel or 16 x 16 x 64 tiles
@@ -4868,6 +4912,7 @@ int plan_layers(msi_net_plan *pl) {
     if (Q.halo_t) {
       Q.halo = 1;
       Q.halo_x3 = x3_on;
+      Q.halo_x2 = x3_on && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
       p.nclass = 2;                                      // tiles are enumerated per (ph, tile_m, tile_n, sample): a workgroup owns pw = 0, 1
       if (L.cpt0 + L.cpt1 < max_split) max_split = L.cpt0 + L.cpt1;
     }
@@ -5334,7 +5379,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_UNIFORM_SPLIT] = 0;
   pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD] = 0;
   pl->opt[MSI_NET_OPT_BF16_WAVES] = 8;
-  pl->opt[MSI_NET_OPT_F32_SPLIT_F16] = 0;
+  pl->opt[MSI_NET_OPT_F32_SPLIT_F16] = 0x3ffff;   // (r04: the error of a plain fp32 convolution against fp64, half the matrix work of the bf16 form: profiles/r04_split_numerics.txt)
   pl->opt[MSI_NET_OPT_F32_SPLIT3] = 0x3ffff;   // every layer that has the kernel (r04: same error against the oracle as the native path, 1.35-1.45 x faster per layer)
   pl->opt[MSI_NET_OPT_BF16_STAGE_RAW] = 1;   // (bit 1, conv8_1 staging its raw sources: measured 50 us per 16 frames SLOWER -- ~180 VALU per chunk
                                                // against 2 048 matrix cycles of the 128 x 64 tile; bit 0, conv8_2: 130 us faster.  Three interleaved repeats)
@@ -5403,9 +5448,10 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
                                     plan->opt[MSI_NET_OPT_BF16_WAVES] == 8 ? 8 : 4);
     else snprintf(name, name_bytes, "conv_halo_bf16_kernel<256, 64, 1, %d, 4>", Q.halo_apply ? 1 : 0);
   } else if (Q.halo_t) {
-    snprintf(name, name_bytes, Q.halo_x3 ? "convt_halo_x3_kernel" : "convt_halo_kernel");
+    if (Q.halo_x3) snprintf(name, name_bytes, "convt_halo_x3_kernel<%d>", Q.halo_x2 ? 2 : 3);
+    else snprintf(name, name_bytes, "convt_halo_kernel");
   } else if (Q.halo) {
-    if (Q.halo_s2 && Q.halo_x3) snprintf(name, name_bytes, "conv_halo_s2_x3_kernel<%d>", Q.halo_apply ? 1 : 0);
+    if (Q.halo_s2 && Q.halo_x3) snprintf(name, name_bytes, "conv_halo_s2_x3_kernel<%d, %d>", Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);
     else if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_s2_kernel<%d>", Q.halo_apply ? 1 : 0);
     else if (Q.halo_x3) snprintf(name, name_bytes, "conv_halo_x3_kernel<%d, %d, %d>", L.rate, Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);
     else snprintf(name, name_bytes, "conv_halo_kernel<%d, %d>", L.rate, Q.halo_apply ? 1 : 0);
@@ -5640,9 +5686,10 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
         p.ln_beta1 = packed + S.beta_off;
       }
       if (Q.halo_x3) {
-        p.wpk_x3 = reinterpret_cast<const char *>(packed + L.x3_off);
-        constexpr int lds_ct = HaloGeomX3<1, 3>::LDS_BYTES;
-        hipLaunchKernelGGL(convt_halo_x3_kernel, dim3(Q.nblocks), dim3(256), lds_ct, stream, p);
+        p.wpk_x3 = reinterpret_cast<const char *>(packed + (Q.halo_x2 ? L.x2_off : L.x3_off));
+        constexpr int lds_ct3 = HaloGeomX3<1, 3, 3>::LDS_BYTES, lds_ct2 = HaloGeomX3<1, 3, 2>::LDS_BYTES;
+        if (Q.halo_x2) hipLaunchKernelGGL(convt_halo_x3_kernel<2>, dim3(Q.nblocks), dim3(256), lds_ct2, stream, p);
+        else hipLaunchKernelGGL(convt_halo_x3_kernel<3>, dim3(Q.nblocks), dim3(256), lds_ct3, stream, p);
       } else {
         hipLaunchKernelGGL(convt_halo_kernel, dim3(Q.nblocks), dim3(256), ConvtHaloGeom::LDS_BYTES, stream, p);
       }
@@ -5660,9 +5707,14 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       }
       const dim3 grid(Q.nblocks), block(256);
       if (Q.halo_s2 && Q.halo_x3) {
-        p.wpk_x3 = reinterpret_cast<const char *>(packed + L.x3_off);
-        if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_x3_kernel<1>), grid, block, HaloGeomS2X3::LDS_BYTES, stream, p);
-        else hipLaunchKernelGGL((conv_halo_s2_x3_kernel<0>), grid, block, HaloGeomS2X3::LDS_BYTES, stream, p);
+        p.wpk_x3 = reinterpret_cast<const char *>(packed + (Q.halo_x2 ? L.x2_off : L.x3_off));
+        if (Q.halo_x2) {
+          if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_x3_kernel<1, 2>), grid, block, HaloGeomS2X3<2>::LDS_BYTES, stream, p);
+          else hipLaunchKernelGGL((conv_halo_s2_x3_kernel<0, 2>), grid, block, HaloGeomS2X3<2>::LDS_BYTES, stream, p);
+        } else {
+          if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_x3_kernel<1, 3>), grid, block, HaloGeomS2X3<3>::LDS_BYTES, stream, p);
+          else hipLaunchKernelGGL((conv_halo_s2_x3_kernel<0, 3>), grid, block, HaloGeomS2X3<3>::LDS_BYTES, stream, p);
+        }
       } else if (Q.halo_s2) {
         if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_kernel<1>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
         else hipLaunchKernelGGL((conv_halo_s2_kernel<0>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);

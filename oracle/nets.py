@@ -163,7 +163,28 @@ def conv_split3(fn, x, w):
     return ((fn(xm, wm) + fn(xl, wh)) + fn(xh, wl)) + ((fn(xm, wh) + fn(xh, wm)) + fn(xh, wh))
 
 
+def split_f16(t):
+    """x = h + m' 2^-11 with fp16 parts (11 + 11 significand bits; m' is the remainder scaled into the fp16 normal range):
+    the operand format of the three-product form (plan option F32_SPLIT_F16)."""
+    h = t.half().float()
+    return h, ((t - h) * 2048.0).half().float()
+
+
+def conv_split_f16(fn, x, w):
+    """STUDY ONLY (tools/split3_study.py; not a product path): fp32 convolution emulated by THREE fp16 x fp16 products with fp32
+    accumulation -- h.h + (h.m' + m'.h) 2^-11; operands carry 22 significand bits, the dropped m'.m' term is <= 2^-22 of the
+    leading one.  Each term is an fp32 torch convolution of fp16-representable operands (exact products, fp32 sums)."""
+    xh, xm = split_f16(x)
+    wh, wm = split_f16(w)
+    return fn(xh, wh) + (fn(xm, wh) + fn(xh, wm)) * (1.0 / 2048.0)
+
+
 def forward(weights, net_input, coord_net=True, return_activations=False, bf16=False, split3_products=False):
+    """split3_products: False | True (six bf16 products, conv_split3) | "f16" (three fp16 products, conv_split_f16)."""
+    return _forward(weights, net_input, coord_net, return_activations, bf16, split3_products)
+
+
+def _forward(weights, net_input, coord_net=True, return_activations=False, bf16=False, split3_products=False):
     """msi_coord_train_net (nets.py:471-515) / msi_train_net (:387-450).
     net_input: np [B,H,W,Cin] fp32.  Returns np [B,H,W,num_outputs] fp32.
 
@@ -174,6 +195,7 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
     fp16 (r03: half the activation bytes; measured here: mean |bf16 variant - fp32 network| + 0.3 %, max within
     its seed-to-seed noise; a bf16 raw output would be + 19 %) and the affine, the head bias and tanh are fp32."""
     rnd = bf16_round if bf16 else (lambda t: t)
+    split_fn = conv_split_f16 if split3_products == "f16" else conv_split3
     x = rnd(torch.from_numpy(np.ascontiguousarray(np.transpose(net_input, (0, 3, 1, 2)))).float())
     acts = {}
     affines = {}
@@ -195,7 +217,7 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
         else:
             x = wrap_pad(x, rate, rate)
         if split3_products:
-            y = conv_split3(lambda a, b_: TF.conv2d(a, b_, stride=stride, dilation=rate), x, w)
+            y = split_fn(lambda a, b_: TF.conv2d(a, b_, stride=stride, dilation=rate), x, w)
         else:
             y = TF.conv2d(x, w, stride=stride, dilation=rate)
         acts[name + "/raw"] = y
@@ -207,7 +229,7 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
         w = rnd(_convT_w(weights[name + "/weights"]))
         if coord_net:
             if split3_products:
-                y = conv_split3(lambda a, b_: TF.conv_transpose2d(a, b_, stride=2, padding=1), x, w)
+                y = split_fn(lambda a, b_: TF.conv_transpose2d(a, b_, stride=2, padding=1), x, w)
             else:
                 y = TF.conv_transpose2d(x, w, stride=2, padding=1)
             acts[name + "/raw"] = y
@@ -245,7 +267,7 @@ def forward(weights, net_input, coord_net=True, return_activations=False, bf16=F
         w = rnd(_conv_w(weights["color_pred/weights"]))
         b = torch.from_numpy(weights["color_pred/biases"])
         if split3_products:
-            pred = torch.tanh(conv_split3(lambda a, b_: TF.conv2d(a, b_), c82, w) + b.view(1, -1, 1, 1))
+            pred = torch.tanh(split_fn(lambda a, b_: TF.conv2d(a, b_), c82, w) + b.view(1, -1, 1, 1))
         else:
             pred = torch.tanh(TF.conv2d(c82, w, bias=b))
     out = np.ascontiguousarray(pred.permute(0, 2, 3, 1).numpy())

@@ -20,11 +20,15 @@ TOL = 1e-3
 
 # graph order conv1_1 ... conv8_2 (the head runs inside head_assemble_kernel on the blend_psv path)
 # (r04: the stride-1 halo layers of an fp32 plan run the six-product bf16 split by default -- conv_halo_x3_kernel)
-F32_BIG_GRID = ["conv_halo_x3_kernel<1, 0>", "conv_halo_s2_x3_kernel<1>", "conv_halo_x3_kernel<1, 1>", "conv_halo_s2_x3_kernel<1>",
-                "conv_halo_x3_kernel<1, 1>", "conv_halo_x3_kernel<1, 1>", "conv_halo_s2_x3_kernel<1>", "conv_halo_x3_kernel<2, 1>",
-                "conv_halo_x3_kernel<2, 1>", "conv_halo_x3_kernel<2, 1>", "convt_halo_x3_kernel", "conv_halo_x3_kernel<1, 1>",
-                "conv_halo_x3_kernel<1, 1>", "convt_halo_x3_kernel", "conv_halo_x3_kernel<1, 1>",
-                "convt_halo_x3_kernel", "conv_halo_x3_kernel<1, 1>"]
+# (the kernels' last template argument: operand planes -- 3 = bf16 h | m | l, six products; 2 = fp16 h | m', three products)
+def f32_big_grid(np_):
+    c = lambda r, a: "conv_halo_x3_kernel<%d, %d, %d>" % (r, a, np_)      # noqa: E731
+    s2, ct = "conv_halo_s2_x3_kernel<1, %d>" % np_, "convt_halo_x3_kernel<%d>" % np_
+    return [c(1, 0), s2, c(1, 1), s2, c(1, 1), c(1, 1), s2, c(2, 1), c(2, 1), c(2, 1), ct, c(1, 1), c(1, 1), ct, c(1, 1), ct, c(1, 1)]
+
+
+DEFAULT_PLANES = 2          # (r04: plan option F32_SPLIT_F16 is on by default)
+F32_BIG_GRID = f32_big_grid(DEFAULT_PLANES)
 BF16_CONFIG2 = ["conv_halo_bf16_kernel<256, 64, 1, 0, 4>", "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>", "conv_halo_bf16_kernel<128, 128, 1, 1, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 2, 0, 8>", "conv_halo_bf16_kernel<128, 128, 2, 1, 8>",
