@@ -89,7 +89,7 @@ def cnn_flops(h, w, cin, nout, ngf, coord):
 def is_f16_split(kernel_name):
     """A plan kernel name (NetPlan.layer_kernel) of the fp16 three-product form: the x3 kernels' last template argument is the
     number of operand planes (2 = fp16 h | m', 3 = bf16 h | m | l)."""
-    return "_x3_kernel" in kernel_name and kernel_name.rstrip(">").endswith(", 2")
+    return "_x3_kernel" in kernel_name and kernel_name.split("(")[0].rstrip("> ").replace("<", ",").split(",")[-1].strip() == "2"
 
 
 def split_peak(kernel_name):

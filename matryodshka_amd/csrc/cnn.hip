@@ -1680,8 +1680,11 @@ __device__ __forceinline__ void wait_lgkm6(v4f &a, v4f &b, v4f &c, v4f &d, v4f &
 #ifndef MSI_X2_NSTG   // weight ring of the fp16 form (half the matrix work per tap: the DMA latency budget of a two-stage ring is one SHORT tap)
 #define MSI_X2_NSTG 3
 #endif
+#ifndef MSI_X2_WAVES
+#define MSI_X2_WAVES 2
+#endif
 template <int RATE, int APPLY, int NPL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPL == 2 ? MSI_X2_WAVES : 2)))
 conv_halo_x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef HaloGeomX3<RATE, (NPL == 2 ? MSI_X2_NSTG : (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3))), NPL> G;

@@ -76,6 +76,7 @@ def main():
               "halo<...> = the halo-patch kernels); %% of the %s MFMA peak %.1f TFLOP/s" % (W, H, D, batch, cfg["dtype"], cfg["dtype"], peak))
         fix = c.execute("select start, end from kernels where name like '%conv_fixup%' order by start").fetchall()
         tot_us = 0.0
+        peak_time = 0.0   # us the listed launches would take at their instructions' peaks
         # the 1x1 head is a conv_igemm launch (template MODE 2) only on the unfused path; on the blend_psv path it is
         # part of head_assemble_kernel and a step has 17 conv launches
         last = conv[-1][0]
@@ -90,13 +91,18 @@ def main():
             fus = sum(fx[:1])
             tot_us += us + fus
             kind = short(r[0]).split("<")[0].replace("conv_igemm_kernel", "tile").replace("_kernel", "")
-            print("%-10s %s<%s> blocks=%d lds=%d vgpr=%d agpr=%d  %8.1f us + fixup %5.1f us  %7.1f TFLOP/s (%4.1f%%)" % (
+            # the peak of the instruction this launch runs on (fp32 plans: native fp32 MFMA 157.3, six-product bf16 split 416.7,
+            # three-product fp16 split 833.3 fp32-equivalent TFLOP/s -- bench.split_peak)
+            lpk = peak if bf16 else bench.split_peak(short(r[0]).split("(")[0])
+            peak_time += fl / lpk / 1e6
+            print("%-10s %s<%s> blocks=%d lds=%d vgpr=%d agpr=%d  %8.1f us + fixup %5.1f us  %7.1f TFLOP/s (%4.1f%% of %.1f)" % (
                 nm, kind, tmpl, (r[3] // r[6]) * r[4] * r[5], r[7], r[8], r[9], us, fus, fl / (us + fus) / 1e6,
-                100 * fl / (us + fus) / 1e6 / peak))
+                100 * fl / (us + fus) / 1e6 / lpk, lpk))
         if fused_tail and ha:
             print("color_pred fused with the RGBA assembly: head_assemble_kernel %8.1f us (HBM-bound; not a conv launch)" % ((ha[-1][1] - ha[-1][0]) / 1e3))
-        print("sum %.1f us -> %.1f TFLOP/s = %.3f of the %s MFMA peak (conv launches listed above)" % (
-            tot_us, sum(flops[:nl]) / tot_us / 1e6, sum(flops[:nl]) / tot_us / 1e6 / peak, cfg["dtype"]))
+        blended = sum(flops[:nl]) / peak_time / 1e6
+        print("sum %.1f us -> %.1f TFLOP/s = %.3f of the flops-weighted peak %.1f TFLOP/s of the instructions the launches run on (conv launches listed above)" % (
+            tot_us, sum(flops[:nl]) / tot_us / 1e6, sum(flops[:nl]) / tot_us / 1e6 / blended, blended))
         ln = [r for r in rows if "ln_apply" in r[0]]
         if ln and steps:
             print("ln_apply: %.2f launches and %.1f us per step" % (sum(r[1] for r in ln) / steps, sum(r[2] for r in ln) / 1e3 / steps))
