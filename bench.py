@@ -624,7 +624,7 @@ def main():
         "repeats": {"ms_per_step": [round(r / args.steps * 1e3, 4) for r in [elapsed] + repeats],
                     "median_ms_per_step": round(float(np.median([elapsed] + repeats)) / args.steps * 1e3, 4),
                     "note": "region 0 is the contract region `value` / `ms_per_step` are computed from"},
-        "roofline": {"kernel": "conv_halo*_kernel + conv_igemm_kernel (the 3x3 / 4x4 conv launches of one forward, %s implicit GEMM)" % ("bf16 MFMA" if bf16 else "fp32: " + str(arithmetic)),
+        "roofline": {"kernel": "conv_halo*_kernel + conv_igemm_kernel (the 3x3 / 4x4 conv launches of one forward, %s implicit GEMM)" % ("bf16 MFMA" if bf16 else str(arithmetic)),
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": round(peak, 2),
                      "peak_note": "dense MFMA peak of the instruction each layer runs on, blended by the layers' flops (fp32 MFMA 157.3; six-product bf16 split 2500 / 6 = 416.7, three-product fp16 split 2500 / 3 = 833.3 fp32-equivalent; bf16 2500 TFLOP/s)",
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4), "traffic": traffic,
