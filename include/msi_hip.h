@@ -58,7 +58,8 @@ const char *msi_version(void);
  * msi_abi_version() of the library it loaded with the MSI_ABI_VERSION it was compiled against and refuses to run on
  * a mismatch; packed blobs are not portable across versions (re-pack from the parameter blob).
  *   3: msi_layer_info.ln_scale_offset; LayerNorm window doubles in the packed blob (round 3)
- *   4: msi_net_plan_layer_kernel; render status word (msi_render_status_*); sweep volume takes shared poses (round 4) */
+ *   4: msi_net_plan_layer_kernel; render status word (msi_render_status_*); sweep volume takes shared poses (round 4)
+ *   5: packed blob carries the fp16-split (x2) block; MSI_NET_OPT_F32_SPLIT_F16, MSI_NET_STATUS_F16_SPLIT_RANGE (round 4) */
 #define MSI_ABI_VERSION 5
 int32_t msi_abi_version(void);
 const char *msi_last_error_string(void);
