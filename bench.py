@@ -296,6 +296,8 @@ def main():
                          "product; plan option F32_SPLIT3); split_f16 = 2-way fp16 split (22 significand bits), THREE products on the fp16 MFMA "
                          "(plan option F32_SPLIT_F16; operands limited to the fp16 range, flagged in the status word).  Default: the library's "
                          "default plan.  Reported as config.arithmetic")
+    ap.add_argument("--net-opt", action="append", default=[], metavar="K=V",
+                    help="tuning: msi_net_plan_set_option(K, V) on every plan of the run (integers; include/msi_hip.h MSI_NET_OPT_*); reported as config.net_options")
     ap.add_argument("--strong-frames", type=int, default=8,
                     help="config 1: after the contract region, also time a FIXED batch of this many frames sharded over the "
                          "ranks (strong-scaling reading of the same path, reported under `strong_scaling`; 0 = skip)")
@@ -366,6 +368,10 @@ def main():
         for mm in models:
             mm.net_options[_N.NET_OPT_F32_SPLIT3] = 0 if args.arithmetic == "native" else 0x3ffff
             mm.net_options[_N.NET_OPT_F32_SPLIT_F16] = 0x3ffff if args.arithmetic == "split_f16" else 0
+    for kv in args.net_opt:
+        k_, v_ = kv.split("=")
+        for mm in models:
+            mm.net_options[int(k_)] = int(v_, 0)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, args.substreams) - 1)]
     planes = model.inv_depths(1.0, 100.0, D)
 
@@ -612,7 +618,7 @@ def main():
                    "num_spheres": D, "ngf": NGF, "frames_per_step": frames_total, "frames_per_step_rank0": B,
                    "parallelism": "frames sharded over %d GPU(s) (dist.shard_frames), no data-path collective" % world,
                    "streams_per_gpu": args.streams, "substreams": args.substreams,
-                   "arithmetic": arithmetic},
+                   "arithmetic": arithmetic, "net_options": args.net_opt or None},
         "distributed": {"world_size_env": world, "world_size_process_group": nccl_world, "backend": backend,
                         "frame_ranges_per_rank": ranges,
                         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],

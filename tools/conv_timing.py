@@ -3,7 +3,7 @@
 e.g. tools/_variants/libmsi_timing.so installed as matryodshka_amd/libmsi_hip.so):
 s_memtime stamps at kernel entry, k-loop start, k-loop end and exit of every workgroup.
 
-    python tools/conv_timing.py [--bf16] [--split3] [--batch N] [--planes D] [layer ...]
+    python tools/conv_timing.py [--bf16] [--split3] [--bf16x6] [--batch N] [--planes D] [layer ...]
 (--bf16: the bf16 plan's conv_halo_bf16_kernel layers at batch N; stamps are 100 MHz s_memtime ticks, 10 ns each)
 """
 import ctypes
@@ -26,11 +26,14 @@ bf16 = "--bf16" in argv
 batch = int(argv[argv.index("--batch") + 1]) if "--batch" in argv else 1
 planes = int(argv[argv.index("--planes") + 1]) if "--planes" in argv else (64 if bf16 else 32)
 split3 = "--split3" in argv
-argv = [a for i, a in enumerate(argv) if a not in ("--bf16", "--batch", "--planes", "--split3") and (i == 0 or argv[i - 1] not in ("--batch", "--planes"))]
+bf16x6 = "--bf16x6" in argv     # the six-product bf16 form of the split (plan option F32_SPLIT_F16 = 0)
+argv = [a for i, a in enumerate(argv) if a not in ("--bf16", "--batch", "--planes", "--split3", "--bf16x6") and (i == 0 or argv[i - 1] not in ("--batch", "--planes"))]
 layers = [int(a) for a in argv] or [0, 1, 4, 7, 16]
 m = MSI(weights=nets.init_weights(6 * planes, 2 * planes, 64, True), coord_net=True, dtype="bf16" if bf16 else "f32")
 if split3:
     m.net_options[_native.NET_OPT_F32_SPLIT3] = 0x3ffff
+if bf16x6:
+    m.net_options[_native.NET_OPT_F32_SPLIT_F16] = 0
 x = torch.rand((batch, 320, 640, 6 * planes), device="cuda") * 2 - 1
 if bf16:
     x = x.to(torch.bfloat16)
