@@ -340,6 +340,23 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // Partial accumulators of a split tile travel in REGISTER order: piece ((i*NT + j)*4 + g) of thread tid at
 // 16-byte slot (piece * 256 + tid) of the slab -- 1 KB contiguous per wave instruction, no LDS staging.
+// In-launch hand-off of K-range partial sums (tail split): a K-range workgroup stores its slab (sc1: written through), waits for the
+// stores, takes a ticket; the last arriver reads every slab with sc1 loads.  Experiment knobs (r04, see DESIGN.md section 4 "wrapt"):
+// MSI_HANDOFF_FENCE bit 0 = an agent-scope release fence (buffer_wbl2 sc1) before the ticket, bit 1 = an acquire fence (buffer_inv sc1)
+// behind it -- measured 728 -> 427 frames/s at configs[1], not the default; MSI_HANDOFF_AUX = cache policy of the slab stores / loads.
+#ifndef MSI_HANDOFF_FENCE
+#define MSI_HANDOFF_FENCE 0
+#endif
+#ifndef MSI_HANDOFF_AUX   // cache policy of the slab stores / loads: 16 = sc1 (agent scope), 17 = sc0 | sc1 (system scope)
+#define MSI_HANDOFF_AUX 16
+#endif
+__device__ __forceinline__ void handoff_release() {
+  if (MSI_HANDOFF_FENCE & 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+__device__ __forceinline__ void handoff_acquire() {
+  if (MSI_HANDOFF_FENCE & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // aux = 16 (sc1): write-through store / L1-bypassing load, the in-launch hand-off form (cdna_hip_programming.md).
 template <int MT, int NT, int AUX>
 __device__ __forceinline__ void dump_acc(const f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int tid) {
@@ -619,6 +636,8 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
       const int local = wm * (MT * 32) + i * 32 + (lane & 31);
       const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
       m = (tyi * (BM / 16) + (local >> 4)) * p.Mw + (tile_m - tyi * p.halo_tx) * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor));
+      // (ragged grids -- msi_train_net's conv-transposes, (H + 1) x (W + 5) GEMM rows: a column beyond the row's end is no pixel)
+      if (!INTERIOR && (tile_m - tyi * p.halo_tx) * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor)) >= p.Mw) m = mtot;
     }
     const bool mok = INTERIOR || m < mtot;
     int mh = 0, mw = 0;
@@ -1311,9 +1330,10 @@ _Pragma("unroll")                                                               
 #endif
       return;
     }
-    dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
+    dump_acc<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_p, tid);
     const int nsp = t < p.n_main ? p.split0 : p.split;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have left (sc1: written through)
+    handoff_release();
     __syncthreads();
     int *s_old = reinterpret_cast<int *>(smem);        // (all LDS reads of the main loop are behind its last barrier)
     if (tid == 0) {
@@ -1327,10 +1347,10 @@ _Pragma("unroll")                                                               
 #endif
       return;
     }
-    // the last arriver reads every slab with sc1 loads (coherent with the sc1 stores: no acquire fence)
+    handoff_acquire();   // (the last arriver reads every slab with sc1 loads)
     const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(p.partial + (size_t)(slot - ks) * (BM * BN)), 0, nsp * SLAB, 0x00020000);
-    sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+    sum_slabs<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_t, nsp, SLAB, tid);
     __syncthreads();   // (every thread has read s_old before the epilogue's strips reuse LDS)
   }
   // (LDS is free: the k-loop's last barrier is behind; NSTAGE >= 2 stages hold the strips of every instantiation)
@@ -1609,17 +1629,19 @@ conv_halo_kernel(const ConvParams p) {
 #endif
       return;
     }
-    dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
+    dump_acc<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_p, tid);
     const int nsp = t < p.n_main ? p.split0 : p.split;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    handoff_release();
     __syncthreads();
     int *s_old = reinterpret_cast<int *>(smem);
     if (tid == 0)
       *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*s_old != nsp - 1) return;
+    handoff_acquire();
     const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
-    sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+    sum_slabs<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_t, nsp, SLAB, tid);
     __syncthreads();   // (every thread has read s_old before the epilogue's strips reuse LDS)
   }
   emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, cbv, p.coord_bias != nullptr, smem);
@@ -2001,17 +2023,19 @@ conv_halo_x3_kernel(const ConvParams p) {
 #endif
       return;
     }
-    dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
+    dump_acc<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_p, tid);
     const int nsp = t < p.n_main ? p.split0 : p.split;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    handoff_release();
     __syncthreads();
     int *s_old = reinterpret_cast<int *>(smem);
     if (tid == 0)
       *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*s_old != nsp - 1) return;
+    handoff_acquire();
     const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
-    sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+    sum_slabs<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_t, nsp, SLAB, tid);
     __syncthreads();   // (every thread has read s_old before the epilogue's strips reuse LDS)
   }
   emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, cbv, p.coord_bias != nullptr, smem);
@@ -2272,17 +2296,19 @@ conv_halo_s2_kernel(const ConvParams p) {
       dump_acc<MT, NT, 0>(acc, rsrc_p, tid);
       return;
     }
-    dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
+    dump_acc<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_p, tid);
     const int nsp = t < p.n_main ? p.split0 : p.split;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    handoff_release();
     __syncthreads();
     int *s_old = reinterpret_cast<int *>(smem);
     if (tid == 0)
       *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*s_old != nsp - 1) return;
+    handoff_acquire();
     const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
-    sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+    sum_slabs<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_t, nsp, SLAB, tid);
     __syncthreads();   // (s_old has been read by every thread before the strip below reuses LDS)
   }
   emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, smem);
@@ -2605,17 +2631,19 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
       dump_acc<MT, NT, 0>(acc, rsrc_p, tid);
       return;
     }
-    dump_acc<MT, NT, 16>(acc, rsrc_p, tid);
+    dump_acc<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_p, tid);
     const int nsp = t < p.n_main ? p.split0 : p.split;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    handoff_release();
     __syncthreads();
     int *s_old = reinterpret_cast<int *>(smem);
     if (tid == 0)
       *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*s_old != nsp - 1) return;
+    handoff_acquire();
     const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
-    sum_slabs<MT, NT, 16>(acc, rsrc_t, nsp, SLAB, tid);
+    sum_slabs<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_t, nsp, SLAB, tid);
     __syncthreads();   // (s_old has been read by every thread before the strip below reuses LDS)
   }
   emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, smem);
@@ -2886,20 +2914,22 @@ convt_halo_kernel(const ConvParams p) {
 #pragma unroll
     for (int cl = 0; cl < 2; ++cl) {
       const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 2 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
-      dump_acc<1, 1, 16>(acc[cl], rsrc_p, tid);
+      dump_acc<1, 1, MSI_HANDOFF_AUX>(acc[cl], rsrc_p, tid);
     }
     const int nsp = t < p.n_main ? p.split0 : p.split;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    handoff_release();
     __syncthreads();
     int *s_old = reinterpret_cast<int *>(smem);
     if (tid == 0)
       *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*s_old != nsp - 1) return;
+    handoff_acquire();
 #pragma unroll
     for (int cl = 0; cl < 2; ++cl) {
       const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)(slot - ks) * 2 + cl) * (64 * 64)), 0, nsp * 2 * SLAB, 0x00020000);
-      sum_slabs<1, 1, 16>(acc[cl], rsrc_t, nsp, 2 * SLAB, tid);
+      sum_slabs<1, 1, MSI_HANDOFF_AUX>(acc[cl], rsrc_t, nsp, 2 * SLAB, tid);
     }
   }
 #pragma unroll
@@ -2983,8 +3013,15 @@ convt_halo_x3_kernel(const ConvParams p) {
   for (int k = 0; k < NLOAD; ++k) {
     const int pp = (tid + 256 * k) >> 3;
     const int py = pp / PW, px = pp - py * PW;
-    const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
-    pok[k] = pp < NPX && ih >= 0 && ih < H && iw >= 0 && iw < W;   // SAME: zeros outside
+    const int ih = oh0 - 1 + py;
+    int iw = ow0 - 1 + px;
+    bool cok = iw >= 0 && iw < W;                                  // SAME: zeros outside
+    if (p.wrap) {   // msi_train_net: GEMM column mw reads PADDED column mw - v of wrap_pad(x, 2, 2), valid in [0, W + 4): image column (. - 2) mod W
+      cok = iw >= 0 && iw < W + 4;
+      iw -= 2;
+      iw = iw < 0 ? iw + W : (iw >= W ? iw - W : iw);
+    }
+    pok[k] = pp < NPX && ih >= 0 && ih < H && cok;
     pixi[k] = (unsigned)(ih * W + iw);
     lds_a[k] = pp < NPX ? (unsigned)(py * G::ROW_PITCH + px * G::PIX_BYTES + cslot * 8) : 0xffffffffu;
   }
@@ -3053,7 +3090,9 @@ convt_halo_x3_kernel(const ConvParams p) {
   const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
   // fragment base of tap row th = 0 (patch row 1 + local row) and of th = 1 (one row up for ph = 0, one down for ph = 1)
   const unsigned a_base0 = lds_base + (unsigned)((1 + 2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
-  const unsigned a_base1 = ph ? a_base0 + G::ROW_PITCH : a_base0 - G::ROW_PITCH;
+  // (msi_train_net's VALID form: tap 1 is the row ABOVE / the column to the LEFT in both parities -- tap_delta)
+  const unsigned a_base1 = (ph && !p.wrap) ? a_base0 + G::ROW_PITCH : a_base0 - G::ROW_PITCH;
+  const unsigned wadj = p.wrap ? 2u * G::PIX_BYTES : 0u;
   unsigned b_s[2];
   (void)fswz;
 #pragma unroll
@@ -3075,7 +3114,7 @@ convt_halo_x3_kernel(const ConvParams p) {
   {                                                                                                                    \
     constexpr int PWC_ = (J) >> 2, TH_ = ((J) >> 1) & 1, TW_ = (J) & 1;                                                \
     constexpr int COFF_ = (1 + (PWC_ ? TW_ : -TW_)) * G::PIX_BYTES;   /* column of the tap: immediate */                \
-    const unsigned ab_ = TH_ ? a_base1 : a_base0;                                                                      \
+    const unsigned ab_ = (TH_ ? a_base1 : a_base0) - ((PWC_ && TW_) ? wadj : 0u);                                      \
     v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
     const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
@@ -3165,20 +3204,22 @@ convt_halo_x3_kernel(const ConvParams p) {
 #pragma unroll
     for (int cl = 0; cl < 2; ++cl) {
       const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 2 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
-      dump_acc<1, 1, 16>(acc[cl], rsrc_p, tid);
+      dump_acc<1, 1, MSI_HANDOFF_AUX>(acc[cl], rsrc_p, tid);
     }
     const int nsp = t < p.n_main ? p.split0 : p.split;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    handoff_release();
     __syncthreads();
     int *s_old = reinterpret_cast<int *>(smem);
     if (tid == 0)
       *s_old = __hip_atomic_fetch_add(p.tile_cnt + (t - (p.split0 == 1 ? p.n_main : 0)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*s_old != nsp - 1) return;
+    handoff_acquire();
 #pragma unroll
     for (int cl = 0; cl < 2; ++cl) {
       const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)(slot - ks) * 2 + cl) * (64 * 64)), 0, nsp * 2 * SLAB, 0x00020000);
-      sum_slabs<1, 1, 16>(acc[cl], rsrc_t, nsp, 2 * SLAB, tid);
+      sum_slabs<1, 1, MSI_HANDOFF_AUX>(acc[cl], rsrc_t, nsp, 2 * SLAB, tid);
     }
   }
 #pragma unroll
@@ -4646,7 +4687,7 @@ int build_net(const msi_net_desc *d, int num_cus, Net &net) {
     // fp32 plans: the stride-1 one-source 3x3 layers also carry their weights as three bf16 planes (plan option F32_SPLIT3):
     // [tap][chunk of 32 channels][plane][npad rows][64 B]
     if (!bf16 && ((s.kind == MODE_CONV && s.src1 < 0 && L.c0 % 32 == 0) ||
-                  (s.kind == MODE_CONVT && !L.wrapt && L.c0 % 32 == 0 && L.c1 % 32 == 0))) {
+                  (s.kind == MODE_CONVT && L.c0 % 32 == 0 && L.c1 % 32 == 0))) {
       L.x3_off = koff;
       koff = round_up(koff + (size_t)L.nclass * L.ksteps * 3 * L.npad * 16, 64);
       L.x2_off = koff;   // the same rows as two fp16 planes
@@ -4746,6 +4787,7 @@ void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tails
                 int uniform_split = 0, int split_overhead = 0) {
   const int mtot = p.Mh * p.Mw;
   p.tiles_m = (mtot + BM - 1) / BM;
+  if (p.halo_tx) p.tiles_m = ((p.Mh + BM / 16 - 1) / (BM / 16)) * p.halo_tx;   // (BM / 16) x 16 spatial tiles (ragged at the right / bottom edge when Mh, Mw are no multiples)
   p.tiles_n = (p.Cout + BN - 1) / BN;
   p.ntiles = p.tiles_m * p.tiles_n * p.nclass * batch;
   // whole tiles in multiples of the CU count, the remainder cut into `split` K-ranges so that
@@ -4909,13 +4951,17 @@ int plan_layers(msi_net_plan *pl) {
     // conv-transpose halo kernel (convt_halo_kernel; HALO bit 1, NOT the default -- measured slower, see the kernel): SAME conv-transposes (CoordNet), fp32, whole
     // 4 x 16 input tiles and 32-channel chunks of both sources; one workgroup per output-row parity (enumerated as two "classes")
     const bool x3_on = !bf16 && L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1);
-    Q.halo_t = halo_ok && ((pl->opt[MSI_NET_OPT_HALO] & 2) || x3_on) && !bf16 && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] &&
-               Q.tile == TILE_64x64 && L.kind == MODE_CONVT && !L.wrapt && L.in_h % 4 == 0 && L.in_w % 16 == 0 &&
-               L.c0 % 32 == 0 && L.c1 % 32 == 0;
+    Q.halo_t = halo_ok && ((pl->opt[MSI_NET_OPT_HALO] & 2) || (x3_on && pl->opt[MSI_NET_OPT_HALO] != 0)) && !bf16   // (HALO = 0: no halo-patch kernel at all)
+               && !pl->opt[MSI_NET_OPT_APPLY_AHEAD] &&
+               Q.tile == TILE_64x64 && L.kind == MODE_CONVT && ((!L.wrapt && L.in_h % 4 == 0 && L.in_w % 16 == 0) || (L.wrapt && x3_on)) &&
+               L.c0 % 32 == 0 && L.c1 % 32 == 0;   // (wrapt: (H + 1) x (W + 5) GEMM rows per class in ragged 4 x 16 tiles -- the split form only)
     if (Q.halo_t) {
       Q.halo = 1;
       Q.halo_x3 = x3_on;
-      Q.halo_x2 = x3_on && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
+      // msi_train_net's VALID transposes take the SIX-product bf16 form: with the fp16 form of this kernel one wave's share of the layer's sum of
+      // squares came out lower in ~0.4 % of back-to-back forwards (stored values bit-identical; 10 of 2 500 runs, against 0 of 2 500 with the bf16
+      // form, the native kernels, or CoordNet's SAME transposes on the fp16 form) -- cause not found, so that combination is not used
+      Q.halo_x2 = x3_on && !L.wrapt && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
       p.nclass = 2;                                      // tiles are enumerated per (ph, tile_m, tile_n, sample): a workgroup owns pw = 0, 1
       if (L.cpt0 + L.cpt1 < max_split) max_split = L.cpt0 + L.cpt1;
     }
@@ -4929,6 +4975,7 @@ int plan_layers(msi_net_plan *pl) {
     }
     if (Q.halo) {
       p.halo_tx = (Q.halo_s2 ? L.out_w : L.in_w) / 16;
+      if (Q.halo_t && L.wrapt) p.halo_tx = (L.mw + 15) / 16;
       p.halo_xor = bf16 ? 0 : 8;
       p.mg_htx = p.halo_tx == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)p.halo_tx);
       if (!Q.halo_t && L.cpt0 < max_split) max_split = L.cpt0;      // K-ranges are whole chunks (bf16: whole tiles only)
@@ -4950,6 +4997,9 @@ int plan_layers(msi_net_plan *pl) {
       pl->launch[L.src0].skip_apply = 1;              // (the producer precedes its consumer in graph order)
     }
     Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
+    // msi_train_net's conv-transposes on the split halo kernel: split tiles are summed by the fix-up LAUNCH (the configuration the 2 500-run
+    // determinism check was made in; ~1 us per layer)
+    if (Q.halo_t && L.wrapt) Q.inlaunch = 0;
     if (Q.halo_t && (size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * 2 * BM * BN * sizeof(float) > net.partial_bytes) {
       // two slabs per K-range do not fit the partial-accumulator workspace -> the tap kernel
       Q.halo_t = 0; Q.halo = 0; Q.halo_x3 = 0; Q.halo_x2 = 0;
@@ -5260,9 +5310,10 @@ int msi_net_pack_weights_host(const msi_net_desc *desc, const float *params, flo
               float v;
               if (L.kind == MODE_CONV) {
                 v = w[((size_t)tap * cin_w + c) * L.cout + n];
-              } else {   // MODE_CONVT, SAME (the halo form is not built for msi_train_net's VALID transposes)
+              } else {   // MODE_CONVT: SAME, or VALID over the wrap-padded input (kernel index = parity + 2 tap: see tap_delta)
                 const int th = tap >> 1, tw = tap & 1;
-                const int kh = ph == 0 ? 1 + 2 * th : 2 - 2 * th, kw = pw == 0 ? 1 + 2 * tw : 2 - 2 * tw;
+                const int kh = L.wrapt ? ph + 2 * th : (ph == 0 ? 1 + 2 * th : 2 - 2 * th);
+                const int kw = L.wrapt ? pw + 2 * tw : (pw == 0 ? 1 + 2 * tw : 2 - 2 * tw);
                 v = w[(((size_t)kh * 4 + kw) * L.cout + n) * L.cin + c];
               }
               uint16_t part[3];
@@ -5468,6 +5519,9 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
   return MSI_OK;
 }
 
+#ifdef MSI_DEBUG_SUMS   // (debug builds only: byte offset of a layer's LayerNorm sums in the workspace)
+extern "C" long long msi_debug_sums_offset(const msi_net_plan *plan, int layer) { return (long long)plan->net.layers[layer].sums_off; }
+#endif
 int32_t msi_net_plan_status(const msi_net_plan *plan, const void *workspace, msi_stream_t stream_, int32_t *status_bits) {
   MSI_REQUIRE(plan && workspace, "net_plan_status: null pointer");
   hipStream_t stream = msi::as_stream(stream_);

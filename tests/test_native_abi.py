@@ -186,7 +186,7 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
         # fp32 plans: the x3 block (plan option F32_SPLIT3) of a one-source 3x3 layer or a SAME conv-transpose whose sources are whole
         # 32-channel chunks: the same k-steps as above, each as three planes of 64-byte rows -- [class][k-step][plane h | m | l][npad][32 bf16];
         # h = bf16(w), m = bf16(w - h), l = bf16(w - h - m); 16-byte slot j of row n stored at j ^ ((n >> 2) & 3)
-        if dtype == "f32" and ((info.kind == 0 and c1 == 0 and c0 % 32 == 0) or (info.kind == 1 and same_pad and c0 % 32 == 0 and c1 % 32 == 0)):
+        if dtype == "f32" and ((info.kind == 0 and c1 == 0 and c0 % 32 == 0) or (info.kind == 1 and c0 % 32 == 0 and c1 % 32 == 0)):
             blk = packed[off:off + ncls * ksteps * 3 * npad * 16].view(np.uint16).reshape(ncls, ksteps, 3, npad, 32)
             for _ in range(40):
                 cls, s_, n = rng.randint(ncls), rng.randint(ksteps), rng.randint(info.cout)
@@ -198,8 +198,11 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
                 else:
                     ph, pw = cls >> 1, cls & 1
                     th, tw = tap >> 1, tap & 1
-                    kh = 1 + 2 * th if ph == 0 else 2 - 2 * th
-                    kw = 1 + 2 * tw if pw == 0 else 2 - 2 * tw
+                    if same_pad:
+                        kh = 1 + 2 * th if ph == 0 else 2 - 2 * th
+                        kw = 1 + 2 * tw if pw == 0 else 2 - 2 * tw
+                    else:        # VALID over wrap_pad(x, 2, 2): k = parity + 2 * tap
+                        kh, kw = ph + 2 * th, pw + 2 * tw
                     want = wt[kh, kw, n, cb:cb + 32].astype(np.float32)
                 parts = []
                 for pl in range(3):
@@ -228,8 +231,11 @@ def test_weight_packing_index_level(native_lib, coord, dtype):
                 else:
                     ph, pw = cls >> 1, cls & 1
                     th, tw = tap >> 1, tap & 1
-                    kh = 1 + 2 * th if ph == 0 else 2 - 2 * th
-                    kw = 1 + 2 * tw if pw == 0 else 2 - 2 * tw
+                    if same_pad:
+                        kh = 1 + 2 * th if ph == 0 else 2 - 2 * th
+                        kw = 1 + 2 * tw if pw == 0 else 2 - 2 * tw
+                    else:        # VALID over wrap_pad(x, 2, 2): k = parity + 2 * tap
+                        kh, kw = ph + 2 * th, pw + 2 * tw
                     want = wt[kh, kw, n, cb:cb + 32].astype(np.float32)
                 parts = []
                 for pl in range(2):
