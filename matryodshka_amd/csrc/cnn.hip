@@ -2942,8 +2942,14 @@ convt_halo_kernel(const ConvParams p) {
 // per CU.  The tap kernel cannot split its operands (both arrive by DMA), this one stages the patch through registers anyway:
 // with 192 instead of 512 matrix cycles per 16 channels it wins (conv8_1 197 -> ... us, see profiles/r04_*), and its sources
 // need no ln_apply launch.
+#ifndef MSI_CT_MAXW
+#define MSI_CT_MAXW 8
+#endif
+#ifndef MSI_DBG_WRAPT_F16   // (debug: msi_train_net's transposes on the fp16 form -- the open finding of DESIGN.md section 4)
+#define MSI_DBG_WRAPT_F16 0
+#endif
 template <int NP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, MSI_CT_MAXW)))
 convt_halo_x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef HaloGeomX3<1, 3, NP> G;
@@ -4961,7 +4967,7 @@ int plan_layers(msi_net_plan *pl) {
       // msi_train_net's VALID transposes take the SIX-product bf16 form: with the fp16 form of this kernel one wave's share of the layer's sum of
       // squares came out lower in ~0.4 % of back-to-back forwards (stored values bit-identical; 10 of 2 500 runs, against 0 of 2 500 with the bf16
       // form, the native kernels, or CoordNet's SAME transposes on the fp16 form) -- cause not found, so that combination is not used
-      Q.halo_x2 = x3_on && !L.wrapt && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
+      Q.halo_x2 = x3_on && (!L.wrapt || MSI_DBG_WRAPT_F16) && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
       p.nclass = 2;                                      // tiles are enumerated per (ph, tile_m, tile_n, sample): a workgroup owns pw = 0, 1
       if (L.cpt0 + L.cpt1 < max_split) max_split = L.cpt0 + L.cpt1;
     }
