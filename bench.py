@@ -633,8 +633,10 @@ def main():
         "roofline": {"kernel": "conv_halo*_kernel + conv_igemm_kernel (the 3x3 / 4x4 conv launches of one forward, %s implicit GEMM)" % ("bf16 MFMA" if bf16 else str(arithmetic)),
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": round(peak, 2),
                      "peak_note": "dense MFMA peak of the instruction each layer runs on, blended by the layers' flops (fp32 MFMA 157.3; six-product bf16 split 2500 / 6 = 416.7, three-product fp16 split 2500 / 3 = 833.3 fp32-equivalent; bf16 2500 TFLOP/s) -- all quoted at the 2.4 GHz peak clock; under the split kernels the part clocks ~1.4-1.6 GHz "
-                                  "(s_memtime ticks against wall time, tools/conv_timing.py / profiles/r04_e_conv_phase_timing.txt): the conv kernels are power-bound (DESIGN.md section 4)",
-                     "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4), "traffic": traffic,
+                                  "(s_memtime ticks against wall time, tools/conv_timing.py / profiles/r04_e_conv_phase_timing.txt): the conv kernels are power-bound (DESIGN.md section 4); a matrix-only loop with CHANGING fp16 operands sustains 1.61-1.79 PFLOP/s on this part (tools/ubench/lds_mfma_rate.hip, "
+                                  "profiles/r04_f_lds_mfma_rate.txt), i.e. 537-595 fp32-equivalent TFLOP/s for the three-product form",
+                     "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4),
+                     "frac_of_fp32_mfma_peak": None if bf16 else round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                      "traffic_stale": traffic_stale,
                      "algorithmic_bytes": conv_bytes,
                      "traffic_ratio": None if traffic is None else round(traffic / conv_bytes, 3),

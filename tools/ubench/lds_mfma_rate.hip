@@ -129,12 +129,70 @@ void run(float *d, unsigned long long *dc, int wg_per_cu, int iters) {
          mcyc, mcyc / (ms * 1e6), cmin, csum / blocks, cmax, cmax / (ms * 1e6));
 }
 
+
+// RAND: matrix-only with operand registers that CHANGE between consecutive MFMAs (eight pre-loaded sets of pseudo-random fp16 bits in [-2, 2), or
+// post-ReLU-like data: half of the values zero) -- how far does operand toggling alone pull the clock down?
+template <int KIND>
+__global__ void __launch_bounds__(256) kr(float *out, int iters, unsigned long long *cyc) {
+  const int tid = threadIdx.x;
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  f16x8 a[8], b[8];
+  unsigned s = 0x9e3779b9u * (blockIdx.x * 256 + tid + 1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s = s * 1664525u + 1013904223u; const float u = (float)(s >> 8) * (1.f / 16777216.f) * 4.f - 2.f;
+      s = s * 1664525u + 1013904223u; const float v = (float)(s >> 8) * (1.f / 16777216.f) * 4.f - 2.f;
+      a[i][j] = (_Float16)(KIND == 1 ? (u > 0.f ? u : 0.f) : u);
+      b[i][j] = (_Float16)(v * 0.05f);
+    }
+  f32x16 acc0 = {0}, acc1 = {0};
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {
+      if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[m & 7], a[(m + 3) & 7], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[m & 7], a[(m + 5) & 7], acc0, 0, 0, 0);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float r = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r += acc0[i] + acc1[i];
+  out[blockIdx.x * 256 + tid] = r;
+  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int KIND>
+void run_rand(float *d, unsigned long long *dc, int wg_per_cu, int iters) {
+  const int lds = wg_per_cu == 2 ? 65536 : wg_per_cu == 3 ? 49152 : 40960;
+  const int blocks = 256 * wg_per_cu;
+  hipFuncSetAttribute((const void *)kr<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(kr<KIND>, dim3(blocks), dim3(256), lds, 0, d, iters, dc);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(kr<KIND>, dim3(blocks), dim3(256), lds, 0, d, iters, dc);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  static unsigned long long hc[1024];
+  hipMemcpy(hc, dc, blocks * 8, hipMemcpyDeviceToHost);
+  double cmax = 0;
+  for (int i = 0; i < blocks; ++i) cmax = hc[i] > cmax ? hc[i] : cmax;
+  printf("matrix-only, %s fp16 operands changing every MFMA, wg/cu %d : %8.3f ms  ticks max %.0f = %.3f GHz  (%.0f TFLOP/s of fp16 MFMA on 256 CUs)\n",
+         KIND == 1 ? "post-ReLU-like (half zeros)" : "random                     ", wg_per_cu, ms, cmax, cmax / (ms * 1e6),
+         (double)blocks * 4 * iters * 12 * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e12);
+}
+
 int main() {
   float *d;
   unsigned long long *dc;
   hipMalloc(&d, 1024 * 256 * 4);
   hipMalloc(&dc, 1024 * 8);
   const int iters = 20000;
+  for (int w = 2; w <= 4; ++w) { run_rand<0>(d, dc, w, iters); run_rand<1>(d, dc, w, iters); }
   for (int w = 2; w <= 4; ++w) {
     run<0, 0, 12>(d, dc, w, iters);
     run<6, 0, 12>(d, dc, w, iters);
