@@ -112,3 +112,26 @@ def test_split_f16_flags_operands_beyond_the_fp16_range(env):
     m6.net_options[N.NET_OPT_F32_SPLIT_F16] = 0
     y6 = m6.run_net(x, nout, ngf)
     assert bool(torch.isfinite(y6).all())
+
+
+@pytest.mark.parametrize("coord,b,h,w,cin,nout,ngf", [(True, 1, 160, 320, 96, 32, 64), (False, 4, 128, 256, 48, 16, 64), (True, 2, 64, 128, 96, 32, 64)])
+def test_different_frames_back_to_back_equal_their_solo_runs(env, coord, b, h, w, cin, nout, ngf):
+    """Repeating ONE input cannot show a stale hand-off (a K-range slab, a ticket, a LayerNorm shard left over from the previous forward
+    holds the very values the next one would write): eight DIFFERENT inputs are queued back to back without a host sync in between and
+    every prediction must equal, bit for bit, the one the same input gives when it runs alone on an idle device."""
+    torch, MSI, nets, N, onets = env
+    weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=41, randomize_affine=True)
+    m = MSI(weights=weights, coord_net=coord)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    xs = [torch.rand((b, h, w, cin), device="cuda", generator=g) * (0.5 + 0.25 * i) - 0.3 * i for i in range(8)]
+    solo = []
+    for x in xs:
+        torch.cuda.synchronize()
+        solo.append(m.run_net(x, nout, ngf).clone())
+        torch.cuda.synchronize()
+    assert m.network_status() == 0
+    for rep in range(6):
+        queued = [m.run_net(x, nout, ngf).clone() for x in xs]          # (clone: run_net returns the model's output buffer)
+        torch.cuda.synchronize()
+        for i, (q, s) in enumerate(zip(queued, solo)):
+            assert torch.equal(q, s), (rep, i, float((q - s).abs().max()))
