@@ -146,7 +146,7 @@ struct ConvParams {
   int *ap_err;               // set to 1 if a tile workgroup gave up waiting (never in a healthy launch)
   double ap_inv_n;
   int n_apply, ap_units_per_row, ap_unit_vec, ap_row_vec;   // workgroups; units per row; float4 per unit / per row
-#ifdef MSI_CONV_TIMING
+#if defined(MSI_CONV_TIMING) || defined(MSI_DEBUG_STATS)
   unsigned long long *dbg;   // [block][6]: s_memtime at start, loop start, loop end, end; HW_ID; XCC_ID (tools/conv_timing.py)
 #endif
 };
@@ -721,6 +721,15 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
       if (RAW16 && !(s2 * raw_mul * raw_mul <= 1.0727e9f)) __hip_atomic_fetch_or(p.status, STATUS_LN_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ln_atomic_add(dst, (n * P + a) * scl_s1, p.status);
       ln_atomic_add(dst + 1, ((double)s2 + 2.0 * P * a + n * P * P) * scl_s2, p.status);
+#if defined(MSI_DEBUG_STATS)   // (debug: every wave's share, for run-to-run comparison -- tools/conv_timing.py area + 16384 * 24)
+      if (p.dbg) {
+        unsigned long long *o = p.dbg + 16384 * 24 + ((size_t)((blockIdx.x + gridDim.x * blockIdx.y) * 2 + (cls & 1)) * 4 + wave) * 4;
+        o[0] = ((unsigned long long)__builtin_bit_cast(unsigned, s2) << 32) | __builtin_bit_cast(unsigned, s1);
+        o[1] = ((unsigned long long)__builtin_bit_cast(unsigned, pivot) << 32) | __builtin_bit_cast(unsigned, wcnt);
+        o[2] = __builtin_bit_cast(unsigned long long, (n * P + a) * scl_s1);
+        o[3] = __builtin_bit_cast(unsigned long long, ((double)s2 + 2.0 * P * a + n * P * P) * scl_s2);
+      }
+#endif
     }
   }
 }
@@ -5160,7 +5169,7 @@ int launch_conv(const LayerLaunch &Q, const ConvParams &p, int bf16, hipStream_t
 
 }  // namespace
 
-#ifdef MSI_CONV_TIMING
+#if defined(MSI_CONV_TIMING) || defined(MSI_DEBUG_STATS)
 // tools/conv_timing.py: per-workgroup phase stamps of one layer's conv launch (debug builds only)
 static unsigned long long *g_timing_buf = nullptr;
 static int g_timing_layer = -1;
@@ -5689,7 +5698,7 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       p.ap_flags = reinterpret_cast<int *>(ws + S.flags_off);
       p.ap_err = reinterpret_cast<int *>(ws + net.err_off);
     }
-#ifdef MSI_CONV_TIMING
+#if defined(MSI_CONV_TIMING) || defined(MSI_DEBUG_STATS)
     p.dbg = (li == g_timing_layer) ? g_timing_buf : nullptr;
 #endif
     int rc;
