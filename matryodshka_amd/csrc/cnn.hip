@@ -1711,11 +1711,14 @@ __device__ __forceinline__ void wait_lgkm6(v4f &a, v4f &b, v4f &c, v4f &d, v4f &
 #ifndef MSI_X2_NSTG   // weight ring of the fp16 form (half the matrix work per tap: the DMA latency budget of a two-stage ring is one SHORT tap)
 #define MSI_X2_NSTG 3
 #endif
-#ifndef MSI_X2_WAVES
-#define MSI_X2_WAVES 2
+#ifndef MSI_X2_WAVES    // fp16 form at rate 1: four waves per SIMD = four workgroups per CU (40.7 KB of LDS each).  With the coordinate-bias registers requested
+#define MSI_X2_WAVES 4  // AFTER the k-loop (MSI_X2_LATE_CB: 147 -> 131 VGPRs) the allocator reaches 128 without a spill: measured 57.5 -> 54.4 us per layer
+#endif                  // (r04; forcing 128 with the bias registers held through the loop spilled 68 bytes and gained nothing)
+#ifndef MSI_X2_LATE_CB
+#define MSI_X2_LATE_CB 1
 #endif
 template <int RATE, int APPLY, int NPL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPL == 2 ? MSI_X2_WAVES : 2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL == 2 && RATE == 1) ? MSI_X2_WAVES : 2)))
 conv_halo_x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef HaloGeomX3<RATE, (NPL == 2 ? MSI_X2_NSTG : (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3))), NPL> G;
@@ -1765,7 +1768,7 @@ conv_halo_x3_kernel(const ConvParams p) {
   const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
   const int H = p.Hin, W = p.Win, C = p.C0;
   v4f cbv[4];
-  load_coord_bias(p, tile_m, tile_n, tid, cbv);           // in flight during the prologue and the k-loop
+  if (!MSI_X2_LATE_CB || NPL != 2) load_coord_bias(p, tile_m, tile_n, tid, cbv);           // in flight during the prologue and the k-loop
   // the first two weight k-steps go out before the patch addresses are worked out (they depend on tile_n and the wave only)
   const int S = p.ksteps;                                 // 9 CH
   // x3 block of the packed blob: [tap][chunk][plane h | m | l][npad rows][64 B = 32 bf16 channels], 16-byte slots swizzled by
@@ -2003,6 +2006,7 @@ conv_halo_x3_kernel(const ConvParams p) {
 #undef MSI_B_ISSUE
 #undef MSI_PATCH_STORE
 #undef MSI_PATCH_LOAD
+  if (MSI_X2_LATE_CB && NPL == 2) load_coord_bias(p, tile_m, tile_n, tid, cbv);   // (fp16 form: 16 registers less through the loop -- a fourth workgroup per CU)
   if (NPL == 2) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_fmaf(acc_lo[r], 1.f / 2048.f, acc[0][0][r]);
