@@ -362,8 +362,15 @@ __device__ __forceinline__ void ods_tail(const OdsQuad &q, float order, const Pi
   const float dzf = q.zlx ? -dz : -dx;
   dx = dxf;
   dz = dzf;
+#if MSI_FAST_TAIL && !defined(MSI_SWEEP_OLD_ANGLES)
+  // (r04: the render kernel's half-angle forms -- one square root more, two range reductions less; where disc < 0 everything
+  // here is NaN or garbage and the override below applies, as before)
+  float theta, phi;
+  t_angles(dx, q.y, dz, t_sqrt((dx * dx + dz * dz) + q.y * q.y), theta, phi);
+#else
   const float theta = -t_atan2(dz, dx);
   float phi = t_atan2(q.y, t_sqrt(dx * dx + dz * dz));
+#endif
   if (phi != phi) phi = 1.0f;
   phi = (phi <= K.half_pi) ? phi : K.half_pi;
   phi = (phi >= -K.half_pi) ? phi : -K.half_pi;
