@@ -229,7 +229,7 @@ def test_fused_head_assembly_is_bit_identical(env, coord, b, h, w, d, ngf):
 @pytest.mark.parametrize("halo_opt", [1, 3, 5, 7])
 @pytest.mark.parametrize("coord,b,h,w,cin,nout,ngf", [(True, 1, 160, 320, 96, 32, 64), (False, 2, 32, 64, 32, 8, 32),
                                                      (True, 2, 16, 48, 64, 16, 32), (True, 1, 320, 640, 192, 64, 64),
-                                                     (False, 4, 128, 256, 48, 16, 64)])
+                                                     (False, 4, 128, 256, 48, 16, 64), (False, 1, 24, 48, 32, 8, 32)])
 def test_halo_patch_kernel_matches_tap_kernel_and_oracle(env, coord, b, h, w, cin, nout, ngf, halo_opt):
     """conv_halo_kernel (plan option HALO, default on: stride-1 3x3 fp32 layers stage one LDS-stationary halo patch per
     input chunk and apply the producer's LayerNorm on the way) against the tap-DMA kernel: same products, chunk-major
