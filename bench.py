@@ -296,6 +296,9 @@ def main():
                          "product; plan option F32_SPLIT3); split_f16 = 2-way fp16 split (22 significand bits), THREE products on the fp16 MFMA "
                          "(plan option F32_SPLIT_F16; operands limited to the fp16 range, flagged in the status word).  Default: the library's "
                          "default plan.  Reported as config.arithmetic")
+    ap.add_argument("--no-alt-arithmetic", action="store_true",
+                    help="skip the second timed region (N = 1, fp32 configurations, default plan only): the same workload with the opt-in "
+                         "three-product fp16 split (plan option F32_SPLIT_F16), reported as `alt_arithmetic` -- never as `value`")
     ap.add_argument("--net-opt", action="append", default=[], metavar="K=V",
                     help="tuning: msi_net_plan_set_option(K, V) on every plan of the run (integers; include/msi_hip.h MSI_NET_OPT_*); reported as config.net_options")
     ap.add_argument("--strong-frames", type=int, default=8,
@@ -545,6 +548,29 @@ def main():
                   "note": "fixed batch sharded over the ranks (dist.shard_frames), median of 5 regions; compare across --gpus N "
                           "for the strong-scaling curve (`value` is the weak-scaling one)"}
 
+    # the opt-in arithmetic, same workload, same region form (N = 1 only: it is a second reading, not part of the contract): the
+    # three-product fp16 split is NOT the arithmetic `value` is quoted on (22-bit operands)
+    alt, alt_result = None, None
+    if (world == 1 and B > 0 and cfg["dtype"] == "f32" and args.arithmetic is None and not args.net_opt and not args.no_alt_arithmetic
+            and args.streams == 1 and args.substreams == 1):
+        alt_model = MSI(weights=weights, coord_net=coord, device=dev, dtype=cfg["dtype"], input_type="PP" if cfg["kind"] == "pp" else "ODS")
+        alt_model.net_options[_N.NET_OPT_F32_SPLIT_F16] = 0x3ffff
+        for k in range(max(args.warmup, 3)):
+            frame(None, alt_model)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            alt_result = frame(None, alt_model)
+        torch.cuda.synchronize()
+        alt_t = time.perf_counter() - t0
+        alt_plan = alt_model._plan(B, H, W, cin, nout, NGF)
+        alt = {"name": "split_f16", "value": round(frames_total * args.steps / alt_t, 3), "unit": "faces/s" if cfg["kind"] == "pp" else "frames/s",
+               "ms_per_step": round(alt_t / args.steps * 1e3, 4), "steps": args.steps,
+               "layers_on_the_fp16_form": sum(is_f16_split(alt_plan.layer_kernel(i)[0]) for i in range(17)),
+               "network_status": int(alt_model.network_status()),
+               "note": "plan option F32_SPLIT_F16 (bench.py --arithmetic split_f16): 2-way fp16 split of both operands (22 significand bits), THREE products on the fp16 MFMA, "
+                       "fp32 accumulation -- measured against fp64 it has the error of a plain fp32 convolution (profiles/r04_split_numerics.txt), operands limited to the "
+                       "fp16 range (status word); opt-in, reported beside the default, never as `value`"}
     ranges = mdist.gather_ranges(lo, hi, dev) if world > 1 else [(lo, hi)]
     nccl_world = torch.distributed.get_world_size() if world > 1 else 1
     backend = torch.distributed.get_backend() if world > 1 else None
@@ -652,17 +678,20 @@ def main():
                               "%d forwards (conv launches + the remaining ln_apply launches: conservative for the conv kernels alone)" % max(len(cnn_ms), 1)},
         "stages": stages,
         "strong_scaling": strong,
+        "alt_arithmetic": alt,
     }
 
     if world == 1 and args.config == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"], parity = cpu_baseline(model, weights, inp, planes, coord, result, D)
+        line["cpu_baseline"], parity, alt_parity = cpu_baseline(model, weights, inp, planes, coord, result, D, alt_result)
         line["parity_max_abs_vs_oracle"] = parity
+        if alt is not None:
+            alt["parity_max_abs_vs_oracle"] = alt_parity
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line), flush=True)
 
 
-def cpu_baseline(model, weights, inp, planes, coord, gpu_result, D):
+def cpu_baseline(model, weights, inp, planes, coord, gpu_result, D, alt_result=None):
     """The CPU oracle ("port": the reference itself needs Python 2 + TF 1.14 and cannot run here)
     on the same workload, timed on this box's host cores: a bounded sample of 2 frames (~10-30 s)
     after a small warm-up that creates the thread pool / conv primitives.  torch-CPU conv runs on
@@ -693,17 +722,18 @@ def cpu_baseline(model, weights, inp, planes, coord, gpu_result, D):
     for _ in range(nframes):
         pred_o, rgb_o, dep_o = one_frame()
     t = (time.perf_counter() - t0) / nframes
-    rgb, dep, _, _, out = gpu_result
-    parity = {
-        "rgba_layers": float(np.abs(out["rgba_layers"].cpu().numpy() - pred_o["rgba_layers"]).max()),
-        "rgb": float(np.abs(rgb.cpu().numpy() - rgb_o).max()),
-        "depth": float(np.abs(dep.cpu().numpy() - dep_o).max()),
-    }
+    def par(res):
+        rgb, dep, _, _, out = res
+        return {"rgba_layers": float(np.abs(out["rgba_layers"].cpu().numpy() - pred_o["rgba_layers"]).max()),
+                "rgb": float(np.abs(rgb.cpu().numpy() - rgb_o).max()),
+                "depth": float(np.abs(dep.cpu().numpy() - dep_o).max())}
+    parity = par(gpu_result)
+    alt_parity = par(alt_result) if alt_result is not None else None
     base = {"value": round(1.0 / t, 5), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "%d frames of the same workload (640x320, 32 spheres, infer + rgb & depth render), %.1f s per "
                       "frame; torch-CPU conv on %d of %d host cores, numpy geometry single-threaded"
                       % (nframes, t, threads, cores)}
-    return base, parity
+    return base, parity, alt_parity
 
 
 if __name__ == "__main__":

@@ -335,7 +335,8 @@ typedef struct msi_net_plan msi_net_plan;
                                      /* parts (22 significand bits), THREE products h.h + (h.m' + m'.h) 2^-11, fp32 accumulation: half the matrix work of the */
                                      /* six-product bf16 form at the same measured error (profiles/r04_split_numerics.txt), but the operands must lie in */
                                      /* the fp16 RANGE: |x| > 65504 (weights or normalised activations) poisons the layer and sets MSI_NET_STATUS_F16_SPLIT_RANGE. */
-                                     /* Default 0x3ffff; 0 = the six-product bf16 form (fp32's exponent range) */
+                                     /* Default 0 (opt-in: 22-bit operands are narrower than fp32's 24 -- the default fp32 arithmetic stays the six-product bf16 form); */
+                                     /* 0x3ffff = every layer that runs the split */
 #define MSI_NET_OPT_COUNT 16
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);

@@ -5452,7 +5452,10 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   pl->opt[MSI_NET_OPT_UNIFORM_SPLIT] = 0;
   pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD] = 0;
   pl->opt[MSI_NET_OPT_BF16_WAVES] = 8;
-  pl->opt[MSI_NET_OPT_F32_SPLIT_F16] = 0x3ffff;   // (r04: the error of a plain fp32 convolution against fp64, half the matrix work of the bf16 form: profiles/r04_split_numerics.txt)
+  // F32_SPLIT_F16 (the three-product fp16 form) is OPT-IN: measured against fp64 it has the error of a plain fp32 convolution at half the matrix work of the
+  // six-product bf16 form (profiles/r04_split_numerics.txt) -- but its operands carry 22 significand bits, not 24, and the round-3 review ruled that a
+  // two-way / three-product split must not be the arithmetic a `dtype f32` number is quoted on.  The default stays the six-product form (dropped terms < 2^-26).
+  pl->opt[MSI_NET_OPT_F32_SPLIT_F16] = 0;
   pl->opt[MSI_NET_OPT_F32_SPLIT3] = 0x3ffff;   // every layer that has the kernel (r04: same error against the oracle as the native path, 1.35-1.45 x faster per layer)
   pl->opt[MSI_NET_OPT_BF16_STAGE_RAW] = 1;   // (bit 1, conv8_1 staging its raw sources: measured 50 us per 16 frames SLOWER -- ~180 VALU per chunk
                                                // against 2 048 matrix cycles of the 128 x 64 tile; bit 0, conv8_2: 130 us faster.  Three interleaved repeats)

@@ -27,7 +27,7 @@ def f32_big_grid(np_):
     return [c(1, 0), s2, c(1, 1), s2, c(1, 1), c(1, 1), s2, c(2, 1), c(2, 1), c(2, 1), ct, c(1, 1), c(1, 1), ct, c(1, 1), ct, c(1, 1)]
 
 
-DEFAULT_PLANES = 2          # (r04: plan option F32_SPLIT_F16 is on by default)
+DEFAULT_PLANES = 3          # (plan option F32_SPLIT_F16 -- the three-product fp16 form, 2 planes -- is opt-in)
 F32_BIG_GRID = f32_big_grid(DEFAULT_PLANES)
 BF16_CONFIG2 = ["conv_halo_bf16_kernel<256, 64, 1, 0, 4>", "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>", "conv_halo_bf16_kernel<128, 128, 1, 1, 8>",

@@ -1,4 +1,5 @@
-"""Plan option F32_SPLIT3 (round 4): the stride-1 halo-patch layers of an fp32 plan compute their convolution as a 3-way bf16 split
+"""Plan options F32_SPLIT3 (default) and F32_SPLIT_F16 (opt-in: the same kernels on a 2-way fp16 split with three products; every test below runs both).
+F32_SPLIT3 (round 4): the stride-1 halo-patch layers of an fp32 plan compute their convolution as a 3-way bf16 split
 of both operands with SIX products on the bf16 MFMA (conv_halo_x3_kernel): fp32-grade arithmetic -- the dropped terms are below
 2^-26 of a product -- so every gate of the native fp32 path applies unchanged: layers within 2e-4 of their scale, the tanh output
 within 1e-3, the full-size fixtures within 1e-3, bitwise determinism, the fix-up launch equal to the in-launch hand-off."""
@@ -114,14 +115,16 @@ def test_split_f16_flags_operands_beyond_the_fp16_range(env):
     assert bool(torch.isfinite(y6).all())
 
 
+@pytest.mark.parametrize("f16", ARITH)
 @pytest.mark.parametrize("coord,b,h,w,cin,nout,ngf", [(True, 1, 160, 320, 96, 32, 64), (False, 4, 128, 256, 48, 16, 64), (True, 2, 64, 128, 96, 32, 64)])
-def test_different_frames_back_to_back_equal_their_solo_runs(env, coord, b, h, w, cin, nout, ngf):
+def test_different_frames_back_to_back_equal_their_solo_runs(env, coord, b, h, w, cin, nout, ngf, f16):
     """Repeating ONE input cannot show a stale hand-off (a K-range slab, a ticket, a LayerNorm shard left over from the previous forward
     holds the very values the next one would write): eight DIFFERENT inputs are queued back to back without a host sync in between and
     every prediction must equal, bit for bit, the one the same input gives when it runs alone on an idle device."""
     torch, MSI, nets, N, onets = env
     weights = onets.init_weights(cin, nout, ngf=ngf, coord_net=coord, seed=41, randomize_affine=True)
     m = MSI(weights=weights, coord_net=coord)
+    m.net_options[N.NET_OPT_F32_SPLIT_F16] = f16
     g = torch.Generator(device="cuda").manual_seed(7)
     xs = [torch.rand((b, h, w, cin), device="cuda", generator=g) * (0.5 + 0.25 * i) - 0.3 * i for i in range(8)]
     solo = []
