@@ -318,7 +318,11 @@ typedef struct msi_net_plan msi_net_plan;
                                    /* convt_halo_kernel (the two classes of one output-row parity per workgroup, either source's       */
                                    /* LayerNorm applied while staging); bit 2: the fp32 stride-2 3x3 layers run conv_halo_s2_kernel    */
                                    /* (four parity-plane patches per 32-channel group, the producer's LayerNorm applied while staging);*/
-                                   /* 0: tap-DMA kernel everywhere                                                                     */
+                                   /* 0: tap-DMA kernel everywhere.  With F32_SPLIT3 on for a layer (the default) ANY non-zero HALO    */
+                                   /* value lets that layer take its split halo kernel: the conv-transposes run convt_halo_x3_kernel    */
+                                   /* without bit 1 and the stride-2 layers conv_halo_s2_x3_kernel whatever their grid size (the native */
+                                   /* stride-2 form is only chosen at >= 3 tiles per CU); set F32_SPLIT3 = 0 to get the bit-by-bit      */
+                                   /* selection described above                                                                         */
 #define MSI_NET_OPT_HALO_SKIP 9     /* bit i = layer i (graph order) does NOT take a halo kernel although it qualifies (tuning)          */
 #define MSI_NET_OPT_UNIFORM_SPLIT 10 /* s >= 2: layers with one to two 64x64 tiles per CU cut EVERY tile into s equal K-ranges (tuning; 0 = default split) */
 #define MSI_NET_OPT_BF16_STAGE_RAW 11 /* bf16 plans: bit 0 the 256x64 conv tile (conv8_2), bit 1 the 128x64 conv-transpose tile (conv8_1) read their  */
@@ -327,7 +331,8 @@ typedef struct msi_net_plan msi_net_plan;
 #define MSI_NET_OPT_BF16_WAVES 13 /* waves per workgroup of the bf16 halo-patch conv kernel's 128x128 tile: 8 (default; 4 x 2 waves of 32 pixels x 64 channels: */
                                   /* four waves per SIMD with two workgroups per CU, so that a workgroup's prologue / epilogue has neighbours to hide behind) */
                                   /* or 4 (r02 shape).  The 256x64 tile always runs four (eight measured slower) */
-#define MSI_NET_OPT_F32_SPLIT3 14 /* fp32 plans, bit i = layer i (graph order): a stride-1 halo-patch 3x3 layer computes its fp32 convolution as a 3-way */
+#define MSI_NET_OPT_F32_SPLIT3 14 /* fp32 plans, bit i = layer i (graph order): a 3x3 layer (stride 1 or 2, rate 1 or 2) or conv-transpose (SAME, or msi_train_net's */
+                                  /* wrap_pad + VALID form) that qualifies for a halo-patch kernel (MSI_NET_OPT_HALO != 0) computes its fp32 convolution as a 3-way */
                                   /* bf16 split of both operands with SIX products (h.h, h.m, m.h, h.l, l.h, m.m; exact products, fp32 accumulation; */
                                   /* dropped terms <= 2^-26 of a product: fp32-grade, NOT the 3-product TF32-grade split) on the 16x faster bf16 MFMA */
                                   /* (conv_halo_x3_kernel).  Default 0x3ffff (every layer that qualifies); 0 = native fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere */
@@ -335,8 +340,12 @@ typedef struct msi_net_plan msi_net_plan;
                                      /* parts (22 significand bits), THREE products h.h + (h.m' + m'.h) 2^-11, fp32 accumulation: half the matrix work of the */
                                      /* six-product bf16 form at the same measured error (profiles/r04_split_numerics.txt), but the operands must lie in */
                                      /* the fp16 RANGE: |x| > 65504 (weights or normalised activations) poisons the layer and sets MSI_NET_STATUS_F16_SPLIT_RANGE. */
+                                     /* The 22 bits hold for |x| >= 2^-14 only: below that h, and below 2^-25 m' too, are fp16 subnormals (absolute resolution 2^-24 and */
+                                     /* 2^-35) -- LayerNorm'd activations and slim-initialised weights sit far above; nothing flags an operand that small.  NaN operands */
+                                     /* set the status bit like |x| > 65504. */
                                      /* Default 0 (opt-in: 22-bit operands are narrower than fp32's 24 -- the default fp32 arithmetic stays the six-product bf16 form); */
-                                     /* 0x3ffff = every layer that runs the split */
+                                     /* 0x3ffff = every layer that runs the split, msi_train_net's conv-transposes included (until r05 those ignored the bit: the r04 */
+                                     /* finding that kept them on the bf16 form is closed, DESIGN.md section 4 "the wobble") */
 #define MSI_NET_OPT_COUNT 16
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);

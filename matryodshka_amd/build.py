@@ -15,10 +15,14 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
           "-Wall", "-Wno-unused-function"]
 # (source, extra flags).  geometry.hip must not contract a*b+c into fma: see its header.
+# -fno-slp-vectorize (r05): the SLP vectorizer packs scalar fp32 code into v_pk_*_f32 with cross-half operand selects; one such instruction of the
+# conv epilogue was the source of a rare wrong LayerNorm statistic (matryodshka_amd/isa_lint.py, DESIGN.md section 4 "the wobble").  Packed math
+# that pays is written by hand as two-float vectors; the lint below refuses a library that contains the operand routing again.
+NO_SLP = ["-fno-slp-vectorize"]
 SOURCES = [
     ("common.cpp", ["-x", "hip"]),
-    ("geometry.hip", ["-ffp-contract=off"] + os.environ.get("MSI_GEO_DEFINES", "").split()),   # e.g. MSI_GEO_DEFINES="-DMSI_SWEEP_WAVES=5" (tuning)
-    ("cnn.hip", os.environ.get("MSI_CNN_DEFINES", "").split()),   # e.g. MSI_CNN_DEFINES="-DMSI_NSTAGE=2" (tuning)
+    ("geometry.hip", ["-ffp-contract=off"] + NO_SLP + os.environ.get("MSI_GEO_DEFINES", "").split()),   # e.g. MSI_GEO_DEFINES="-DMSI_SWEEP_WAVES=5" (tuning)
+    ("cnn.hip", NO_SLP + os.environ.get("MSI_CNN_DEFINES", "").split()),   # e.g. MSI_CNN_DEFINES="-DMSI_NSTAGE=2" (tuning)
 ]
 
 
@@ -57,6 +61,13 @@ def build(force=False, verbose=True):
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        if not os.environ.get("MSI_SKIP_ISA_LINT"):
+            from matryodshka_amd import isa_lint
+            bad = isa_lint.lint(LIB, verbose=verbose)
+            if bad:
+                os.replace(LIB, LIB + ".rejected")
+                raise RuntimeError("isa_lint: %d packed-fp32 instructions route a HIGH register half to the LOW lane (first: %s in %s); see matryodshka_amd/isa_lint.py"
+                                   % (len(bad), bad[0][1], bad[0][0]))
     return LIB
 
 

@@ -1699,6 +1699,15 @@ struct HaloGeomX3 {
   static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
   static constexpr int NLOAD = (NPX * 8 + 255) / 256;
 };
+// fp16-split range tracking (NPL / NP == 2): the largest operand magnitude a lane stored, as the BIT PATTERN of |x| in an unsigned max -- for sign-cleared floats integer
+// order is float order, and every NaN pattern lies above +inf, so a NaN operand trips the check as |x| > 65504 does (fmaxf drops NaNs: ADVICE r04)
+__device__ __forceinline__ void f16_range_track(unsigned &amax, v4f y) {
+  const unsigned a = __builtin_bit_cast(unsigned, y.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, y.y) & 0x7fffffffu;
+  const unsigned c = __builtin_bit_cast(unsigned, y.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, y.w) & 0x7fffffffu;
+  amax = max(max(amax, a), max(b, max(c, d)));
+}
+constexpr unsigned F16_MAX_BITS = 0x477fe000u;   // 65504.0f
+
 template <int N>
 __device__ __forceinline__ void wait_lgkm4(v4f &a, v4f &b, v4f &c, v4f &d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
@@ -1815,7 +1824,7 @@ conv_halo_x3_kernel(const ConvParams p) {
     has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
   }
   v4f araw[NLOAD], g4, be4;
-  float amax_ = 0.f;   // (NPL == 2: the largest operand magnitude this lane stored -- the fp16 range check)
+  unsigned amax_ = 0u;   // (NPL == 2: the largest operand magnitude this lane stored -- the fp16 range check, f16_range_track)
   // patch of chunk c -> registers (+ gamma / beta of the lane's channels)
 #define MSI_PATCH_LOAD(c)                                                                                              \
   {                                                                                                                    \
@@ -1844,7 +1853,7 @@ conv_halo_x3_kernel(const ConvParams p) {
       if (NPL == 2) {   /* y = h + m' 2^-11, fp16 parts (round to nearest even; y - h is exact in fp32) */                 \
         typedef _Float16 h2_t __attribute__((ext_vector_type(2)));                                                     \
         typedef unsigned u2x_t __attribute__((ext_vector_type(2)));                                                    \
-        amax_ = __builtin_fmaxf(amax_, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(y.x), __builtin_fabsf(y.y)), __builtin_fmaxf(__builtin_fabsf(y.z), __builtin_fabsf(y.w)))); \
+        f16_range_track(amax_, y);                                                                                       \
         const h2_t ha = {(_Float16)y.x, (_Float16)y.y}, hb = {(_Float16)y.z, (_Float16)y.w};                          \
         const h2_t ma = {(_Float16)((y.x - (float)ha.x) * 2048.f), (_Float16)((y.y - (float)ha.y) * 2048.f)};          \
         const h2_t mb = {(_Float16)((y.z - (float)hb.x) * 2048.f), (_Float16)((y.w - (float)hb.y) * 2048.f)};          \
@@ -2011,7 +2020,7 @@ conv_halo_x3_kernel(const ConvParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_fmaf(acc_lo[r], 1.f / 2048.f, acc[0][0][r]);
     // an operand beyond the fp16 range became inf (h) and NaN (m'): the layer's output is garbage -- say so
-    if (__builtin_amdgcn_ballot_w64(!(amax_ <= 65504.f)) != 0 && lane == 0) atomicOr(p.status, STATUS_F16_SPLIT_RANGE);
+    if (__builtin_amdgcn_ballot_w64(amax_ > F16_MAX_BITS) != 0 && lane == 0) atomicOr(p.status, STATUS_F16_SPLIT_RANGE);
   }
 
   // ---- epilogue: as conv_igemm_kernel ----
@@ -2331,11 +2340,11 @@ conv_halo_s2_kernel(const ConvParams p) {
 
 // ---- shared pieces of the split kernels' stride-2 / conv-transpose forms (NP = 3: bf16 h | m | l, six products; NP = 2: fp16 h | m', three) ----
 template <int NP>
-__device__ __forceinline__ void split_store(char *smem, unsigned off, v4f y, float &amax) {
+__device__ __forceinline__ void split_store(char *smem, unsigned off, v4f y, unsigned &amax) {
   typedef unsigned u2x_t __attribute__((ext_vector_type(2)));
   if (NP == 2) {   // y = h + m' 2^-11, fp16 parts (round to nearest even; y - h is exact in fp32)
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(y.x), __builtin_fabsf(y.y)), __builtin_fmaxf(__builtin_fabsf(y.z), __builtin_fabsf(y.w))));
+    f16_range_track(amax, y);
     const h2_t ha = {(_Float16)y.x, (_Float16)y.y}, hb = {(_Float16)y.z, (_Float16)y.w};
     const h2_t ma = {(_Float16)((y.x - (float)ha.x) * 2048.f), (_Float16)((y.y - (float)ha.y) * 2048.f)};
     const h2_t mb = {(_Float16)((y.z - (float)hb.x) * 2048.f), (_Float16)((y.w - (float)hb.y) * 2048.f)};
@@ -2382,11 +2391,11 @@ __device__ __forceinline__ void split_mfma(f32x16 &acc, f32x16 &lo, const v4f &a
 }
 // NP = 2, after the k-loop: acc += lo 2^-11; an operand beyond the fp16 range (h = inf, m' = NaN) is reported
 template <int NP>
-__device__ __forceinline__ void split_finish(f32x16 &acc, const f32x16 &lo, float amax, int lane, int *status) {
+__device__ __forceinline__ void split_finish(f32x16 &acc, const f32x16 &lo, unsigned amax, int lane, int *status) {
   if (NP == 2) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(lo[r], 1.f / 2048.f, acc[r]);
-    if (__builtin_amdgcn_ballot_w64(!(amax <= 65504.f)) != 0 && lane == 0) atomicOr(status, STATUS_F16_SPLIT_RANGE);
+    if (__builtin_amdgcn_ballot_w64(amax > F16_MAX_BITS) != 0 && lane == 0) atomicOr(status, STATUS_F16_SPLIT_RANGE);
   }
 }
 
@@ -2475,7 +2484,7 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
   const size_t in_bytes = (size_t)H * W * C * 4;
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x0 + (size_t)b * in_bytes), 0, (int)in_bytes, 0x00020000);
   v4f araw[NLOAD], g4, be4;
-  float amax_ = 0.f;
+  unsigned amax_ = 0u;
   // (unit 0 first and its patch of group c0 requested at once: the other units' offsets are worked out under that round trip)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -2958,9 +2967,6 @@ convt_halo_kernel(const ConvParams p) {
 #ifndef MSI_CT_MAXW
 #define MSI_CT_MAXW 8
 #endif
-#ifndef MSI_DBG_WRAPT_F16   // (debug: msi_train_net's transposes on the fp16 form -- the open finding of DESIGN.md section 4)
-#define MSI_DBG_WRAPT_F16 0
-#endif
 template <int NP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, MSI_CT_MAXW)))
 convt_halo_x3_kernel(const ConvParams p) {
@@ -3058,7 +3064,7 @@ convt_halo_x3_kernel(const ConvParams p) {
     has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
   }
   v4f araw[NLOAD], g4, be4;
-  float amax_ = 0.f;
+  unsigned amax_ = 0u;
   int src_ld = 0;                                         // source of the patch held in araw
   // patch of chunk c -> registers (+ gamma / beta of the lane's channels when that source is raw)
 #define MSI_PATCH_LOAD(c)                                                                                              \
@@ -4977,10 +4983,11 @@ int plan_layers(msi_net_plan *pl) {
     if (Q.halo_t) {
       Q.halo = 1;
       Q.halo_x3 = x3_on;
-      // msi_train_net's VALID transposes take the SIX-product bf16 form: with the fp16 form of this kernel one wave's share of the layer's sum of
-      // squares came out lower in ~0.4 % of back-to-back forwards (stored values bit-identical; 10 of 2 500 runs, against 0 of 2 500 with the bf16
-      // form, the native kernels, or CoordNet's SAME transposes on the fp16 form) -- cause not found, so that combination is not used
-      Q.halo_x2 = x3_on && (!L.wrapt || MSI_DBG_WRAPT_F16) && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
+      // (r04 kept msi_train_net's VALID transposes off the fp16 form: one wave's share of the layer's sum of squares came out low in ~0.1 % of
+      // back-to-back forwards.  r05 found the instruction: a compiler-made `v_pk_mul_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]` of the generic
+      // epilogue's statistics -- low lane = a.lo * b.HI -- evaluated to 0 for lanes 48-63; this file is now built with -fno-slp-vectorize, which
+      // is what forms that operand routing, and matryodshka_amd/build.py refuses a library that contains it.  DESIGN.md section 4, "the wobble".)
+      Q.halo_x2 = x3_on && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
       p.nclass = 2;                                      // tiles are enumerated per (ph, tile_m, tile_n, sample): a workgroup owns pw = 0, 1
       if (L.cpt0 + L.cpt1 < max_split) max_split = L.cpt0 + L.cpt1;
     }
@@ -5016,9 +5023,6 @@ int plan_layers(msi_net_plan *pl) {
       pl->launch[L.src0].skip_apply = 1;              // (the producer precedes its consumer in graph order)
     }
     Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
-    // msi_train_net's conv-transposes on the split halo kernel: split tiles are summed by the fix-up LAUNCH (the configuration the 2 500-run
-    // determinism check was made in; ~1 us per layer)
-    if (Q.halo_t && L.wrapt) Q.inlaunch = 0;
     if (Q.halo_t && (size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * 2 * BM * BN * sizeof(float) > net.partial_bytes) {
       // two slabs per K-range do not fit the partial-accumulator workspace -> the tap kernel
       Q.halo_t = 0; Q.halo = 0; Q.halo_x3 = 0; Q.halo_x2 = 0;
@@ -5543,6 +5547,7 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
 
 #ifdef MSI_DEBUG_SUMS   // (debug builds only: byte offset of a layer's LayerNorm sums in the workspace)
 extern "C" long long msi_debug_sums_offset(const msi_net_plan *plan, int layer) { return (long long)plan->net.layers[layer].sums_off; }
+extern "C" long long msi_debug_partial_offset(const msi_net_plan *plan) { return (long long)plan->net.partial_off; }
 #endif
 int32_t msi_net_plan_status(const msi_net_plan *plan, const void *workspace, msi_stream_t stream_, int32_t *status_bits) {
   MSI_REQUIRE(plan && workspace, "net_plan_status: null pointer");

@@ -177,8 +177,12 @@ __device__ __forceinline__ float t_atan2(float y, float x) {
 //               = copysign(pi, z) - 2 atan(z / (h - x))  for x < 0   (both arguments in [-1, 1])
 // -- no min / max / swap range reduction, no quadrant fix-ups, one shared square root: ~14 instead of ~30 instructions
 // per angle in the render kernel, which is bound by its VALU stream.  Same 1.3e-7 rad polynomial (doubled: 2.6e-7 rad =
-// 3e-5 px at W = 640); atan2(+-0, +-0) = +-0 like libm's for (+0, +0).  Render kernel only: its chain has no data-dependent
-// reference branch and its inputs are finite (no NaN propagation needed).
+// 3e-5 px at W = 640); atan2(+-0, +-0) = +-0 like libm's for (+0, +0).  Used by the render kernel (no data-dependent reference
+// branch in its chain, finite inputs) and, since r04, by the sweep's continuous tail (ods_tail): there the angles feed floor() of
+// the pixel coordinates, so a sample within 3e-5 px of an integer may take the neighbouring tap pair -- with weights (1 - eps, eps)
+// against (eps', 1 - eps') on the same two texels, i.e. the bilinear value moves by <= 3e-5 of a texel difference (the resample is
+// continuous across tap boundaries); the reference's branch-deciding values (disc, |z| > |x|, sign(pz)) are computed before this,
+// IEEE op for op.  NaN inputs (disc < 0 pixels) produce NaN / garbage angles that ods_tail overrides as the reference does.
 __device__ __forceinline__ float t_atan_unit(float a) {
   const float s = a * a;
   float p = -0.0040545277297496796f;
@@ -923,7 +927,8 @@ render_kernel(const float4 *__restrict__ rgba, const float *__restrict__ pose_rt
   // the ray origin of this sample is not inside every sphere it was intersected with: outside the reference's domain
   // (spherical.py:316-318 takes the square root of a negative number there); the clamp above kept the pixels finite, the
   // status word says so (one lane per wave; the origin is a property of the sample, so all lanes agree)
-  if (status != nullptr && threadIdx.x == 0 && !(qc_max < 0.0f)) atomicOr(status, MSI_RENDER_STATUS_ORIGIN_OUTSIDE);
+  // (fmaxf drops NaNs: a NaN pose / target position makes cc NaN and leaves qc_max at -1 -- tested separately)
+  if (status != nullptr && threadIdx.x == 0 && (!(qc_max < 0.0f) || cc != cc)) atomicOr(status, MSI_RENDER_STATUS_ORIGIN_OUTSIDE);
   if (MODE & RENDER_LAYERS) return;            // (nothing to combine)
   s_part[seg][threadIdx.x][0] = o0; s_part[seg][threadIdx.x][1] = o1; s_part[seg][threadIdx.x][2] = o2;
   s_part[seg][threadIdx.x][3] = od; s_part[seg][threadIdx.x][4] = tr;

@@ -109,13 +109,22 @@ def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_o
     pos = np.asarray(tgt_pos, dtype=np.float32)[None]
     outs, net_input = model.infer_msi(src, ref, None, None, eye, eye, intr, which_color_pred, num_planes, planes,
                                       extra_outputs="blend_weights alphas psv", ngf=ngf)
-    model.network_status()           # (after EVERY forward: the status word is reset by the next one -- ADVICE r03)
+    # (after EVERY forward: the status word is reset by the next one -- ADVICE r03.  A flagged forward does not stop the sample: its
+    # files are written first and the error is raised at the end, so that main()'s "flag and continue" finds them on disk -- ADVICE r04)
+    from ._native import MsiError
+    deferred = []
+    def check_status():
+        try:
+            model.network_status()
+        except MsiError as e:
+            deferred.append(e)
+    check_status()
     jouts = None
     if jitter_pose is not None:      # test.py:141-147: second inference with the sweep rotated by jitter_pose^-1
         jinv = np.linalg.inv(np.asarray(jitter_pose, dtype=np.float64)).astype(np.float32)
         jouts, _ = model.infer_msi(src, ref, None, None, eye, eye, intr, which_color_pred, num_planes, planes,
                                    extra_outputs="blend_weights alphas psv", ngf=ngf, jitter_pose_inv=jinv)
-        model.network_status()
+        check_status()
     os.makedirs(output_dir, exist_ok=True)
     if "tgt_image" in test_outputs:
         rgb, dep = model.msi_render_equirect_view_and_depth(outs["rgba_layers"], eye, pos, planes, intr)
@@ -143,6 +152,8 @@ def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_o
             write_image(os.path.join(output_dir, "output_ptgt%d_%s.png" % (vw, dirname)),
                         model.deprocess_image(o)[0].cpu().numpy())
     write_layer_outputs(outs, jouts, src, ref, num_planes, test_outputs, output_dir, dirname, which_color_pred)
+    if deferred:
+        raise deferred[0]
     return outs
 
 
@@ -314,6 +325,7 @@ def main(argv=None):
                     raise
                 failed.append(dirname)
                 print("WARNING: sample %s is outside the range the kernels resolve: %s" % (dirname, e))
+                os.makedirs(out_dir, exist_ok=True)   # (a ValueError of the host-side domain guard can precede the first file)
                 with open(os.path.join(out_dir, "UNRELIABLE.txt"), "w") as f:
                     f.write(str(e) + "\n")
             n += 1

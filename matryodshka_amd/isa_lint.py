@@ -1,0 +1,89 @@
+"""ISA lint of the built library (run by matryodshka_amd.build after linking; `python -m matryodshka_amd.isa_lint [lib]`).
+
+Round 5 traced a rare wrong LayerNorm statistic (one wave's sum of squares low in ~0.1 % of forwards, stored values
+bit-identical) to ONE compiler-generated instruction of the generic conv epilogue:
+
+    v_pk_mul_f32 v[46:47], v[18:19], v[50:51] op_sel:[0,1] op_sel_hi:[1,0]      ; low lane = v18 * v51 (the HIGH half of src1)
+
+whose low product came out 0 for lanes 48-63 in the first-resident workgroups of a launch ("the
+wobble"; tools/asmpatch, tools/wobble_hunt.py: replacing that one instruction by an unpacked v_mul_f32, or by the same
+packed multiply without the cross-half operand select, gave 0 events in 10 000 forwards against 10-18 per 6 000-10 000).
+The SLP vectorizer is what forms such operand routing from scalar code; the kernels are built with -fno-slp-vectorize and
+this lint REFUSES a library in which any packed-fp32 VALU instruction takes the HIGH half of a register pair for its LOW
+lane (`op_sel:[...]` with a 1) -- the hand-written two-float code only ever broadcasts a low half (`op_sel_hi`)."""
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+FORBIDDEN = re.compile(r"^\s*(v_pk_(?:mul|add|fma)_f32|v_pk_mov_b32)\b.*\bop_sel:\[[01,]*1[01,]*\]")
+
+
+def _fatbin_section(path):
+    data = open(path, "rb").read()
+    assert data[:4] == b"\x7fELF" and data[4] == 2, "64-bit ELF expected"
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    def sh(i):
+        name, typ, flags, addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, strsize = sh(shstrndx)
+    for i in range(shnum):
+        name, off, size = sh(i)
+        end = data.index(b"\0", stroff + name)
+        if data[stroff + name:end] == b".hip_fatbin":
+            return data[off:off + size]
+    raise RuntimeError("no .hip_fatbin section in " + path)
+
+
+def code_objects(path):
+    """[(triple, bytes)] of every device code object embedded in the shared library."""
+    sec = _fatbin_section(path)
+    out = []
+    pos = sec.find(MAGIC)
+    while pos >= 0:
+        n, = struct.unpack_from("<Q", sec, pos + len(MAGIC))
+        p = pos + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", sec, p)
+            triple = sec[p + 24:p + 24 + tlen].decode()
+            p += 24 + tlen
+            if "amdgcn" in triple and size:
+                out.append((triple, sec[pos + off:pos + off + size]))
+        pos = sec.find(MAGIC, pos + len(MAGIC))
+    return out
+
+
+def lint(path, verbose=False):
+    """Returns the list of offending (kernel, instruction) pairs; empty = clean."""
+    bad = []
+    ninst = 0
+    for triple, blob in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".hsaco") as f:
+            f.write(blob); f.flush()
+            txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], check=True, stdout=subprocess.PIPE).stdout.decode()
+        kernel = "?"
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+            if m:
+                kernel = m.group(1); continue
+            ins = line.split("//")[0]
+            if "v_pk_" in ins:
+                ninst += 1
+                if FORBIDDEN.match(ins):
+                    bad.append((kernel, ins.strip()))
+    if verbose:
+        print("[isa_lint] %s: %d packed VALU instructions checked, %d with a high-half -> low-lane operand select" % (os.path.basename(path), ninst, len(bad)))
+    return bad
+
+
+if __name__ == "__main__":
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmsi_hip.so")
+    found = lint(lib, verbose=True)
+    for k, i in found[:20]:
+        print("  %s: %s" % (k, i))
+    sys.exit(1 if found else 0)

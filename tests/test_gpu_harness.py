@@ -332,3 +332,42 @@ def test_harness_at_baseline_config0_size_equals_the_oracle(tmp_path, coord):
     e_bw, e_al = np.abs(bw - pred["blend_weights"]).max(), np.abs(al - pred["alphas"]).max()
     print("configs[0] size, coord=%s: blend_weights %.2e alphas %.2e" % (coord, e_bw, e_al))
     assert e_bw <= 1e-3 and e_al <= 1e-3
+
+
+def test_harness_flags_unreliable_samples_and_continues(tmp_path):
+    """a forward whose LayerNorm statistics leave the fixed-point window (here: a NaN weight -> MSI_NET_STATUS_LN_OVERFLOW) and a
+    target position outside the innermost sphere must NOT abort the run: every sample's files are written, the flagged ones carry UNRELIABLE.txt,
+    the remaining samples are processed; --strict aborts at the first."""
+    from PIL import Image
+    from matryodshka_amd import harness, nets
+    from matryodshka_amd._native import MsiError
+    h, w, d, ngf = 16, 32, 4, 8
+    img_dir = tmp_path / "images"; img_dir.mkdir()
+    rng = np.random.RandomState(0)
+    for name in ("000", "001", "002", "003"):
+        arr = np.clip(rng.uniform(0, 255, size=(2 * h, 2 * w, 3)), 0, 255).astype(np.uint8)
+        Image.fromarray(arr).save(str(img_dir / ("room_0_pos%s.jpeg" % name)), quality=95)
+    cam = tmp_path / "cams.txt"
+    # second sample: target 2.5 units from the origin with the innermost sphere at radius 1 (spherical.py:316-318 takes sqrt of a negative number there)
+    cam.write_text("room_0 000 001 002 0.032 0.01 -0.02 0.03\nroom_0 000 001 003 0.032 2.5 0.0 0.0\n")
+    weights = nets.init_weights(6 * d, 2 * d, ngf, False)
+    good = tmp_path / "good.npz"; np.savez(str(good), **weights)
+    bad_w = {k: v.copy() for k, v in weights.items()}
+    bad_w["conv3_1/weights"][0, 0, 0, 0] = np.nan
+    bad = tmp_path / "bad.npz"; np.savez(str(bad), **bad_w)
+    common = ["--cameras_glob", str(cam), "--image_dir", str(img_dir), "--height", str(h), "--width", str(w), "--num_msi_planes", str(d),
+              "--num_psv_planes", str(d), "--ngf", str(ngf), "--test_outputs", "tgt_image_blend_weights_alphas"]
+    # (a) healthy weights: sample 1 clean, sample 2 flagged by the domain guard; both directories exist, the run goes on
+    n = harness.main(common + ["--output_root", str(tmp_path / "o1"), "--experiment_name", "e", "--weights", str(good)])
+    assert n == 2
+    s1, s2 = tmp_path / "o1" / "e" / "room_0_000001002", tmp_path / "o1" / "e" / "room_0_000001003"
+    assert (s1 / "output_tgt_room_0_000001002.png").exists() and not (s1 / "UNRELIABLE.txt").exists()
+    assert (s2 / "UNRELIABLE.txt").exists() and "innermost sphere" in (s2 / "UNRELIABLE.txt").read_text()
+    # (b) a NaN weight: the status word fires on every forward; the files are written all the same and flagged
+    n = harness.main(common + ["--output_root", str(tmp_path / "o2"), "--experiment_name", "e", "--weights", str(bad)])
+    assert n == 2
+    t1 = tmp_path / "o2" / "e" / "room_0_000001002"
+    assert (t1 / "UNRELIABLE.txt").exists() and (t1 / "output_tgt_room_0_000001002.png").exists() and (t1 / "blend_weights.npy").exists()
+    # (c) --strict: the first flagged sample aborts
+    with pytest.raises((MsiError, ValueError)):
+        harness.main(common + ["--output_root", str(tmp_path / "o3"), "--experiment_name", "e", "--weights", str(bad), "--strict"])

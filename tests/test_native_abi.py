@@ -25,6 +25,20 @@ def test_every_header_symbol_is_exported(native_lib):
     assert native_lib.lib.msi_version().startswith(b"msi_hip")
 
 
+def test_library_has_no_high_half_to_low_lane_packed_operand(native_lib):
+    """matryodshka_amd/isa_lint.py (r05, DESIGN.md section 4 "the wobble"): no packed-fp32 VALU instruction of the linked library routes the HIGH
+    half of a register pair to its LOW lane -- the compiler-made form whose low product came out 0 for 16 lanes in ~0.1 % of forwards.  The lint
+    must also recognise the form (checked on the instruction that failed, as llvm-objdump prints it)."""
+    from matryodshka_amd import isa_lint
+    assert isa_lint.FORBIDDEN.match("\tv_pk_mul_f32 v[46:47], v[18:19], v[50:51] op_sel:[0,1] op_sel_hi:[1,0]")
+    assert isa_lint.FORBIDDEN.match("\tv_pk_add_f32 v[18:19], v[46:47], v[18:19] op_sel:[1,0] op_sel_hi:[0,1]")
+    assert not isa_lint.FORBIDDEN.match("\tv_pk_add_f32 v[24:25], v[14:15], s[50:51] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")
+    assert not isa_lint.FORBIDDEN.match("\tv_pk_fma_f32 v[16:17], v[80:81], s[4:5], v[64:65] op_sel_hi:[1,0,1]")
+    objs = isa_lint.code_objects(native_lib.LIB_PATH)
+    assert len(objs) >= 2 and all("gfx950" in t for t, _ in objs), [t for t, _ in objs]
+    assert isa_lint.lint(native_lib.LIB_PATH) == []
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under matryodshka_amd/ or include/ may mention it."""
     for base in ("matryodshka_amd", "include"):
