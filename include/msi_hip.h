@@ -346,7 +346,12 @@ typedef struct msi_net_plan msi_net_plan;
                                      /* Default 0 (opt-in: 22-bit operands are narrower than fp32's 24 -- the default fp32 arithmetic stays the six-product bf16 form); */
                                      /* 0x3ffff = every layer that runs the split, msi_train_net's conv-transposes included (until r05 those ignored the bit: the r04 */
                                      /* finding that kept them on the bf16 form is closed, DESIGN.md section 4 "the wobble") */
-#define MSI_NET_OPT_COUNT 16
+#define MSI_NET_OPT_X3_TILE8 16 /* fp32 plans, bit i = layer i: a stride-1, rate-1 layer on the six-product split (F32_SPLIT3 without F32_SPLIT_F16) whose input height is a  */
+                                /* multiple of 8 runs conv_halo8_x3_kernel: 8 x 16-pixel x 64-channel tiles, two accumulators per wave sharing the weight fragments -- half */
+                                /* the weight bytes L2 -> LDS, half the prologues / patch swaps per output, 0.75 fragment reads per MFMA, two workgroups per CU.  Same        */
+                                /* arithmetic and per-accumulator summation order as the 4-row tile.  Applied only where the layer's grid stays >= 3 such tiles per CU       */
+                                /* (smaller grids are cut into K-ranges either way and lose); bit 30 forces it on every eligible layer (tests).  Default 0x3ffff             */
+#define MSI_NET_OPT_COUNT 17
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
 int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);

@@ -33,6 +33,7 @@ NET_OPT_FIXUP_KERNEL, NET_OPT_TAILSPLIT, NET_OPT_BIGTILE, NET_OPT_HEAD_FUSE_LN, 
 NET_OPT_F32_TILE, NET_OPT_F32_TILE_MASK, NET_OPT_APPLY_AHEAD, NET_OPT_HALO, NET_OPT_HALO_SKIP = 5, 6, 7, 8, 9
 NET_OPT_UNIFORM_SPLIT, NET_OPT_BF16_STAGE_RAW, NET_OPT_SPLIT_OVERHEAD, NET_OPT_BF16_WAVES, NET_OPT_F32_SPLIT3 = 10, 11, 12, 13, 14
 NET_OPT_F32_SPLIT_F16 = 15
+NET_OPT_X3_TILE8 = 16
 NET_STATUS_F16_SPLIT_RANGE = 8
 
 

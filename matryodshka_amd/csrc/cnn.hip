@@ -1687,9 +1687,9 @@ conv_halo_kernel(const ConvParams p) {
 #endif
 // NPL = 3: x = h + m + l in bf16, six products (F32_SPLIT3).  NPL = 2: x = h + m' 2^-11 in fp16, three products h.h + (h.m' + m'.h) 2^-11
 // (F32_SPLIT_F16: 22 significand bits per operand, operands limited to the fp16 RANGE -- the patch store flags |x| > 65504 in the status word)
-template <int RATE, int NS = (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3)), int NPL = 3>
+template <int RATE, int NS = (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3)), int NPL = 3, int TH = 4>
 struct HaloGeomX3 {
-  static constexpr int PW = 16 + 2 * RATE, PH = 4 + 2 * RATE, NPX = PW * PH;
+  static constexpr int PW = 16 + 2 * RATE, PH = TH + 2 * RATE, NPX = PW * PH;   // TH x 16 output pixels per workgroup (TH = 4, or 8: conv_halo8_x3_kernel)
   static constexpr int PIX_BYTES = NPL * 64 + 16;         // NPL planes x 32 two-byte parts + 16 (13 or 9 sixteen-byte slots: odd)
   static constexpr int ROW_PITCH = ((PW * PIX_BYTES + 127) / 256) * 256 + 128;
   static constexpr int A_BYTES = PH * ROW_PITCH;
@@ -1702,8 +1702,10 @@ struct HaloGeomX3 {
 // fp16-split range tracking (NPL / NP == 2): the largest operand magnitude a lane stored, as the BIT PATTERN of |x| in an unsigned max -- for sign-cleared floats integer
 // order is float order, and every NaN pattern lies above +inf, so a NaN operand trips the check as |x| > 65504 does (fmaxf drops NaNs: ADVICE r04)
 __device__ __forceinline__ void f16_range_track(unsigned &amax, v4f y) {
-  const unsigned a = __builtin_bit_cast(unsigned, y.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, y.y) & 0x7fffffffu;
-  const unsigned c = __builtin_bit_cast(unsigned, y.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, y.w) & 0x7fffffffu;
+  // (through float temporaries: clang 22 evaluates __builtin_bit_cast(unsigned, y.y) on an ext-vector ELEMENT as element 0 -- found when the range test stopped firing)
+  const float fx = y.x, fy = y.y, fz = y.z, fw = y.w;
+  const unsigned a = __builtin_bit_cast(unsigned, fx) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, fy) & 0x7fffffffu;
+  const unsigned c = __builtin_bit_cast(unsigned, fz) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, fw) & 0x7fffffffu;
   amax = max(max(amax, a), max(b, max(c, d)));
 }
 constexpr unsigned F16_MAX_BITS = 0x477fe000u;   // 65504.0f
@@ -1726,17 +1728,21 @@ __device__ __forceinline__ void wait_lgkm6(v4f &a, v4f &b, v4f &c, v4f &d, v4f &
 #ifndef MSI_X2_LATE_CB
 #define MSI_X2_LATE_CB 1
 #endif
-template <int RATE, int APPLY, int NPL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL == 2 && RATE == 1) ? MSI_X2_WAVES : 2)))
-conv_halo_x3_kernel(const ConvParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef HaloGeomX3<RATE, (NPL == 2 ? MSI_X2_NSTG : (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3))), NPL> G;
+template <int NP>
+__device__ __forceinline__ void split_mfma(f32x16 &acc, f32x16 &lo, const v4f &ah, const v4f &am, const v4f &al, const v4f &bh, const v4f &bm, const v4f &bl);
+// TH = 4: the 4 x 16-pixel x 64-channel tile (one 32 x 32 accumulator per wave).  TH = 8 (r05, conv_halo8_x3_kernel, six-product form at rate 1): an 8 x 16-pixel
+// tile -- a wave owns four tile rows = TWO 32 x 32 accumulators that share the weight fragments (18 instead of 24 fragment reads per 24 MFMAs), the 10 x 18 patch
+// serves twice the outputs of the 6 x 18 one (halo 1.41 instead of 1.69), and per output pixel the workgroup moves HALF the weight bytes from L2 into LDS and runs
+// half the prologues / patch swaps / barriers; 64.3 KB of LDS: two workgroups per CU.
+template <int RATE, int APPLY, int NPL, int TH>
+__device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *smem) {
+  typedef HaloGeomX3<RATE, (NPL == 2 ? MSI_X2_NSTG : (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3))), NPL, TH> G;
   constexpr int R = RATE, PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
-  constexpr int MT = 1, NT = 1;
+  constexpr int MT = TH / 4, NT = 1, BM = 16 * TH;
+  static_assert(TH == 4 || (TH == 8 && NPL == 3 && RATE == 1), "the 8-row tile is built for the six-product form at rate 1");
 #ifdef MSI_CONV_TIMING
   const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -1774,10 +1780,10 @@ conv_halo_x3_kernel(const ConvParams p) {
   LnShard shard = {0, 0};   // (the lane's shard of the source's LayerNorm sums: requested here, reduced after the patch requests)
   if (APPLY) shard = ln_shard_load(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, tid);
   const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
-  const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
+  const int oh0 = tyi * TH, ow0 = (tile_m - tyi * p.halo_tx) * 16;
   const int H = p.Hin, W = p.Win, C = p.C0;
-  v4f cbv[4];
-  if (!MSI_X2_LATE_CB || NPL != 2) load_coord_bias(p, tile_m, tile_n, tid, cbv);           // in flight during the prologue and the k-loop
+  v4f cbv[4] = {};
+  if (MT == 1 && (!MSI_X2_LATE_CB || NPL != 2)) load_coord_bias(p, tile_m, tile_n, tid, cbv);   // in flight during the prologue and the k-loop (MT = 2: read by the epilogue)
   // the first two weight k-steps go out before the patch addresses are worked out (they depend on tile_n and the wave only)
   const int S = p.ksteps;                                 // 9 CH
   // x3 block of the packed blob: [tap][chunk][plane h | m | l][npad rows][64 B = 32 bf16 channels], 16-byte slots swizzled by
@@ -1888,7 +1894,8 @@ conv_halo_x3_kernel(const ConvParams p) {
   const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
   // A: plane P, K16-step s of the lane's pixel at + P * 64 + s * 32 (fh * 16 in the base); B: row wn * 32 + frow of plane P
   // at + P * B_PLANE, slot (2 s + fh) ^ ((row >> 2) & 3)
-  const unsigned a_base = lds_base + (unsigned)((2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
+  // (MT = 2: the wave's second 32-pixel block is the two tile rows below: + 2 ROW_PITCH, an immediate)
+  const unsigned a_base = lds_base + (unsigned)((2 * MT * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
   unsigned b_s[2];
   (void)fswz;
 #pragma unroll
@@ -1896,9 +1903,11 @@ conv_halo_x3_kernel(const ConvParams p) {
     b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-  f32x16 acc[1][1], acc_lo;   // (NPL == 2: acc = h.h, acc_lo = (h.m' + m'.h), folded as acc + acc_lo 2^-11 after the loop)
+  f32x16 acc[MT][1], acc_lo;   // (NPL == 2: acc = h.h, acc_lo = (h.m' + m'.h), folded as acc + acc_lo 2^-11 after the loop)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][0][r] = acc_lo[r] = 0.f;
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = acc_lo[r] = 0.f;
 
   // one k-step = tap TAP of the current chunk, weights in ring stage TAP % 3; the DMA of the k-step two ahead is issued
   // after the first MFMA quarter; before the closing barrier the NEXT k-step's weights must have landed: every VMEM
@@ -1938,6 +1947,29 @@ conv_halo_x3_kernel(const ConvParams p) {
           }                                                                                                            \
         }                                                                                                              \
       }                                                                                                                \
+    } else if (MT == 2) {                                                                                              \
+      /* two pixel blocks i = 0, 1 against ONE set of weight fragments per K16 step s: 18 reads (at most 12 in flight: lgkmcnt is four bits), 24 MFMAs */ \
+      constexpr int A1_ = AOFF_ + 2 * G::ROW_PITCH;                                                                    \
+      v4f xh_[2][2], xm_[2][2], xl_[2][2];   /* [s][i] */                                                              \
+      bh_[0] = lds_read128<0>(b_s[0] + bst_); bm_[0] = lds_read128<G::B_PLANE>(b_s[0] + bst_); bl_[0] = lds_read128<2 * G::B_PLANE>(b_s[0] + bst_); \
+      xh_[0][0] = lds_read128<AOFF_>(a_base); xm_[0][0] = lds_read128<AOFF_ + 64>(a_base); xl_[0][0] = lds_read128<AOFF_ + 128>(a_base); \
+      xh_[0][1] = lds_read128<A1_>(a_base); xm_[0][1] = lds_read128<A1_ + 64>(a_base); xl_[0][1] = lds_read128<A1_ + 128>(a_base); \
+      bh_[1] = lds_read128<0>(b_s[1] + bst_); bm_[1] = lds_read128<G::B_PLANE>(b_s[1] + bst_); bl_[1] = lds_read128<2 * G::B_PLANE>(b_s[1] + bst_); \
+      wait_lgkm6<6>(bh_[0], bm_[0], bl_[0], xh_[0][0], xm_[0][0], xl_[0][0]);                                          \
+      split_mfma<3>(acc[0][0], acc_lo, xh_[0][0], xm_[0][0], xl_[0][0], bh_[0], bm_[0], bl_[0]);                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      xh_[1][0] = lds_read128<AOFF_ + 32>(a_base); xm_[1][0] = lds_read128<AOFF_ + 96>(a_base); xl_[1][0] = lds_read128<AOFF_ + 160>(a_base); \
+      xh_[1][1] = lds_read128<A1_ + 32>(a_base); xm_[1][1] = lds_read128<A1_ + 96>(a_base); xl_[1][1] = lds_read128<A1_ + 160>(a_base); \
+      if ((TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                              \
+      wait_lgkm6<9>(xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);                                          \
+      split_mfma<3>(acc[1][0], acc_lo, xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      wait_lgkm6<3>(bh_[1], bm_[1], bl_[1], xh_[1][0], xm_[1][0], xl_[1][0]);                                          \
+      split_mfma<3>(acc[0][0], acc_lo, xh_[1][0], xm_[1][0], xl_[1][0], bh_[1], bm_[1], bl_[1]);                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      wait_lgkm6<0>(xh_[1][1], xm_[1][1], xl_[1][1], bh_[1], bm_[1], bl_[1]);                                          \
+      split_mfma<3>(acc[1][0], acc_lo, xh_[1][1], xm_[1][1], xl_[1][1], bh_[1], bm_[1], bl_[1]);                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
     } else {                                                                                                           \
     if (!(MSI_X3_ABLATE & 8))                                                                                         \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
@@ -2036,8 +2068,8 @@ conv_halo_x3_kernel(const ConvParams p) {
   };
 #endif
   if (!full) {
-    constexpr int SLAB = 64 * 64 * 4;
-    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)slot * (64 * 64)), 0, SLAB, 0x00020000);
+    constexpr int SLAB = BM * 64 * 4;
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)slot * (BM * 64)), 0, SLAB, 0x00020000);
     if (p.tile_cnt == nullptr) {
       dump_acc<MT, NT, 0>(acc, rsrc_p, tid);
 #ifdef MSI_CONV_TIMING
@@ -2056,14 +2088,31 @@ conv_halo_x3_kernel(const ConvParams p) {
     __syncthreads();
     if (*s_old != nsp - 1) return;
     handoff_acquire();
-    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (BM * 64)), 0, nsp * SLAB, 0x00020000);
     sum_slabs<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_t, nsp, SLAB, tid);
     __syncthreads();   // (every thread has read s_old before the epilogue's strips reuse LDS)
   }
-  emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, cbv, p.coord_bias != nullptr, smem);
+  emit_tile<BM, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, cbv, MT == 1 && p.coord_bias != nullptr, smem);
 #ifdef MSI_CONV_TIMING
   stamp();
 #endif
+}
+
+template <int RATE, int APPLY, int NPL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL == 2 && RATE == 1) ? MSI_X2_WAVES : 2)))
+conv_halo_x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv_halo_x3_body<RATE, APPLY, NPL, 4>(p, smem);
+#endif
+}
+// the 8 x 16-pixel tile of the six-product form at rate 1 (conv_halo_x3_body, TH = 8): two workgroups per CU
+template <int APPLY, int NPL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+conv_halo8_x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv_halo_x3_body<1, APPLY, NPL, 8>(p, smem);
 #endif
 }
 
@@ -2149,7 +2198,7 @@ conv_halo_s2_kernel(const ConvParams p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
   }
   MSI_B_ISSUE(c0, 0, 0)
-  MSI_B_ISSUE(c0, 2, 1)
+  if (G::NSTG == 3) MSI_B_ISSUE(c0, 2, 1)
 
   // ---- per-lane patch slots of the four units: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 ----
   unsigned voff[4][NLOAD], lds_a[NLOAD];
@@ -2400,6 +2449,9 @@ __device__ __forceinline__ void split_finish(f32x16 &acc, const f32x16 &lo, unsi
 }
 
 // ---- the stride-2 halo-patch kernel through the six-product bf16 split (conv_halo_s2_kernel x conv_halo_x3_kernel; r04) ----------
+#ifndef MSI_S2X3_NSTG   // weight ring of the six-product stride-2 kernel: 2 (r05: 43.1 KB of LDS, three workgroups per CU; the DMA of a k-step is issued at the head of
+#define MSI_S2X3_NSTG 2 // the one before it, as in conv_halo_x3_kernel at rate 1) or 3 (r04: 55.4 KB, two workgroups per CU)
+#endif
 template <int NP>
 struct HaloGeomS2X3 {
   static constexpr int PW = 17, PH = 5, NPX = PW * PH;
@@ -2407,7 +2459,7 @@ struct HaloGeomS2X3 {
   static constexpr int ROW_PITCH = ((PW * PIX_BYTES + 127) / 256) * 256 + 128;
   static constexpr int A_BYTES = PH * ROW_PITCH;
   static constexpr int B_ROW = 64, B_PLANE = 64 * B_ROW, B_STAGE = NP * B_PLANE;
-  static constexpr int NSTG = 3;
+  static constexpr int NSTG = NP == 3 ? MSI_S2X3_NSTG : 3;
   static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
   static constexpr int NLOAD = (NPX * 8 + 255) / 256;
 };
@@ -2416,7 +2468,7 @@ struct HaloGeomS2X3 {
 #define MSI_S2X_WAVES 3
 #endif
 template <int APPLY, int NP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? MSI_S2X_WAVES : 2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? MSI_S2X_WAVES : (MSI_S2X3_NSTG == 2 ? 3 : 2))))
 conv_halo_s2_x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef HaloGeomS2X3<NP> G;
@@ -2475,7 +2527,7 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
     if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
   }
   MSI_B_ISSUE(c0, 0, 0)
-  MSI_B_ISSUE(c0, 2, 1)
+  if (G::NSTG == 3) MSI_B_ISSUE(c0, 2, 1)
 
   // ---- per-lane patch slots of the four units: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 ----
   unsigned voff[4][NLOAD], lds_a[NLOAD];
@@ -2569,20 +2621,27 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
 #define MSI_S2_UNIT(J) ((J) < 4 ? 0 : (J) < 6 ? 1 : (J) < 8 ? 2 : 3)
 #define MSI_S2STEP(J)                                                                                                  \
   {                                                                                                                    \
-    constexpr int TAP_ = MSI_S2_TAP(J), U_ = MSI_S2_UNIT(J), ST_ = (J) % 3;                                            \
+    constexpr int TAP_ = MSI_S2_TAP(J), U_ = MSI_S2_UNIT(J);                                                           \
     constexpr int DY_ = (TAP_ / 3) >> 1, DX_ = (TAP_ % 3) >> 1;                                                        \
     constexpr bool FIRST_ = (J) == 0 || (J) == 4 || (J) == 6 || (J) == 8, LAST_ = (J) == 3 || (J) == 5 || (J) == 7 || (J) == 8; \
     constexpr int AOFF_ = DY_ * G::ROW_PITCH + DX_ * G::PIX_BYTES;                                                     \
     const bool more_ = U_ < 3 || c + 1 < c1;               /* a unit follows this one */                               \
+    /* ring stage of this k-step: three stages -> J % 3 (a literal); two -> (J + group parity) & 1 (nine k-steps per group flip it) */ \
+    const unsigned bst_ = (unsigned)(G::NSTG == 3 ? (J) % 3 : (((J) ^ cpar) & 1)) * G::B_STAGE;                         \
+    if (G::NSTG == 2) {   /* the NEXT k-step's weights into the other stage: it was last read in the previous k-step (closing barrier passed) */ \
+      const int stn_ = (((J) ^ cpar) & 1) ^ 1;                                                                         \
+      if ((J) + 1 < 9) { MSI_B_ISSUE(c, MSI_S2_TAP(((J) + 1) % 9), stn_) }                                             \
+      else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, MSI_S2_TAP(0), stn_) }                                                 \
+    }                                                                                                                  \
     v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
       ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);                                \
-      bh_[s_] = lds_read128<ST_ * G::B_STAGE>(b_s[s_]);                                                                \
+      bh_[s_] = lds_read128<0>(b_s[s_] + bst_);                                                                        \
       am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);                           \
-      bm_[s_] = lds_read128<ST_ * G::B_STAGE + G::B_PLANE>(b_s[s_]);                                                   \
+      bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);                                                               \
       if (NP == 3) {                                                                                                   \
         al_[s_] = s_ == 0 ? lds_read128<AOFF_ + 128>(a_base) : lds_read128<AOFF_ + 160>(a_base);                       \
-        bl_[s_] = lds_read128<ST_ * G::B_STAGE + 2 * G::B_PLANE>(b_s[s_]);                                             \
+        bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);                                                         \
       } else { al_[s_] = ah_[s_]; bl_[s_] = bh_[s_]; }                                                                 \
     }                                                                                                                  \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
@@ -2599,15 +2658,20 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
         if (FIRST_ && more_) {                                                                                         \
           if (U_ < 3) MSI_PATCH_LOAD(c, (U_ + 1) & 3) else MSI_PATCH_LOAD(c + 1, 0)                                    \
         }                                                                                                              \
-        /* k-step two ahead: (c, J + 2) or (c + 1, J - 7) */                                                           \
+        /* (three stages) k-step two ahead: (c, J + 2) or (c + 1, J - 7) */                                            \
+        if (G::NSTG == 3) {                                                                                            \
         if ((J) + 2 < 9) { MSI_B_ISSUE(c, MSI_S2_TAP(((J) + 2) % 9), ((J) + 2) % 3) }                                  \
         else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, MSI_S2_TAP(((J) + 2) % 9), ((J) + 2) % 3) }                          \
+        }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
     {                                                                                                                  \
       const bool issued_ = ((J) + 2 < 9) || (c + 1 < c1);                                                              \
       /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */ \
-      if (FIRST_ && !LAST_ && more_) wait_vmcnt<NP + NLOAD>();                                                          \
+      if (G::NSTG == 2) {   /* (the DMA went out BEFORE the patch loads of this k-step: in-order return) */                \
+        if (FIRST_ && !LAST_ && more_) wait_vmcnt<NLOAD>();                                                            \
+        else wait_vmcnt<0>();                                                                                          \
+      } else if (FIRST_ && !LAST_ && more_) wait_vmcnt<NP + NLOAD>();                                                   \
       else if (issued_) wait_vmcnt<NP>();                                                                              \
       else wait_vmcnt<0>();                                                                                            \
     }                                                                                                                  \
@@ -2635,6 +2699,8 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (; c < c1; ++c) {
+    const int cpar = (c - c0) & 1;   // (two-stage ring: nine k-steps per group flip the stage parity)
+    (void)cpar;
     MSI_S2STEP(0) MSI_S2STEP(1) MSI_S2STEP(2) MSI_S2STEP(3) MSI_S2STEP(4) MSI_S2STEP(5) MSI_S2STEP(6) MSI_S2STEP(7) MSI_S2STEP(8)
   }
 #undef MSI_S2STEP
@@ -2967,13 +3033,16 @@ convt_halo_kernel(const ConvParams p) {
 #ifndef MSI_CT_MAXW
 #define MSI_CT_MAXW 8
 #endif
+#ifndef MSI_CT3_NSTG   // weight ring of the six-product conv-transpose kernel: 2 (r05: 48.4 KB of LDS, three workgroups per CU; eight k-steps per chunk, so the
+#define MSI_CT3_NSTG 2 // stage of k-step J is the literal J & 1 and the DMA of k-step J + 1 goes out at the head of k-step J) or 3 (r04: 60.7 KB, two per CU)
+#endif
 template <int NP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, MSI_CT_MAXW)))
 convt_halo_x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  typedef HaloGeomX3<1, 3, NP> G;
+  typedef HaloGeomX3<1, (NP == 3 ? MSI_CT3_NSTG : 3), NP> G;
   constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, NSTG = G::NSTG, PD = NSTG - 1;
-  static_assert(NSTG == 3 && PD == 2, "prefetch distance two");
+  static_assert(NSTG == 3 || NSTG == 2, "prefetch distance two or one");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3028,7 +3097,7 @@ convt_halo_x3_kernel(const ConvParams p) {
     if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
   }
   MSI_B_ISSUE(2 * ph, 0, c0, 0)
-  MSI_B_ISSUE(2 * ph, 1, c0, 1)
+  if (NSTG == 3) MSI_B_ISSUE(2 * ph, 1, c0, 1)
 
   // ---- per-lane patch elements (as conv_halo_kernel; the byte offset depends on the source's channel count) ----
   unsigned pixi[NLOAD], lds_a[NLOAD];
@@ -3142,6 +3211,12 @@ convt_halo_x3_kernel(const ConvParams p) {
     const unsigned ab_ = (TH_ ? a_base1 : a_base0) - ((PWC_ && TW_) ? wadj : 0u);                                      \
     v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
     const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
+    bool issued_ = false;                                                                                              \
+    if (NSTG == 2) {   /* the NEXT k-step's weights into the other stage (last read in the previous k-step: closing barrier passed) */ \
+      constexpr int JN_ = ((J) + 1) & 7;                                                                               \
+      if ((J) + 1 < 8) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c, st ^ 1) }                        \
+      else if (c + 1 < c1) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, st ^ 1) }                \
+    }                                                                                                                  \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
       ah_[s_] = s_ == 0 ? lds_read128<COFF_>(ab_) : lds_read128<COFF_ + 32>(ab_);                                      \
       bh_[s_] = lds_read128<0>(b_s[s_] + bst_);                                                                        \
@@ -3152,7 +3227,6 @@ convt_halo_x3_kernel(const ConvParams p) {
         bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);                                                         \
       } else { al_[s_] = ah_[s_]; bl_[s_] = bh_[s_]; }                                                                 \
     }                                                                                                                  \
-    bool issued_ = false;                                                                                              \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
       if (NP == 3) {                                                                                                   \
         if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                    \
@@ -3165,13 +3239,18 @@ convt_halo_x3_kernel(const ConvParams p) {
       __builtin_amdgcn_sched_barrier(0);                                                                               \
       if (s_ == 0) {                                                                                                   \
         if ((J) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                              \
+        if (NSTG == 3) {                                                                                               \
         int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                       \
         constexpr int JN_ = ((J) + PD) & 7;                                                                            \
         if ((J) + PD < 8) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c, sn_) }                        \
         else if (c + 1 < c1) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_) }                 \
+        }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
-    if ((J) == 0 && c + 1 < c1) wait_vmcnt<NP + NPLD>();                                                                 \
+    if (NSTG == 2) {   /* (the DMA went out before this k-step's patch loads: in-order return) */                      \
+      if ((J) == 0 && c + 1 < c1) wait_vmcnt<NPLD>();                                                                  \
+      else wait_vmcnt<0>();                                                                                            \
+    } else if ((J) == 0 && c + 1 < c1) wait_vmcnt<NP + NPLD>();                                                          \
     else if (issued_) wait_vmcnt<NP>();                                                                                \
     else wait_vmcnt<0>();                                                                                              \
     __builtin_amdgcn_s_barrier();                                                                                      \
@@ -4788,6 +4867,7 @@ struct LayerLaunch {
   int halo_s2;      // ... conv_halo_s2_kernel: the stride-2 3x3 layers through parity-plane patches (fp32)
   int halo_x3;      // ... conv_halo_x3_kernel: fp32 through the 3-way bf16 split with six products (plan option F32_SPLIT3)
   int halo_x2;      // ... its fp16 form: 2-way split, three products (plan option F32_SPLIT_F16; needs halo_x3)
+  int x3_th8;       // ... its 8 x 16-pixel tile (conv_halo8_x3_kernel: six-product form, rate 1; plan option X3_TILE8)
   int hbm, hbn;     // bf16 halo tile: 128 x 128 or 256 x 64
   int halo_t;       // convt_halo_kernel (conv-transpose, fp32): the two classes of one output-row parity per workgroup
   int halo_tb;      // convt_halo_bf16_kernel (conv-transpose, bf16): the two classes of one output-row parity per workgroup
@@ -4809,7 +4889,7 @@ namespace {
 
 // Work decomposition of one layer ("tail split", see the kernel) for a BM x BN tile.
 void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tailsplit, int max_split, int *nblocks, int *nfix,
-                int uniform_split = 0, int split_overhead = 0) {
+                int uniform_split = 0, int split_overhead = 0, bool split_any_tile = false) {
   const int mtot = p.Mh * p.Mw;
   p.tiles_m = (mtot + BM - 1) / BM;
   if (p.halo_tx) p.tiles_m = ((p.Mh + BM / 16 - 1) / (BM / 16)) * p.halo_tx;   // (BM / 16) x 16 spatial tiles (ragged at the right / bottom edge when Mh, Mw are no multiples)
@@ -4847,7 +4927,7 @@ void plan_tiles(ConvParams &p, int BM, int BN, int batch, int num_cus, int tails
                        uniform_split <= max_split && p.ksteps >= 2 * MAX_SPLIT;
   if (uniform) { p.n_main = 0; p.split0 = 1; p.split = uniform_split; }
   const int rem = p.ntiles % num_cus;
-  if (!uniform && BM * BN == 64 * 64 && p.split == 1 &&   // (big tiles are only chosen for big grids)
+  if (!uniform && (BM * BN == 64 * 64 || split_any_tile) && p.split == 1 &&   // (the bf16 big tiles are only chosen for big grids)
       rem != 0 && p.ntiles > num_cus / 2 && p.ksteps >= 2 * MAX_SPLIT && tailsplit && !(tailsplit == 2 && p.ntiles >= Q)) {
     int best = 1;
     // time of the tail in k-steps: ceil(rem * s / CUs) rounds of K / s k-steps, each visit paying `split_overhead` k-steps of
@@ -4958,6 +5038,12 @@ int plan_layers(msi_net_plan *pl) {
     if (Q.halo_s2) Q.halo = 1;
     Q.halo_x3 = Q.halo && !bf16 && L.x3_off != 0 && ((pl->opt[MSI_NET_OPT_F32_SPLIT3] >> li) & 1);
     Q.halo_x2 = Q.halo_x3 && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
+    // the 8 x 16-pixel tile of the six-product form (conv_halo8_x3_kernel): stride 1, rate 1, whole 8-row tiles
+    // where the grid stays >= 3 tiles per CU (measured at 640 x 320, profiles/r05_tile8.txt: conv1_1 215 -> 201, conv2_1 80 -> 74, conv7_2 82 -> 75, conv8_2 87 -> 81 us;
+    // the 400-tile layers conv3_x / conv6_x, cut into K-ranges either way, LOSE 12 %); bit 30 of the option forces it on every eligible layer (tests)
+    Q.x3_th8 = Q.halo_x3 && !Q.halo_x2 && !Q.halo_s2 && L.rate == 1 && L.in_h % 8 == 0 && ((pl->opt[MSI_NET_OPT_X3_TILE8] >> li) & 1) &&
+               ((long)(L.in_h / 8) * (L.in_w / 16) * ((L.cout + 63) / 64) * desc->batch >= 3L * pl->num_cus || ((pl->opt[MSI_NET_OPT_X3_TILE8] >> 30) & 1));
+    if (Q.x3_th8) BM = 128;
     int max_split = MAX_SPLIT;
     // bf16 halo-patch kernel (conv_halo_bf16_kernel): the same layers with 64-channel chunks and whole
     // 8 x 16 pixel x 128 channel or 16 x 16 x 64 tiles
@@ -5007,7 +5093,7 @@ int plan_layers(msi_net_plan *pl) {
       if (!Q.halo_t && L.cpt0 < max_split) max_split = L.cpt0;      // K-ranges are whole chunks (bf16: whole tiles only)
     }
     plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], max_split, &Q.nblocks, &Q.nfix,
-               pl->opt[MSI_NET_OPT_UNIFORM_SPLIT], pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD]);
+               pl->opt[MSI_NET_OPT_UNIFORM_SPLIT], pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD], Q.x3_th8 != 0);
     // apply-ahead (see apply_ahead): this launch also normalises its source 0
     if (pl->opt[MSI_NET_OPT_APPLY_AHEAD] && !bf16 && L.src0 >= 0 && L.kind != MODE_HEAD && L.c0 <= 512 && L.c0 % 4 == 0 &&   // (bf16: fp16 raw outputs, r03)
         ((long)L.in_w * L.c0) % 4 == 0) {
@@ -5460,6 +5546,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   // six-product bf16 form (profiles/r04_split_numerics.txt) -- but its operands carry 22 significand bits, not 24, and the round-3 review ruled that a
   // two-way / three-product split must not be the arithmetic a `dtype f32` number is quoted on.  The default stays the six-product form (dropped terms < 2^-26).
   pl->opt[MSI_NET_OPT_F32_SPLIT_F16] = 0;
+  pl->opt[MSI_NET_OPT_X3_TILE8] = 0x3ffff;   // (r05: every eligible layer whose grid is >= 3 tiles per CU)
   pl->opt[MSI_NET_OPT_F32_SPLIT3] = 0x3ffff;   // every layer that has the kernel (r04: same error against the oracle as the native path, 1.35-1.45 x faster per layer)
   pl->opt[MSI_NET_OPT_BF16_STAGE_RAW] = 1;   // (bit 1, conv8_1 staging its raw sources: measured 50 us per 16 frames SLOWER -- ~180 VALU per chunk
                                                // against 2 048 matrix cycles of the 128 x 64 tile; bit 0, conv8_2: 130 us faster.  Three interleaved repeats)
@@ -5533,6 +5620,7 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
   } else if (Q.halo) {
     if (Q.halo_s2 && Q.halo_x3) snprintf(name, name_bytes, "conv_halo_s2_x3_kernel<%d, %d>", Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);
     else if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_s2_kernel<%d>", Q.halo_apply ? 1 : 0);
+    else if (Q.x3_th8) snprintf(name, name_bytes, "conv_halo8_x3_kernel<%d, 3>", Q.halo_apply ? 1 : 0);
     else if (Q.halo_x3) snprintf(name, name_bytes, "conv_halo_x3_kernel<%d, %d, %d>", L.rate, Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);
     else snprintf(name, name_bytes, "conv_halo_kernel<%d, %d>", L.rate, Q.halo_apply ? 1 : 0);
   } else {
@@ -5771,7 +5859,7 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       }
       if (Q.halo_x3) {
         p.wpk_x3 = reinterpret_cast<const char *>(packed + (Q.halo_x2 ? L.x2_off : L.x3_off));
-        constexpr int lds_ct3 = HaloGeomX3<1, 3, 3>::LDS_BYTES, lds_ct2 = HaloGeomX3<1, 3, 2>::LDS_BYTES;
+        constexpr int lds_ct3 = HaloGeomX3<1, MSI_CT3_NSTG, 3>::LDS_BYTES, lds_ct2 = HaloGeomX3<1, 3, 2>::LDS_BYTES;
         if (Q.halo_x2) hipLaunchKernelGGL(convt_halo_x3_kernel<2>, dim3(Q.nblocks), dim3(256), lds_ct2, stream, p);
         else hipLaunchKernelGGL(convt_halo_x3_kernel<3>, dim3(Q.nblocks), dim3(256), lds_ct3, stream, p);
       } else {
@@ -5802,6 +5890,12 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       } else if (Q.halo_s2) {
         if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_kernel<1>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
         else hipLaunchKernelGGL((conv_halo_s2_kernel<0>), grid, block, HaloGeomS2::LDS_BYTES, stream, p);
+      } else if (Q.x3_th8) {
+        p.wpk_x3 = reinterpret_cast<const char *>(packed + L.x3_off);
+        typedef HaloGeomX3<1, (MSI_X3_NSTG ? MSI_X3_NSTG : 2), 3, 8> G8_;
+        static_assert(G8_::LDS_BYTES <= 65536, "conv_halo8_x3_kernel: LDS without the launch attribute");
+        if (Q.halo_apply) hipLaunchKernelGGL((conv_halo8_x3_kernel<1, 3>), grid, block, G8_::LDS_BYTES, stream, p);
+        else hipLaunchKernelGGL((conv_halo8_x3_kernel<0, 3>), grid, block, G8_::LDS_BYTES, stream, p);
       } else if (Q.halo_x3) {
         p.wpk_x3 = reinterpret_cast<const char *>(packed + (Q.halo_x2 ? L.x2_off : L.x3_off));
         static thread_local unsigned long long done2[8] = {0};       // (above 64 KB of LDS the launch needs the attribute)
@@ -5835,7 +5929,8 @@ static int run_layers(const msi_net_plan *plan, const float *packed, const void 
       }
       rc = msi::check_launch("conv_halo");
       if (!rc && Q.nfix > 0 && p.tile_cnt == nullptr) {
-        hipLaunchKernelGGL((conv_fixup_kernel<64, 64, MODE_CONV>), dim3(Q.nfix), dim3(256), 0, stream, p);
+        if (Q.x3_th8) hipLaunchKernelGGL((conv_fixup_kernel<128, 64, MODE_CONV>), dim3(Q.nfix), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_fixup_kernel<64, 64, MODE_CONV>), dim3(Q.nfix), dim3(256), 0, stream, p);
         rc = msi::check_launch("conv_fixup");
       }
     } else

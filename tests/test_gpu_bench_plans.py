@@ -21,14 +21,21 @@ TOL = 1e-3
 # graph order conv1_1 ... conv8_2 (the head runs inside head_assemble_kernel on the blend_psv path)
 # (r04: the stride-1 halo layers of an fp32 plan run the six-product bf16 split by default -- conv_halo_x3_kernel)
 # (the kernels' last template argument: operand planes -- 3 = bf16 h | m | l, six products; 2 = fp16 h | m', three products)
-def f32_big_grid(np_):
+# (r05: the stride-1, rate-1 layers of the six-product form whose grid is >= 3 tiles of 8 x 16 pixels per CU run conv_halo8_x3_kernel -- plan option X3_TILE8:
+#  every such layer at the batches of configs[3] / [4]; conv1_1, conv2_1, conv7_2, conv8_2 at configs[1])
+def f32_big_grid(np_, wide=(0, 2, 4, 5, 11, 12, 14, 16)):
     c = lambda r, a: "conv_halo_x3_kernel<%d, %d, %d>" % (r, a, np_)      # noqa: E731
     s2, ct = "conv_halo_s2_x3_kernel<1, %d>" % np_, "convt_halo_x3_kernel<%d>" % np_
-    return [c(1, 0), s2, c(1, 1), s2, c(1, 1), c(1, 1), s2, c(2, 1), c(2, 1), c(2, 1), ct, c(1, 1), c(1, 1), ct, c(1, 1), ct, c(1, 1)]
+    k = [c(1, 0), s2, c(1, 1), s2, c(1, 1), c(1, 1), s2, c(2, 1), c(2, 1), c(2, 1), ct, c(1, 1), c(1, 1), ct, c(1, 1), ct, c(1, 1)]
+    if np_ == 3:
+        for i in wide:
+            k[i] = "conv_halo8_x3_kernel<%d, 3>" % (0 if i == 0 else 1)
+    return k
 
 
 DEFAULT_PLANES = 3          # (plan option F32_SPLIT_F16 -- the three-product fp16 form, 2 planes -- is opt-in)
 F32_BIG_GRID = f32_big_grid(DEFAULT_PLANES)
+F32_CONFIG1 = f32_big_grid(DEFAULT_PLANES, wide=(0, 2, 14, 16))
 BF16_CONFIG2 = ["conv_halo_bf16_kernel<256, 64, 1, 0, 4>", "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>", "conv_halo_bf16_kernel<128, 128, 1, 1, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 2, 0, 8>", "conv_halo_bf16_kernel<128, 128, 2, 1, 8>",
@@ -165,8 +172,8 @@ def test_config1_plan_is_the_profiled_one():
     from matryodshka_amd import _native as N, nets
     plan = N.NetPlan(nets.make_desc(1, 320, 640, 192, 64, 64, True, "f32"))
     k = [plan.layer_kernel(i) for i in range(18)]
-    assert [x[0] for x in k[:17]] == F32_BIG_GRID and k[17][0] == "conv_igemm_kernel<64, 64, 2, 0>", k
-    assert [x[2] for x in k[:17]] == [128, 64, 64, 32, 32, 32, 400, 400, 400, 400, 400, 32, 32, 32, 64, 64, 128], k
+    assert [x[0] for x in k[:17]] == F32_CONFIG1 and k[17][0] == "conv_igemm_kernel<64, 64, 2, 0>", k
+    assert [x[2] for x in k[:17]] == [64, 64, 32, 32, 32, 32, 400, 400, 400, 400, 400, 32, 32, 32, 32, 64, 64], k
     plan.set_option(N.NET_OPT_F32_SPLIT3, 0)
     k = [plan.layer_kernel(i)[0] for i in range(17)]
     assert k[6] == "conv_igemm_kernel<64, 64, 0, 0>" and k[0] == "conv_halo_kernel<1, 0>" and k[1] == "conv_halo_s2_kernel<1>" and k[10] == "conv_igemm_kernel<64, 64, 1, 0>", k
