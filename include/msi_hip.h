@@ -59,8 +59,9 @@ const char *msi_version(void);
  * a mismatch; packed blobs are not portable across versions (re-pack from the parameter blob).
  *   3: msi_layer_info.ln_scale_offset; LayerNorm window doubles in the packed blob (round 3)
  *   4: msi_net_plan_layer_kernel; render status word (msi_render_status_*); sweep volume takes shared poses (round 4)
- *   5: packed blob carries the fp16-split (x2) block; MSI_NET_OPT_F32_SPLIT_F16, MSI_NET_STATUS_F16_SPLIT_RANGE (round 4) */
-#define MSI_ABI_VERSION 5
+ *   5: packed blob carries the fp16-split (x2) block; MSI_NET_OPT_F32_SPLIT_F16, MSI_NET_STATUS_F16_SPLIT_RANGE (round 4)
+ *   6: msi_net_plan_calibrate; MSI_NET_OPT_X3_TILE8 (round 5) */
+#define MSI_ABI_VERSION 6
 int32_t msi_abi_version(void);
 const char *msi_last_error_string(void);
 /* CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 for a new message): the per-tensor checksum of
@@ -379,6 +380,14 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
 #define MSI_NET_STATUS_LN_UNDERFLOW 4
 #define MSI_NET_STATUS_F16_SPLIT_RANGE 8 /* an operand of a layer on the fp16 split (F32_SPLIT_F16) exceeded 65504: rerun with that option 0 */
 int32_t msi_net_plan_status(const msi_net_plan *plan, const void *workspace, msi_stream_t stream, int32_t *status_bits);
+/* LayerNorm window calibration (round 5).  The fixed-point window of a layer's LayerNorm sums (MSI_NET_STATUS_LN_*) follows an exponent the packer
+ * estimates from the weights; a checkpoint whose trained gamma / beta / weights put a layer's raw output far from that estimate would end every forward in
+ * MSI_E_RANGE.  msi_net_plan_calibrate measures instead: layer by layer it runs the network on `net_input` (a representative frame, device memory, the
+ * forward's layout), moves / centres each layer's window on the measured raw rms and rewrites the four scale doubles at ln_scale_offset of `packed`
+ * (DEVICE memory, modified in place; every plan that shares the blob sees the new windows).  Blocking (it synchronises `stream` several times per layer),
+ * a one-off of a few dozen forwards; *layers_changed (may be NULL) = layers whose exponent moved.  MSI_E_RANGE if a layer has no finite, non-constant output. */
+int32_t msi_net_plan_calibrate(const msi_net_plan *plan, float *packed, const void *net_input, void *workspace, size_t workspace_bytes,
+                               msi_stream_t stream, int32_t *layers_changed);
 /* net_input [B,H,W,in_channels] (fp32, or bf16 when desc.dtype = MSI_DTYPE_BF16) -> pred [B,H,W,num_outputs] fp32. */
 int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
                          void *workspace, size_t workspace_bytes, msi_stream_t stream);

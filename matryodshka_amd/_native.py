@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmsi_hip.so")
 MSI_OK = 0
 MSI_NET_NUM_LAYERS = 18
 RENDER_STATUS_ORIGIN_OUTSIDE = 1
-MSI_ABI_VERSION = 5          # include/msi_hip.h: the version this binding's struct layouts and signatures are written for
+MSI_ABI_VERSION = 6          # include/msi_hip.h: the version this binding's struct layouts and signatures are written for
 
 
 class MsiError(RuntimeError):
@@ -89,6 +89,7 @@ SIGNATURES = {
     "msi_net_plan_layer_is_normalized": (_I, [_P, _I]),
     "msi_net_plan_layer_kernel": (_I, [_P, _I, _P, c_size_t, POINTER(c_int32), POINTER(c_int32)]),
     "msi_net_plan_status": (_I, [_P, _P, _P, POINTER(c_int32)]),
+    "msi_net_plan_calibrate": (_I, [_P, _P, _P, _P, c_size_t, _P, POINTER(c_int32)]),
     "msi_net_plan_forward": (_I, [_P, _P, _P, _P, _P, c_size_t, _P]),
     "msi_net_plan_forward_rgba": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "msi_net_forward_f32": (_I, [POINTER(NetDesc), _P, _P, _P, _P, c_size_t, _P]),

@@ -5653,6 +5653,75 @@ int32_t msi_net_plan_status(const msi_net_plan *plan, const void *workspace, msi
                    (word & STATUS_APPLY_AHEAD_TIMEOUT) ? " an apply-ahead wait timed out" : "");
 }
 
+// LayerNorm window calibration.  The fixed-point window of a layer's sums follows an exponent the packer ESTIMATES from the weights
+// (sqrt(K) rms(w) rms(input)); trained gamma / beta / weights may put a layer's real raw output 2^+-12 away from that estimate, and then every forward ends in
+// MSI_E_RANGE.  This entry point MEASURES instead: layer by layer (a layer's input is only right once its producers' windows are), run layers 0 .. L, read L's sums
+// and the status word, move the exponent by 12 while the sums overflow / underflow, then centre it on the measured rms (log-mid of the smallest and largest sample),
+// write {S1, S2, 1 / S1, 1 / S2} into the packed blob ON THE DEVICE and run 0 .. L once more so that L's consumers see sums in the new unit.  Synchronous (it reads
+// the sums back: a one-off, ~40 forwards' worth of kernels), allocates nothing, leaves the workspace as a forward of layers 0 .. 16 would.
+int32_t msi_net_plan_calibrate(const msi_net_plan *plan, float *packed, const void *net_input, void *workspace, size_t workspace_bytes,
+                               msi_stream_t stream_, int32_t *layers_changed) {
+  MSI_REQUIRE(plan && packed && net_input && workspace, "net_plan_calibrate: null pointer");
+  const Net &net = plan->net;
+  const msi_net_desc *desc = &plan->desc;
+  hipStream_t stream = msi::as_stream(stream_);
+  if (layers_changed) *layers_changed = 0;
+  if (desc->batch == 0) return MSI_OK;
+  const size_t nwords = (size_t)desc->batch * LN_SHARDS * LN_WORDS;
+  std::vector<long long> sums(nwords);
+  char *ws = static_cast<char *>(workspace);
+  for (int li = 0; li < MSI_NET_NUM_LAYERS - 1; ++li) {
+    const Layer &L = net.layers[li];
+    double scl[LN_SCL_DOUBLES];
+    hipError_t he = hipMemcpyAsync(scl, packed + L.lnscl_off, sizeof(scl), hipMemcpyDeviceToHost, stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(stream);
+    if (he != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_plan_calibrate: %s", hipGetErrorString(he));
+    int e0 = LN_S1_BITS - (int)lrint(log2(scl[0])), e = e0;
+    bool settled = false;
+    for (int it = 0; it < 24 && !settled; ++it) {
+      const double ns[LN_SCL_DOUBLES] = {ldexp(1.0, LN_S1_BITS - e), ldexp(1.0, LN_S2_BITS - 2 * e), ldexp(1.0, -(LN_S1_BITS - e)), ldexp(1.0, -(LN_S2_BITS - 2 * e))};
+      he = hipMemcpyAsync(packed + L.lnscl_off, ns, sizeof(ns), hipMemcpyHostToDevice, stream);
+      if (he == hipSuccess) he = hipStreamSynchronize(stream);   // (ns is on this stack frame)
+      if (he != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_plan_calibrate: %s", hipGetErrorString(he));
+      int rc = run_layers(plan, packed, net_input, nullptr, workspace, workspace_bytes, stream_, li + 1);
+      if (rc) return rc;
+      int word = 0;
+      he = hipMemcpyAsync(sums.data(), ws + L.sums_off, nwords * sizeof(long long), hipMemcpyDeviceToHost, stream);
+      if (he == hipSuccess) he = hipMemcpyAsync(&word, ws + net.err_off, sizeof(int), hipMemcpyDeviceToHost, stream);
+      if (he == hipSuccess) he = hipStreamSynchronize(stream);
+      if (he != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_plan_calibrate: %s", hipGetErrorString(he));
+      if (word & STATUS_LN_OVERFLOW) { e += 12; if (e > 120) break; continue; }   // a share left the window (or the data is not finite: the loop gives up at 2^120)
+      // per sample: sum x^2 in units of 1 / S2; below ~1e6 sqrt(waves) units the variance is resolved to < 6 digits (ln_mean_inv's rule, restated on the host)
+      double rmin = 1e300, rmax = 0.0;
+      bool under = false;
+      for (int b = 0; b < desc->batch; ++b) {
+        double h1 = 0.0, h2 = 0.0;
+        for (int sh = 0; sh < LN_SHARDS; ++sh) {
+          h1 += (double)sums[((size_t)b * LN_SHARDS + sh) * LN_WORDS];
+          h2 += (double)sums[((size_t)b * LN_SHARDS + sh) * LN_WORDS + 1];
+        }
+        if (h2 * h2 < LN_UNDERFLOW_UNITS_SQ * (L.ln_count / 1024.0 + 1.0)) under = true;
+        const double mu = h1 * ns[2] / L.ln_count;
+        double ms = h2 * ns[3] / L.ln_count;               // E[x^2]: the window has to hold the raw values themselves
+        (void)mu;
+        const double r = sqrt(ms > 0.0 ? ms : 0.0);
+        rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax;
+      }
+      if (under && rmax == 0.0) { e -= 12; if (e < -120) break; continue; }        // nothing resolved at all: look lower
+      if (rmax > 0.0) {
+        const int ec = (int)lrint(0.5 * (log2(rmax) + log2(rmin > 0.0 ? rmin : rmax)));
+        if (ec > e + 1 || ec < e - 1) { e = ec; continue; }                         // centre the window (to within an octave) and measure once more in the new unit
+      }
+      if (under) { e -= 12; if (e < -120) break; continue; }
+      settled = true;
+    }
+    if (!settled)
+      return msi::fail(MSI_E_RANGE, "net_plan_calibrate: layer %s has no finite, non-constant raw output to centre a LayerNorm window on (non-finite input or weights?)", L.name);
+    if (e != e0 && layers_changed) ++*layers_changed;
+  }
+  return MSI_OK;
+}
+
 int msi_net_plan_forward(const msi_net_plan *plan, const float *packed, const void *net_input, float *pred,
                          void *workspace, size_t workspace_bytes, msi_stream_t stream_) {
   MSI_REQUIRE(pred, "net_forward: null pointer");

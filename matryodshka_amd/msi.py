@@ -167,6 +167,25 @@ class MSI(object):
         N.check(N.lib.msi_net_plan_status(plan.handle, ws.data_ptr(), self._stream(), N.ctypes.byref(bits)), "msi_net_plan_status")
         return int(bits.value)
 
+    def calibrate(self, net_input, num_outputs=None, ngf=64):
+        """msi_net_plan_calibrate: centre every layer's LayerNorm fixed-point window on the raw output this network really produces for `net_input`
+        ([B,H,W,Cin], the forward's layout; a representative frame).  The packer derives the windows from the weights alone; a checkpoint whose trained
+        gamma / beta / weights break that estimate makes network_status() raise MSI_E_RANGE on every frame -- call this once (the harness does, on the
+        first flagged sample) and the windows follow the measurement.  The packed blob is modified in place on the device: every plan of this model
+        (any batch size) uses the new windows.  Blocking; returns the number of layers whose window moved."""
+        b, h, w, cin = net_input.shape
+        if num_outputs is None:
+            num_outputs = cin // 3          # blend_psv: 6 D -> 2 D
+        desc, packed, ws = self._net(b, h, w, cin, num_outputs, ngf)
+        want = torch.bfloat16 if self.dtype == 'bf16' else torch.float32
+        if net_input.dtype != want or not net_input.is_contiguous():
+            net_input = net_input.to(want).contiguous()
+        plan = self._plan(b, h, w, cin, num_outputs, ngf)
+        changed = N.c_int32(0)
+        N.check(N.lib.msi_net_plan_calibrate(plan.handle, packed.data_ptr(), net_input.data_ptr(), ws.data_ptr(), ws.numel(), self._stream(),
+                                             N.ctypes.byref(changed)), "msi_net_plan_calibrate")
+        return int(changed.value)
+
     def render_status(self):
         """Status word of the renders since the last call (include/msi_hip.h: MSI_RENDER_STATUS_*): raises ValueError when a
         ray origin -- handed over in DEVICE memory, where the host-side guard cannot look without a sync -- was not inside

@@ -103,6 +103,24 @@ def main():
         blended = sum(flops[:nl]) / peak_time / 1e6
         print("sum %.1f us -> %.1f TFLOP/s = %.3f of the flops-weighted peak %.1f TFLOP/s of the instructions the launches run on (conv launches listed above)" % (
             tot_us, sum(flops[:nl]) / tot_us / 1e6, sum(flops[:nl]) / tot_us / 1e6 / blended, blended))
+        # the HBM-bound stages of the same step: algorithmic bytes (bench.geometry_bytes: SURVEY.md 8d) / average launch duration against the 8 TB/s HBM3E peak,
+        # so that bench.py's stages.*.frac can be re-derived from this file alone.  head_assemble = the fused tail (head + K3's bytes)
+        gb = bench.geometry_bytes(H, W, D, 2 if bf16 else 4)
+        stage_of = (("ods_sweep_kernel", "sweep"), ("pp_sweep_kernel", "sweep"), ("head_assemble_kernel", "assemble"), ("assemble_kernel", "assemble"),
+                    ("mpi_render_kernel", "render"), ("render_kernel", "render"))
+        print("\n# HBM-bound kernels (per launch of %d frame(s); algorithmic bytes / average duration; peak %.0f GB/s):" % (batch, bench.PEAK_HBM_GBS))
+        seen = set()
+        for r in rows:
+            nm = short(r[0])
+            for key, stage in stage_of:
+                if nm.startswith(key) and nm not in seen and steps:
+                    seen.add(nm)
+                    per_step = r[1] / steps                       # launches per step (the sweep of a big batch may run in chunks)
+                    us = r[2] / 1e3 / steps                       # time per step in this kernel
+                    byt = gb[stage] * batch
+                    print("%-44s %5.2f launch(es) per step  %9.1f us per step  %8.1f MB algorithmic  %7.1f GB/s = %.3f of the HBM peak" % (
+                        nm[:44], per_step, us, byt / 1e6, byt / us / 1e3, byt / us / 1e3 / bench.PEAK_HBM_GBS))
+                    break
         ln = [r for r in rows if "ln_apply" in r[0]]
         if ln and steps:
             print("ln_apply: %.2f launches and %.1f us per step" % (sum(r[1] for r in ln) / steps, sum(r[2] for r in ln) / 1e3 / steps))
