@@ -22,8 +22,10 @@ NO_SLP = ["-fno-slp-vectorize"]
 SOURCES = [
     ("common.cpp", ["-x", "hip"]),
     ("geometry.hip", ["-ffp-contract=off"] + NO_SLP + os.environ.get("MSI_GEO_DEFINES", "").split()),   # e.g. MSI_GEO_DEFINES="-DMSI_SWEEP_WAVES=5" (tuning)
-    ("cnn.hip", NO_SLP + os.environ.get("MSI_CNN_DEFINES", "").split()),   # e.g. MSI_CNN_DEFINES="-DMSI_NSTAGE=2" (tuning)
 ]
+# the K2 convolution path: one translation unit per kernel family (r05; cnn_device.h holds what they share), compiled in parallel
+CNN_UNITS = ["cnn.hip", "cnn_igemm.hip", "cnn_halo.hip", "cnn_x3.hip", "cnn_bf16.hip", "cnn_tail.hip"]
+SOURCES += [(u, NO_SLP + os.environ.get("MSI_CNN_DEFINES", "").split()) for u in CNN_UNITS]   # e.g. MSI_CNN_DEFINES="-DMSI_NSTAGE=2" (tuning)
 
 
 def _hipcc():
@@ -43,9 +45,9 @@ def _newer(target, deps):
 def build(force=False, verbose=True):
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(INCLUDE, "msi_hip.h"), os.path.join(CSRC, "msi_common.h"), __file__]
+    headers = [os.path.join(INCLUDE, "msi_hip.h"), os.path.join(CSRC, "msi_common.h"), os.path.join(CSRC, "cnn_device.h"), __file__]
     objs = []
-    rebuilt = False
+    jobs = []
     for src, extra in SOURCES:
         spath = os.path.join(CSRC, src)
         opath = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
@@ -54,8 +56,11 @@ def build(force=False, verbose=True):
             cmd = [hipcc] + COMMON + extra + ["-c", spath, "-o", opath]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-            rebuilt = True
+            jobs.append((src, subprocess.Popen(cmd)))
+    rebuilt = bool(jobs)
+    failed = [src for src, proc in jobs if proc.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for " + ", ".join(failed))
     if rebuilt or force or _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -10,16 +10,18 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 ap = argparse.ArgumentParser()
 ap.add_argument("--flags", default="-DMSI_DEBUG_SUMS -DMSI_DBG_WRAPT_F16=1")
 ap.add_argument("--regen", action="store_true")
+ap.add_argument("--unit", default="cnn_x3.hip", help="translation unit of the kernel (r05 split of cnn.hip; the hunt itself ran on the unsplit file)")
 ap.add_argument("--kernel", default="_ZN12_GLOBAL__N_120convt_halo_x3_kernelILi2EEEvNS_10ConvParamsE")
 ap.add_argument("names", nargs="*")
 a = ap.parse_args()
 os.makedirs(W, exist_ok=True)
-dev_s, host_s = W + "/cnn-hip-amdgcn-amd-amdhsa-gfx950.s", W + "/cnn-host-x86_64-unknown-linux-gnu.s"
+_stem = os.path.splitext(a.unit)[0] if os.path.exists(W + "/" + os.path.splitext(a.unit)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s") or a.regen else "cnn"
+dev_s, host_s = W + "/%s-hip-amdgcn-amd-amdhsa-gfx950.s" % _stem, W + "/%s-host-x86_64-unknown-linux-gnu.s" % _stem
 def run(cmd, **kw):
     subprocess.check_call(cmd, **kw)
 if a.regen or not os.path.exists(dev_s):
     run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + ROOT + "/include", "-I" + ROOT + "/matryodshka_amd/csrc", "-Wno-unused-function"]
-        + a.flags.split() + ["-c", ROOT + "/matryodshka_amd/csrc/cnn.hip", "-o", "cnn.o", "-save-temps"], cwd=W, stderr=subprocess.DEVNULL)
+        + a.flags.split() + ["-fno-slp-vectorize", "-c", ROOT + "/matryodshka_amd/csrc/" + a.unit, "-o", "cnn.o", "-save-temps"], cwd=W, stderr=subprocess.DEVNULL)
     subprocess.check_call([sys.executable, "-m", "matryodshka_amd.build"], cwd=ROOT, stdout=subprocess.DEVNULL)
 spec = importlib.util.spec_from_file_location("patches", os.path.join(os.path.dirname(os.path.abspath(__file__)), "patches.py"))
 patches = importlib.util.module_from_spec(spec); spec.loader.exec_module(patches)
@@ -54,5 +56,6 @@ for name in a.names:
     run([LLVM + "/clang", "-cc1as", "-triple", "x86_64-unknown-linux-gnu", "-filetype", "obj", "-main-file-name", "cnn.hip", "-target-cpu", "x86-64", "-mrelocation-model", "pic", "-o", "%s/cnn_%s.o" % (W, name), hp])
     os.makedirs(ROOT + "/tools/_variants", exist_ok=True)
     run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", "%s/tools/_variants/libmsi_%s.so" % (ROOT, name),
-         ROOT + "/matryodshka_amd/csrc/_obj/common.o", ROOT + "/matryodshka_amd/csrc/_obj/geometry.o", "%s/cnn_%s.o" % (W, name)])
+         ROOT + "/matryodshka_amd/csrc/_obj/common.o", ROOT + "/matryodshka_amd/csrc/_obj/geometry.o", "%s/cnn_%s.o" % (W, name)] +
+        [ROOT + "/matryodshka_amd/csrc/_obj/" + u[:-4] + ".o" for u in ("cnn.hip", "cnn_igemm.hip", "cnn_halo.hip", "cnn_x3.hip", "cnn_bf16.hip", "cnn_tail.hip") if u != a.unit])
     print("built", name, "(%d -> %d lines)" % (k1 - k0, len(body)))

@@ -1,8 +1,9 @@
 #!/bin/bash
-# tools/kres.sh [defines]: VGPRs / AGPRs / scratch bytes / LDS of every kernel in cnn.hip (hipcc -Rpass-analysis=kernel-resource-usage)
+# tools/kres.sh [defines]: VGPRs / AGPRs / scratch bytes / LDS of every kernel of the convolution path's units (hipcc -Rpass-analysis=kernel-resource-usage)
 cd "$(dirname "$0")/.." || exit 1
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imatryodshka_amd/csrc --offload-device-only "$@" -c matryodshka_amd/csrc/cnn.hip -o /tmp/cnn_kres.o \
-  -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
+for u in cnn_igemm cnn_halo cnn_x3 cnn_bf16 cnn_tail; do
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Iinclude -Imatryodshka_amd/csrc --offload-device-only "$@" -c matryodshka_amd/csrc/$u.hip -o /tmp/cnn_kres.o \
+  -Rpass-analysis=kernel-resource-usage 2>&1; done | python3 -c '
 import re, sys
 cur = None
 for l in sys.stdin:
