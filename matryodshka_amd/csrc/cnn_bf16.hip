@@ -111,55 +111,54 @@ conv_halo_bf16_kernel(const ConvParams p) {
   }
   v4f araw[NRAW];   // (eight bf16 operands, or eight fp16 raw values, per 16-byte slot)
   float *s_tab = reinterpret_cast<float *>(smem + G::LDS_BYTES);   // APPLY: scale[C] | shift[C] of the source's LayerNorm
-#define MSI_PATCH_LOAD(c)                                                                                              \
-  {                                                                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
-      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], (c) * 128, 0)); \
-    if (APPLY) c_ld = (c);                                                                                             \
-  }
-#define MSI_PATCH_STORE()                                                                                              \
-  {                                                                                                                    \
-    v4f s_[2], t_[2];                                                                                                  \
-    if (APPLY) {   /* the thread's eight channels of chunk c_ld: four ds_read_b128 from the table built in the prologue */ \
-      const float *sp_ = s_tab + c_ld * 64 + cslot * 8;                                                                \
-      s_[0] = *reinterpret_cast<const v4f *>(sp_); s_[1] = *reinterpret_cast<const v4f *>(sp_ + 4);                    \
-      t_[0] = *reinterpret_cast<const v4f *>(sp_ + C); t_[1] = *reinterpret_cast<const v4f *>(sp_ + C + 4);            \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
-      v4f o_;                                                                                                          \
-      if (APPLY) {                                                                                                     \
-        const v4f z_ = {0.f, 0.f, 0.f, 0.f};                                                                           \
-        typedef _Float16 h8_t __attribute__((ext_vector_type(8)));                                                     \
-        const h8_t hx_ = __builtin_bit_cast(h8_t, araw[k_]);   /* eight fp16 raw values x * 2^-e (s_ carries 2^e) */    \
-        const v4f x0_ = {(float)hx_[0], (float)hx_[1], (float)hx_[2], (float)hx_[3]};                                  \
-        const v4f x1_ = {(float)hx_[4], (float)hx_[5], (float)hx_[6], (float)hx_[7]};                                  \
-        v4f y0 = __builtin_elementwise_max(__builtin_elementwise_fma(x0_, s_[0], t_[0]), z_);                          \
-        v4f y1 = __builtin_elementwise_max(__builtin_elementwise_fma(x1_, s_[1], t_[1]), z_);                          \
-        if (has_pad && !pok[k_]) { y0 = z_; y1 = z_; }   /* padding is zero AFTER the normalisation */                 \
-        unsigned w0, w1, w2, w3;                                                                                       \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w0) : "v"(y0.x), "v"(y0.y));                                         \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1) : "v"(y0.z), "v"(y0.w));                                         \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2) : "v"(y1.x), "v"(y1.y));                                         \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w3) : "v"(y1.z), "v"(y1.w));                                         \
-        o_ = __builtin_bit_cast(v4f, u32x4_t{w0, w1, w2, w3});                                                         \
-      } else {                                                                                                         \
-        o_ = araw[k_];                                                                                                 \
-      }                                                                                                                \
-      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = o_;                                   \
-    }                                                                                                                  \
-  }
+  auto patch_load = [&](const int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_)
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], c * 128, 0));
+    if (APPLY) c_ld = c;
+  };
+  auto patch_store = [&]() __attribute__((always_inline)) {
+    v4f s_[2], t_[2];
+    if (APPLY) {   /* the thread's eight channels of chunk c_ld: four ds_read_b128 from the table built in the prologue */
+      const float *sp_ = s_tab + c_ld * 64 + cslot * 8;
+      s_[0] = *reinterpret_cast<const v4f *>(sp_); s_[1] = *reinterpret_cast<const v4f *>(sp_ + 4);
+      t_[0] = *reinterpret_cast<const v4f *>(sp_ + C); t_[1] = *reinterpret_cast<const v4f *>(sp_ + C + 4);
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_) {
+      v4f o_;
+      if (APPLY) {
+        const v4f z_ = {0.f, 0.f, 0.f, 0.f};
+        typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+        const h8_t hx_ = __builtin_bit_cast(h8_t, araw[k_]);   /* eight fp16 raw values x * 2^-e (s_ carries 2^e) */
+        const v4f x0_ = {(float)hx_[0], (float)hx_[1], (float)hx_[2], (float)hx_[3]};
+        const v4f x1_ = {(float)hx_[4], (float)hx_[5], (float)hx_[6], (float)hx_[7]};
+        v4f y0 = __builtin_elementwise_max(__builtin_elementwise_fma(x0_, s_[0], t_[0]), z_);
+        v4f y1 = __builtin_elementwise_max(__builtin_elementwise_fma(x1_, s_[1], t_[1]), z_);
+        if (has_pad && !pok[k_]) { y0 = z_; y1 = z_; }   /* padding is zero AFTER the normalisation */
+        unsigned w0, w1, w2, w3;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w0) : "v"(y0.x), "v"(y0.y));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1) : "v"(y0.z), "v"(y0.w));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2) : "v"(y1.x), "v"(y1.y));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w3) : "v"(y1.z), "v"(y1.w));
+        o_ = __builtin_bit_cast(v4f, u32x4_t{w0, w1, w2, w3});
+      } else {
+        o_ = araw[k_];
+      }
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = o_;
+    }
+  };
   // weights of k-step (chunk c, tap) -> ring stage st (run-time); the packed blob is tap-major: row block tap * CH + c
-#define MSI_B_ISSUE(c, tap, st)                                                                                        \
-  {                                                                                                                    \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * (BN / NW) * ROW_BYTES;                                  \
-    const int soff_ = ((tap) * CH + (c)) * p.npad * ROW_BYTES;                                                         \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    if (BI >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0); \
-    if (BI == 4) {                                                                                                     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 16 * ROW_BYTES, 0);         \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 24 * ROW_BYTES, 0);         \
-    }                                                                                                                  \
-  }
+  auto b_issue = [&](const int c, const int tap, const int st) __attribute__((always_inline)) {
+    char *sB_ = smem + G::A_BYTES + st * G::B_STAGE + wave * (BN / NW) * ROW_BYTES;
+    const int soff_ = (tap * CH + c) * p.npad * ROW_BYTES;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);
+    if (BI >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);
+    if (BI == 4) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 16 * ROW_BYTES, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 24 * ROW_BYTES, 0);
+    }
+  };
 
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
@@ -182,71 +181,81 @@ conv_halo_bf16_kernel(const ConvParams p) {
   // first; quarter q waits for its own; the next chunk's patch loads (tap 0) and the DMA of the k-step PD ahead are issued
   // after the first quarter.  Before the closing barrier the NEXT k-step's weights must have landed: with PD = 2 they
   // were issued one k-step ago, and only what this k-step issued may still be in flight (in-order return).
-#define MSI_HQ(Q)                                                                                                      \
-  wait_lgkm_frag<(3 - (Q)) * (MT + NT), MT, NT>(fa_[Q], fb_[Q]);                                                       \
-  _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                                    \
-    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                                  \
-      acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb_[Q][j_]),                    \
-                                                            __builtin_bit_cast(bf16x8, fa_[Q][i_]), acc[i_][j_], 0, 0, 0); \
-  __builtin_amdgcn_sched_barrier(0);
-#define MSI_HTAP(TAP)                                                                                                  \
-  {                                                                                                                    \
-    constexpr int KH_ = (TAP) / 3, KW_ = (TAP) % 3;                                                                    \
-    constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;                                             \
-    constexpr int AROW_ = 2 * G::ROW_PITCH;   /* next 32-pixel block: two patch rows down */                           \
-    v4f fa_[4][MT], fb_[4][NT];                                                                                        \
-    const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
-    if (ABL & 8) {                                                                                                     \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                               \
-        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) asm volatile("" : "=v"(fa_[q_][i_]));                        \
-        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) asm volatile("" : "=v"(fb_[q_][j_]));                        \
-      }                                                                                                                \
-    } else                                                                                                             \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
-      const unsigned ba_ = b_q[q_] + bst_;                                                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                                \
-        fa_[q_][i_] = i_ == 0 ? (q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 32>(a_base)      \
-                                : q_ == 2 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base))         \
-                    : i_ == 1 ? (q_ == 0 ? lds_read128<AOFF_ + AROW_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + AROW_ + 32>(a_base) \
-                                : q_ == 2 ? lds_read128<AOFF_ + AROW_ + 64>(a_base) : lds_read128<AOFF_ + AROW_ + 96>(a_base)) \
-                    : i_ == 2 ? (q_ == 0 ? lds_read128<AOFF_ + 2 * AROW_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 2 * AROW_ + 32>(a_base) \
-                                : q_ == 2 ? lds_read128<AOFF_ + 2 * AROW_ + 64>(a_base) : lds_read128<AOFF_ + 2 * AROW_ + 96>(a_base)) \
-                              : (q_ == 0 ? lds_read128<AOFF_ + 3 * AROW_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 3 * AROW_ + 32>(a_base) \
-                                : q_ == 2 ? lds_read128<AOFF_ + 3 * AROW_ + 64>(a_base) : lds_read128<AOFF_ + 3 * AROW_ + 96>(a_base)); \
-      _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                                \
-        fb_[q_][j_] = j_ == 0 ? lds_read128<0>(ba_) : lds_read128<32 * ROW_BYTES>(ba_);                                \
-    }                                                                                                                  \
-    MSI_HQ(0)                                                                                                          \
-    bool issued_;                                                                                                      \
-    {                                                                                                                  \
-      if (!(ABL & 2) && (TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                \
-      int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                         \
-      issued_ = ((TAP) + PD < 9) || (c + 1 < c1);                                                                      \
-      if (ABL & 1) { }                                                                                                 \
-      else if ((TAP) + PD < 9) { MSI_B_ISSUE(c, (TAP) + PD, sn_) }                                                     \
-      else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) + PD - 9, sn_) }                                                 \
-    }                                                                                                                  \
-    MSI_HQ(1) MSI_HQ(2) MSI_HQ(3)                                                                                      \
-    if (ABL & 3) {                                                                                                     \
-      wait_vmcnt<0>();                                                                                                 \
-    } else if (PD == 2) {                                                                                              \
-      if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<BI + NPL>();                                                            \
-      else if (issued_) wait_vmcnt<BI>();                                                                              \
-      else wait_vmcnt<0>();                                                                                            \
-    } else {                                                                                                           \
-      wait_vmcnt<0>();                                                                                                 \
-    }                                                                                                                  \
-    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                                                      \
-    st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
-  }
-
-  // ---- prologue: first patch, first PD weight k-steps ----
+  auto hq = [&](auto Q_c, v4f (&fa_)[4][MT], v4f (&fb_)[4][NT]) __attribute__((always_inline)) {
+    constexpr int Q = decltype(Q_c)::value;
+    wait_lgkm_frag<(3 - Q) * (MT + NT), MT, NT>(fa_[Q], fb_[Q]);
+#pragma unroll
+    for (int i_ = 0; i_ < MT; ++i_)
+#pragma unroll
+      for (int j_ = 0; j_ < NT; ++j_)
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb_[Q][j_]),
+                                                              __builtin_bit_cast(bf16x8, fa_[Q][i_]), acc[i_][j_], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   const int c0 = 0, c1 = CH;
   int c = c0, st = 0;
+  auto htap = [&](auto TAP_c) __attribute__((always_inline)) {
+    constexpr int TAP = decltype(TAP_c)::value;
+    constexpr int KH_ = TAP / 3, KW_ = TAP % 3;
+    constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;
+    constexpr int AROW_ = 2 * G::ROW_PITCH;   /* next 32-pixel block: two patch rows down */
+    v4f fa_[4][MT], fb_[4][NT];
+    const unsigned bst_ = (unsigned)st * G::B_STAGE;
+    if (ABL & 8) {
+#pragma unroll
+      for (int q_ = 0; q_ < 4; ++q_) {
+#pragma unroll
+        for (int i_ = 0; i_ < MT; ++i_) asm volatile("" : "=v"(fa_[q_][i_]));
+#pragma unroll
+        for (int j_ = 0; j_ < NT; ++j_) asm volatile("" : "=v"(fb_[q_][j_]));
+      }
+    } else
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_) {
+      const unsigned ba_ = b_q[q_] + bst_;
+#pragma unroll
+      for (int i_ = 0; i_ < MT; ++i_)
+        fa_[q_][i_] = i_ == 0 ? (q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 32>(a_base)
+                                : q_ == 2 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base))
+                    : i_ == 1 ? (q_ == 0 ? lds_read128<AOFF_ + AROW_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + AROW_ + 32>(a_base)
+                                : q_ == 2 ? lds_read128<AOFF_ + AROW_ + 64>(a_base) : lds_read128<AOFF_ + AROW_ + 96>(a_base))
+                    : i_ == 2 ? (q_ == 0 ? lds_read128<AOFF_ + 2 * AROW_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 2 * AROW_ + 32>(a_base)
+                                : q_ == 2 ? lds_read128<AOFF_ + 2 * AROW_ + 64>(a_base) : lds_read128<AOFF_ + 2 * AROW_ + 96>(a_base))
+                              : (q_ == 0 ? lds_read128<AOFF_ + 3 * AROW_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 3 * AROW_ + 32>(a_base)
+                                : q_ == 2 ? lds_read128<AOFF_ + 3 * AROW_ + 64>(a_base) : lds_read128<AOFF_ + 3 * AROW_ + 96>(a_base));
+#pragma unroll
+      for (int j_ = 0; j_ < NT; ++j_)
+        fb_[q_][j_] = j_ == 0 ? lds_read128<0>(ba_) : lds_read128<32 * ROW_BYTES>(ba_);
+    }
+    hq(IC<0>{}, fa_, fb_);
+    bool issued_;
+    {
+      if (!(ABL & 2) && TAP == 0 && c + 1 < c1) patch_load(c + 1);
+      int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;
+      issued_ = (TAP + PD < 9) || (c + 1 < c1);
+      if (ABL & 1) { }
+      else if (TAP + PD < 9) { b_issue(c, TAP + PD, sn_); }
+      else if (c + 1 < c1) { b_issue(c + 1, TAP + PD - 9, sn_); }
+    }
+    hq(IC<1>{}, fa_, fb_); hq(IC<2>{}, fa_, fb_); hq(IC<3>{}, fa_, fb_);
+    if (ABL & 3) {
+      wait_vmcnt<0>();
+    } else if (PD == 2) {
+      if (TAP == 0 && c + 1 < c1) wait_vmcnt<BI + NPL>();
+      else if (issued_) wait_vmcnt<BI>();
+      else wait_vmcnt<0>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+    st = st + 1 == NSTG ? 0 : st + 1;
+  };
+
+  // ---- prologue: first patch, first PD weight k-steps ----
   MSI_STAMP(6)
-  MSI_PATCH_LOAD(c0)
-  MSI_B_ISSUE(c0, 0, 0)
-  if (PD == 2) MSI_B_ISSUE(c0, 1, 1)
+  patch_load(c0);
+  b_issue(c0, 0, 0);
+  if (PD == 2) b_issue(c0, 1, 1);
   MSI_STAMP(7)
   if (APPLY) {
     // the affine of the source's LayerNorm for every input channel, once per workgroup: scale = 2^e inv gamma (the stored
@@ -277,25 +286,20 @@ conv_halo_bf16_kernel(const ConvParams p) {
   MSI_STAMP(9)
   wait_vmcnt<0>();
   MSI_STAMP(10)
-  MSI_PATCH_STORE()
+  patch_store();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #ifdef MSI_CONV_TIMING
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
   for (; c < c1; ++c) {
-    MSI_HTAP(0) MSI_HTAP(1) MSI_HTAP(2) MSI_HTAP(3) MSI_HTAP(4) MSI_HTAP(5) MSI_HTAP(6) MSI_HTAP(7) MSI_HTAP(8)
+    htap(IC<0>{}); htap(IC<1>{}); htap(IC<2>{}); htap(IC<3>{}); htap(IC<4>{}); htap(IC<5>{}); htap(IC<6>{}); htap(IC<7>{}); htap(IC<8>{});
     if (c + 1 < c1 && !(ABL & 2)) {
-      MSI_PATCH_STORE()
+      patch_store();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
-#undef MSI_HTAP
-#undef MSI_HQ
-#undef MSI_B_ISSUE
-#undef MSI_PATCH_STORE
-#undef MSI_PATCH_LOAD
 #ifdef MSI_CONV_TIMING
   const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -404,55 +408,56 @@ conv_halo_bf16_s2_kernel(const ConvParams p) {
   }
   v4f araw[NRAW];   // (eight bf16 operands, or eight fp16 raw values, per 16-byte slot)
   float *s_tab = reinterpret_cast<float *>(smem + G::LDS_BYTES);   // APPLY: scale[C] | shift[C] of the source's LayerNorm
-#define MSI_PATCH_LOAD(c, U)                                                                                           \
-  {                                                                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
-      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[U][k_], (c) * 128, 0)); \
-    if (APPLY) c_ld = (c);                                                                                             \
-  }
-#define MSI_PATCH_STORE(U)                                                                                             \
-  {                                                                                                                    \
-    v4f s_[2], t_[2];                                                                                                  \
-    if (APPLY) {   /* the thread's eight channels of chunk c_ld: four ds_read_b128 from the table built in the prologue */ \
-      const float *sp_ = s_tab + c_ld * 64 + cslot * 8;                                                                \
-      s_[0] = *reinterpret_cast<const v4f *>(sp_); s_[1] = *reinterpret_cast<const v4f *>(sp_ + 4);                    \
-      t_[0] = *reinterpret_cast<const v4f *>(sp_ + C); t_[1] = *reinterpret_cast<const v4f *>(sp_ + C + 4);            \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
-      v4f o_;                                                                                                          \
-      if (APPLY) {                                                                                                     \
-        const v4f z_ = {0.f, 0.f, 0.f, 0.f};                                                                           \
-        typedef _Float16 h8_t __attribute__((ext_vector_type(8)));                                                     \
-        const h8_t hx_ = __builtin_bit_cast(h8_t, araw[k_]);   /* eight fp16 raw values x * 2^-e (s_ carries 2^e) */    \
-        const v4f x0_ = {(float)hx_[0], (float)hx_[1], (float)hx_[2], (float)hx_[3]};                                  \
-        const v4f x1_ = {(float)hx_[4], (float)hx_[5], (float)hx_[6], (float)hx_[7]};                                  \
-        v4f y0 = __builtin_elementwise_max(__builtin_elementwise_fma(x0_, s_[0], t_[0]), z_);                          \
-        v4f y1 = __builtin_elementwise_max(__builtin_elementwise_fma(x1_, s_[1], t_[1]), z_);                          \
-        if (has_pad && !pok[U][k_]) { y0 = z_; y1 = z_; }   /* padding is zero AFTER the normalisation */                 \
-        unsigned w0, w1, w2, w3;                                                                                       \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w0) : "v"(y0.x), "v"(y0.y));                                         \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1) : "v"(y0.z), "v"(y0.w));                                         \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2) : "v"(y1.x), "v"(y1.y));                                         \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w3) : "v"(y1.z), "v"(y1.w));                                         \
-        o_ = __builtin_bit_cast(v4f, u32x4_t{w0, w1, w2, w3});                                                         \
-      } else {                                                                                                         \
-        o_ = araw[k_];                                                                                                 \
-      }                                                                                                                \
-      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = o_;                                   \
-    }                                                                                                                  \
-  }
+  auto patch_load = [&](const int c, auto U_c) __attribute__((always_inline)) {
+    constexpr int U = decltype(U_c)::value;
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_)
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[U][k_], c * 128, 0));
+    if (APPLY) c_ld = c;
+  };
+  auto patch_store = [&](auto U_c) __attribute__((always_inline)) {
+    constexpr int U = decltype(U_c)::value;
+    v4f s_[2], t_[2];
+    if (APPLY) {   /* the thread's eight channels of chunk c_ld: four ds_read_b128 from the table built in the prologue */
+      const float *sp_ = s_tab + c_ld * 64 + cslot * 8;
+      s_[0] = *reinterpret_cast<const v4f *>(sp_); s_[1] = *reinterpret_cast<const v4f *>(sp_ + 4);
+      t_[0] = *reinterpret_cast<const v4f *>(sp_ + C); t_[1] = *reinterpret_cast<const v4f *>(sp_ + C + 4);
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_) {
+      v4f o_;
+      if (APPLY) {
+        const v4f z_ = {0.f, 0.f, 0.f, 0.f};
+        typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+        const h8_t hx_ = __builtin_bit_cast(h8_t, araw[k_]);   /* eight fp16 raw values x * 2^-e (s_ carries 2^e) */
+        const v4f x0_ = {(float)hx_[0], (float)hx_[1], (float)hx_[2], (float)hx_[3]};
+        const v4f x1_ = {(float)hx_[4], (float)hx_[5], (float)hx_[6], (float)hx_[7]};
+        v4f y0 = __builtin_elementwise_max(__builtin_elementwise_fma(x0_, s_[0], t_[0]), z_);
+        v4f y1 = __builtin_elementwise_max(__builtin_elementwise_fma(x1_, s_[1], t_[1]), z_);
+        if (has_pad && !pok[U][k_]) { y0 = z_; y1 = z_; }   /* padding is zero AFTER the normalisation */
+        unsigned w0, w1, w2, w3;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w0) : "v"(y0.x), "v"(y0.y));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1) : "v"(y0.z), "v"(y0.w));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2) : "v"(y1.x), "v"(y1.y));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w3) : "v"(y1.z), "v"(y1.w));
+        o_ = __builtin_bit_cast(v4f, u32x4_t{w0, w1, w2, w3});
+      } else {
+        o_ = araw[k_];
+      }
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = o_;
+    }
+  };
   // weights of k-step (chunk c, tap) -> ring stage st (run-time); the packed blob is tap-major: row block tap * CH + c
-#define MSI_B_ISSUE(c, tap, st)                                                                                        \
-  {                                                                                                                    \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * (BN / NW) * ROW_BYTES;                                  \
-    const int soff_ = ((tap) * CH + (c)) * p.npad * ROW_BYTES;                                                         \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    if (BI >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0); \
-    if (BI == 4) {                                                                                                     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 16 * ROW_BYTES, 0);         \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 24 * ROW_BYTES, 0);         \
-    }                                                                                                                  \
-  }
+  auto b_issue = [&](const int c, const int tap, const int st) __attribute__((always_inline)) {
+    char *sB_ = smem + G::A_BYTES + st * G::B_STAGE + wave * (BN / NW) * ROW_BYTES;
+    const int soff_ = (tap * CH + c) * p.npad * ROW_BYTES;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);
+    if (BI >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);
+    if (BI == 4) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 16 * ROW_BYTES, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 24 * ROW_BYTES, 0);
+    }
+  };
 
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
@@ -475,68 +480,73 @@ conv_halo_bf16_s2_kernel(const ConvParams p) {
   // first; quarter q waits for its own; the next chunk's patch loads (tap 0) and the DMA of the k-step PD ahead are issued
   // after the first quarter.  Before the closing barrier the NEXT k-step's weights must have landed: with PD = 2 they
   // were issued one k-step ago, and only what this k-step issued may still be in flight (in-order return).
-#define MSI_HQ(Q)                                                                                                      \
-  wait_lgkm_frag<(3 - (Q)) * (MT + NT), MT, NT>(fa_[Q], fb_[Q]);                                                       \
-  _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                                    \
-    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                                  \
-      acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb_[Q][j_]),                    \
-                                                            __builtin_bit_cast(bf16x8, fa_[Q][i_]), acc[i_][j_], 0, 0, 0); \
-  __builtin_amdgcn_sched_barrier(0);
-#define MSI_S2_TAP(J) ((J) == 0 ? 0 : (J) == 1 ? 2 : (J) == 2 ? 6 : (J) == 3 ? 8 : (J) == 4 ? 1 : (J) == 5 ? 7 : (J) == 6 ? 3 : (J) == 7 ? 5 : 4)
-#define MSI_S2_UNIT(J) ((J) < 4 ? 0 : (J) < 6 ? 1 : (J) < 8 ? 2 : 3)
+  auto hq = [&](auto Q_c, v4f (&fa_)[4][MT], v4f (&fb_)[4][NT]) __attribute__((always_inline)) {
+    constexpr int Q = decltype(Q_c)::value;
+    wait_lgkm_frag<(3 - Q) * (MT + NT), MT, NT>(fa_[Q], fb_[Q]);
+#pragma unroll
+    for (int i_ = 0; i_ < MT; ++i_)
+#pragma unroll
+      for (int j_ = 0; j_ < NT; ++j_)
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb_[Q][j_]),
+                                                              __builtin_bit_cast(bf16x8, fa_[Q][i_]), acc[i_][j_], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   // k-step J = 0..8 of the current 64-channel group: unit, tap and patch offsets are literals (conv_halo_s2_kernel's order)
-#define MSI_S2STEP(J)                                                                                                  \
-  {                                                                                                                    \
-    constexpr int TAP_ = MSI_S2_TAP(J), U_ = MSI_S2_UNIT(J);                                                           \
-    constexpr int DY_ = (TAP_ / 3) >> 1, DX_ = (TAP_ % 3) >> 1;                                                        \
-    constexpr bool FIRST_ = (J) == 0 || (J) == 4 || (J) == 6 || (J) == 8, LAST_ = (J) == 3 || (J) == 5 || (J) == 7 || (J) == 8; \
-    constexpr int AOFF_ = DY_ * G::ROW_PITCH + DX_ * G::PIX_BYTES;                                                     \
-    constexpr int AROW_ = 2 * G::ROW_PITCH;   /* next 32-pixel block: two patch rows down */                           \
-    const bool more_ = U_ < 3 || c + 1 < c1;               /* a unit follows this one */                               \
-    v4f fa_[4][MT], fb_[4][NT];                                                                                        \
-    const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
-      const unsigned ba_ = b_q[q_] + bst_;                                                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                                \
-        fa_[q_][i_] = i_ == 0 ? (q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 32>(a_base)      \
-                                : q_ == 2 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base))         \
-                              : (q_ == 0 ? lds_read128<AOFF_ + AROW_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + AROW_ + 32>(a_base) \
-                                : q_ == 2 ? lds_read128<AOFF_ + AROW_ + 64>(a_base) : lds_read128<AOFF_ + AROW_ + 96>(a_base)); \
-      _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                                \
-        fb_[q_][j_] = j_ == 0 ? lds_read128<0>(ba_) : lds_read128<32 * ROW_BYTES>(ba_);                                \
-    }                                                                                                                  \
-    MSI_HQ(0)                                                                                                          \
-    bool issued_;                                                                                                      \
-    {                                                                                                                  \
-      if (FIRST_ && more_) {                                                                                           \
-        if (U_ < 3) MSI_PATCH_LOAD(c, (U_ + 1) & 3) else MSI_PATCH_LOAD(c + 1, 0)                                      \
-      }                                                                                                                \
-      int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                         \
-      issued_ = ((J) + PD < 9) || (c + 1 < c1);                                                                        \
-      if ((J) + PD < 9) { MSI_B_ISSUE(c, MSI_S2_TAP(((J) + PD) % 9), sn_) }                                            \
-      else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, MSI_S2_TAP(((J) + PD) % 9), sn_) }                                     \
-    }                                                                                                                  \
-    MSI_HQ(1) MSI_HQ(2) MSI_HQ(3)                                                                                      \
-    /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */ \
-    if (FIRST_ && !LAST_ && more_) wait_vmcnt<BI + NPL>();                                                             \
-    else if (issued_) wait_vmcnt<BI>();                                                                                \
-    else wait_vmcnt<0>();                                                                                              \
-    __builtin_amdgcn_s_barrier();                                                                                      \
-    st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
-    if (LAST_ && more_) {   /* every wave has read this unit's last tap: swap the patch */                             \
-      MSI_PATCH_STORE((U_ + 1) & 3)                                                                                    \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
-      __builtin_amdgcn_s_barrier();                                                                                    \
-    }                                                                                                                  \
-  }
+  const int c0 = 0, c1 = CH;
+  int c = c0, st = 0;
+  auto s2step = [&](auto J_c) __attribute__((always_inline)) {
+    constexpr int J = decltype(J_c)::value;
+    constexpr int TAP_ = s2_tap(J), U_ = s2_unit(J);
+    constexpr int DY_ = (TAP_ / 3) >> 1, DX_ = (TAP_ % 3) >> 1;
+    constexpr bool FIRST_ = J == 0 || J == 4 || J == 6 || J == 8, LAST_ = J == 3 || J == 5 || J == 7 || J == 8;
+    constexpr int AOFF_ = DY_ * G::ROW_PITCH + DX_ * G::PIX_BYTES;
+    constexpr int AROW_ = 2 * G::ROW_PITCH;   /* next 32-pixel block: two patch rows down */
+    const bool more_ = U_ < 3 || c + 1 < c1;               /* a unit follows this one */
+    v4f fa_[4][MT], fb_[4][NT];
+    const unsigned bst_ = (unsigned)st * G::B_STAGE;
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_) {
+      const unsigned ba_ = b_q[q_] + bst_;
+#pragma unroll
+      for (int i_ = 0; i_ < MT; ++i_)
+        fa_[q_][i_] = i_ == 0 ? (q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 32>(a_base)
+                                : q_ == 2 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base))
+                              : (q_ == 0 ? lds_read128<AOFF_ + AROW_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + AROW_ + 32>(a_base)
+                                : q_ == 2 ? lds_read128<AOFF_ + AROW_ + 64>(a_base) : lds_read128<AOFF_ + AROW_ + 96>(a_base));
+#pragma unroll
+      for (int j_ = 0; j_ < NT; ++j_)
+        fb_[q_][j_] = j_ == 0 ? lds_read128<0>(ba_) : lds_read128<32 * ROW_BYTES>(ba_);
+    }
+    hq(IC<0>{}, fa_, fb_);
+    bool issued_;
+    {
+      if (FIRST_ && more_) {
+        if (U_ < 3) patch_load(c, IC<(U_ + 1) & 3>{}); else patch_load(c + 1, IC<0>{});
+      }
+      int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;
+      issued_ = (J + PD < 9) || (c + 1 < c1);
+      if (J + PD < 9) { b_issue(c, s2_tap((J + PD) % 9), sn_); }
+      else if (c + 1 < c1) { b_issue(c + 1, s2_tap((J + PD) % 9), sn_); }
+    }
+    hq(IC<1>{}, fa_, fb_); hq(IC<2>{}, fa_, fb_); hq(IC<3>{}, fa_, fb_);
+    /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */
+    if (FIRST_ && !LAST_ && more_) wait_vmcnt<BI + NPL>();
+    else if (issued_) wait_vmcnt<BI>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    st = st + 1 == NSTG ? 0 : st + 1;
+    if (LAST_ && more_) {   /* every wave has read this unit's last tap: swap the patch */
+      patch_store(IC<(U_ + 1) & 3>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
 
   // ---- prologue: unit 0 of the first group, the first two weight k-steps (taps (0,0), (0,2)) ----
   static_assert(PD == 2 && MT <= 2, "three-stage weight ring; one or two 32-pixel blocks per wave");
-  const int c0 = 0, c1 = CH;
-  int c = c0, st = 0;
-  MSI_PATCH_LOAD(c0, 0)
-  MSI_B_ISSUE(c0, MSI_S2_TAP(0), 0)
-  MSI_B_ISSUE(c0, MSI_S2_TAP(1), 1)
+  patch_load(c0, IC<0>{});
+  b_issue(c0, s2_tap(0), 0);
+  b_issue(c0, s2_tap(1), 1);
   if (APPLY) {
     // the affine of the source's LayerNorm for every input channel, once per workgroup (as conv_halo_bf16_kernel)
     double *s_stat = reinterpret_cast<double *>(smem);
@@ -560,19 +570,12 @@ conv_halo_bf16_s2_kernel(const ConvParams p) {
     __syncthreads();
   }
   wait_vmcnt<0>();
-  MSI_PATCH_STORE(0)
+  patch_store(IC<0>{});
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (; c < c1; ++c) {
-    MSI_S2STEP(0) MSI_S2STEP(1) MSI_S2STEP(2) MSI_S2STEP(3) MSI_S2STEP(4) MSI_S2STEP(5) MSI_S2STEP(6) MSI_S2STEP(7) MSI_S2STEP(8)
+    s2step(IC<0>{}); s2step(IC<1>{}); s2step(IC<2>{}); s2step(IC<3>{}); s2step(IC<4>{}); s2step(IC<5>{}); s2step(IC<6>{}); s2step(IC<7>{}); s2step(IC<8>{});
   }
-#undef MSI_S2STEP
-#undef MSI_S2_UNIT
-#undef MSI_S2_TAP
-#undef MSI_HQ
-#undef MSI_B_ISSUE
-#undef MSI_PATCH_STORE
-#undef MSI_PATCH_LOAD
   emit_tile<BM, BN, MODE_CONV, 1, WR>(p, acc, tile_m, tile_n, 0, b, tid, smem, raw_mul_pre);   // (the k-loop ended with a barrier: LDS is free)
 #endif
 }
@@ -660,77 +663,78 @@ convt_halo_bf16_kernel(const ConvParams p) {
     has_pad = __builtin_amdgcn_ballot_w64(bad) != 0;
   }
   constexpr int NPL = NLOAD + (APPLY ? 4 : 0);            // VMEM operations of a patch load
-#define MSI_PATCH_LOAD(c)                                                                                              \
-  {                                                                                                                    \
-    const int s_ = (c) >= p.cpt0 ? 1 : 0, cc_ = s_ ? (c) - p.cpt0 : (c);                                               \
-    const unsigned cb_ = (unsigned)((s_ ? p.C1 : p.C0) * 2);                                                           \
-    src_ld = s_;                                                                                                       \
-    if (APPLY) {   /* gamma / beta of the thread's 8 channels (dummy rows when this source is not raw: the vmcnt  */   \
-      /* arithmetic of the k-steps counts the same number of VMEM operations on both paths)                      */   \
-      const bool raw_ = (p.halo_apply >> s_) & 1;                                                                      \
-      const float *gb_ = raw_ ? (s_ ? p.ln_gamma1 : p.ln_gamma) : reinterpret_cast<const float *>(p.wpk);              \
-      const float *bb_ = raw_ ? (s_ ? p.ln_beta1 : p.ln_beta) : reinterpret_cast<const float *>(p.wpk);                \
-      const float *gp_ = gb_ + (raw_ ? cc_ * 64 : 0) + cslot * 8, *bp_ = bb_ + (raw_ ? cc_ * 64 : 64) + cslot * 8;     \
-      g8[0] = *reinterpret_cast<const v4f *>(gp_); g8[1] = *reinterpret_cast<const v4f *>(gp_ + 4);                     \
-      be8[0] = *reinterpret_cast<const v4f *>(bp_); be8[1] = *reinterpret_cast<const v4f *>(bp_ + 4);                   \
-    }                                                                                                                  \
-    if (s_ == 0) {                                                                                                     \
-      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
-        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
-            rsrc_a0, pok[k_] ? pixi[k_] * cb_ + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));                    \
-    } else {                                                                                                           \
-      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
-        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
-            rsrc_a1, pok[k_] ? pixi[k_] * cb_ + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));                    \
-    }                                                                                                                  \
-  }
-#define MSI_PATCH_STORE()                                                                                              \
-  {                                                                                                                    \
-    const bool ap_ = APPLY && ((p.halo_apply >> src_ld) & 1);                                                          \
-    v4f s_[2], t_[2];                                                                                                  \
-    if (ap_) {                                                                                                         \
-      const float ih_ = src_ld ? inv1 : inv0, mh_ = src_ld ? mh1 : mh0, ml_ = src_ld ? ml1 : ml0;                       \
-      const float uf_ = src_ld ? up1 : up0;                                                                            \
-      const v4f nh = {-mh_, -mh_, -mh_, -mh_}, nl = {-ml_, -ml_, -ml_, -ml_};                                          \
-      _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                               \
-        const v4f su_ = ih_ * g8[h_];                                                                                  \
-        t_[h_] = __builtin_elementwise_fma(nl, su_, __builtin_elementwise_fma(nh, su_, be8[h_]));                      \
-        s_[h_] = uf_ * su_;                                                                                            \
-      }                                                                                                                \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
-      v4f o_ = araw[k_];                                                                                               \
-      if (ap_) {                                                                                                       \
-        const v4f z_ = {0.f, 0.f, 0.f, 0.f};                                                                           \
-        typedef _Float16 h8_t __attribute__((ext_vector_type(8)));                                                     \
-        const h8_t hx_ = __builtin_bit_cast(h8_t, araw[k_]);                                                           \
-        const v4f x0_ = {(float)hx_[0], (float)hx_[1], (float)hx_[2], (float)hx_[3]};                                  \
-        const v4f x1_ = {(float)hx_[4], (float)hx_[5], (float)hx_[6], (float)hx_[7]};                                  \
-        v4f y0 = __builtin_elementwise_max(__builtin_elementwise_fma(x0_, s_[0], t_[0]), z_);                          \
-        v4f y1 = __builtin_elementwise_max(__builtin_elementwise_fma(x1_, s_[1], t_[1]), z_);                          \
-        if (has_pad && !pok[k_]) { y0 = z_; y1 = z_; }   /* padding is zero AFTER the normalisation */                 \
-        unsigned w0, w1, w2, w3;                                                                                       \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w0) : "v"(y0.x), "v"(y0.y));                                         \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1) : "v"(y0.z), "v"(y0.w));                                         \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2) : "v"(y1.x), "v"(y1.y));                                         \
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w3) : "v"(y1.z), "v"(y1.w));                                         \
-        o_ = __builtin_bit_cast(v4f, u32x4_t{w0, w1, w2, w3});                                                         \
-      }                                                                                                                \
-      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = o_;                                   \
-    }                                                                                                                  \
-  }
+  auto patch_load = [&](const int c) __attribute__((always_inline)) {
+    const int s_ = c >= p.cpt0 ? 1 : 0, cc_ = s_ ? c - p.cpt0 : c;
+    const unsigned cb_ = (unsigned)((s_ ? p.C1 : p.C0) * 2);
+    src_ld = s_;
+    if (APPLY) {   /* gamma / beta of the thread's 8 channels (dummy rows when this source is not raw: the vmcnt  */
+      /* arithmetic of the k-steps counts the same number of VMEM operations on both paths)                      */
+      const bool raw_ = (p.halo_apply >> s_) & 1;
+      const float *gb_ = raw_ ? (s_ ? p.ln_gamma1 : p.ln_gamma) : reinterpret_cast<const float *>(p.wpk);
+      const float *bb_ = raw_ ? (s_ ? p.ln_beta1 : p.ln_beta) : reinterpret_cast<const float *>(p.wpk);
+      const float *gp_ = gb_ + (raw_ ? cc_ * 64 : 0) + cslot * 8, *bp_ = bb_ + (raw_ ? cc_ * 64 : 64) + cslot * 8;
+      g8[0] = *reinterpret_cast<const v4f *>(gp_); g8[1] = *reinterpret_cast<const v4f *>(gp_ + 4);
+      be8[0] = *reinterpret_cast<const v4f *>(bp_); be8[1] = *reinterpret_cast<const v4f *>(bp_ + 4);
+    }
+    if (s_ == 0) {
+#pragma unroll
+      for (int k_ = 0; k_ < NLOAD; ++k_)
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(
+            rsrc_a0, pok[k_] ? pixi[k_] * cb_ + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));
+    } else {
+#pragma unroll
+      for (int k_ = 0; k_ < NLOAD; ++k_)
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(
+            rsrc_a1, pok[k_] ? pixi[k_] * cb_ + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));
+    }
+  };
+  auto patch_store = [&]() __attribute__((always_inline)) {
+    const bool ap_ = APPLY && ((p.halo_apply >> src_ld) & 1);
+    v4f s_[2], t_[2];
+    if (ap_) {
+      const float ih_ = src_ld ? inv1 : inv0, mh_ = src_ld ? mh1 : mh0, ml_ = src_ld ? ml1 : ml0;
+      const float uf_ = src_ld ? up1 : up0;
+      const v4f nh = {-mh_, -mh_, -mh_, -mh_}, nl = {-ml_, -ml_, -ml_, -ml_};
+#pragma unroll
+      for (int h_ = 0; h_ < 2; ++h_) {
+        const v4f su_ = ih_ * g8[h_];
+        t_[h_] = __builtin_elementwise_fma(nl, su_, __builtin_elementwise_fma(nh, su_, be8[h_]));
+        s_[h_] = uf_ * su_;
+      }
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_) {
+      v4f o_ = araw[k_];
+      if (ap_) {
+        const v4f z_ = {0.f, 0.f, 0.f, 0.f};
+        typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+        const h8_t hx_ = __builtin_bit_cast(h8_t, araw[k_]);
+        const v4f x0_ = {(float)hx_[0], (float)hx_[1], (float)hx_[2], (float)hx_[3]};
+        const v4f x1_ = {(float)hx_[4], (float)hx_[5], (float)hx_[6], (float)hx_[7]};
+        v4f y0 = __builtin_elementwise_max(__builtin_elementwise_fma(x0_, s_[0], t_[0]), z_);
+        v4f y1 = __builtin_elementwise_max(__builtin_elementwise_fma(x1_, s_[1], t_[1]), z_);
+        if (has_pad && !pok[k_]) { y0 = z_; y1 = z_; }   /* padding is zero AFTER the normalisation */
+        unsigned w0, w1, w2, w3;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w0) : "v"(y0.x), "v"(y0.y));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1) : "v"(y0.z), "v"(y0.w));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2) : "v"(y1.x), "v"(y1.y));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w3) : "v"(y1.z), "v"(y1.w));
+        o_ = __builtin_bit_cast(v4f, u32x4_t{w0, w1, w2, w3});
+      }
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = o_;
+    }
+  };
   // weights of k-step (class, tap, chunk c) -> ring stage st (run-time)
-#define MSI_B_ISSUE(cls, tap, c, st)                                                                                   \
-  {                                                                                                                    \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * (BN / 4) * ROW_BYTES;                                   \
-    const int soff_ = (((cls) * S + (tap) * CH + (c)) * p.npad) * ROW_BYTES;                                           \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
-    if (BI == 4) {                                                                                                     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 16 * ROW_BYTES, 0);         \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 24 * ROW_BYTES, 0);         \
-    }                                                                                                                  \
-  }
+  auto b_issue = [&](const int cls, const int tap, const int c, const int st) __attribute__((always_inline)) {
+    char *sB_ = smem + G::A_BYTES + st * G::B_STAGE + wave * (BN / 4) * ROW_BYTES;
+    const int soff_ = ((cls * S + tap * CH + c) * p.npad) * ROW_BYTES;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);
+    if (BI == 4) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 16 * ROW_BYTES, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 24 * ROW_BYTES, 0);
+    }
+  };
 
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
@@ -754,58 +758,66 @@ convt_halo_bf16_kernel(const ConvParams p) {
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
   // k-step J of the chunk: class pw = J / 4, tap (th, tw) = ((J / 2) & 1, J & 1); weights in ring stage st
-#define MSI_CQ(Q, PWC)                                                                                                 \
-  wait_lgkm_frag<(3 - (Q)) * (MT + NT), MT, NT>(fa_[Q], fb_[Q]);                                                       \
-  _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                                    \
-    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                                  \
-      acc[PWC][i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb_[Q][j_]),               \
-                                                                 __builtin_bit_cast(bf16x8, fa_[Q][i_]), acc[PWC][i_][j_], 0, 0, 0); \
-  __builtin_amdgcn_sched_barrier(0);
-#define MSI_CTSTEP(J)                                                                                                  \
-  {                                                                                                                    \
-    constexpr int PWC_ = (J) >> 2, TH_ = ((J) >> 1) & 1, TW_ = (J) & 1;                                                \
-    constexpr int COFF_ = (1 + (PWC_ ? TW_ : -TW_)) * G::PIX_BYTES;   /* column of the tap: immediate */                \
-    constexpr int AROW_ = 2 * G::ROW_PITCH;                                                                            \
-    const unsigned ab_ = TH_ ? a_base1 : a_base0;                                                                      \
-    v4f fa_[4][MT], fb_[4][NT];                                                                                        \
-    const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
-      const unsigned ba_ = b_q[q_] + bst_;                                                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                                                \
-        fa_[q_][i_] = i_ == 0 ? (q_ == 0 ? lds_read128<COFF_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 32>(ab_)            \
-                                : q_ == 2 ? lds_read128<COFF_ + 64>(ab_) : lds_read128<COFF_ + 96>(ab_))               \
-                    : i_ == 1 ? (q_ == 0 ? lds_read128<COFF_ + AROW_>(ab_) : q_ == 1 ? lds_read128<COFF_ + AROW_ + 32>(ab_) \
-                                : q_ == 2 ? lds_read128<COFF_ + AROW_ + 64>(ab_) : lds_read128<COFF_ + AROW_ + 96>(ab_)) \
-                    : i_ == 2 ? (q_ == 0 ? lds_read128<COFF_ + 2 * AROW_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 2 * AROW_ + 32>(ab_) \
-                                : q_ == 2 ? lds_read128<COFF_ + 2 * AROW_ + 64>(ab_) : lds_read128<COFF_ + 2 * AROW_ + 96>(ab_)) \
-                              : (q_ == 0 ? lds_read128<COFF_ + 3 * AROW_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 3 * AROW_ + 32>(ab_) \
-                                : q_ == 2 ? lds_read128<COFF_ + 3 * AROW_ + 64>(ab_) : lds_read128<COFF_ + 3 * AROW_ + 96>(ab_)); \
-      _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                                \
-        fb_[q_][j_] = j_ == 0 ? lds_read128<0>(ba_) : lds_read128<32 * ROW_BYTES>(ba_);                                \
-    }                                                                                                                  \
-    MSI_CQ(0, PWC_)                                                                                                    \
-    bool issued_;                                                                                                      \
-    {                                                                                                                  \
-      if ((J) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                                \
-      int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                         \
-      constexpr int JN_ = ((J) + PD) & 7;                                                                              \
-      issued_ = ((J) + PD < 8) || (c + 1 < c1);                                                                        \
-      if ((J) + PD < 8) { MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c, sn_) }                                          \
-      else if (c + 1 < c1) { MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_) }                                   \
-    }                                                                                                                  \
-    MSI_CQ(1, PWC_) MSI_CQ(2, PWC_) MSI_CQ(3, PWC_)                                                                    \
-    if ((J) == 0 && c + 1 < c1) wait_vmcnt<BI + NPL>();                                                                \
-    else if (issued_) wait_vmcnt<BI>();                                                                                \
-    else wait_vmcnt<0>();                                                                                              \
-    __builtin_amdgcn_s_barrier();                                                                                      \
-    st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
-  }
-
+  auto cq = [&](auto Q_c, auto PWC_c, v4f (&fa_)[4][MT], v4f (&fb_)[4][NT]) __attribute__((always_inline)) {
+    constexpr int Q = decltype(Q_c)::value;
+    constexpr int PWC = decltype(PWC_c)::value;
+    wait_lgkm_frag<(3 - Q) * (MT + NT), MT, NT>(fa_[Q], fb_[Q]);
+#pragma unroll
+    for (int i_ = 0; i_ < MT; ++i_)
+#pragma unroll
+      for (int j_ = 0; j_ < NT; ++j_)
+        acc[PWC][i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb_[Q][j_]),
+                                                                   __builtin_bit_cast(bf16x8, fa_[Q][i_]), acc[PWC][i_][j_], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   const int c0 = 0, c1 = CH;
   int c = c0, st = 0;
-  MSI_PATCH_LOAD(c0)
-  MSI_B_ISSUE(2 * ph, 0, c0, 0)
-  MSI_B_ISSUE(2 * ph, 1, c0, 1)
+  auto ctstep = [&](auto J_c) __attribute__((always_inline)) {
+    constexpr int J = decltype(J_c)::value;
+    constexpr int PWC_ = J >> 2, TH_ = (J >> 1) & 1, TW_ = J & 1;
+    constexpr int COFF_ = (1 + (PWC_ ? TW_ : -TW_)) * G::PIX_BYTES;   /* column of the tap: immediate */
+    constexpr int AROW_ = 2 * G::ROW_PITCH;
+    const unsigned ab_ = TH_ ? a_base1 : a_base0;
+    v4f fa_[4][MT], fb_[4][NT];
+    const unsigned bst_ = (unsigned)st * G::B_STAGE;
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_) {
+      const unsigned ba_ = b_q[q_] + bst_;
+#pragma unroll
+      for (int i_ = 0; i_ < MT; ++i_)
+        fa_[q_][i_] = i_ == 0 ? (q_ == 0 ? lds_read128<COFF_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 32>(ab_)
+                                : q_ == 2 ? lds_read128<COFF_ + 64>(ab_) : lds_read128<COFF_ + 96>(ab_))
+                    : i_ == 1 ? (q_ == 0 ? lds_read128<COFF_ + AROW_>(ab_) : q_ == 1 ? lds_read128<COFF_ + AROW_ + 32>(ab_)
+                                : q_ == 2 ? lds_read128<COFF_ + AROW_ + 64>(ab_) : lds_read128<COFF_ + AROW_ + 96>(ab_))
+                    : i_ == 2 ? (q_ == 0 ? lds_read128<COFF_ + 2 * AROW_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 2 * AROW_ + 32>(ab_)
+                                : q_ == 2 ? lds_read128<COFF_ + 2 * AROW_ + 64>(ab_) : lds_read128<COFF_ + 2 * AROW_ + 96>(ab_))
+                              : (q_ == 0 ? lds_read128<COFF_ + 3 * AROW_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 3 * AROW_ + 32>(ab_)
+                                : q_ == 2 ? lds_read128<COFF_ + 3 * AROW_ + 64>(ab_) : lds_read128<COFF_ + 3 * AROW_ + 96>(ab_));
+#pragma unroll
+      for (int j_ = 0; j_ < NT; ++j_)
+        fb_[q_][j_] = j_ == 0 ? lds_read128<0>(ba_) : lds_read128<32 * ROW_BYTES>(ba_);
+    }
+    cq(IC<0>{}, IC<PWC_>{}, fa_, fb_);
+    bool issued_;
+    {
+      if (J == 0 && c + 1 < c1) patch_load(c + 1);
+      int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;
+      constexpr int JN_ = (J + PD) & 7;
+      issued_ = (J + PD < 8) || (c + 1 < c1);
+      if (J + PD < 8) { b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c, sn_); }
+      else if (c + 1 < c1) { b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_); }
+    }
+    cq(IC<1>{}, IC<PWC_>{}, fa_, fb_); cq(IC<2>{}, IC<PWC_>{}, fa_, fb_); cq(IC<3>{}, IC<PWC_>{}, fa_, fb_);
+    if (J == 0 && c + 1 < c1) wait_vmcnt<BI + NPL>();
+    else if (issued_) wait_vmcnt<BI>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    st = st + 1 == NSTG ? 0 : st + 1;
+  };
+
+  patch_load(c0);
+  b_issue(2 * ph, 0, c0, 0);
+  b_issue(2 * ph, 1, c0, 1);
   if (APPLY && p.halo_apply) {
     double *s_stat = reinterpret_cast<double *>(smem);
     if (p.halo_apply & 1) {
@@ -824,25 +836,20 @@ convt_halo_bf16_kernel(const ConvParams p) {
     }
   }
   wait_vmcnt<0>();
-  MSI_PATCH_STORE()
+  patch_store();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #ifdef MSI_CONV_TIMING
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
   for (; c < c1; ++c) {
-    MSI_CTSTEP(0) MSI_CTSTEP(1) MSI_CTSTEP(2) MSI_CTSTEP(3) MSI_CTSTEP(4) MSI_CTSTEP(5) MSI_CTSTEP(6) MSI_CTSTEP(7)
+    ctstep(IC<0>{}); ctstep(IC<1>{}); ctstep(IC<2>{}); ctstep(IC<3>{}); ctstep(IC<4>{}); ctstep(IC<5>{}); ctstep(IC<6>{}); ctstep(IC<7>{});
     if (c + 1 < c1) {
-      MSI_PATCH_STORE()
+      patch_store();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
-#undef MSI_CTSTEP
-#undef MSI_CQ
-#undef MSI_B_ISSUE
-#undef MSI_PATCH_STORE
-#undef MSI_PATCH_LOAD
 #ifdef MSI_CONV_TIMING
   const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "msi_common.h"
@@ -185,6 +186,8 @@ inline int set_max_lds(const void *fn, int lds, unsigned long long &done, const 
   return MSI_OK;
 }
 
+// a compile-time integer as a lambda argument: the k-steps of the kernels are generic lambdas called with their tap / step index (r05: they used to be macros)
+template <int N> using IC = std::integral_constant<int, N>;
 }  // namespace msi_cnn
 using namespace msi_cnn;
 
@@ -940,5 +943,9 @@ __device__ __forceinline__ void rows_wait(const ConvParams &p, int b, int r0, in
 }
 
 #endif  // MSI_EXPERIMENTS
+
+// k-step J of a 32-channel group of the stride-2 form -> tap (unit by unit: the four units' taps in the order the patches are swapped) and unit
+__device__ constexpr int s2_tap(int J) { return J == 0 ? 0 : J == 1 ? 2 : J == 2 ? 6 : J == 3 ? 8 : J == 4 ? 1 : J == 5 ? 7 : J == 6 ? 3 : J == 7 ? 5 : 4; }
+__device__ constexpr int s2_unit(int J) { return J < 4 ? 0 : J < 6 ? 1 : J < 8 ? 2 : 3; }
 
 }  // namespace

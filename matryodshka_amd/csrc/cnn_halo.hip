@@ -129,41 +129,40 @@ conv_halo_kernel(const ConvParams p) {
   }
   v4f araw[NLOAD], g4, be4;
   // patch of chunk c -> registers (+ gamma / beta of the lane's channels)
-#define MSI_PATCH_LOAD(c)                                                                                              \
-  {                                                                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
-      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], (c) * ROW_BYTES, 0)); \
-    if (APPLY) {                                                                                                       \
-      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 32 + cslot * 4);                                          \
-      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 32 + cslot * 4);                                          \
-    }                                                                                                                  \
-  }
+  auto patch_load = [&](const int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_)
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], c * ROW_BYTES, 0));
+    if (APPLY) {
+      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + c * 32 + cslot * 4);
+      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + c * 32 + cslot * 4);
+    }
+  };
   // registers -> LDS patch, the producer's affine + ReLU applied (ln_apply_kernel's expressions: same bits)
-#define MSI_PATCH_STORE()                                                                                              \
-  {                                                                                                                    \
-    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};                                                          \
-    if (APPLY) {   /* scale = inv * gamma; shift = beta - mean * scale with the mean as hi + lo floats: fp32 ops only */ \
-      s4 = inv_f * g4;                                                                                                 \
-      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};                          \
-      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
-      v4f y = araw[k_];                                                                                                \
-      if (APPLY) {                                                                                                     \
-        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
-        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */          \
-      }                                                                                                                \
-      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = y;                                    \
-    }                                                                                                                  \
-  }
+  auto patch_store = [&]() __attribute__((always_inline)) {
+    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+    if (APPLY) {   /* scale = inv * gamma; shift = beta - mean * scale with the mean as hi + lo floats: fp32 ops only */
+      s4 = inv_f * g4;
+      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_) {
+      v4f y = araw[k_];
+      if (APPLY) {
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});
+        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */
+      }
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = y;
+    }
+  };
   // weights of k-step (chunk c, tap) -> ring stage st; the packed blob is tap-major: row block tap * CH + c
-#define MSI_B_ISSUE(c, tap, st)                                                                                        \
-  {                                                                                                                    \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * ROW_BYTES;                                         \
-    const int soff_ = ((tap) * CH + (c)) * p.npad * ROW_BYTES;                                                         \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
-  }
+  auto b_issue = [&](const int c, const int tap, const int st) __attribute__((always_inline)) {
+    char *sB_ = smem + G::A_BYTES + st * G::B_STAGE + wave * 16 * ROW_BYTES;
+    const int soff_ = (tap * CH + c) * p.npad * ROW_BYTES;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);
+  };
 
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
@@ -180,45 +179,47 @@ conv_halo_kernel(const ConvParams p) {
   // one k-step = tap TAP of the current chunk, weights in ring stage TAP % 3; the DMA of the k-step two ahead is issued
   // after the first MFMA quarter; before the closing barrier the NEXT k-step's weights must have landed: every VMEM
   // operation issued before them (the next chunk's patch loads, issued in tap 0) completes first (in-order return)
-#define MSI_HTAP(TAP)                                                                                                  \
-  {                                                                                                                    \
-    constexpr int KH_ = (TAP) / 3, KW_ = (TAP) % 3, ST_ = (TAP) % 3;                                                   \
-    constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;                                             \
-    v4f a_[4], b_[4];                                                                                                  \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
-      a_[q_] = q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 16>(a_base)                        \
-             : q_ == 2 ? lds_read128<AOFF_ + 32>(a_base) : lds_read128<AOFF_ + 48>(a_base);                            \
-      b_[q_] = lds_read128<ST_ * G::B_STAGE>(b_q[q_]);                                                                 \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
-      if (q_ == 0) wait_lgkm<6>(a_[0], b_[0]);                                                                         \
-      if (q_ == 1) wait_lgkm<4>(a_[1], b_[1]);                                                                         \
-      if (q_ == 2) wait_lgkm<2>(a_[2], b_[2]);                                                                         \
-      if (q_ == 3) wait_lgkm<0>(a_[3], b_[3]);                                                                         \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[0][0], 0, 0, 0);                        \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[0][0], 0, 0, 0);                        \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[0][0], 0, 0, 0);                        \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[0][0], 0, 0, 0);                        \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-      if (q_ == 0) {                                                                                                   \
-        if ((TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                            \
-        /* k-step two ahead: (c, TAP + 2) or (c + 1, TAP - 7) */                                                       \
-        if ((TAP) + 2 < 9) { MSI_B_ISSUE(c, (TAP) + 2, ((TAP) + 2) % 3) }                                              \
-        else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) - 7, ((TAP) + 2) % 3) }                                        \
-      }                                                                                                                \
-    }                                                                                                                  \
-    {                                                                                                                  \
-      const bool issued_ = ((TAP) + 2 < 9) || (c + 1 < c1);                                                            \
-      if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<2 + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight */ \
-      else if (issued_) wait_vmcnt<2>();                                                                               \
-      else wait_vmcnt<0>();                                                                                            \
-    }                                                                                                                  \
-    __builtin_amdgcn_s_barrier();                                                                                      \
-  }
+  int c = c0;
+  auto htap = [&](auto TAP_c) __attribute__((always_inline)) {
+    constexpr int TAP = decltype(TAP_c)::value;
+    constexpr int KH_ = TAP / 3, KW_ = TAP % 3, ST_ = TAP % 3;
+    constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;
+    v4f a_[4], b_[4];
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_) {
+      a_[q_] = q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 16>(a_base)
+             : q_ == 2 ? lds_read128<AOFF_ + 32>(a_base) : lds_read128<AOFF_ + 48>(a_base);
+      b_[q_] = lds_read128<ST_ * G::B_STAGE>(b_q[q_]);
+    }
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_) {
+      if (q_ == 0) wait_lgkm<6>(a_[0], b_[0]);
+      if (q_ == 1) wait_lgkm<4>(a_[1], b_[1]);
+      if (q_ == 2) wait_lgkm<2>(a_[2], b_[2]);
+      if (q_ == 3) wait_lgkm<0>(a_[3], b_[3]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q_ == 0) {
+        if (TAP == 0 && c + 1 < c1) patch_load(c + 1);
+        /* k-step two ahead: (c, TAP + 2) or (c + 1, TAP - 7) */
+        if (TAP + 2 < 9) { b_issue(c, TAP + 2, (TAP + 2) % 3); }
+        else if (c + 1 < c1) { b_issue(c + 1, TAP - 7, (TAP + 2) % 3); }
+      }
+    }
+    {
+      const bool issued_ = (TAP + 2 < 9) || (c + 1 < c1);
+      if (TAP == 0 && c + 1 < c1) wait_vmcnt<2 + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight */
+      else if (issued_) wait_vmcnt<2>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+  };
 
   // ---- prologue: first patch, first two weight k-steps ----
-  int c = c0;
-  MSI_PATCH_LOAD(c0)                                      // (the weights of k-steps 0 and 1 are on their way already)
+  patch_load(c0);                                      // (the weights of k-steps 0 and 1 are on their way already)
   if (APPLY) {   // the sums' round trip rides on the patch's (s_stat sits in the A region: read back before the patch lands)
     double *s_stat = reinterpret_cast<double *>(smem);
     ln_mean_inv_pre(shard, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
@@ -229,24 +230,20 @@ conv_halo_kernel(const ConvParams p) {
     __syncthreads();
   }
   wait_vmcnt<0>();
-  MSI_PATCH_STORE()
+  patch_store();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #ifdef MSI_CONV_TIMING
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
   for (; c < c1; ++c) {
-    MSI_HTAP(0) MSI_HTAP(1) MSI_HTAP(2) MSI_HTAP(3) MSI_HTAP(4) MSI_HTAP(5) MSI_HTAP(6) MSI_HTAP(7) MSI_HTAP(8)
+    htap(IC<0>{}); htap(IC<1>{}); htap(IC<2>{}); htap(IC<3>{}); htap(IC<4>{}); htap(IC<5>{}); htap(IC<6>{}); htap(IC<7>{}); htap(IC<8>{});
     if (c + 1 < c1) {   // every wave has read the last tap of this chunk (closing barrier of tap 8): swap the patch
-      MSI_PATCH_STORE()
+      patch_store();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
-#undef MSI_HTAP
-#undef MSI_B_ISSUE
-#undef MSI_PATCH_STORE
-#undef MSI_PATCH_LOAD
 
   // ---- epilogue: as conv_igemm_kernel ----
 #ifdef MSI_CONV_TIMING
@@ -366,15 +363,14 @@ conv_halo_s2_kernel(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, (int)((size_t)S * p.npad * ROW_BYTES), 0x00020000);
   const int drow = lane >> 3, dslot = lane & 7;
   const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + drow) * ROW_BYTES + dslot * 16);
-#define MSI_B_ISSUE(c, tap, st)                                                                                        \
-  {                                                                                                                    \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * ROW_BYTES;                                         \
-    const int soff_ = ((tap) * CH + (c)) * p.npad * ROW_BYTES;                                                         \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
-  }
-  MSI_B_ISSUE(c0, 0, 0)
-  if (G::NSTG == 3) MSI_B_ISSUE(c0, 2, 1)
+  auto b_issue = [&](const int c, const int tap, const int st) __attribute__((always_inline)) {
+    char *sB_ = smem + G::A_BYTES + st * G::B_STAGE + wave * 16 * ROW_BYTES;
+    const int soff_ = (tap * CH + c) * p.npad * ROW_BYTES;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);
+  };
+  b_issue(c0, 0, 0);
+  if (G::NSTG == 3) b_issue(c0, 2, 1);
 
   // ---- per-lane patch slots of the four units: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 ----
   unsigned voff[4][NLOAD], lds_a[NLOAD];
@@ -421,32 +417,34 @@ conv_halo_s2_kernel(const ConvParams p) {
   }
   v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};   // the group's affine (the lane's four channels): set with unit 0
   // patch of (group c, unit U) -> registers (+ gamma / beta of the lane's channels with unit 0)
-#define MSI_PATCH_LOAD(c, U)                                                                                           \
-  {                                                                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
-      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[U][k_], (c) * ROW_BYTES, 0)); \
-    if (APPLY && (U) == 0) {                                                                                           \
-      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 32 + cslot * 4);                                          \
-      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 32 + cslot * 4);                                          \
-    }                                                                                                                  \
-  }
+  auto patch_load = [&](const int c, auto U_c) __attribute__((always_inline)) {
+    constexpr int U = decltype(U_c)::value;
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_)
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[U][k_], c * ROW_BYTES, 0));
+    if (APPLY && U == 0) {
+      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + c * 32 + cslot * 4);
+      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + c * 32 + cslot * 4);
+    }
+  };
   // registers -> LDS patch, the producer's affine + ReLU applied (ln_apply_kernel's expressions: same bits)
-#define MSI_PATCH_STORE(U)                                                                                             \
-  {                                                                                                                    \
-    if (APPLY && (U) == 0) {                                                                                           \
-      s4 = inv_f * g4;                                                                                                 \
-      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};                          \
-      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
-      v4f y = araw[k_];                                                                                                \
-      if (APPLY) {                                                                                                     \
-        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
-        if (has_pad && !pok[U][k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */       \
-      }                                                                                                                \
-      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = y;                                    \
-    }                                                                                                                  \
-  }
+  auto patch_store = [&](auto U_c) __attribute__((always_inline)) {
+    constexpr int U = decltype(U_c)::value;
+    if (APPLY && U == 0) {
+      s4 = inv_f * g4;
+      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_) {
+      v4f y = araw[k_];
+      if (APPLY) {
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});
+        if (has_pad && !pok[U][k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */
+      }
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = y;
+    }
+  };
 
   // ---- MFMA side (as conv_halo_kernel: a wave owns two tile rows x 16 columns x 32 channels) ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
@@ -461,57 +459,57 @@ conv_halo_s2_kernel(const ConvParams p) {
   for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
 
   // k-step J = 0..8 of the current group: unit, tap and patch offsets are literals
-#define MSI_S2_TAP(J) ((J) == 0 ? 0 : (J) == 1 ? 2 : (J) == 2 ? 6 : (J) == 3 ? 8 : (J) == 4 ? 1 : (J) == 5 ? 7 : (J) == 6 ? 3 : (J) == 7 ? 5 : 4)
-#define MSI_S2_UNIT(J) ((J) < 4 ? 0 : (J) < 6 ? 1 : (J) < 8 ? 2 : 3)
-#define MSI_S2STEP(J)                                                                                                  \
-  {                                                                                                                    \
-    constexpr int TAP_ = MSI_S2_TAP(J), U_ = MSI_S2_UNIT(J), ST_ = (J) % 3;                                            \
-    constexpr int DY_ = (TAP_ / 3) >> 1, DX_ = (TAP_ % 3) >> 1;                                                        \
-    constexpr bool FIRST_ = (J) == 0 || (J) == 4 || (J) == 6 || (J) == 8, LAST_ = (J) == 3 || (J) == 5 || (J) == 7 || (J) == 8; \
-    constexpr int AOFF_ = DY_ * G::ROW_PITCH + DX_ * G::PIX_BYTES;                                                     \
-    const bool more_ = U_ < 3 || c + 1 < c1;               /* a unit follows this one */                               \
-    v4f a_[4], b_[4];                                                                                                  \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
-      a_[q_] = q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 16>(a_base)                        \
-             : q_ == 2 ? lds_read128<AOFF_ + 32>(a_base) : lds_read128<AOFF_ + 48>(a_base);                            \
-      b_[q_] = lds_read128<ST_ * G::B_STAGE>(b_q[q_]);                                                                 \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
-      if (q_ == 0) wait_lgkm<6>(a_[0], b_[0]);                                                                         \
-      if (q_ == 1) wait_lgkm<4>(a_[1], b_[1]);                                                                         \
-      if (q_ == 2) wait_lgkm<2>(a_[2], b_[2]);                                                                         \
-      if (q_ == 3) wait_lgkm<0>(a_[3], b_[3]);                                                                         \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[0][0], 0, 0, 0);                        \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[0][0], 0, 0, 0);                        \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[0][0], 0, 0, 0);                        \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[0][0], 0, 0, 0);                        \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-      if (q_ == 0) {                                                                                                   \
-        if (FIRST_ && more_) {                                                                                         \
-          if (U_ < 3) MSI_PATCH_LOAD(c, (U_ + 1) & 3) else MSI_PATCH_LOAD(c + 1, 0)                                    \
-        }                                                                                                              \
-        /* k-step two ahead: (c, J + 2) or (c + 1, J - 7) */                                                           \
-        if ((J) + 2 < 9) { MSI_B_ISSUE(c, MSI_S2_TAP(((J) + 2) % 9), ((J) + 2) % 3) }                                  \
-        else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, MSI_S2_TAP(((J) + 2) % 9), ((J) + 2) % 3) }                          \
-      }                                                                                                                \
-    }                                                                                                                  \
-    {                                                                                                                  \
-      const bool issued_ = ((J) + 2 < 9) || (c + 1 < c1);                                                              \
-      /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */ \
-      if (FIRST_ && !LAST_ && more_) wait_vmcnt<2 + NLOAD>();                                                          \
-      else if (issued_) wait_vmcnt<2>();                                                                               \
-      else wait_vmcnt<0>();                                                                                            \
-    }                                                                                                                  \
-    __builtin_amdgcn_s_barrier();                                                                                      \
-    if (LAST_ && more_) {   /* every wave has read this unit's last tap: swap the patch */                             \
-      MSI_PATCH_STORE((U_ + 1) & 3)                                                                                    \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
-      __builtin_amdgcn_s_barrier();                                                                                    \
-    }                                                                                                                  \
-  }
+  int c = c0;   // (unit 0's patch of group c0 is on its way)
+  auto s2step = [&](auto J_c) __attribute__((always_inline)) {
+    constexpr int J = decltype(J_c)::value;
+    constexpr int TAP_ = s2_tap(J), U_ = s2_unit(J), ST_ = J % 3;
+    constexpr int DY_ = (TAP_ / 3) >> 1, DX_ = (TAP_ % 3) >> 1;
+    constexpr bool FIRST_ = J == 0 || J == 4 || J == 6 || J == 8, LAST_ = J == 3 || J == 5 || J == 7 || J == 8;
+    constexpr int AOFF_ = DY_ * G::ROW_PITCH + DX_ * G::PIX_BYTES;
+    const bool more_ = U_ < 3 || c + 1 < c1;               /* a unit follows this one */
+    v4f a_[4], b_[4];
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_) {
+      a_[q_] = q_ == 0 ? lds_read128<AOFF_>(a_base) : q_ == 1 ? lds_read128<AOFF_ + 16>(a_base)
+             : q_ == 2 ? lds_read128<AOFF_ + 32>(a_base) : lds_read128<AOFF_ + 48>(a_base);
+      b_[q_] = lds_read128<ST_ * G::B_STAGE>(b_q[q_]);
+    }
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_) {
+      if (q_ == 0) wait_lgkm<6>(a_[0], b_[0]);
+      if (q_ == 1) wait_lgkm<4>(a_[1], b_[1]);
+      if (q_ == 2) wait_lgkm<2>(a_[2], b_[2]);
+      if (q_ == 3) wait_lgkm<0>(a_[3], b_[3]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q_ == 0) {
+        if (FIRST_ && more_) {
+          if (U_ < 3) patch_load(c, IC<(U_ + 1) & 3>{}); else patch_load(c + 1, IC<0>{});
+        }
+        /* k-step two ahead: (c, J + 2) or (c + 1, J - 7) */
+        if (J + 2 < 9) { b_issue(c, s2_tap((J + 2) % 9), (J + 2) % 3); }
+        else if (c + 1 < c1) { b_issue(c + 1, s2_tap((J + 2) % 9), (J + 2) % 3); }
+      }
+    }
+    {
+      const bool issued_ = (J + 2 < 9) || (c + 1 < c1);
+      /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */
+      if (FIRST_ && !LAST_ && more_) wait_vmcnt<2 + NLOAD>();
+      else if (issued_) wait_vmcnt<2>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (LAST_ && more_) {   /* every wave has read this unit's last tap: swap the patch */
+      patch_store(IC<(U_ + 1) & 3>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
 
   // ---- prologue: unit 0 of the first group ----
-  int c = c0;   // (unit 0's patch of group c0 is on its way)
   if (APPLY) {
     double *s_stat = reinterpret_cast<double *>(smem);
     ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
@@ -522,18 +520,12 @@ conv_halo_s2_kernel(const ConvParams p) {
     __syncthreads();
   }
   wait_vmcnt<0>();
-  MSI_PATCH_STORE(0)
+  patch_store(IC<0>{});
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (; c < c1; ++c) {
-    MSI_S2STEP(0) MSI_S2STEP(1) MSI_S2STEP(2) MSI_S2STEP(3) MSI_S2STEP(4) MSI_S2STEP(5) MSI_S2STEP(6) MSI_S2STEP(7) MSI_S2STEP(8)
+    s2step(IC<0>{}); s2step(IC<1>{}); s2step(IC<2>{}); s2step(IC<3>{}); s2step(IC<4>{}); s2step(IC<5>{}); s2step(IC<6>{}); s2step(IC<7>{}); s2step(IC<8>{});
   }
-#undef MSI_S2STEP
-#undef MSI_S2_UNIT
-#undef MSI_S2_TAP
-#undef MSI_B_ISSUE
-#undef MSI_PATCH_STORE
-#undef MSI_PATCH_LOAD
 
   // ---- epilogue: as conv_halo_kernel ----
   if (!full) {
@@ -637,15 +629,14 @@ convt_halo_kernel(const ConvParams p) {
   const int drow = lane >> 3, dslot = lane & 7;
   const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + drow) * ROW_BYTES + dslot * 16);
   // weights of k-step (class, tap, chunk c) -> ring stage st; packed blob: [class][tap * CH + c][npad][128 B]
-#define MSI_B_ISSUE(cls, tap, c, st)                                                                                   \
-  {                                                                                                                    \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * ROW_BYTES;                                         \
-    const int soff_ = (((cls) * S + (tap) * CH + (c)) * p.npad) * ROW_BYTES;                                           \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);            \
-  }
-  MSI_B_ISSUE(2 * ph, 0, c0, 0)
-  MSI_B_ISSUE(2 * ph, 1, c0, 1)
+  auto b_issue = [&](const int cls, const int tap, const int c, const int st) __attribute__((always_inline)) {
+    char *sB_ = smem + G::A_BYTES + st * G::B_STAGE + wave * 16 * ROW_BYTES;
+    const int soff_ = ((cls * S + tap * CH + c) * p.npad) * ROW_BYTES;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 8 * ROW_BYTES, 0);
+  };
+  b_issue(2 * ph, 0, c0, 0);
+  b_issue(2 * ph, 1, c0, 1);
 
   // ---- per-lane patch elements (as conv_halo_kernel; the byte offset depends on the source's channel count) ----
   unsigned pixi[NLOAD], lds_a[NLOAD];
@@ -676,48 +667,49 @@ convt_halo_kernel(const ConvParams p) {
   v4f araw[NLOAD], g4, be4;
   int src_ld = 0;                                         // source of the patch held in araw
   // patch of chunk c -> registers (+ gamma / beta of the lane's channels when that source is raw)
-#define MSI_PATCH_LOAD(c)                                                                                              \
-  {                                                                                                                    \
-    const int s_ = (c) >= p.cpt0 ? 1 : 0, cc_ = s_ ? (c) - p.cpt0 : (c);                                               \
-    const unsigned cb_ = (unsigned)((s_ ? p.C1 : p.C0) * 4);                                                           \
-    src_ld = s_;                                                                                                       \
-    if (s_ == 0) {                                                                                                     \
-      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
-        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
-            rsrc_a0, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));           \
-    } else {                                                                                                           \
-      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
-        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
-            rsrc_a1, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));           \
-    }                                                                                                                  \
-    const float *gp_ = (s_ ? p.ln_gamma1 : p.ln_gamma), *bp_ = (s_ ? p.ln_beta1 : p.ln_beta);                          \
-    if ((p.halo_apply >> s_) & 1) {                                                                                    \
-      g4 = *reinterpret_cast<const v4f *>(gp_ + cc_ * 32 + cslot * 4);                                                 \
-      be4 = *reinterpret_cast<const v4f *>(bp_ + cc_ * 32 + cslot * 4);                                                \
-    } else {   /* (same number of VMEM operations on both paths: the vmcnt arithmetic of the k-steps counts them) */   \
-      g4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16);                                                         \
-      be4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16 + 128);                                                  \
-    }                                                                                                                  \
-  }
-#define MSI_PATCH_STORE()                                                                                              \
-  {                                                                                                                    \
-    const bool ap_ = (p.halo_apply >> src_ld) & 1;                                                                     \
-    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};                                                          \
-    if (ap_) {                                                                                                         \
-      const float ih_ = src_ld ? inv_f[1] : inv_f[0], mh_ = src_ld ? mu_hi[1] : mu_hi[0], ml_ = src_ld ? mu_lo[1] : mu_lo[0]; \
-      s4 = ih_ * g4;                                                                                                   \
-      const v4f nh = {-mh_, -mh_, -mh_, -mh_}, nl = {-ml_, -ml_, -ml_, -ml_};                                          \
-      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
-      v4f y = araw[k_];                                                                                                \
-      if (ap_) {                                                                                                       \
-        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
-        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};                                                          \
-      }                                                                                                                \
-      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = y;                                    \
-    }                                                                                                                  \
-  }
+  auto patch_load = [&](const int c) __attribute__((always_inline)) {
+    const int s_ = c >= p.cpt0 ? 1 : 0, cc_ = s_ ? c - p.cpt0 : c;
+    const unsigned cb_ = (unsigned)((s_ ? p.C1 : p.C0) * 4);
+    src_ld = s_;
+    if (s_ == 0) {
+#pragma unroll
+      for (int k_ = 0; k_ < NLOAD; ++k_)
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(
+            rsrc_a0, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));
+    } else {
+#pragma unroll
+      for (int k_ = 0; k_ < NLOAD; ++k_)
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(
+            rsrc_a1, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));
+    }
+    const float *gp_ = (s_ ? p.ln_gamma1 : p.ln_gamma), *bp_ = (s_ ? p.ln_beta1 : p.ln_beta);
+    if ((p.halo_apply >> s_) & 1) {
+      g4 = *reinterpret_cast<const v4f *>(gp_ + cc_ * 32 + cslot * 4);
+      be4 = *reinterpret_cast<const v4f *>(bp_ + cc_ * 32 + cslot * 4);
+    } else {   /* (same number of VMEM operations on both paths: the vmcnt arithmetic of the k-steps counts them) */
+      g4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16);
+      be4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16 + 128);
+    }
+  };
+  auto patch_store = [&]() __attribute__((always_inline)) {
+    const bool ap_ = (p.halo_apply >> src_ld) & 1;
+    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+    if (ap_) {
+      const float ih_ = src_ld ? inv_f[1] : inv_f[0], mh_ = src_ld ? mu_hi[1] : mu_hi[0], ml_ = src_ld ? mu_lo[1] : mu_lo[0];
+      s4 = ih_ * g4;
+      const v4f nh = {-mh_, -mh_, -mh_, -mh_}, nl = {-ml_, -ml_, -ml_, -ml_};
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_) {
+      v4f y = araw[k_];
+      if (ap_) {
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});
+        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      if (lds_a[k_] != 0xffffffffu) *reinterpret_cast<v4f *>(smem + lds_a[k_]) = y;
+    }
+  };
 
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
@@ -740,47 +732,49 @@ convt_halo_kernel(const ConvParams p) {
   // before the closing barrier the NEXT k-step's weights must have landed: they were issued one k-step ago, so only what
   // THIS k-step issued (2 DMA, + the patch loads of J == 0) may still be in flight (in-order return).
   constexpr int NPL = NLOAD + 2;                          // VMEM operations of a patch load
-#define MSI_CTSTEP(J)                                                                                                  \
-  {                                                                                                                    \
-    constexpr int PWC_ = (J) >> 2, TH_ = ((J) >> 1) & 1, TW_ = (J) & 1;                                                \
-    constexpr int COFF_ = (1 + (PWC_ ? TW_ : -TW_)) * G::PIX_BYTES;   /* column of the tap: immediate */                \
-    const unsigned ab_ = TH_ ? a_base1 : a_base0;                                                                      \
-    v4f a_[4], b_[4];                                                                                                  \
-    const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
-      a_[q_] = q_ == 0 ? lds_read128<COFF_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 16>(ab_)                              \
-             : q_ == 2 ? lds_read128<COFF_ + 32>(ab_) : lds_read128<COFF_ + 48>(ab_);                                  \
-      b_[q_] = lds_read128<0>(b_q[q_] + bst_);                                                                         \
-    }                                                                                                                  \
-    bool issued_ = false;                                                                                              \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                 \
-      if (q_ == 0) wait_lgkm<6>(a_[0], b_[0]);                                                                         \
-      if (q_ == 1) wait_lgkm<4>(a_[1], b_[1]);                                                                         \
-      if (q_ == 2) wait_lgkm<2>(a_[2], b_[2]);                                                                         \
-      if (q_ == 3) wait_lgkm<0>(a_[3], b_[3]);                                                                         \
-      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[PWC_][0][0], 0, 0, 0);            \
-      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[PWC_][0][0], 0, 0, 0);            \
-      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[PWC_][0][0], 0, 0, 0);            \
-      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[PWC_][0][0], 0, 0, 0);            \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-      if (q_ == 0) {                                                                                                   \
-        if ((J) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                              \
-        int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                       \
-        constexpr int JN_ = ((J) + PD) & 7;                                                                            \
-        if ((J) + PD < 8) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c, sn_) }                        \
-        else if (c + 1 < c1) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_) }                 \
-      }                                                                                                                \
-    }                                                                                                                  \
-    if ((J) == 0 && c + 1 < c1) wait_vmcnt<2 + NPL>();                                                                 \
-    else if (issued_) wait_vmcnt<2>();                                                                                 \
-    else wait_vmcnt<0>();                                                                                              \
-    __builtin_amdgcn_s_barrier();                                                                                      \
-    st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
-  }
+  int c = c0, st = 0;
+  auto ctstep = [&](auto J_c) __attribute__((always_inline)) {
+    constexpr int J = decltype(J_c)::value;
+    constexpr int PWC_ = J >> 2, TH_ = (J >> 1) & 1, TW_ = J & 1;
+    constexpr int COFF_ = (1 + (PWC_ ? TW_ : -TW_)) * G::PIX_BYTES;   /* column of the tap: immediate */
+    const unsigned ab_ = TH_ ? a_base1 : a_base0;
+    v4f a_[4], b_[4];
+    const unsigned bst_ = (unsigned)st * G::B_STAGE;
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_) {
+      a_[q_] = q_ == 0 ? lds_read128<COFF_>(ab_) : q_ == 1 ? lds_read128<COFF_ + 16>(ab_)
+             : q_ == 2 ? lds_read128<COFF_ + 32>(ab_) : lds_read128<COFF_ + 48>(ab_);
+      b_[q_] = lds_read128<0>(b_q[q_] + bst_);
+    }
+    bool issued_ = false;
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_) {
+      if (q_ == 0) wait_lgkm<6>(a_[0], b_[0]);
+      if (q_ == 1) wait_lgkm<4>(a_[1], b_[1]);
+      if (q_ == 2) wait_lgkm<2>(a_[2], b_[2]);
+      if (q_ == 3) wait_lgkm<0>(a_[3], b_[3]);
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].x, a_[q_].x, acc[PWC_][0][0], 0, 0, 0);
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].y, a_[q_].y, acc[PWC_][0][0], 0, 0, 0);
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].z, a_[q_].z, acc[PWC_][0][0], 0, 0, 0);
+      acc[PWC_][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_[q_].w, a_[q_].w, acc[PWC_][0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q_ == 0) {
+        if (J == 0 && c + 1 < c1) patch_load(c + 1);
+        int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;
+        constexpr int JN_ = (J + PD) & 7;
+        if (J + PD < 8) { issued_ = true; b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c, sn_); }
+        else if (c + 1 < c1) { issued_ = true; b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_); }
+      }
+    }
+    if (J == 0 && c + 1 < c1) wait_vmcnt<2 + NPL>();
+    else if (issued_) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    st = st + 1 == NSTG ? 0 : st + 1;
+  };
 
   // ---- prologue: first patch (the first two weight k-steps are on their way), the sources' LayerNorm statistics ----
-  int c = c0, st = 0;
-  MSI_PATCH_LOAD(c0)
+  patch_load(c0);
   if (p.halo_apply) {
     double *s_stat = reinterpret_cast<double *>(smem);
     if (p.halo_apply & 1) {
@@ -797,21 +791,17 @@ convt_halo_kernel(const ConvParams p) {
     }
   }
   wait_vmcnt<0>();
-  MSI_PATCH_STORE()
+  patch_store();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (; c < c1; ++c) {
-    MSI_CTSTEP(0) MSI_CTSTEP(1) MSI_CTSTEP(2) MSI_CTSTEP(3) MSI_CTSTEP(4) MSI_CTSTEP(5) MSI_CTSTEP(6) MSI_CTSTEP(7)
+    ctstep(IC<0>{}); ctstep(IC<1>{}); ctstep(IC<2>{}); ctstep(IC<3>{}); ctstep(IC<4>{}); ctstep(IC<5>{}); ctstep(IC<6>{}); ctstep(IC<7>{});
     if (c + 1 < c1) {
-      MSI_PATCH_STORE()
+      patch_store();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
-#undef MSI_CTSTEP
-#undef MSI_B_ISSUE
-#undef MSI_PATCH_STORE
-#undef MSI_PATCH_LOAD
 
   // ---- epilogue: two class tiles ----
   if (!full) {

@@ -134,16 +134,20 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
   const int plane_bytes = p.npad * G::B_ROW;
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)S * NPL * plane_bytes), 0x00020000);
   const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + (lane >> 2)) * G::B_ROW + (lane & 3) * 16);
-#define MSI_B_ISSUE(c, tap, st)                                                                                        \
-  if (!(MSI_X3_ABLATE & 1)) {                                                                                          \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;                                          \
-    const int soff_ = ((tap) * CH + (c)) * NPL * plane_bytes;                                                          \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0); \
-    if (NPL == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
+  int c = c0, cpar = 0;   // chunk of the k-loop and (two-stage ring) its stage parity: captured by the k-step lambdas below
+  (void)cpar;
+  auto b_issue = [&](const int c, const int tap, const int st) __attribute__((always_inline)) {
+
+  if (!(MSI_X3_ABLATE & 1)) {
+    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;
+    const int soff_ = ((tap) * CH + (c)) * NPL * plane_bytes;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0);
+    if (NPL == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0);
   }
-  MSI_B_ISSUE(c0, 0, 0)
-  if (G::NSTG == 3) MSI_B_ISSUE(c0, 1, 1)
+  };
+  b_issue(c0, 0, 0);
+  if (G::NSTG == 3) b_issue(c0, 1, 1);
 
   // ---- per-lane patch elements: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 (= tid % 8) ----
   unsigned voff[NLOAD], lds_a[NLOAD];
@@ -175,63 +179,71 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
   v4f araw[NLOAD], g4, be4;
   unsigned amax_ = 0u;   // (NPL == 2: the largest operand magnitude this lane stored -- the fp16 range check, f16_range_track)
   // patch of chunk c -> registers (+ gamma / beta of the lane's channels)
-#define MSI_PATCH_LOAD(c)                                                                                              \
-  {                                                                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
-      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], (c) * ROW_BYTES, 0)); \
-    if (APPLY) {                                                                                                       \
-      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 32 + cslot * 4);                                          \
-      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 32 + cslot * 4);                                          \
-    }                                                                                                                  \
+  auto patch_load = [&](const int c) __attribute__((always_inline)) {
+
+  {
+    
+#pragma unroll
+      for (int k_ = 0; k_ < NLOAD; ++k_)
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], (c) * ROW_BYTES, 0));
+    if (APPLY) {
+      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 32 + cslot * 4);
+      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 32 + cslot * 4);
+    }
   }
+  };
   // registers -> LDS patch, the producer's affine + ReLU applied (ln_apply_kernel's expressions: same bits)
-#define MSI_PATCH_STORE()                                                                                              \
-  {                                                                                                                    \
-    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};                                                          \
-    if (APPLY) {   /* scale = inv * gamma; shift = beta - mean * scale with the mean as hi + lo floats: fp32 ops only */ \
-      s4 = inv_f * g4;                                                                                                 \
-      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};                          \
-      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
-      v4f y = araw[k_];                                                                                                \
-      if (APPLY) {                                                                                                     \
-        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
-        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */          \
-      }                                                                                                                \
-      if (NPL == 2) {   /* y = h + m' 2^-11, fp16 parts (round to nearest even; y - h is exact in fp32) */                 \
-        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));                                                     \
-        typedef unsigned u2x_t __attribute__((ext_vector_type(2)));                                                    \
-        f16_range_track(amax_, y);                                                                                       \
-        const h2_t ha = {(_Float16)y.x, (_Float16)y.y}, hb = {(_Float16)y.z, (_Float16)y.w};                          \
-        const h2_t ma = {(_Float16)((y.x - (float)ha.x) * 2048.f), (_Float16)((y.y - (float)ha.y) * 2048.f)};          \
-        const h2_t mb = {(_Float16)((y.z - (float)hb.x) * 2048.f), (_Float16)((y.w - (float)hb.y) * 2048.f)};          \
-        if (lds_a[k_] != 0xffffffffu) {                                                                                \
-          *reinterpret_cast<u2x_t *>(smem + lds_a[k_]) = u2x_t{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)}; \
-          *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 64) = u2x_t{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)}; \
-        }                                                                                                              \
-      } else {                                                                                                         \
-      /* y = h + m + l, bf16 parts (round to nearest even; y - h and (y - h) - m are exact in fp32) */                  \
-      unsigned h0, h1, m0, m1, l0, l1;                                                                                 \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h0) : "v"(y.x), "v"(y.y));                                             \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h1) : "v"(y.z), "v"(y.w));                                             \
-      v4f r = y - v4f{__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h0 & 0xffff0000u),               \
-                      __builtin_bit_cast(float, h1 << 16), __builtin_bit_cast(float, h1 & 0xffff0000u)};              \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m0) : "v"(r.x), "v"(r.y));                                             \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m1) : "v"(r.z), "v"(r.w));                                             \
-      r = r - v4f{__builtin_bit_cast(float, m0 << 16), __builtin_bit_cast(float, m0 & 0xffff0000u),                    \
-                  __builtin_bit_cast(float, m1 << 16), __builtin_bit_cast(float, m1 & 0xffff0000u)};                  \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l0) : "v"(r.x), "v"(r.y));                                             \
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l1) : "v"(r.z), "v"(r.w));                                             \
-      if (lds_a[k_] != 0xffffffffu) {                                                                                  \
-        typedef unsigned u2x_t __attribute__((ext_vector_type(2)));                                                    \
-        *reinterpret_cast<u2x_t *>(smem + lds_a[k_]) = u2x_t{h0, h1};                                                  \
-        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 64) = u2x_t{m0, m1};                                             \
-        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 128) = u2x_t{l0, l1};                                            \
-      }                                                                                                                \
-    }                                                                                                                  \
-    }                                                                                                                  \
+  auto patch_store = [&]() __attribute__((always_inline)) {
+
+  {
+    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+    if (APPLY) {   /* scale = inv * gamma; shift = beta - mean * scale with the mean as hi + lo floats: fp32 ops only */
+      s4 = inv_f * g4;
+      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));
+    }
+    
+#pragma unroll
+      for (int k_ = 0; k_ < NLOAD; ++k_) {
+      v4f y = araw[k_];
+      if (APPLY) {
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});
+        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */
+      }
+      if (NPL == 2) {   /* y = h + m' 2^-11, fp16 parts (round to nearest even; y - h is exact in fp32) */
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        typedef unsigned u2x_t __attribute__((ext_vector_type(2)));
+        f16_range_track(amax_, y);
+        const h2_t ha = {(_Float16)y.x, (_Float16)y.y}, hb = {(_Float16)y.z, (_Float16)y.w};
+        const h2_t ma = {(_Float16)((y.x - (float)ha.x) * 2048.f), (_Float16)((y.y - (float)ha.y) * 2048.f)};
+        const h2_t mb = {(_Float16)((y.z - (float)hb.x) * 2048.f), (_Float16)((y.w - (float)hb.y) * 2048.f)};
+        if (lds_a[k_] != 0xffffffffu) {
+          *reinterpret_cast<u2x_t *>(smem + lds_a[k_]) = u2x_t{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+          *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 64) = u2x_t{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+        }
+      } else {
+      /* y = h + m + l, bf16 parts (round to nearest even; y - h and (y - h) - m are exact in fp32) */
+      unsigned h0, h1, m0, m1, l0, l1;
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h0) : "v"(y.x), "v"(y.y));
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h1) : "v"(y.z), "v"(y.w));
+      v4f r = y - v4f{__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h0 & 0xffff0000u),
+                      __builtin_bit_cast(float, h1 << 16), __builtin_bit_cast(float, h1 & 0xffff0000u)};
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m0) : "v"(r.x), "v"(r.y));
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m1) : "v"(r.z), "v"(r.w));
+      r = r - v4f{__builtin_bit_cast(float, m0 << 16), __builtin_bit_cast(float, m0 & 0xffff0000u),
+                  __builtin_bit_cast(float, m1 << 16), __builtin_bit_cast(float, m1 & 0xffff0000u)};
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l0) : "v"(r.x), "v"(r.y));
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l1) : "v"(r.z), "v"(r.w));
+      if (lds_a[k_] != 0xffffffffu) {
+        typedef unsigned u2x_t __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_]) = u2x_t{h0, h1};
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 64) = u2x_t{m0, m1};
+        *reinterpret_cast<u2x_t *>(smem + lds_a[k_] + 128) = u2x_t{l0, l1};
+      }
+    }
+    }
   }
+  };
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
   const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
@@ -255,112 +267,121 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
   // one k-step = tap TAP of the current chunk, weights in ring stage TAP % 3; the DMA of the k-step two ahead is issued
   // after the first MFMA quarter; before the closing barrier the NEXT k-step's weights must have landed: every VMEM
   // operation issued before them (the next chunk's patch loads, issued in tap 0) completes first (in-order return)
-#define MSI_HTAP(TAP)                                                                                                  \
-  {                                                                                                                    \
-    constexpr int KH_ = (TAP) / 3, KW_ = (TAP) % 3;                                                                    \
-    /* ring stage of this k-step: three stages -> TAP % 3 (a literal); two stages -> (TAP + chunk parity) & 1 (run-time scalar) */ \
-    const unsigned bst_ = (unsigned)(G::NSTG == 3 ? (TAP) % 3 : (((TAP) ^ cpar) & 1)) * G::B_STAGE;                     \
-    constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;                                             \
-    v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
-    if (MSI_X3_EARLY_DMA || G::NSTG == 2) {   /* the k-step NSTG - 1 ahead: its ring stage was last read in the previous k-step (closing barrier passed) */ \
-      constexpr int PD_ = G::NSTG - 1;                                                                                 \
-      const int stn_ = G::NSTG == 3 ? ((TAP) + 2) % 3 : ((((TAP) ^ cpar) & 1) ^ 1);   /* (two stages: the other one) */  \
-      if ((TAP) + PD_ < 9) { MSI_B_ISSUE(c, (TAP) + PD_, stn_) }                                                       \
-      else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) + PD_ - 9, stn_) }                                               \
-    }                                                                                                                  \
-    if (NPL == 2) {                                                                                                    \
-      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                               \
-        ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);                              \
-        bh_[s_] = lds_read128<0>(b_s[s_] + bst_);                                                                      \
-        am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);                         \
-        bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);                                                             \
-      }                                                                                                                \
-      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                               \
-        if (s_ == 0) wait_lgkm4<4>(ah_[0], bh_[0], am_[0], bm_[0]);                                                    \
-        else wait_lgkm4<0>(ah_[1], bh_[1], am_[1], bm_[1]);                                                            \
-        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bm_[s_]), __builtin_bit_cast(f16x8, ah_[s_]), acc_lo, 0, 0, 0); \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh_[s_]), __builtin_bit_cast(f16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
-        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh_[s_]), __builtin_bit_cast(f16x8, am_[s_]), acc_lo, 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (s_ == 0) {                                                                                                 \
-          if ((TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                          \
-          if (!MSI_X3_EARLY_DMA && G::NSTG == 3) {                                                                     \
-            if ((TAP) + 2 < 9) { MSI_B_ISSUE(c, (TAP) + 2, ((TAP) + 2) % 3) }                                          \
-            else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) - 7, ((TAP) + 2) % 3) }                                    \
-          }                                                                                                            \
-        }                                                                                                              \
-      }                                                                                                                \
-    } else if (MT == 2) {                                                                                              \
-      /* two pixel blocks i = 0, 1 against ONE set of weight fragments per K16 step s: 18 reads (at most 12 in flight: lgkmcnt is four bits), 24 MFMAs */ \
-      constexpr int A1_ = AOFF_ + 2 * G::ROW_PITCH;                                                                    \
-      v4f xh_[2][2], xm_[2][2], xl_[2][2];   /* [s][i] */                                                              \
-      bh_[0] = lds_read128<0>(b_s[0] + bst_); bm_[0] = lds_read128<G::B_PLANE>(b_s[0] + bst_); bl_[0] = lds_read128<2 * G::B_PLANE>(b_s[0] + bst_); \
-      xh_[0][0] = lds_read128<AOFF_>(a_base); xm_[0][0] = lds_read128<AOFF_ + 64>(a_base); xl_[0][0] = lds_read128<AOFF_ + 128>(a_base); \
-      xh_[0][1] = lds_read128<A1_>(a_base); xm_[0][1] = lds_read128<A1_ + 64>(a_base); xl_[0][1] = lds_read128<A1_ + 128>(a_base); \
-      bh_[1] = lds_read128<0>(b_s[1] + bst_); bm_[1] = lds_read128<G::B_PLANE>(b_s[1] + bst_); bl_[1] = lds_read128<2 * G::B_PLANE>(b_s[1] + bst_); \
-      wait_lgkm6<6>(bh_[0], bm_[0], bl_[0], xh_[0][0], xm_[0][0], xl_[0][0]);                                          \
-      split_mfma<3>(acc[0][0], acc_lo, xh_[0][0], xm_[0][0], xl_[0][0], bh_[0], bm_[0], bl_[0]);                       \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-      xh_[1][0] = lds_read128<AOFF_ + 32>(a_base); xm_[1][0] = lds_read128<AOFF_ + 96>(a_base); xl_[1][0] = lds_read128<AOFF_ + 160>(a_base); \
-      xh_[1][1] = lds_read128<A1_ + 32>(a_base); xm_[1][1] = lds_read128<A1_ + 96>(a_base); xl_[1][1] = lds_read128<A1_ + 160>(a_base); \
-      if ((TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                              \
-      wait_lgkm6<9>(xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);                                          \
-      split_mfma<3>(acc[1][0], acc_lo, xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);                       \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-      wait_lgkm6<3>(bh_[1], bm_[1], bl_[1], xh_[1][0], xm_[1][0], xl_[1][0]);                                          \
-      split_mfma<3>(acc[0][0], acc_lo, xh_[1][0], xm_[1][0], xl_[1][0], bh_[1], bm_[1], bl_[1]);                       \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-      wait_lgkm6<0>(xh_[1][1], xm_[1][1], xl_[1][1], bh_[1], bm_[1], bl_[1]);                                          \
-      split_mfma<3>(acc[1][0], acc_lo, xh_[1][1], xm_[1][1], xl_[1][1], bh_[1], bm_[1], bl_[1]);                       \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-    } else {                                                                                                           \
-    if (!(MSI_X3_ABLATE & 8))                                                                                         \
-    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
-      ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);                                \
-      bh_[s_] = lds_read128<0>(b_s[s_] + bst_);                                                                \
-      am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);                           \
-      bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);                                                   \
-      al_[s_] = s_ == 0 ? lds_read128<AOFF_ + 128>(a_base) : lds_read128<AOFF_ + 160>(a_base);                         \
-      bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);                                               \
-    }                                                                                                                  \
-    /* six products per K16 step, small terms first: m.m, l.h, h.l, m.h, h.m, h.h (weights = the MFMA's row operand) */  \
-    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
-      if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                      \
-      else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                              \
-      if (!(MSI_X3_ABLATE & 16)) {                                                                                     \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0); \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, al_[s_]), acc[0][0], 0, 0, 0); \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0); \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0); \
-      }                                                                                                                \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-      if (s_ == 0) {                                                                                                   \
-        if ((TAP) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                            \
-        /* k-step two ahead: (c, TAP + 2) or (c + 1, TAP - 7) */                                                       \
-        if (!MSI_X3_EARLY_DMA && G::NSTG == 3) {                                                                       \
-        if ((TAP) + 2 < 9) { MSI_B_ISSUE(c, (TAP) + 2, ((TAP) + 2) % 3) }                                              \
-        else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, (TAP) - 7, ((TAP) + 2) % 3) }                                        \
-        }                                                                                                              \
-      }                                                                                                                \
-    }                                                                                                                  \
-    }                                                                                                                  \
-    {                                                                                                                  \
-      const bool issued_ = ((TAP) + 2 < 9) || (c + 1 < c1);                                                            \
-      if (G::NSTG == 2) {                                                                                              \
-        if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<NLOAD + (APPLY ? 2 : 0)>();   /* (the patch loads were issued after the DMA) */ \
-        else wait_vmcnt<0>();                                                                                          \
-      } else if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<NPL + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight (either order) */ \
-      else if (issued_) wait_vmcnt<NPL>();                                                                             \
-      else wait_vmcnt<0>();                                                                                            \
-    }                                                                                                                  \
-    if (!(MSI_X3_ABLATE & 4)) __builtin_amdgcn_s_barrier();                                                            \
+  auto htap = [&](auto TAP_c) __attribute__((always_inline)) {
+    constexpr int TAP = decltype(TAP_c)::value;
+  {
+    constexpr int KH_ = (TAP) / 3, KW_ = (TAP) % 3;
+    /* ring stage of this k-step: three stages -> TAP % 3 (a literal); two stages -> (TAP + chunk parity) & 1 (run-time scalar) */
+    const unsigned bst_ = (unsigned)(G::NSTG == 3 ? (TAP) % 3 : (((TAP) ^ cpar) & 1)) * G::B_STAGE;
+    constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;
+    v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];
+    if (MSI_X3_EARLY_DMA || G::NSTG == 2) {   /* the k-step NSTG - 1 ahead: its ring stage was last read in the previous k-step (closing barrier passed) */
+      constexpr int PD_ = G::NSTG - 1;
+      const int stn_ = G::NSTG == 3 ? ((TAP) + 2) % 3 : ((((TAP) ^ cpar) & 1) ^ 1);   /* (two stages: the other one) */
+      if ((TAP) + PD_ < 9) { b_issue(c, (TAP) + PD_, stn_); }
+      else if (c + 1 < c1) { b_issue(c + 1, (TAP) + PD_ - 9, stn_); }
+    }
+    if (NPL == 2) {
+      
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);
+        bh_[s_] = lds_read128<0>(b_s[s_] + bst_);
+        am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);
+        bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);
+      }
+      
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        if (s_ == 0) wait_lgkm4<4>(ah_[0], bh_[0], am_[0], bm_[0]);
+        else wait_lgkm4<0>(ah_[1], bh_[1], am_[1], bm_[1]);
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bm_[s_]), __builtin_bit_cast(f16x8, ah_[s_]), acc_lo, 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh_[s_]), __builtin_bit_cast(f16x8, ah_[s_]), acc[0][0], 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh_[s_]), __builtin_bit_cast(f16x8, am_[s_]), acc_lo, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s_ == 0) {
+          if ((TAP) == 0 && c + 1 < c1) patch_load(c + 1);
+          if (!MSI_X3_EARLY_DMA && G::NSTG == 3) {
+            if ((TAP) + 2 < 9) { b_issue(c, (TAP) + 2, ((TAP) + 2) % 3); }
+            else if (c + 1 < c1) { b_issue(c + 1, (TAP) - 7, ((TAP) + 2) % 3); }
+          }
+        }
+      }
+    } else if constexpr (MT == 2) {
+      /* two pixel blocks i = 0, 1 against ONE set of weight fragments per K16 step s: 18 reads (at most 12 in flight: lgkmcnt is four bits), 24 MFMAs */
+      constexpr int A1_ = AOFF_ + 2 * G::ROW_PITCH;
+      v4f xh_[2][2], xm_[2][2], xl_[2][2];   /* [s][i] */
+      bh_[0] = lds_read128<0>(b_s[0] + bst_); bm_[0] = lds_read128<G::B_PLANE>(b_s[0] + bst_); bl_[0] = lds_read128<2 * G::B_PLANE>(b_s[0] + bst_);
+      xh_[0][0] = lds_read128<AOFF_>(a_base); xm_[0][0] = lds_read128<AOFF_ + 64>(a_base); xl_[0][0] = lds_read128<AOFF_ + 128>(a_base);
+      xh_[0][1] = lds_read128<A1_>(a_base); xm_[0][1] = lds_read128<A1_ + 64>(a_base); xl_[0][1] = lds_read128<A1_ + 128>(a_base);
+      bh_[1] = lds_read128<0>(b_s[1] + bst_); bm_[1] = lds_read128<G::B_PLANE>(b_s[1] + bst_); bl_[1] = lds_read128<2 * G::B_PLANE>(b_s[1] + bst_);
+      wait_lgkm6<6>(bh_[0], bm_[0], bl_[0], xh_[0][0], xm_[0][0], xl_[0][0]);
+      split_mfma<3>(acc[0][0], acc_lo, xh_[0][0], xm_[0][0], xl_[0][0], bh_[0], bm_[0], bl_[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      xh_[1][0] = lds_read128<AOFF_ + 32>(a_base); xm_[1][0] = lds_read128<AOFF_ + 96>(a_base); xl_[1][0] = lds_read128<AOFF_ + 160>(a_base);
+      xh_[1][1] = lds_read128<A1_ + 32>(a_base); xm_[1][1] = lds_read128<A1_ + 96>(a_base); xl_[1][1] = lds_read128<A1_ + 160>(a_base);
+      if ((TAP) == 0 && c + 1 < c1) patch_load(c + 1);
+      wait_lgkm6<9>(xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);
+      split_mfma<3>(acc[1][0], acc_lo, xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm6<3>(bh_[1], bm_[1], bl_[1], xh_[1][0], xm_[1][0], xl_[1][0]);
+      split_mfma<3>(acc[0][0], acc_lo, xh_[1][0], xm_[1][0], xl_[1][0], bh_[1], bm_[1], bl_[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm6<0>(xh_[1][1], xm_[1][1], xl_[1][1], bh_[1], bm_[1], bl_[1]);
+      split_mfma<3>(acc[1][0], acc_lo, xh_[1][1], xm_[1][1], xl_[1][1], bh_[1], bm_[1], bl_[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+    if (!(MSI_X3_ABLATE & 8))
+    
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+      ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);
+      bh_[s_] = lds_read128<0>(b_s[s_] + bst_);
+      am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);
+      bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);
+      al_[s_] = s_ == 0 ? lds_read128<AOFF_ + 128>(a_base) : lds_read128<AOFF_ + 160>(a_base);
+      bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);
+    }
+    /* six products per K16 step, small terms first: m.m, l.h, h.l, m.h, h.m, h.h (weights = the MFMA's row operand) */
+    
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+      if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);
+      else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);
+      if (!(MSI_X3_ABLATE & 16)) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, al_[s_]), acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, am_[s_]), acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bm_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh_[s_]), __builtin_bit_cast(bf16x8, ah_[s_]), acc[0][0], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_ == 0) {
+        if ((TAP) == 0 && c + 1 < c1) patch_load(c + 1);
+        /* k-step two ahead: (c, TAP + 2) or (c + 1, TAP - 7) */
+        if (!MSI_X3_EARLY_DMA && G::NSTG == 3) {
+        if ((TAP) + 2 < 9) { b_issue(c, (TAP) + 2, ((TAP) + 2) % 3); }
+        else if (c + 1 < c1) { b_issue(c + 1, (TAP) - 7, ((TAP) + 2) % 3); }
+        }
+      }
+    }
+    }
+    {
+      const bool issued_ = ((TAP) + 2 < 9) || (c + 1 < c1);
+      if (G::NSTG == 2) {
+        if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<NLOAD + (APPLY ? 2 : 0)>();   /* (the patch loads were issued after the DMA) */
+        else wait_vmcnt<0>();
+      } else if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<NPL + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight (either order) */
+      else if (issued_) wait_vmcnt<NPL>();
+      else wait_vmcnt<0>();
+    }
+    if (!(MSI_X3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
   }
+  };
 
   // ---- prologue: first patch, first two weight k-steps ----
-  int c = c0;
-  MSI_PATCH_LOAD(c0)                                      // (the weights of k-steps 0 and 1 are on their way already)
+  patch_load(c0);                                      // (the weights of k-steps 0 and 1 are on their way already)
   if (APPLY) {   // the sums' round trip rides on the patch's (s_stat sits in the A region: read back before the patch lands)
     double *s_stat = reinterpret_cast<double *>(smem);
     ln_mean_inv_pre(shard, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
@@ -371,25 +392,21 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
     __syncthreads();
   }
   wait_vmcnt<0>();
-  MSI_PATCH_STORE()
+  patch_store();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #ifdef MSI_CONV_TIMING
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
   for (; c < c1; ++c) {
-    const int cpar = (c - c0) & 1;   // (two-stage ring: nine k-steps per chunk flip the stage parity)
-    MSI_HTAP(0) MSI_HTAP(1) MSI_HTAP(2) MSI_HTAP(3) MSI_HTAP(4) MSI_HTAP(5) MSI_HTAP(6) MSI_HTAP(7) MSI_HTAP(8)
+    cpar = (c - c0) & 1;   // (two-stage ring: nine k-steps per chunk flip the stage parity)
+    htap(IC<0>{}); htap(IC<1>{}); htap(IC<2>{}); htap(IC<3>{}); htap(IC<4>{}); htap(IC<5>{}); htap(IC<6>{}); htap(IC<7>{}); htap(IC<8>{});
     if (c + 1 < c1 && !(MSI_X3_ABLATE & 32)) {   // every wave has read the last tap of this chunk (closing barrier of tap 8): swap the patch
-      MSI_PATCH_STORE()
+      patch_store();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
-#undef MSI_HTAP
-#undef MSI_B_ISSUE
-#undef MSI_PATCH_STORE
-#undef MSI_PATCH_LOAD
   if (MSI_X2_LATE_CB && NPL == 2) load_coord_bias(p, tile_m, tile_n, tid, cbv);   // (fp16 form: 16 registers less through the loop -- a fourth workgroup per CU)
   if (NPL == 2) {
 #pragma unroll
@@ -538,6 +555,9 @@ struct HaloGeomS2X3 {
 
 #ifndef MSI_S2X_WAVES
 #define MSI_S2X_WAVES 3
+#ifndef MSI_S2X3_ABLATE   // timing experiments only (wrong results): 1 no weight DMA, 4 no per-k-step barrier, 8 no fragment reads, 16 no MFMAs, 32 no patch swap, 64 no patch loads
+#define MSI_S2X3_ABLATE 0
+#endif
 #endif
 template <int APPLY, int NP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? MSI_S2X_WAVES : (MSI_S2X3_NSTG == 2 ? 3 : 2))))
@@ -590,16 +610,16 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
   const int plane_bytes = p.npad * G::B_ROW;
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)S * NP * plane_bytes), 0x00020000);
   const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + (lane >> 2)) * G::B_ROW + (lane & 3) * 16);
-#define MSI_B_ISSUE(c, tap, st)                                                                                        \
-  {                                                                                                                    \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;                                          \
-    const int soff_ = ((tap) * CH + (c)) * NP * plane_bytes;                                                           \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0); \
-    if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
-  }
-  MSI_B_ISSUE(c0, 0, 0)
-  if (G::NSTG == 3) MSI_B_ISSUE(c0, 2, 1)
+  auto b_issue = [&](const int c, const int tap, const int st) __attribute__((always_inline)) {
+    if (MSI_S2X3_ABLATE & 1) return;
+    char *sB_ = smem + G::A_BYTES + st * G::B_STAGE + wave * 16 * G::B_ROW;
+    const int soff_ = (tap * CH + c) * NP * plane_bytes;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0);
+    if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0);
+  };
+  b_issue(c0, 0, 0);
+  if (G::NSTG == 3) b_issue(c0, 2, 1);
 
   // ---- per-lane patch slots of the four units: e = tid + 256 k -> patch pixel e / 8, 16-byte channel slot e % 8 ----
   unsigned voff[4][NLOAD], lds_a[NLOAD];
@@ -647,32 +667,35 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
   }
   v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};   // the group's affine (the lane's four channels): set with unit 0
   // patch of (group c, unit U) -> registers (+ gamma / beta of the lane's channels with unit 0)
-#define MSI_PATCH_LOAD(c, U)                                                                                           \
-  {                                                                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                               \
-      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[U][k_], (c) * ROW_BYTES, 0)); \
-    if (APPLY && (U) == 0) {                                                                                           \
-      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 32 + cslot * 4);                                          \
-      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 32 + cslot * 4);                                          \
-    }                                                                                                                  \
-  }
+  auto patch_load = [&](const int c, auto U_c) __attribute__((always_inline)) {
+    constexpr int U = decltype(U_c)::value;
+    if (MSI_S2X3_ABLATE & 64) return;
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_)
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[U][k_], c * ROW_BYTES, 0));
+    if (APPLY && U == 0) {
+      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + c * 32 + cslot * 4);
+      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + c * 32 + cslot * 4);
+    }
+  };
   // registers -> LDS patch, the producer's affine + ReLU applied (ln_apply_kernel's expressions: same bits)
-#define MSI_PATCH_STORE(U)                                                                                             \
-  {                                                                                                                    \
-    if (APPLY && (U) == 0) {                                                                                           \
-      s4 = inv_f * g4;                                                                                                 \
-      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};                          \
-      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
-      v4f y = araw[k_];                                                                                                \
-      if (APPLY) {                                                                                                     \
-        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
-        if (has_pad && !pok[U][k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */       \
-      }                                                                                                                \
-      split_store<NP>(smem, lds_a[k_], y, amax_);                                                                      \
-    }                                                                                                                  \
-  }
+  auto patch_store = [&](auto U_c) __attribute__((always_inline)) {
+    constexpr int U = decltype(U_c)::value;
+    if (APPLY && U == 0) {
+      s4 = inv_f * g4;
+      const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_) {
+      v4f y = araw[k_];
+      if (APPLY) {
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});
+        if (has_pad && !pok[U][k_]) y = v4f{0.f, 0.f, 0.f, 0.f};   /* padding is zero AFTER the normalisation */
+      }
+      split_store<NP>(smem, lds_a[k_], y, amax_);
+    }
+  };
 
   // ---- MFMA side (as conv_halo_kernel: a wave owns two tile rows x 16 columns x 32 channels) ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
@@ -689,74 +712,76 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
   for (int r = 0; r < 16; ++r) acc[0][0][r] = acc_lo[r] = 0.f;
 
   // k-step J = 0..8 of the current group: unit, tap and patch offsets are literals
-#define MSI_S2_TAP(J) ((J) == 0 ? 0 : (J) == 1 ? 2 : (J) == 2 ? 6 : (J) == 3 ? 8 : (J) == 4 ? 1 : (J) == 5 ? 7 : (J) == 6 ? 3 : (J) == 7 ? 5 : 4)
-#define MSI_S2_UNIT(J) ((J) < 4 ? 0 : (J) < 6 ? 1 : (J) < 8 ? 2 : 3)
-#define MSI_S2STEP(J)                                                                                                  \
-  {                                                                                                                    \
-    constexpr int TAP_ = MSI_S2_TAP(J), U_ = MSI_S2_UNIT(J);                                                           \
-    constexpr int DY_ = (TAP_ / 3) >> 1, DX_ = (TAP_ % 3) >> 1;                                                        \
-    constexpr bool FIRST_ = (J) == 0 || (J) == 4 || (J) == 6 || (J) == 8, LAST_ = (J) == 3 || (J) == 5 || (J) == 7 || (J) == 8; \
-    constexpr int AOFF_ = DY_ * G::ROW_PITCH + DX_ * G::PIX_BYTES;                                                     \
-    const bool more_ = U_ < 3 || c + 1 < c1;               /* a unit follows this one */                               \
-    /* ring stage of this k-step: three stages -> J % 3 (a literal); two -> (J + group parity) & 1 (nine k-steps per group flip it) */ \
-    const unsigned bst_ = (unsigned)(G::NSTG == 3 ? (J) % 3 : (((J) ^ cpar) & 1)) * G::B_STAGE;                         \
-    if (G::NSTG == 2) {   /* the NEXT k-step's weights into the other stage: it was last read in the previous k-step (closing barrier passed) */ \
-      const int stn_ = (((J) ^ cpar) & 1) ^ 1;                                                                         \
-      if ((J) + 1 < 9) { MSI_B_ISSUE(c, MSI_S2_TAP(((J) + 1) % 9), stn_) }                                             \
-      else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, MSI_S2_TAP(0), stn_) }                                                 \
-    }                                                                                                                  \
-    v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
-    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
-      ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);                                \
-      bh_[s_] = lds_read128<0>(b_s[s_] + bst_);                                                                        \
-      am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);                           \
-      bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);                                                               \
-      if (NP == 3) {                                                                                                   \
-        al_[s_] = s_ == 0 ? lds_read128<AOFF_ + 128>(a_base) : lds_read128<AOFF_ + 160>(a_base);                       \
-        bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);                                                         \
-      } else { al_[s_] = ah_[s_]; bl_[s_] = bh_[s_]; }                                                                 \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
-      if (NP == 3) {                                                                                                   \
-        if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                    \
-        else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                            \
-      } else {                                                                                                         \
-        if (s_ == 0) wait_lgkm4<4>(ah_[0], bh_[0], am_[0], bm_[0]);                                                    \
-        else wait_lgkm4<0>(ah_[1], bh_[1], am_[1], bm_[1]);                                                            \
-      }                                                                                                                \
-      split_mfma<NP>(acc[0][0], acc_lo, ah_[s_], am_[s_], al_[s_], bh_[s_], bm_[s_], bl_[s_]);                         \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-      if (s_ == 0) {                                                                                                   \
-        if (FIRST_ && more_) {                                                                                         \
-          if (U_ < 3) MSI_PATCH_LOAD(c, (U_ + 1) & 3) else MSI_PATCH_LOAD(c + 1, 0)                                    \
-        }                                                                                                              \
-        /* (three stages) k-step two ahead: (c, J + 2) or (c + 1, J - 7) */                                            \
-        if (G::NSTG == 3) {                                                                                            \
-        if ((J) + 2 < 9) { MSI_B_ISSUE(c, MSI_S2_TAP(((J) + 2) % 9), ((J) + 2) % 3) }                                  \
-        else if (c + 1 < c1) { MSI_B_ISSUE(c + 1, MSI_S2_TAP(((J) + 2) % 9), ((J) + 2) % 3) }                          \
-        }                                                                                                              \
-      }                                                                                                                \
-    }                                                                                                                  \
-    {                                                                                                                  \
-      const bool issued_ = ((J) + 2 < 9) || (c + 1 < c1);                                                              \
-      /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */ \
-      if (G::NSTG == 2) {   /* (the DMA went out BEFORE the patch loads of this k-step: in-order return) */                \
-        if (FIRST_ && !LAST_ && more_) wait_vmcnt<NLOAD>();                                                            \
-        else wait_vmcnt<0>();                                                                                          \
-      } else if (FIRST_ && !LAST_ && more_) wait_vmcnt<NP + NLOAD>();                                                   \
-      else if (issued_) wait_vmcnt<NP>();                                                                              \
-      else wait_vmcnt<0>();                                                                                            \
-    }                                                                                                                  \
-    __builtin_amdgcn_s_barrier();                                                                                      \
-    if (LAST_ && more_) {   /* every wave has read this unit's last tap: swap the patch */                             \
-      MSI_PATCH_STORE((U_ + 1) & 3)                                                                                    \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
-      __builtin_amdgcn_s_barrier();                                                                                    \
-    }                                                                                                                  \
-  }
+  int c = c0, cpar = 0;   // (the group being multiplied -- unit 0's patch of group c0 is on its way -- and its ring parity)
+  auto s2step = [&](auto J_c) __attribute__((always_inline)) {
+    constexpr int J = decltype(J_c)::value;
+    constexpr int TAP_ = s2_tap(J), U_ = s2_unit(J);
+    constexpr int DY_ = (TAP_ / 3) >> 1, DX_ = (TAP_ % 3) >> 1;
+    constexpr bool FIRST_ = J == 0 || J == 4 || J == 6 || J == 8, LAST_ = J == 3 || J == 5 || J == 7 || J == 8;
+    constexpr int AOFF_ = DY_ * G::ROW_PITCH + DX_ * G::PIX_BYTES;
+    const bool more_ = U_ < 3 || c + 1 < c1;               /* a unit follows this one */
+    /* ring stage of this k-step: three stages -> J % 3 (a literal); two -> (J + group parity) & 1 (nine k-steps per group flip it) */
+    const unsigned bst_ = (unsigned)(G::NSTG == 3 ? J % 3 : ((J ^ cpar) & 1)) * G::B_STAGE;
+    if (G::NSTG == 2) {   /* the NEXT k-step's weights into the other stage: it was last read in the previous k-step (closing barrier passed) */
+      const int stn_ = ((J ^ cpar) & 1) ^ 1;
+      if (J + 1 < 9) b_issue(c, s2_tap((J + 1) % 9), stn_);
+      else if (c + 1 < c1) b_issue(c + 1, s2_tap(0), stn_);
+    }
+    v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];
+    if (!(MSI_S2X3_ABLATE & 8))
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);
+      bh_[s_] = lds_read128<0>(b_s[s_] + bst_);
+      am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);
+      bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);
+      if (NP == 3) {
+        al_[s_] = s_ == 0 ? lds_read128<AOFF_ + 128>(a_base) : lds_read128<AOFF_ + 160>(a_base);
+        bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);
+      } else { al_[s_] = ah_[s_]; bl_[s_] = bh_[s_]; }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      if (NP == 3) {
+        if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);
+        else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);
+      } else {
+        if (s_ == 0) wait_lgkm4<4>(ah_[0], bh_[0], am_[0], bm_[0]);
+        else wait_lgkm4<0>(ah_[1], bh_[1], am_[1], bm_[1]);
+      }
+      if (!(MSI_S2X3_ABLATE & 16)) split_mfma<NP>(acc[0][0], acc_lo, ah_[s_], am_[s_], al_[s_], bh_[s_], bm_[s_], bl_[s_]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_ == 0) {
+        if (FIRST_ && more_) {
+          if (U_ < 3) patch_load(c, IC<(U_ + 1) & 3>{});
+          else patch_load(c + 1, IC<0>{});
+        }
+        /* (three stages) k-step two ahead: (c, J + 2) or (c + 1, J - 7) */
+        if (G::NSTG == 3) {
+        if (J + 2 < 9) b_issue(c, s2_tap((J + 2) % 9), (J + 2) % 3);
+        else if (c + 1 < c1) b_issue(c + 1, s2_tap((J + 2) % 9), (J + 2) % 3);
+        }
+      }
+    }
+    {
+      const bool issued_ = (J + 2 < 9) || (c + 1 < c1);
+      /* the NEXT k-step's weights must have landed; the patch requested in this k-step may stay in flight unless it is stored now */
+      if (G::NSTG == 2) {   /* (the DMA went out BEFORE the patch loads of this k-step: in-order return) */
+        if (FIRST_ && !LAST_ && more_) wait_vmcnt<NLOAD>();
+        else wait_vmcnt<0>();
+      } else if (FIRST_ && !LAST_ && more_) wait_vmcnt<NP + NLOAD>();
+      else if (issued_) wait_vmcnt<NP>();
+      else wait_vmcnt<0>();
+    }
+    if (!(MSI_S2X3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+    if (LAST_ && more_ && !(MSI_S2X3_ABLATE & 32)) {   /* every wave has read this unit's last tap: swap the patch */
+      patch_store(IC<(U_ + 1) & 3>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
 
   // ---- prologue: unit 0 of the first group ----
-  int c = c0;   // (unit 0's patch of group c0 is on its way)
   if (APPLY) {
     double *s_stat = reinterpret_cast<double *>(smem);
     ln_mean_inv(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, p.ln_inv_n, p.ln_scl_src, p.status, s_stat, tid);
@@ -767,20 +792,14 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
     __syncthreads();
   }
   wait_vmcnt<0>();
-  MSI_PATCH_STORE(0)
+  patch_store(IC<0>{});
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (; c < c1; ++c) {
-    const int cpar = (c - c0) & 1;   // (two-stage ring: nine k-steps per group flip the stage parity)
-    (void)cpar;
-    MSI_S2STEP(0) MSI_S2STEP(1) MSI_S2STEP(2) MSI_S2STEP(3) MSI_S2STEP(4) MSI_S2STEP(5) MSI_S2STEP(6) MSI_S2STEP(7) MSI_S2STEP(8)
+    cpar = (c - c0) & 1;   // (two-stage ring: nine k-steps per group flip the stage parity)
+    s2step(IC<0>{}); s2step(IC<1>{}); s2step(IC<2>{}); s2step(IC<3>{}); s2step(IC<4>{});
+    s2step(IC<5>{}); s2step(IC<6>{}); s2step(IC<7>{}); s2step(IC<8>{});
   }
-#undef MSI_S2STEP
-#undef MSI_S2_UNIT
-#undef MSI_S2_TAP
-#undef MSI_B_ISSUE
-#undef MSI_PATCH_STORE
-#undef MSI_PATCH_LOAD
   split_finish<NP>(acc[0][0], acc_lo, amax_, lane, p.status);
 
   // ---- epilogue: as conv_halo_kernel ----
@@ -817,6 +836,9 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
 // need no ln_apply launch.
 #ifndef MSI_CT_MAXW
 #define MSI_CT_MAXW 8
+#ifndef MSI_CT3_ABLATE   // timing experiments only (wrong results): bits as MSI_S2X3_ABLATE
+#define MSI_CT3_ABLATE 0
+#endif
 #endif
 #ifndef MSI_CT3_NSTG   // weight ring of the six-product conv-transpose kernel: 2 (r05: 48.4 KB of LDS, three workgroups per CU; eight k-steps per chunk, so the
 #define MSI_CT3_NSTG 2 // stage of k-step J is the literal J & 1 and the DMA of k-step J + 1 goes out at the head of k-step J) or 3 (r04: 60.7 KB, two per CU)
@@ -873,16 +895,16 @@ convt_halo_x3_kernel(const ConvParams p) {
   const int plane_bytes = p.npad * G::B_ROW;
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk_x3, 0, (int)((size_t)4 * S * NP * plane_bytes), 0x00020000);
   const unsigned b_voff = (unsigned)((tile_n * 64 + wave * 16 + (lane >> 2)) * G::B_ROW + (lane & 3) * 16);
-#define MSI_B_ISSUE(cls, tap, c, st)                                                                                   \
-  {                                                                                                                    \
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;                                          \
-    const int soff_ = ((cls) * S + (tap) * CH + (c)) * NP * plane_bytes;                                               \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0); \
-    if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0); \
-  }
-  MSI_B_ISSUE(2 * ph, 0, c0, 0)
-  if (NSTG == 3) MSI_B_ISSUE(2 * ph, 1, c0, 1)
+  auto b_issue = [&](const int cls, const int tap, const int c, const int st) __attribute__((always_inline)) {
+    if (MSI_CT3_ABLATE & 1) return;
+    char *sB_ = smem + G::A_BYTES + st * G::B_STAGE + wave * 16 * G::B_ROW;
+    const int soff_ = (cls * S + tap * CH + c) * NP * plane_bytes;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0);
+    if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0);
+  };
+  b_issue(2 * ph, 0, c0, 0);
+  if (NSTG == 3) b_issue(2 * ph, 1, c0, 1);
 
   // ---- per-lane patch elements (as conv_halo_kernel; the byte offset depends on the source's channel count) ----
   unsigned pixi[NLOAD], lds_a[NLOAD];
@@ -921,48 +943,50 @@ convt_halo_x3_kernel(const ConvParams p) {
   unsigned amax_ = 0u;
   int src_ld = 0;                                         // source of the patch held in araw
   // patch of chunk c -> registers (+ gamma / beta of the lane's channels when that source is raw)
-#define MSI_PATCH_LOAD(c)                                                                                              \
-  {                                                                                                                    \
-    const int s_ = (c) >= p.cpt0 ? 1 : 0, cc_ = s_ ? (c) - p.cpt0 : (c);                                               \
-    const unsigned cb_ = (unsigned)((s_ ? p.C1 : p.C0) * 4);                                                           \
-    src_ld = s_;                                                                                                       \
-    if (s_ == 0) {                                                                                                     \
-      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
-        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
-            rsrc_a0, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));           \
-    } else {                                                                                                           \
-      _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_)                                                             \
-        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(                             \
-            rsrc_a1, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));           \
-    }                                                                                                                  \
-    const float *gp_ = (s_ ? p.ln_gamma1 : p.ln_gamma), *bp_ = (s_ ? p.ln_beta1 : p.ln_beta);                          \
-    if ((p.halo_apply >> s_) & 1) {                                                                                    \
-      g4 = *reinterpret_cast<const v4f *>(gp_ + cc_ * 32 + cslot * 4);                                                 \
-      be4 = *reinterpret_cast<const v4f *>(bp_ + cc_ * 32 + cslot * 4);                                                \
-    } else {   /* (same number of VMEM operations on both paths: the vmcnt arithmetic of the k-steps counts them) */   \
-      g4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16);                                                         \
-      be4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16 + 128);                                                  \
-    }                                                                                                                  \
-  }
-#define MSI_PATCH_STORE()                                                                                              \
-  {                                                                                                                    \
-    const bool ap_ = (p.halo_apply >> src_ld) & 1;                                                                     \
-    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};                                                          \
-    if (ap_) {                                                                                                         \
-      const float ih_ = src_ld ? inv_f[1] : inv_f[0], mh_ = src_ld ? mu_hi[1] : mu_hi[0], ml_ = src_ld ? mu_lo[1] : mu_lo[0]; \
-      s4 = ih_ * g4;                                                                                                   \
-      const v4f nh = {-mh_, -mh_, -mh_, -mh_}, nl = {-ml_, -ml_, -ml_, -ml_};                                          \
-      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));                                  \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < NLOAD; ++k_) {                                                             \
-      v4f y = araw[k_];                                                                                                \
-      if (ap_) {                                                                                                       \
-        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});                  \
-        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};                                                          \
-      }                                                                                                                \
-      split_store<NP>(smem, lds_a[k_], y, amax_);                                                                      \
-    }                                                                                                                  \
-  }
+  auto patch_load = [&](const int c) __attribute__((always_inline)) {
+    if (MSI_CT3_ABLATE & 64) return;
+    const int s_ = c >= p.cpt0 ? 1 : 0, cc_ = s_ ? c - p.cpt0 : c;
+    const unsigned cb_ = (unsigned)((s_ ? p.C1 : p.C0) * 4);
+    src_ld = s_;
+    if (s_ == 0) {
+#pragma unroll
+      for (int k_ = 0; k_ < NLOAD; ++k_)
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(
+            rsrc_a0, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));
+    } else {
+#pragma unroll
+      for (int k_ = 0; k_ < NLOAD; ++k_)
+        araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(
+            rsrc_a1, pok[k_] ? __umul24(pixi[k_], cb_) + (unsigned)(cslot * 16) : OOB, cc_ * ROW_BYTES, 0));
+    }
+    const float *gp_ = (s_ ? p.ln_gamma1 : p.ln_gamma), *bp_ = (s_ ? p.ln_beta1 : p.ln_beta);
+    if ((p.halo_apply >> s_) & 1) {
+      g4 = *reinterpret_cast<const v4f *>(gp_ + cc_ * 32 + cslot * 4);
+      be4 = *reinterpret_cast<const v4f *>(bp_ + cc_ * 32 + cslot * 4);
+    } else {   /* (same number of VMEM operations on both paths: the vmcnt arithmetic of the k-steps counts them) */
+      g4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16);
+      be4 = *reinterpret_cast<const v4f *>(p.wpk + cslot * 16 + 128);
+    }
+  };
+  auto patch_store = [&]() __attribute__((always_inline)) {
+    const bool ap_ = (p.halo_apply >> src_ld) & 1;
+    v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+    if (ap_) {
+      const float ih_ = src_ld ? inv_f[1] : inv_f[0], mh_ = src_ld ? mu_hi[1] : mu_hi[0], ml_ = src_ld ? mu_lo[1] : mu_lo[0];
+      s4 = ih_ * g4;
+      const v4f nh = {-mh_, -mh_, -mh_, -mh_}, nl = {-ml_, -ml_, -ml_, -ml_};
+      t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < NLOAD; ++k_) {
+      v4f y = araw[k_];
+      if (ap_) {
+        y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});
+        if (has_pad && !pok[k_]) y = v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      split_store<NP>(smem, lds_a[k_], y, amax_);
+    }
+  };
 
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
@@ -988,63 +1012,66 @@ convt_halo_x3_kernel(const ConvParams p) {
   // The DMA of the k-step PD = 2 ahead and (J == 0) the next chunk's patch loads are issued after the first MFMA quarter;
   // before the closing barrier the NEXT k-step's weights must have landed: they were issued one k-step ago, so only what
   // THIS k-step issued (2 DMA, + the patch loads of J == 0) may still be in flight (in-order return).
+  int c = c0, st = 0;                                     // the chunk being multiplied and the ring stage of the current k-step
   constexpr int NPLD = NLOAD + 2;                         // VMEM operations of a patch load
-#define MSI_CTSTEP(J)                                                                                                  \
-  {                                                                                                                    \
-    constexpr int PWC_ = (J) >> 2, TH_ = ((J) >> 1) & 1, TW_ = (J) & 1;                                                \
-    constexpr int COFF_ = (1 + (PWC_ ? TW_ : -TW_)) * G::PIX_BYTES;   /* column of the tap: immediate */                \
-    const unsigned ab_ = (TH_ ? a_base1 : a_base0) - ((PWC_ && TW_) ? wadj : 0u);                                      \
-    v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];                                                                \
-    const unsigned bst_ = (unsigned)st * G::B_STAGE;                                                                   \
-    bool issued_ = false;                                                                                              \
-    if (NSTG == 2) {   /* the NEXT k-step's weights into the other stage (last read in the previous k-step: closing barrier passed) */ \
-      constexpr int JN_ = ((J) + 1) & 7;                                                                               \
-      if ((J) + 1 < 8) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c, st ^ 1) }                        \
-      else if (c + 1 < c1) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, st ^ 1) }                \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
-      ah_[s_] = s_ == 0 ? lds_read128<COFF_>(ab_) : lds_read128<COFF_ + 32>(ab_);                                      \
-      bh_[s_] = lds_read128<0>(b_s[s_] + bst_);                                                                        \
-      am_[s_] = s_ == 0 ? lds_read128<COFF_ + 64>(ab_) : lds_read128<COFF_ + 96>(ab_);                                 \
-      bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);                                                               \
-      if (NP == 3) {                                                                                                   \
-        al_[s_] = s_ == 0 ? lds_read128<COFF_ + 128>(ab_) : lds_read128<COFF_ + 160>(ab_);                             \
-        bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);                                                         \
-      } else { al_[s_] = ah_[s_]; bl_[s_] = bh_[s_]; }                                                                 \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                 \
-      if (NP == 3) {                                                                                                   \
-        if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);                                    \
-        else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);                                            \
-      } else {                                                                                                         \
-        if (s_ == 0) wait_lgkm4<4>(ah_[0], bh_[0], am_[0], bm_[0]);                                                    \
-        else wait_lgkm4<0>(ah_[1], bh_[1], am_[1], bm_[1]);                                                            \
-      }                                                                                                                \
-      split_mfma<NP>(acc[PWC_][0][0], acc_lo[PWC_], ah_[s_], am_[s_], al_[s_], bh_[s_], bm_[s_], bl_[s_]);             \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-      if (s_ == 0) {                                                                                                   \
-        if ((J) == 0 && c + 1 < c1) MSI_PATCH_LOAD(c + 1)                                                              \
-        if (NSTG == 3) {                                                                                               \
-        int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;                                                       \
-        constexpr int JN_ = ((J) + PD) & 7;                                                                            \
-        if ((J) + PD < 8) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c, sn_) }                        \
-        else if (c + 1 < c1) { issued_ = true; MSI_B_ISSUE(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_) }                 \
-        }                                                                                                              \
-      }                                                                                                                \
-    }                                                                                                                  \
-    if (NSTG == 2) {   /* (the DMA went out before this k-step's patch loads: in-order return) */                      \
-      if ((J) == 0 && c + 1 < c1) wait_vmcnt<NPLD>();                                                                  \
-      else wait_vmcnt<0>();                                                                                            \
-    } else if ((J) == 0 && c + 1 < c1) wait_vmcnt<NP + NPLD>();                                                          \
-    else if (issued_) wait_vmcnt<NP>();                                                                                \
-    else wait_vmcnt<0>();                                                                                              \
-    __builtin_amdgcn_s_barrier();                                                                                      \
-    st = st + 1 == NSTG ? 0 : st + 1;                                                                                  \
-  }
+  auto ctstep = [&](auto J_c) __attribute__((always_inline)) {
+    constexpr int J = decltype(J_c)::value;
+    constexpr int PWC_ = J >> 2, TH_ = (J >> 1) & 1, TW_ = J & 1;
+    constexpr int COFF_ = (1 + (PWC_ ? TW_ : -TW_)) * G::PIX_BYTES;   /* column of the tap: immediate */
+    const unsigned ab_ = (TH_ ? a_base1 : a_base0) - ((PWC_ && TW_) ? wadj : 0u);
+    v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];
+    const unsigned bst_ = (unsigned)st * G::B_STAGE;
+    bool issued_ = false;
+    if (NSTG == 2) {   /* the NEXT k-step's weights into the other stage (last read in the previous k-step: closing barrier passed) */
+      constexpr int JN_ = (J + 1) & 7;
+      if (J + 1 < 8) { issued_ = true; b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c, st ^ 1); }
+      else if (c + 1 < c1) { issued_ = true; b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, st ^ 1); }
+    }
+    if (!(MSI_CT3_ABLATE & 8))
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      ah_[s_] = s_ == 0 ? lds_read128<COFF_>(ab_) : lds_read128<COFF_ + 32>(ab_);
+      bh_[s_] = lds_read128<0>(b_s[s_] + bst_);
+      am_[s_] = s_ == 0 ? lds_read128<COFF_ + 64>(ab_) : lds_read128<COFF_ + 96>(ab_);
+      bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);
+      if (NP == 3) {
+        al_[s_] = s_ == 0 ? lds_read128<COFF_ + 128>(ab_) : lds_read128<COFF_ + 160>(ab_);
+        bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);
+      } else { al_[s_] = ah_[s_]; bl_[s_] = bh_[s_]; }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      if (NP == 3) {
+        if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);
+        else wait_lgkm6<0>(ah_[1], bh_[1], am_[1], bm_[1], al_[1], bl_[1]);
+      } else {
+        if (s_ == 0) wait_lgkm4<4>(ah_[0], bh_[0], am_[0], bm_[0]);
+        else wait_lgkm4<0>(ah_[1], bh_[1], am_[1], bm_[1]);
+      }
+      if (!(MSI_CT3_ABLATE & 16)) split_mfma<NP>(acc[PWC_][0][0], acc_lo[PWC_], ah_[s_], am_[s_], al_[s_], bh_[s_], bm_[s_], bl_[s_]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_ == 0) {
+        if (J == 0 && c + 1 < c1) patch_load(c + 1);
+        if (NSTG == 3) {
+        int sn_ = st + PD; sn_ = sn_ >= NSTG ? sn_ - NSTG : sn_;
+        constexpr int JN_ = (J + PD) & 7;
+        if (J + PD < 8) { issued_ = true; b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c, sn_); }
+        else if (c + 1 < c1) { issued_ = true; b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_); }
+        }
+      }
+    }
+    if (NSTG == 2) {   /* (the DMA went out before this k-step's patch loads: in-order return) */
+      if (J == 0 && c + 1 < c1) wait_vmcnt<NPLD>();
+      else wait_vmcnt<0>();
+    } else if (J == 0 && c + 1 < c1) wait_vmcnt<NP + NPLD>();
+    else if (issued_) wait_vmcnt<NP>();
+    else wait_vmcnt<0>();
+    if (!(MSI_CT3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+    st = st + 1 == NSTG ? 0 : st + 1;
+  };
 
   // ---- prologue: first patch (the first two weight k-steps are on their way), the sources' LayerNorm statistics ----
-  int c = c0, st = 0;
-  MSI_PATCH_LOAD(c0)
+  patch_load(c0);
   if (p.halo_apply) {
     double *s_stat = reinterpret_cast<double *>(smem);
     if (p.halo_apply & 1) {
@@ -1061,21 +1088,17 @@ convt_halo_x3_kernel(const ConvParams p) {
     }
   }
   wait_vmcnt<0>();
-  MSI_PATCH_STORE()
+  patch_store();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (; c < c1; ++c) {
-    MSI_CTSTEP(0) MSI_CTSTEP(1) MSI_CTSTEP(2) MSI_CTSTEP(3) MSI_CTSTEP(4) MSI_CTSTEP(5) MSI_CTSTEP(6) MSI_CTSTEP(7)
-    if (c + 1 < c1) {
-      MSI_PATCH_STORE()
+    ctstep(IC<0>{}); ctstep(IC<1>{}); ctstep(IC<2>{}); ctstep(IC<3>{}); ctstep(IC<4>{}); ctstep(IC<5>{}); ctstep(IC<6>{}); ctstep(IC<7>{});
+    if (c + 1 < c1 && !(MSI_CT3_ABLATE & 32)) {
+      patch_store();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
-#undef MSI_CTSTEP
-#undef MSI_B_ISSUE
-#undef MSI_PATCH_STORE
-#undef MSI_PATCH_LOAD
   split_finish<NP>(acc[0][0][0], acc_lo[0], amax_, lane, p.status);
   split_finish<NP>(acc[1][0][0], acc_lo[1], amax_, lane, p.status);
 
