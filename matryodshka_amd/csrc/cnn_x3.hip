@@ -137,14 +137,12 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
   int c = c0, cpar = 0;   // chunk of the k-loop and (two-stage ring) its stage parity: captured by the k-step lambdas below
   (void)cpar;
   auto b_issue = [&](const int c, const int tap, const int st) __attribute__((always_inline)) {
-
-  if (!(MSI_X3_ABLATE & 1)) {
-    char *sB_ = smem + G::A_BYTES + (st) * G::B_STAGE + wave * 16 * G::B_ROW;
-    const int soff_ = ((tap) * CH + (c)) * NPL * plane_bytes;
+    if (MSI_X3_ABLATE & 1) return;
+    char *sB_ = smem + G::A_BYTES + st * G::B_STAGE + wave * 16 * G::B_ROW;
+    const int soff_ = (tap * CH + c) * NPL * plane_bytes;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)sB_, 16, b_voff, soff_, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + G::B_PLANE), 16, b_voff, soff_ + plane_bytes, 0, 0);
     if (NPL == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(sB_ + 2 * G::B_PLANE), 16, b_voff, soff_ + 2 * plane_bytes, 0, 0);
-  }
   };
   b_issue(c0, 0, 0);
   if (G::NSTG == 3) b_issue(c0, 1, 1);
@@ -180,31 +178,24 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
   unsigned amax_ = 0u;   // (NPL == 2: the largest operand magnitude this lane stored -- the fp16 range check, f16_range_track)
   // patch of chunk c -> registers (+ gamma / beta of the lane's channels)
   auto patch_load = [&](const int c) __attribute__((always_inline)) {
-
-  {
-    
 #pragma unroll
-      for (int k_ = 0; k_ < NLOAD; ++k_)
-      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], (c) * ROW_BYTES, 0));
+    for (int k_ = 0; k_ < NLOAD; ++k_)
+      araw[k_] = __builtin_bit_cast(v4f, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff[k_], c * ROW_BYTES, 0));
     if (APPLY) {
-      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + (c) * 32 + cslot * 4);
-      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + (c) * 32 + cslot * 4);
+      g4 = *reinterpret_cast<const v4f *>(p.ln_gamma + c * 32 + cslot * 4);
+      be4 = *reinterpret_cast<const v4f *>(p.ln_beta + c * 32 + cslot * 4);
     }
-  }
   };
   // registers -> LDS patch, the producer's affine + ReLU applied (ln_apply_kernel's expressions: same bits)
   auto patch_store = [&]() __attribute__((always_inline)) {
-
-  {
     v4f s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
     if (APPLY) {   /* scale = inv * gamma; shift = beta - mean * scale with the mean as hi + lo floats: fp32 ops only */
       s4 = inv_f * g4;
       const v4f nh = {-mu_hi, -mu_hi, -mu_hi, -mu_hi}, nl = {-mu_lo, -mu_lo, -mu_lo, -mu_lo};
       t4 = __builtin_elementwise_fma(nl, s4, __builtin_elementwise_fma(nh, s4, be4));
     }
-    
 #pragma unroll
-      for (int k_ = 0; k_ < NLOAD; ++k_) {
+    for (int k_ = 0; k_ < NLOAD; ++k_) {
       v4f y = araw[k_];
       if (APPLY) {
         y = __builtin_elementwise_max(__builtin_elementwise_fma(y, s4, t4), v4f{0.f, 0.f, 0.f, 0.f});
@@ -242,7 +233,6 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
       }
     }
     }
-  }
   };
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
@@ -269,20 +259,18 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
   // operation issued before them (the next chunk's patch loads, issued in tap 0) completes first (in-order return)
   auto htap = [&](auto TAP_c) __attribute__((always_inline)) {
     constexpr int TAP = decltype(TAP_c)::value;
-  {
-    constexpr int KH_ = (TAP) / 3, KW_ = (TAP) % 3;
+    constexpr int KH_ = TAP / 3, KW_ = TAP % 3;
     /* ring stage of this k-step: three stages -> TAP % 3 (a literal); two stages -> (TAP + chunk parity) & 1 (run-time scalar) */
-    const unsigned bst_ = (unsigned)(G::NSTG == 3 ? (TAP) % 3 : (((TAP) ^ cpar) & 1)) * G::B_STAGE;
+    const unsigned bst_ = (unsigned)(G::NSTG == 3 ? TAP % 3 : ((TAP ^ cpar) & 1)) * G::B_STAGE;
     constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;
     v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];
     if (MSI_X3_EARLY_DMA || G::NSTG == 2) {   /* the k-step NSTG - 1 ahead: its ring stage was last read in the previous k-step (closing barrier passed) */
       constexpr int PD_ = G::NSTG - 1;
-      const int stn_ = G::NSTG == 3 ? ((TAP) + 2) % 3 : ((((TAP) ^ cpar) & 1) ^ 1);   /* (two stages: the other one) */
-      if ((TAP) + PD_ < 9) { b_issue(c, (TAP) + PD_, stn_); }
-      else if (c + 1 < c1) { b_issue(c + 1, (TAP) + PD_ - 9, stn_); }
+      const int stn_ = G::NSTG == 3 ? (TAP + 2) % 3 : (((TAP ^ cpar) & 1) ^ 1);   /* (two stages: the other one) */
+      if (TAP + PD_ < 9) { b_issue(c, TAP + PD_, stn_); }
+      else if (c + 1 < c1) { b_issue(c + 1, TAP + PD_ - 9, stn_); }
     }
     if (NPL == 2) {
-      
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
         ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);
@@ -290,7 +278,6 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
         am_[s_] = s_ == 0 ? lds_read128<AOFF_ + 64>(a_base) : lds_read128<AOFF_ + 96>(a_base);
         bm_[s_] = lds_read128<G::B_PLANE>(b_s[s_] + bst_);
       }
-      
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
         if (s_ == 0) wait_lgkm4<4>(ah_[0], bh_[0], am_[0], bm_[0]);
@@ -300,10 +287,10 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
         acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh_[s_]), __builtin_bit_cast(f16x8, am_[s_]), acc_lo, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (s_ == 0) {
-          if ((TAP) == 0 && c + 1 < c1) patch_load(c + 1);
+          if (TAP == 0 && c + 1 < c1) patch_load(c + 1);
           if (!MSI_X3_EARLY_DMA && G::NSTG == 3) {
-            if ((TAP) + 2 < 9) { b_issue(c, (TAP) + 2, ((TAP) + 2) % 3); }
-            else if (c + 1 < c1) { b_issue(c + 1, (TAP) - 7, ((TAP) + 2) % 3); }
+            if (TAP + 2 < 9) { b_issue(c, TAP + 2, (TAP + 2) % 3); }
+            else if (c + 1 < c1) { b_issue(c + 1, TAP - 7, (TAP + 2) % 3); }
           }
         }
       }
@@ -320,7 +307,7 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
       __builtin_amdgcn_sched_barrier(0);
       xh_[1][0] = lds_read128<AOFF_ + 32>(a_base); xm_[1][0] = lds_read128<AOFF_ + 96>(a_base); xl_[1][0] = lds_read128<AOFF_ + 160>(a_base);
       xh_[1][1] = lds_read128<A1_ + 32>(a_base); xm_[1][1] = lds_read128<A1_ + 96>(a_base); xl_[1][1] = lds_read128<A1_ + 160>(a_base);
-      if ((TAP) == 0 && c + 1 < c1) patch_load(c + 1);
+      if (TAP == 0 && c + 1 < c1) patch_load(c + 1);
       wait_lgkm6<9>(xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);
       split_mfma<3>(acc[1][0], acc_lo, xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);
       __builtin_amdgcn_sched_barrier(0);
@@ -332,7 +319,6 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
       __builtin_amdgcn_sched_barrier(0);
     } else {
     if (!(MSI_X3_ABLATE & 8))
-    
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
       ah_[s_] = s_ == 0 ? lds_read128<AOFF_>(a_base) : lds_read128<AOFF_ + 32>(a_base);
@@ -343,7 +329,6 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
       bl_[s_] = lds_read128<2 * G::B_PLANE>(b_s[s_] + bst_);
     }
     /* six products per K16 step, small terms first: m.m, l.h, h.l, m.h, h.m, h.h (weights = the MFMA's row operand) */
-    
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
       if (s_ == 0) wait_lgkm6<6>(ah_[0], bh_[0], am_[0], bm_[0], al_[0], bl_[0]);
@@ -358,26 +343,25 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
       }
       __builtin_amdgcn_sched_barrier(0);
       if (s_ == 0) {
-        if ((TAP) == 0 && c + 1 < c1) patch_load(c + 1);
+        if (TAP == 0 && c + 1 < c1) patch_load(c + 1);
         /* k-step two ahead: (c, TAP + 2) or (c + 1, TAP - 7) */
         if (!MSI_X3_EARLY_DMA && G::NSTG == 3) {
-        if ((TAP) + 2 < 9) { b_issue(c, (TAP) + 2, ((TAP) + 2) % 3); }
-        else if (c + 1 < c1) { b_issue(c + 1, (TAP) - 7, ((TAP) + 2) % 3); }
+        if (TAP + 2 < 9) { b_issue(c, TAP + 2, (TAP + 2) % 3); }
+        else if (c + 1 < c1) { b_issue(c + 1, TAP - 7, (TAP + 2) % 3); }
         }
       }
     }
     }
     {
-      const bool issued_ = ((TAP) + 2 < 9) || (c + 1 < c1);
+      const bool issued_ = (TAP + 2 < 9) || (c + 1 < c1);
       if (G::NSTG == 2) {
-        if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<NLOAD + (APPLY ? 2 : 0)>();   /* (the patch loads were issued after the DMA) */
+        if (TAP == 0 && c + 1 < c1) wait_vmcnt<NLOAD + (APPLY ? 2 : 0)>();   /* (the patch loads were issued after the DMA) */
         else wait_vmcnt<0>();
-      } else if ((TAP) == 0 && c + 1 < c1) wait_vmcnt<NPL + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight (either order) */
+      } else if (TAP == 0 && c + 1 < c1) wait_vmcnt<NPL + NLOAD + (APPLY ? 2 : 0)>();   /* patch loads + this tap's DMA in flight (either order) */
       else if (issued_) wait_vmcnt<NPL>();
       else wait_vmcnt<0>();
     }
     if (!(MSI_X3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
-  }
   };
 
   // ---- prologue: first patch, first two weight k-steps ----
@@ -424,8 +408,7 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
       o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
       o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
       o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
-    }
-  };
+    };
 #endif
   if (!full) {
     constexpr int SLAB = BM * 64 * 4;
@@ -836,9 +819,9 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
 // need no ln_apply launch.
 #ifndef MSI_CT_MAXW
 #define MSI_CT_MAXW 8
+#endif
 #ifndef MSI_CT3_ABLATE   // timing experiments only (wrong results): bits as MSI_S2X3_ABLATE
 #define MSI_CT3_ABLATE 0
-#endif
 #endif
 #ifndef MSI_CT3_NSTG   // weight ring of the six-product conv-transpose kernel: 2 (r05: 48.4 KB of LDS, three workgroups per CU; eight k-steps per chunk, so the
 #define MSI_CT3_NSTG 2 // stage of k-step J is the literal J & 1 and the DMA of k-step J + 1 goes out at the head of k-step J) or 3 (r04: 60.7 KB, two per CU)
