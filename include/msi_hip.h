@@ -60,8 +60,9 @@ const char *msi_version(void);
  *   3: msi_layer_info.ln_scale_offset; LayerNorm window doubles in the packed blob (round 3)
  *   4: msi_net_plan_layer_kernel; render status word (msi_render_status_*); sweep volume takes shared poses (round 4)
  *   5: packed blob carries the fp16-split (x2) block; MSI_NET_OPT_F32_SPLIT_F16, MSI_NET_STATUS_F16_SPLIT_RANGE (round 4)
- *   6: msi_net_plan_calibrate; MSI_NET_OPT_X3_TILE8 (round 5) */
-#define MSI_ABI_VERSION 6
+ *   6: msi_net_plan_calibrate; MSI_NET_OPT_X3_TILE8 (round 5)
+ *   7: MSI_NET_OPT_X3_ROWPAR (round 5) */
+#define MSI_ABI_VERSION 7
 int32_t msi_abi_version(void);
 const char *msi_last_error_string(void);
 /* CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 for a new message): the per-tensor checksum of
@@ -352,7 +353,11 @@ typedef struct msi_net_plan msi_net_plan;
                                 /* the weight bytes L2 -> LDS, half the prologues / patch swaps per output, 0.75 fragment reads per MFMA, two workgroups per CU.  Same        */
                                 /* arithmetic and per-accumulator summation order as the 4-row tile.  Applied only where the layer's grid stays >= 3 such tiles per CU       */
                                 /* (smaller grids are cut into K-ranges either way and lose); bit 30 forces it on every eligible layer (tests).  Default 0x3ffff             */
-#define MSI_NET_OPT_COUNT 17
+#define MSI_NET_OPT_X3_ROWPAR 17 /* fp32 plans, bit i = layer i: a stride-1, RATE-2 layer on the split (F32_SPLIT3) whose input height is a multiple of 8 runs on ROW-PARITY  */
+                                 /* tiles: a tile's four rows are every other image row (tile row t = 2 t' + parity -> rows 8 t' + parity + 2 r), so along H a dilation-2 tap */
+                                 /* is the NEXT tile row -- a 6 x 20-pixel patch instead of 8 x 20, the two-stage weight ring and three workgroups per CU instead of two.      */
+                                 /* Same arithmetic and summation order per output element (bit-identical to the plain rate-2 tile).  Default 0x3ffff                         */
+#define MSI_NET_OPT_COUNT 18
 int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out_plan);
 void msi_net_plan_destroy(msi_net_plan *plan);
 int msi_net_plan_set_option(msi_net_plan *plan, int32_t option, int32_t value);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmsi_hip.so")
 MSI_OK = 0
 MSI_NET_NUM_LAYERS = 18
 RENDER_STATUS_ORIGIN_OUTSIDE = 1
-MSI_ABI_VERSION = 6          # include/msi_hip.h: the version this binding's struct layouts and signatures are written for
+MSI_ABI_VERSION = 7          # include/msi_hip.h: the version this binding's struct layouts and signatures are written for
 
 
 class MsiError(RuntimeError):
@@ -34,6 +34,7 @@ NET_OPT_F32_TILE, NET_OPT_F32_TILE_MASK, NET_OPT_APPLY_AHEAD, NET_OPT_HALO, NET_
 NET_OPT_UNIFORM_SPLIT, NET_OPT_BF16_STAGE_RAW, NET_OPT_SPLIT_OVERHEAD, NET_OPT_BF16_WAVES, NET_OPT_F32_SPLIT3 = 10, 11, 12, 13, 14
 NET_OPT_F32_SPLIT_F16 = 15
 NET_OPT_X3_TILE8 = 16
+NET_OPT_X3_ROWPAR = 17
 NET_STATUS_F16_SPLIT_RANGE = 8
 
 

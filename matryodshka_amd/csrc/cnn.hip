@@ -427,6 +427,9 @@ int plan_layers(msi_net_plan *pl) {
     Q.x3_th8 = Q.halo_x3 && !Q.halo_x2 && !Q.halo_s2 && L.rate == 1 && L.in_h % 8 == 0 && ((pl->opt[MSI_NET_OPT_X3_TILE8] >> li) & 1) &&
                ((long)(L.in_h / 8) * (L.in_w / 16) * ((L.cout + 63) / 64) * desc->batch >= 3L * pl->num_cus || ((pl->opt[MSI_NET_OPT_X3_TILE8] >> 30) & 1));
     if (Q.x3_th8) BM = 128;
+    // rate-2 layers of the split kernels on row-parity tiles (conv_halo_x3_kernel<3, ...>, halo_row): the dilation along H becomes the tile's row stride --
+    // a 6 x 20-pixel patch, the two-stage weight ring, three workgroups per CU (the plain rate-2 tile: 8 x 20, three stages, two)
+    p.row_par = (Q.halo_x3 && !Q.halo_s2 && L.kind == MODE_CONV && L.rate == 2 && L.in_h % 8 == 0 && ((pl->opt[MSI_NET_OPT_X3_ROWPAR] >> li) & 1)) ? 1 : 0;
     int max_split = MAX_SPLIT;
     // bf16 halo-patch kernel (conv_halo_bf16_kernel): the same layers with 64-channel chunks and whole
     // 8 x 16 pixel x 128 channel or 16 x 16 x 64 tiles
@@ -827,6 +830,7 @@ int msi_net_plan_create(const msi_net_desc *desc, msi_net_plan **out) {
   // two-way / three-product split must not be the arithmetic a `dtype f32` number is quoted on.  The default stays the six-product form (dropped terms < 2^-26).
   pl->opt[MSI_NET_OPT_F32_SPLIT_F16] = 0;
   pl->opt[MSI_NET_OPT_X3_TILE8] = 0x3ffff;   // (r05: every eligible layer whose grid is >= 3 tiles per CU)
+  pl->opt[MSI_NET_OPT_X3_ROWPAR] = 0x3ffff;  // (r05: every rate-2 layer of the split kernels)
   pl->opt[MSI_NET_OPT_F32_SPLIT3] = 0x3ffff;   // every layer that has the kernel (r04: same error against the oracle as the native path, 1.35-1.45 x faster per layer)
   pl->opt[MSI_NET_OPT_BF16_STAGE_RAW] = 1;   // (bit 1, conv8_1 staging its raw sources: measured 50 us per 16 frames SLOWER -- ~180 VALU per chunk
                                                // against 2 048 matrix cycles of the 128 x 64 tile; bit 0, conv8_2: 130 us faster.  Three interleaved repeats)
@@ -901,7 +905,7 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
     if (Q.halo_s2 && Q.halo_x3) snprintf(name, name_bytes, "conv_halo_s2_x3_kernel<%d, %d>", Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);
     else if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_s2_kernel<%d>", Q.halo_apply ? 1 : 0);
     else if (Q.x3_th8) snprintf(name, name_bytes, "conv_halo8_x3_kernel<%d, 3>", Q.halo_apply ? 1 : 0);
-    else if (Q.halo_x3) snprintf(name, name_bytes, "conv_halo_x3_kernel<%d, %d, %d>", L.rate, Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);
+    else if (Q.halo_x3) snprintf(name, name_bytes, "conv_halo_x3_kernel<%d, %d, %d>", Q.p.row_par ? 3 : L.rate, Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);
     else snprintf(name, name_bytes, "conv_halo_kernel<%d, %d>", L.rate, Q.halo_apply ? 1 : 0);
   } else {
     const int bm = Q.tile == TILE_128x128 || Q.tile == TILE_128x64 ? 128 : 64;

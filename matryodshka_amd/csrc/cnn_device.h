@@ -99,6 +99,8 @@ struct ConvParams {
   int halo_tx;               // halo-patch layers (conv_halo_kernel): spatial 4 x 16 tiles, halo_tx = W / 16 tiles per row;
   unsigned mg_htx;           // 0 = the M tiles are 64 consecutive pixels (conv_igemm_kernel)
   int halo_xor;              // 8 (conv_halo_kernel) / 0: odd rows of a halo tile map lane l to column (l & 15) ^ halo_xor (HaloGeom)
+  int row_par;               // 1 (rate-2 layers of the split kernels, r05): a halo tile's rows are every OTHER image row -- tile row index t = 2 t' + parity covers rows
+                             // 2 TH t' + parity + 2 r: a dilation-2 convolution restricted to one row parity is a dilation-1 convolution along H (halo_row)
   // "apply-ahead": the first n_apply workgroups of the launch normalise source 0 (LayerNorm + ReLU of the producer layer)
   // while the tile workgroups behind them already compute; see apply_ahead() below.  n_apply = 0: source 0 is
   // normalised already (separate ln_apply launch, or the network input).
@@ -216,6 +218,11 @@ __device__ __forceinline__ unsigned udiv_magic(unsigned x, unsigned d, unsigned 
   unsigned q = __umulhi(x, mg);
   if (x - q * d >= d) ++q;
   return q;
+}
+
+// image row of row r of halo tile row tyi (rows_per_tile rows per tile): consecutive rows, or (ConvParams::row_par) every other row of one parity
+__device__ __forceinline__ int halo_row(const ConvParams &p, int tyi, int r, int rows_per_tile) {
+  return p.row_par ? (tyi >> 1) * (2 * rows_per_tile) + (tyi & 1) + 2 * r : tyi * rows_per_tile + r;
 }
 
 // tanh of the 1x1 head (nets.py:509-515) as (e^{2|x|} - 1) / (e^{2|x|} + 1) on the hardware exp2 / rcp (1 ulp each): absolute error
@@ -518,7 +525,7 @@ __device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&ac
       int m = tile_m * BM + wm * (MT * 32) + i * 32 + (lane & 31);
       if (p.halo_tx) {   // (BM / 16) x 16 spatial tile: local pixel = 16 * row + column
         const int local = wm * (MT * 32) + i * 32 + (lane & 31);
-        m = (tyi * (BM / 16) + (local >> 4)) * p.Mw + txi * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor));
+        m = halo_row(p, tyi, local >> 4, BM / 16) * p.Mw + txi * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor));
       }
       int mh = 0, mw = 0;
       if (MODE == MODE_CONVT || CB) {
@@ -599,9 +606,9 @@ __device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&ac
     const int rowb = p.Cout * YSZ;                      // bytes per output pixel
     int pix0, rowstep, colstep;                        // the lane's first pixel; what one tile row / column is in output pixels
     if (p.halo_tx) {
-      const int r0 = tyi * (BM / 16) + wm * (MT * 2), c0 = txi * 16 + lane / NP;
+      const int r0 = halo_row(p, tyi, wm * (MT * 2), BM / 16), c0 = txi * 16 + lane / NP;
       if (MODE == MODE_CONVT) { pix0 = (2 * r0 + ph) * p.Wout + 2 * c0 + pw; rowstep = 2 * p.Wout; colstep = 2; }
-      else { pix0 = r0 * p.Mw + c0; rowstep = p.Mw; colstep = 1; }
+      else { pix0 = r0 * p.Mw + c0; rowstep = p.row_par ? 2 * p.Mw : p.Mw; colstep = 1; }
     } else {
       pix0 = tile_m * BM + wm * (MT * 32) + lane / NP; rowstep = 16; colstep = 1;   // (linear pixels: a "row" is 16 of them)
     }
@@ -611,7 +618,11 @@ __device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&ac
 #pragma unroll
       for (int k = 0; k < NRD; ++k) {
         const int ro = 2 * i + ((k * PPI) >> 4), co = (k * PPI) & 15;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pc[i][k]), rsrc_y, v0, (ro * rowstep + co * colstep) * rowb, 0);
+        // The row / column step goes into the VECTOR offset, the scalar offset stays the literal 0.  r05: `buffer_store_dwordx4 vdata, voff, rsrc, sN offen` followed IMMEDIATELY by a
+        // VALU write of vdata lost a few stores per launch on gfx950 (the next instruction was the address arithmetic of the following store, allocated onto the freed data
+        // register).  The compiler's hazard recognizer inserts the wait state for wide stores only when soffset is NOT a register; with an SGPR there it emits none.  Proven by
+        // inserting `s_nop 0` after the stores of ONE kernel in the assembly (profiles/r05_store_hazard.txt); matryodshka_amd/isa_lint.py now refuses a library with that sequence.
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pc[i][k]), rsrc_y, v0 + (unsigned)((ro * rowstep + co * colstep) * rowb), 0, 0);
       }
   }
   MSI_STAMP(17)
@@ -677,7 +688,7 @@ __device__ __forceinline__ void emit_tile_impl(const ConvParams &p, f32x16 (&acc
     if ((MODE == MODE_CONV || MODE == MODE_CONVT) && p.halo_tx) {   // (BM / 16) x 16 spatial tile: local pixel = 16 * row + column
       const int local = wm * (MT * 32) + i * 32 + (lane & 31);
       const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
-      m = (tyi * (BM / 16) + (local >> 4)) * p.Mw + (tile_m - tyi * p.halo_tx) * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor));
+      m = halo_row(p, tyi, local >> 4, BM / 16) * p.Mw + (tile_m - tyi * p.halo_tx) * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor));
       // (ragged grids -- msi_train_net's conv-transposes, (H + 1) x (W + 5) GEMM rows: a column beyond the row's end is no pixel)
       if (!INTERIOR && (tile_m - tyi * p.halo_tx) * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor)) >= p.Mw) m = mtot;
     }
@@ -805,7 +816,7 @@ __device__ __forceinline__ void load_coord_bias(const ConvParams &p, int tile_m,
   if (p.halo_tx) {
     const int local = wm * 32 + (lane & 31);
     const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
-    m = (tyi * 4 + (local >> 4)) * p.Mw + (tile_m - tyi * p.halo_tx) * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor));
+    m = halo_row(p, tyi, local >> 4, 4) * p.Mw + (tile_m - tyi * p.halo_tx) * 16 + ((local & 15) ^ (((local >> 4) & 1) * p.halo_xor));
   }
   m = min(m, p.Mh * p.Mw - 1);
   const int mh = (int)udiv_magic((unsigned)m, (unsigned)p.Mw, p.mg_mw), mw = m - mh * p.Mw;

@@ -30,9 +30,17 @@ namespace {
 #endif
 // NPL = 3: x = h + m + l in bf16, six products (F32_SPLIT3).  NPL = 2: x = h + m' 2^-11 in fp16, three products h.h + (h.m' + m'.h) 2^-11
 // (F32_SPLIT_F16: 22 significand bits per operand, operands limited to the fp16 RANGE -- the patch store flags |x| > 65504 in the status word)
-template <int RATE, int NS = (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3)), int NPL = 3, int TH = 4>
+#ifndef MSI_X2_NSTG   // weight ring of the fp16 form (half the matrix work per tap: the DMA latency budget of a two-stage ring is one SHORT tap)
+#define MSI_X2_NSTG 3
+#endif
+// RATE: 1, 2 = the dilation; 3 (r05) = dilation 2 on a ROW-PARITY tile (ConvParams::row_par): the tile's four rows are every other image row, so along H the taps are one
+// tile row apart (halo 1) and only W keeps the dilation: a 6 x 20-pixel patch (25.3 KB) instead of 8 x 20 (33.8 KB), i.e. the two-stage ring and THREE workgroups per CU.
+constexpr int x3_rate_y(int RATE) { return RATE == 3 ? 1 : RATE; }
+constexpr int x3_rate_x(int RATE) { return RATE == 3 ? 2 : RATE; }
+constexpr int x3_nstg(int RATE, int NPL) { return NPL == 2 ? MSI_X2_NSTG : (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 2 ? 3 : 2)); }
+template <int RATE, int NS = x3_nstg(RATE, 3), int NPL = 3, int TH = 4>
 struct HaloGeomX3 {
-  static constexpr int PW = 16 + 2 * RATE, PH = TH + 2 * RATE, NPX = PW * PH;   // TH x 16 output pixels per workgroup (TH = 4, or 8: conv_halo8_x3_kernel)
+  static constexpr int PW = 16 + 2 * x3_rate_x(RATE), PH = TH + 2 * x3_rate_y(RATE), NPX = PW * PH;   // TH x 16 output pixels per workgroup (TH = 4, or 8: conv_halo8_x3_kernel)
   static constexpr int PIX_BYTES = NPL * 64 + 16;         // NPL planes x 32 two-byte parts + 16 (13 or 9 sixteen-byte slots: odd)
   static constexpr int ROW_PITCH = ((PW * PIX_BYTES + 127) / 256) * 256 + 128;
   static constexpr int A_BYTES = PH * ROW_PITCH;
@@ -62,9 +70,6 @@ __device__ __forceinline__ void wait_lgkm6(v4f &a, v4f &b, v4f &c, v4f &d, v4f &
   asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N) : "memory");
 }
 
-#ifndef MSI_X2_NSTG   // weight ring of the fp16 form (half the matrix work per tap: the DMA latency budget of a two-stage ring is one SHORT tap)
-#define MSI_X2_NSTG 3
-#endif
 #ifndef MSI_X2_WAVES    // fp16 form at rate 1: four waves per SIMD = four workgroups per CU (40.7 KB of LDS each).  With the coordinate-bias registers requested
 #define MSI_X2_WAVES 4  // AFTER the k-loop (MSI_X2_LATE_CB: 147 -> 131 VGPRs) the allocator reaches 128 without a spill: measured 57.5 -> 54.4 us per layer
 #endif                  // (r04; forcing 128 with the bias registers held through the loop spilled 68 bytes and gained nothing)
@@ -79,8 +84,9 @@ __device__ __forceinline__ void split_mfma(f32x16 &acc, f32x16 &lo, const v4f &a
 // half the prologues / patch swaps / barriers; 64.3 KB of LDS: two workgroups per CU.
 template <int RATE, int APPLY, int NPL, int TH>
 __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *smem) {
-  typedef HaloGeomX3<RATE, (NPL == 2 ? MSI_X2_NSTG : (MSI_X3_NSTG ? MSI_X3_NSTG : (RATE == 1 ? 2 : 3))), NPL, TH> G;
-  constexpr int R = RATE, PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
+  typedef HaloGeomX3<RATE, x3_nstg(RATE, NPL), NPL, TH> G;
+  constexpr int RY = x3_rate_y(RATE), RX = x3_rate_x(RATE), PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
+  static_assert(RATE != 3 || TH == 4, "row-parity tiles: four rows");
   constexpr int MT = TH / 4, NT = 1, BM = 16 * TH;
   static_assert(TH == 4 || (TH == 8 && NPL == 3 && RATE == 1), "the 8-row tile is built for the six-product form at rate 1");
 #ifdef MSI_CONV_TIMING
@@ -123,7 +129,7 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
   LnShard shard = {0, 0};   // (the lane's shard of the source's LayerNorm sums: requested here, reduced after the patch requests)
   if (APPLY) shard = ln_shard_load(p.ln_sums + (size_t)b * LN_SHARDS * LN_WORDS, tid);
   const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
-  const int oh0 = tyi * TH, ow0 = (tile_m - tyi * p.halo_tx) * 16;
+  const int ow0 = (tile_m - tyi * p.halo_tx) * 16;
   const int H = p.Hin, W = p.Win, C = p.C0;
   v4f cbv[4] = {};
   if (MT == 1 && (!MSI_X2_LATE_CB || NPL != 2)) load_coord_bias(p, tile_m, tile_n, tid, cbv);   // in flight during the prologue and the k-loop (MT = 2: read by the epilogue)
@@ -155,8 +161,8 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
   for (int k = 0; k < NLOAD; ++k) {
     const int pp = (tid + 256 * k) >> 3;
     const int py = pp / PW, px = pp - py * PW;
-    const int ih = oh0 - R + py;
-    int iw = ow0 - R + px;
+    const int ih = RATE == 3 ? (tyi >> 1) * (2 * TH) + (tyi & 1) + 2 * (py - 1) : tyi * TH - RY + py;   // (row-parity tile: patch row py is image row base + 2 (py - 1))
+    int iw = ow0 - RX + px;
     if (p.wrap) iw = iw < 0 ? iw + W : (iw >= W ? iw - W : iw);   // msi_train_net: wrap along W, zeros along H
     pok[k] = pp < NPX && ih >= 0 && ih < H && iw >= 0 && iw < W;
     voff[k] = pok[k] ? __umul24((unsigned)(ih * W + iw), (unsigned)(C * 4)) + (unsigned)(cslot * 16) : OOB;
@@ -262,7 +268,7 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
     constexpr int KH_ = TAP / 3, KW_ = TAP % 3;
     /* ring stage of this k-step: three stages -> TAP % 3 (a literal); two stages -> (TAP + chunk parity) & 1 (run-time scalar) */
     const unsigned bst_ = (unsigned)(G::NSTG == 3 ? TAP % 3 : ((TAP ^ cpar) & 1)) * G::B_STAGE;
-    constexpr int AOFF_ = KH_ * R * G::ROW_PITCH + KW_ * R * G::PIX_BYTES;
+    constexpr int AOFF_ = KH_ * RY * G::ROW_PITCH + KW_ * RX * G::PIX_BYTES;
     v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];
     if (MSI_X3_EARLY_DMA || G::NSTG == 2) {   /* the k-step NSTG - 1 ahead: its ring stage was last read in the previous k-step (closing barrier passed) */
       constexpr int PD_ = G::NSTG - 1;
@@ -1149,17 +1155,17 @@ int launch_x3(const LayerLaunch &Q, const ConvParams &p, int rate, hipStream_t s
     if (Q.halo_apply) hipLaunchKernelGGL((conv_halo8_x3_kernel<1, 3>), grid, block, G8_::LDS_BYTES, stream, p);
     else hipLaunchKernelGGL((conv_halo8_x3_kernel<0, 3>), grid, block, G8_::LDS_BYTES, stream, p);
   } else {
-    static thread_local unsigned long long done2[8] = {0};       // (above 64 KB of LDS the launch needs the attribute)
+    static thread_local unsigned long long done2[12] = {0};       // (above 64 KB of LDS the launch needs the attribute)
 #define MSI_X3_LAUNCH(R, A, N)                                                                                         \
   {                                                                                                                    \
-    typedef HaloGeomX3<R, (N == 2 ? MSI_X2_NSTG : (MSI_X3_NSTG ? MSI_X3_NSTG : (R == 1 ? 2 : 3))), N> G_;              \
+    typedef HaloGeomX3<R, x3_nstg(R, N), N> G_;                                                                        \
     if (G_::LDS_BYTES > 65536) {                                                                                       \
       int rc0 = set_max_lds(reinterpret_cast<const void *>(conv_halo_x3_kernel<R, A, N>), G_::LDS_BYTES, done2[(R - 1) * 4 + A * 2 + (N - 2)], "conv_halo_x3"); \
       if (rc0) return rc0;                                                                                             \
     }                                                                                                                  \
     hipLaunchKernelGGL((conv_halo_x3_kernel<R, A, N>), grid, block, G_::LDS_BYTES, stream, p);                          \
   }
-    const int sel = (rate == 1 ? 0 : 4) + (Q.halo_apply ? 2 : 0) + (Q.halo_x2 ? 0 : 1);
+    const int sel = (rate == 1 ? 0 : (p.row_par ? 8 : 4)) + (Q.halo_apply ? 2 : 0) + (Q.halo_x2 ? 0 : 1);
     switch (sel) {
       case 0: MSI_X3_LAUNCH(1, 0, 2) break;
       case 1: MSI_X3_LAUNCH(1, 0, 3) break;
@@ -1168,7 +1174,11 @@ int launch_x3(const LayerLaunch &Q, const ConvParams &p, int rate, hipStream_t s
       case 4: MSI_X3_LAUNCH(2, 0, 2) break;
       case 5: MSI_X3_LAUNCH(2, 0, 3) break;
       case 6: MSI_X3_LAUNCH(2, 1, 2) break;
-      default: MSI_X3_LAUNCH(2, 1, 3) break;
+      case 7: MSI_X3_LAUNCH(2, 1, 3) break;
+      case 8: MSI_X3_LAUNCH(3, 0, 2) break;
+      case 9: MSI_X3_LAUNCH(3, 0, 3) break;
+      case 10: MSI_X3_LAUNCH(3, 1, 2) break;
+      default: MSI_X3_LAUNCH(3, 1, 3) break;
     }
 #undef MSI_X3_LAUNCH
   }

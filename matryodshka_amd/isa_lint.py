@@ -10,7 +10,16 @@ wobble"; tools/asmpatch, tools/wobble_hunt.py: replacing that one instruction by
 packed multiply without the cross-half operand select, gave 0 events in 10 000 forwards against 10-18 per 6 000-10 000).
 The SLP vectorizer is what forms such operand routing from scalar code; the kernels are built with -fno-slp-vectorize and
 this lint REFUSES a library in which any packed-fp32 VALU instruction takes the HIGH half of a register pair for its LOW
-lane (`op_sel:[...]` with a 1) -- the hand-written two-float code only ever broadcasts a low half (`op_sel_hi`)."""
+lane (`op_sel:[...]` with a 1) -- the hand-written two-float code only ever broadcasts a low half (`op_sel_hi`).
+
+Second rule (also round 5).  A store of more than 64 bits reads its data registers AFTER it has issued; a VALU write of
+those registers needs one wait state behind the store.  hipcc inserts that wait state for `buffer_store_dwordx3/x4` only
+when the store's soffset operand is NOT a register.  With an SGPR soffset and the very next instruction writing the first
+data register (the address arithmetic of the following store, allocated onto the freed register), a build of this library
+lost a few 16-byte stores per launch on gfx950 -- wrong pixels in conv outputs, different ones each run.  Proven by
+inserting `s_nop 0` behind the stores of one kernel in its assembly: that kernel's layer became exact, the others stayed
+broken (profiles/r05_store_hazard.txt).  The epilogue no longer uses SGPR soffsets for wide stores, and this lint REFUSES
+a library in which any wide buffer / global / flat store is followed immediately by a VALU write of its data registers."""
 import os
 import re
 import struct
@@ -21,6 +30,38 @@ import tempfile
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 FORBIDDEN = re.compile(r"^\s*(v_pk_(?:mul|add|fma)_f32|v_pk_mov_b32)\b.*\bop_sel:\[[01,]*1[01,]*\]")
+# wide stores: (mnemonic pattern, index of the DATA operand among the instruction's operands)
+WIDE_STORE = re.compile(r"^\s*((?:t?buffer_store_(?:dwordx[34]|format_xyzw?|format_d16_xyzw))|(?:global|flat|scratch)_store_dwordx[34])\s+(.*)$")
+VREG = re.compile(r"^v(?:\[(\d+):(\d+)\]|(\d+))$")
+NOT_A_VGPR_WRITE = ("v_cmp", "v_cmpx", "v_readfirstlane", "v_readlane", "v_nop")
+
+
+def _vrange(op):
+    m = VREG.match(op.strip())
+    if not m:
+        return None
+    return (int(m.group(1)), int(m.group(2))) if m.group(1) is not None else (int(m.group(3)), int(m.group(3)))
+
+
+def _store_data(ins):
+    """(first, last) data VGPR of a wide store, or None."""
+    m = WIDE_STORE.match(ins)
+    if not m:
+        return None
+    ops = [o.strip() for o in m.group(2).split(",")]
+    data = ops[0] if "buffer" in m.group(1) else (ops[1] if len(ops) > 1 else "")   # buffer: vdata first; global / flat / scratch: vaddr, vdata, ...
+    return _vrange(data)
+
+
+def _valu_dest(ins):
+    """(first, last) VGPR written by a VALU instruction, or None."""
+    t = ins.strip()
+    if not t.startswith("v_") or t.startswith(NOT_A_VGPR_WRITE):
+        return None
+    parts = t.split(None, 1)
+    if len(parts) < 2:
+        return None
+    return _vrange(parts[1].split(",")[0])
 
 
 def _fatbin_section(path):
@@ -61,23 +102,36 @@ def code_objects(path):
 def lint(path, verbose=False):
     """Returns the list of offending (kernel, instruction) pairs; empty = clean."""
     bad = []
-    ninst = 0
+    ninst = nstore = 0
     for triple, blob in code_objects(path):
         with tempfile.NamedTemporaryFile(suffix=".hsaco") as f:
             f.write(blob); f.flush()
             txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], check=True, stdout=subprocess.PIPE).stdout.decode()
         kernel = "?"
+        pending = None                     # (data range, text) of a wide store whose NEXT instruction has not been seen yet
         for line in txt.splitlines():
             m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
             if m:
-                kernel = m.group(1); continue
+                kernel = m.group(1); pending = None; continue
             ins = line.split("//")[0]
+            if not ins.strip():
+                continue
+            if pending is not None:
+                d = _valu_dest(ins)
+                if d is not None and not (d[1] < pending[0][0] or d[0] > pending[0][1]):
+                    bad.append((kernel, pending[1] + "  ->  " + ins.strip()))
+                pending = None
+            sd = _store_data(ins)
+            if sd is not None:
+                nstore += 1
+                pending = (sd, ins.strip())
             if "v_pk_" in ins:
                 ninst += 1
                 if FORBIDDEN.match(ins):
                     bad.append((kernel, ins.strip()))
     if verbose:
-        print("[isa_lint] %s: %d packed VALU instructions checked, %d with a high-half -> low-lane operand select" % (os.path.basename(path), ninst, len(bad)))
+        print("[isa_lint] %s: %d packed VALU instructions and %d wide stores checked, %d finding(s) (high-half -> low-lane operand select / VALU write of a wide "
+              "store's data in the next instruction)" % (os.path.basename(path), ninst, nstore, len(bad)))
     return bad
 
 

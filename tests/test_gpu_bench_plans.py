@@ -23,10 +23,11 @@ TOL = 1e-3
 # (the kernels' last template argument: operand planes -- 3 = bf16 h | m | l, six products; 2 = fp16 h | m', three products)
 # (r05: the stride-1, rate-1 layers of the six-product form whose grid is >= 3 tiles of 8 x 16 pixels per CU run conv_halo8_x3_kernel -- plan option X3_TILE8:
 #  every such layer at the batches of configs[3] / [4]; conv1_1, conv2_1, conv7_2, conv8_2 at configs[1])
+# (r05: the rate-2 layers conv4_x run on row-parity tiles -- plan option X3_ROWPAR, first template argument 3: dilation 2 along W, row stride 2 along H)
 def f32_big_grid(np_, wide=(0, 2, 4, 5, 11, 12, 14, 16)):
     c = lambda r, a: "conv_halo_x3_kernel<%d, %d, %d>" % (r, a, np_)      # noqa: E731
     s2, ct = "conv_halo_s2_x3_kernel<1, %d>" % np_, "convt_halo_x3_kernel<%d>" % np_
-    k = [c(1, 0), s2, c(1, 1), s2, c(1, 1), c(1, 1), s2, c(2, 1), c(2, 1), c(2, 1), ct, c(1, 1), c(1, 1), ct, c(1, 1), ct, c(1, 1)]
+    k = [c(1, 0), s2, c(1, 1), s2, c(1, 1), c(1, 1), s2, c(3, 1), c(3, 1), c(3, 1), ct, c(1, 1), c(1, 1), ct, c(1, 1), ct, c(1, 1)]
     if np_ == 3:
         for i in wide:
             k[i] = "conv_halo8_x3_kernel<%d, 3>" % (0 if i == 0 else 1)

@@ -39,6 +39,24 @@ def test_library_has_no_high_half_to_low_lane_packed_operand(native_lib):
     assert isa_lint.lint(native_lib.LIB_PATH) == []
 
 
+def test_lint_recognises_a_valu_write_of_a_wide_stores_data_in_the_next_instruction():
+    """matryodshka_amd/isa_lint.py, second rule (r05, DESIGN.md section 4 "the lost stores"): `buffer_store_dwordx4 vdata, ..., sN offen` followed at once by a VALU
+    write of vdata lost a few stores per launch on gfx950 -- hipcc inserts the wait state only when soffset is not a register.  The parsers, on the instructions of
+    the build that failed (the library itself is checked by the test above)."""
+    from matryodshka_amd import isa_lint
+    assert isa_lint._store_data("\tbuffer_store_dwordx4 v[46:49], v86, s[8:11], s14 offen") == (46, 49)
+    assert isa_lint._store_data("\tbuffer_store_dwordx3 v[4:6], v1, s[0:3], 0 offen offset:16") == (4, 6)
+    assert isa_lint._store_data("\tglobal_store_dwordx4 v[2:3], v[10:13], off") == (10, 13)        # (global / flat: the address comes first)
+    assert isa_lint._store_data("\tglobal_store_dwordx4 v8, v[10:13], s[4:5] offset:32") == (10, 13)
+    assert isa_lint._store_data("\tbuffer_store_dwordx2 v[46:47], v86, s[8:11], s14 offen") is None  # (64 bits: no hazard)
+    assert isa_lint._store_data("\tbuffer_load_dwordx4 v[46:49], v86, s[8:11], s14 offen") is None
+    assert isa_lint._valu_dest("\tv_mul_lo_u32 v46, v98, s28") == (46, 46)
+    assert isa_lint._valu_dest("\tv_mad_u64_u32 v[86:87], s[4:5], v86, s14, v[94:95]") == (86, 87)
+    assert isa_lint._valu_dest("\tv_cmp_eq_u32_e32 vcc, s15, v46") is None
+    assert isa_lint._valu_dest("\tv_readfirstlane_b32 s15, v46") is None
+    assert isa_lint._valu_dest("\ts_mov_b64 s[28:29], exec") is None
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under matryodshka_amd/ or include/ may mention it."""
     for base in ("matryodshka_amd", "include"):
