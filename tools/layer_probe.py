@@ -1,3 +1,5 @@
+"""tools/layer_probe.py (GPU box): run_net on uniform noise at 160 x 320, every layer's raw output against the oracle, several weight seeds -- pixels whose worst channel is off by
+more than 1e-3 of the layer's scale are counted per layer.  The probe that exposed the store hazard of profiles/r05_store_hazard.txt ("the lost stores")."""
 import numpy as np, sys
 sys.path.insert(0,'.')
 import torch
