@@ -823,6 +823,16 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
 // per CU.  The tap kernel cannot split its operands (both arrive by DMA), this one stages the patch through registers anyway:
 // with 192 instead of 512 matrix cycles per 16 channels it wins (conv8_1 197 -> ... us, see profiles/r04_*), and its sources
 // need no ln_apply launch.
+// (r05) FIVE patch rows: a class row of parity ph reads the input row itself and ONE neighbour -- the row above (ph = 0, and both parities of msi_train_net's VALID form) or the
+// row below (ph = 1) -- so the sixth row of the stride-1 geometry was staged and never read: 90 instead of 108 patch pixels (three instead of four loads per lane).
+template <int NS, int NPL>
+struct HaloGeomCT3 : HaloGeomX3<1, NS, NPL> {
+  typedef HaloGeomX3<1, NS, NPL> B_;
+  static constexpr int PH = 5, NPX = B_::PW * PH;
+  static constexpr int A_BYTES = PH * B_::ROW_PITCH;
+  static constexpr int LDS_BYTES = A_BYTES + B_::NSTG * B_::B_STAGE;
+  static constexpr int NLOAD = (NPX * 8 + 255) / 256;
+};
 #ifndef MSI_CT_MAXW
 #define MSI_CT_MAXW 8
 #endif
@@ -836,7 +846,7 @@ template <int NP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, MSI_CT_MAXW)))
 convt_halo_x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  typedef HaloGeomX3<1, (NP == 3 ? MSI_CT3_NSTG : 3), NP> G;
+  typedef HaloGeomCT3<(NP == 3 ? MSI_CT3_NSTG : 3), NP> G;
   constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, NSTG = G::NSTG, PD = NSTG - 1;
   static_assert(NSTG == 3 || NSTG == 2, "prefetch distance two or one");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -877,6 +887,7 @@ convt_halo_x3_kernel(const ConvParams p) {
   const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
   const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
   const int H = p.Hin, W = p.Win;
+  const int rowup = (ph && !p.wrap) ? 0 : 1;              // patch rows oh0 - rowup .. oh0 - rowup + 4: the neighbour row is above (1) or below (0) -- HaloGeomCT3
 
   // the first two weight k-steps (class pw = 0, taps 0 and 1 of chunk c0) go out before the patch addresses are worked out
   const int S = p.ksteps;                                 // k-steps per class: 4 CH
@@ -903,7 +914,7 @@ convt_halo_x3_kernel(const ConvParams p) {
   for (int k = 0; k < NLOAD; ++k) {
     const int pp = (tid + 256 * k) >> 3;
     const int py = pp / PW, px = pp - py * PW;
-    const int ih = oh0 - 1 + py;
+    const int ih = oh0 - rowup + py;
     int iw = ow0 - 1 + px;
     bool cok = iw >= 0 && iw < W;                                  // SAME: zeros outside
     if (p.wrap) {   // msi_train_net: GEMM column mw reads PADDED column mw - v of wrap_pad(x, 2, 2), valid in [0, W + 4): image column (. - 2) mod W
@@ -980,10 +991,10 @@ convt_halo_x3_kernel(const ConvParams p) {
   // ---- MFMA side ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
   const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
-  // fragment base of tap row th = 0 (patch row 1 + local row) and of th = 1 (one row up for ph = 0, one down for ph = 1)
-  const unsigned a_base0 = lds_base + (unsigned)((1 + 2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
+  // fragment base of tap row th = 0 (patch row rowup + local row) and of th = 1 (one row up for ph = 0, one down for ph = 1)
+  const unsigned a_base0 = lds_base + (unsigned)((rowup + 2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
   // (msi_train_net's VALID form: tap 1 is the row ABOVE / the column to the LEFT in both parities -- tap_delta)
-  const unsigned a_base1 = (ph && !p.wrap) ? a_base0 + G::ROW_PITCH : a_base0 - G::ROW_PITCH;
+  const unsigned a_base1 = rowup ? a_base0 - G::ROW_PITCH : a_base0 + G::ROW_PITCH;
   const unsigned wadj = p.wrap ? 2u * G::PIX_BYTES : 0u;
   unsigned b_s[2];
   (void)fswz;
@@ -1134,7 +1145,7 @@ namespace msi_cnn {
 int launch_x3(const LayerLaunch &Q, const ConvParams &p, int rate, hipStream_t stream) {
   const dim3 grid(Q.nblocks), block(256);
   if (Q.halo_t) {
-    constexpr int lds_ct3 = HaloGeomX3<1, MSI_CT3_NSTG, 3>::LDS_BYTES, lds_ct2 = HaloGeomX3<1, 3, 2>::LDS_BYTES;
+    constexpr int lds_ct3 = HaloGeomCT3<MSI_CT3_NSTG, 3>::LDS_BYTES, lds_ct2 = HaloGeomCT3<3, 2>::LDS_BYTES;
     if (Q.halo_x2) hipLaunchKernelGGL(convt_halo_x3_kernel<2>, grid, block, lds_ct2, stream, p);
     else hipLaunchKernelGGL(convt_halo_x3_kernel<3>, grid, block, lds_ct3, stream, p);
     int rc = msi::check_launch("convt_halo_x3");
