@@ -18,8 +18,10 @@ when the store's soffset operand is NOT a register.  With an SGPR soffset and th
 data register (the address arithmetic of the following store, allocated onto the freed register), a build of this library
 lost a few 16-byte stores per launch on gfx950 -- wrong pixels in conv outputs, different ones each run.  Proven by
 inserting `s_nop 0` behind the stores of one kernel in its assembly: that kernel's layer became exact, the others stayed
-broken (profiles/r05_store_hazard.txt).  The epilogue no longer uses SGPR soffsets for wide stores, and this lint REFUSES
-a library in which any wide buffer / global / flat store is followed immediately by a VALU write of its data registers."""
+broken (profiles/r05_store_hazard.txt), and stand-alone by tools/ubench/store_data_hazard.hip: of 100 M stored records,
+0.8 % carry the overwritten dword with an SGPR soffset and no wait state, 0 with one; with a literal soffset 24 % / 0.65 % / 0
+for 0 / 1 / 2 wait states.  The epilogue no longer uses SGPR soffsets for wide stores, and this lint REFUSES a library in
+which a VALU instruction writes the data registers of a wide buffer / global / flat store less than TWO wait states behind it."""
 import os
 import re
 import struct
@@ -34,6 +36,7 @@ FORBIDDEN = re.compile(r"^\s*(v_pk_(?:mul|add|fma)_f32|v_pk_mov_b32)\b.*\bop_sel
 WIDE_STORE = re.compile(r"^\s*((?:t?buffer_store_(?:dwordx[34]|format_xyzw?|format_d16_xyzw))|(?:global|flat|scratch)_store_dwordx[34])\s+(.*)$")
 VREG = re.compile(r"^v(?:\[(\d+):(\d+)\]|(\d+))$")
 NOT_A_VGPR_WRITE = ("v_cmp", "v_cmpx", "v_readfirstlane", "v_readlane", "v_nop")
+WIDE_STORE_WAIT_STATES = 2   # measured (tools/ubench/store_data_hazard.hip): an SGPR-soffset store needs 1 wait state before its data is overwritten, a literal-soffset store 2
 
 
 def _vrange(op):
@@ -116,22 +119,27 @@ def lint(path, verbose=False):
             ins = line.split("//")[0]
             if not ins.strip():
                 continue
-            if pending is not None:
+            if pending is not None:                # [data range, text, wait states elapsed since the store]
                 d = _valu_dest(ins)
                 if d is not None and not (d[1] < pending[0][0] or d[0] > pending[0][1]):
-                    bad.append((kernel, pending[1] + "  ->  " + ins.strip()))
-                pending = None
+                    bad.append((kernel, pending[1] + "  -> (%d wait state(s)) ->  " % pending[2] + ins.strip()))
+                    pending = None
+                else:
+                    mn = re.match(r"\s*s_nop\s+(\d+)", ins)
+                    pending[2] += int(mn.group(1)) + 1 if mn else 1
+                    if pending[2] >= WIDE_STORE_WAIT_STATES:
+                        pending = None
             sd = _store_data(ins)
             if sd is not None:
                 nstore += 1
-                pending = (sd, ins.strip())
+                pending = [sd, ins.strip(), 0]
             if "v_pk_" in ins:
                 ninst += 1
                 if FORBIDDEN.match(ins):
                     bad.append((kernel, ins.strip()))
     if verbose:
         print("[isa_lint] %s: %d packed VALU instructions and %d wide stores checked, %d finding(s) (high-half -> low-lane operand select / VALU write of a wide "
-              "store's data in the next instruction)" % (os.path.basename(path), ninst, nstore, len(bad)))
+              "store's data less than two wait states behind it)" % (os.path.basename(path), ninst, nstore, len(bad)))
     return bad
 
 
