@@ -32,6 +32,26 @@ __global__ void __launch_bounds__(256) k(unsigned *out, int iters, unsigned slot
   }
 }
 
+template <int WAIT, int SADDR>   // the same experiment with global_store_dwordx4: SADDR = 1 -> `v, v[4:7], s[base:base+1]`, 0 -> `v[addr:addr+1], v[4:7], off`
+__global__ void __launch_bounds__(256) kg(unsigned *out, int iters, unsigned slot_bytes) {
+  const unsigned tid = blockIdx.x * 256 + threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    const unsigned tag = (tid * 2654435761u + (unsigned)it * 40503u) & 0x7fffffffu;
+    unsigned o0;
+    const unsigned voff = tid * 16u;
+    unsigned char *base = reinterpret_cast<unsigned char *>(out) + (size_t)it * slot_bytes;   // wave-uniform
+    unsigned long long vaddr = (unsigned long long)(base + voff);
+#define MSI_SDG(WS)                                                                                                              \
+    if (SADDR) asm volatile("global_store_dwordx4 %5, v[4:7], %6\n\t" WS "v_mov_b32 v4, 0xdeadbeef"                               \
+                            : "={v4}"(o0) : "0"(tag), "{v5}"(tag), "{v6}"(tag), "{v7}"(tag), "v"(voff), "s"(base) : "memory");       \
+    else asm volatile("global_store_dwordx4 %5, v[4:7], off\n\t" WS "v_mov_b32 v4, 0xdeadbeef"                                     \
+                      : "={v4}"(o0) : "0"(tag), "{v5}"(tag), "{v6}"(tag), "{v7}"(tag), "v"(vaddr) : "memory");
+    if (WAIT == 0) { MSI_SDG("") } else if (WAIT == 1) { MSI_SDG("s_nop 0\n\t") } else { MSI_SDG("s_nop 1\n\t") }
+#undef MSI_SDG
+    if (o0 != 0xdeadbeefu) out[0] = 1;
+  }
+}
+
 int main(int argc, char **argv) {
   const int launches = argc > 1 ? atoi(argv[1]) : 6, iters = argc > 2 ? atoi(argv[2]) : 32;
   const int blocks = 256 * 8;
@@ -66,8 +86,36 @@ int main(int argc, char **argv) {
           else if (!(r[0] == tag && r[1] == tag && r[2] == tag && r[3] == tag) && !(it == 0 && t == 0)) ++other;
         }
     }
-    printf("%-16s soffset, %d wait state(s) before the VALU write: %9ld of %ld stored records carry the overwritten first dword (%ld otherwise wrong)\n",
+    printf("buffer_store %-8s soffset, %d wait state(s) before the VALU write: %9ld of %ld stored records carry the overwritten first dword (%ld otherwise wrong)\n",
            literal ? "literal" : "SGPR", wait, bad, total, other);
+  }
+  for (int form = 0; form < 6; ++form) {
+    const int wait = form >> 1, saddr = form & 1;
+    long bad = 0, total = 0, other = 0;
+    for (int l = 0; l < launches; ++l) {
+      (void)hipMemset(d, 0, slot * iters);
+      const dim3 g(blocks), b(256);
+      switch (form) {
+        case 0: hipLaunchKernelGGL((kg<0, 0>), g, b, 0, 0, d, iters, (unsigned)slot); break;
+        case 1: hipLaunchKernelGGL((kg<0, 1>), g, b, 0, 0, d, iters, (unsigned)slot); break;
+        case 2: hipLaunchKernelGGL((kg<1, 0>), g, b, 0, 0, d, iters, (unsigned)slot); break;
+        case 3: hipLaunchKernelGGL((kg<1, 1>), g, b, 0, 0, d, iters, (unsigned)slot); break;
+        case 4: hipLaunchKernelGGL((kg<2, 0>), g, b, 0, 0, d, iters, (unsigned)slot); break;
+        default: hipLaunchKernelGGL((kg<2, 1>), g, b, 0, 0, d, iters, (unsigned)slot); break;
+      }
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(h.data(), d, slot * iters, hipMemcpyDeviceToHost);
+      for (int it = 0; it < iters; ++it)
+        for (unsigned t = 0; t < (unsigned)blocks * 256; ++t) {
+          const unsigned *r = &h[((size_t)it * blocks * 256 + t) * 4];
+          const unsigned tag = (t * 2654435761u + (unsigned)it * 40503u) & 0x7fffffffu;
+          ++total;
+          if (r[0] == 0xdeadbeefu && r[1] == tag && r[2] == tag && r[3] == tag) ++bad;
+          else if (!(r[0] == tag && r[1] == tag && r[2] == tag && r[3] == tag) && !(it == 0 && t == 0)) ++other;
+        }
+    }
+    printf("global_store %-5s, %d wait state(s) before the VALU write: %9ld of %ld stored records carry the overwritten first dword (%ld otherwise wrong)\n",
+           saddr ? "saddr" : "off", wait, bad, total, other);
   }
   (void)hipFree(d);
   return 0;
