@@ -462,6 +462,11 @@ int plan_layers(msi_net_plan *pl) {
       Q.halo_x2 = x3_on && ((pl->opt[MSI_NET_OPT_F32_SPLIT_F16] >> li) & 1);
       p.nclass = 2;                                      // tiles are enumerated per (ph, tile_m, tile_n, sample): a workgroup owns pw = 0, 1
       if (L.cpt0 + L.cpt1 < max_split) max_split = L.cpt0 + L.cpt1;
+      // the 8 x 16-pixel tile of the six-product conv-transpose (convt_halo8_x3_kernel, r05): same rule as the stride-1 tile (X3_TILE8: bit li, >= 3 tiles per CU or bit 30)
+      if (Q.halo_x3 && !Q.halo_x2 && !L.wrapt && L.in_h % 8 == 0 && ((pl->opt[MSI_NET_OPT_X3_TILE8] >> li) & 1) &&
+          (2L * (L.in_h / 8) * (L.in_w / 16) * ((L.cout + 63) / 64) * desc->batch >= 3L * pl->num_cus || ((pl->opt[MSI_NET_OPT_X3_TILE8] >> 30) & 1))) {
+        Q.x3_th8 = 1; BM = 128;
+      }
     }
     // bf16 conv-transpose halo kernel (convt_halo_bf16_kernel): SAME conv-transposes, 64-channel chunks of both sources,
     // whole 8 x 16 x 128 or 16 x 16 x 64 tiles, one workgroup per output-row parity (enumerated as two "classes")
@@ -495,9 +500,15 @@ int plan_layers(msi_net_plan *pl) {
       pl->launch[L.src0].skip_apply = 1;              // (the producer precedes its consumer in graph order)
     }
     Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
+    if (Q.halo_t && Q.x3_th8 && (size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * 2 * BM * BN * sizeof(float) > net.partial_bytes) {   // (slabs of the 8-row tile do not fit: 4-row tile)
+      Q.x3_th8 = 0; BM = 64;
+      plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], max_split, &Q.nblocks, &Q.nfix,
+                 pl->opt[MSI_NET_OPT_UNIFORM_SPLIT], pl->opt[MSI_NET_OPT_SPLIT_OVERHEAD], false);
+      Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
+    }
     if (Q.halo_t && (size_t)(Q.nblocks - (p.split0 == 1 ? p.nb_main : 0)) * 2 * BM * BN * sizeof(float) > net.partial_bytes) {
       // two slabs per K-range do not fit the partial-accumulator workspace -> the tap kernel
-      Q.halo_t = 0; Q.halo = 0; Q.halo_x3 = 0; Q.halo_x2 = 0;
+      Q.halo_t = 0; Q.halo = 0; Q.halo_x3 = 0; Q.halo_x2 = 0; Q.x3_th8 = 0;
       p.halo_tx = 0; p.halo_xor = 0; p.nclass = L.nclass;
       plan_tiles(p, BM, BN, desc->batch, pl->num_cus, pl->opt[MSI_NET_OPT_TAILSPLIT], MAX_SPLIT, &Q.nblocks, &Q.nfix);
       Q.inlaunch = !pl->opt[MSI_NET_OPT_FIXUP_KERNEL] && Q.nfix <= CONV_SLOTS_PER_CU * pl->num_cus;
@@ -899,7 +910,8 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
                                     plan->opt[MSI_NET_OPT_BF16_WAVES] == 8 ? 8 : 4);
     else snprintf(name, name_bytes, "conv_halo_bf16_kernel<256, 64, 1, %d, 4>", Q.halo_apply ? 1 : 0);
   } else if (Q.halo_t) {
-    if (Q.halo_x3) snprintf(name, name_bytes, "convt_halo_x3_kernel<%d>", Q.halo_x2 ? 2 : 3);
+    if (Q.halo_x3 && Q.x3_th8) snprintf(name, name_bytes, "convt_halo8_x3_kernel");
+    else if (Q.halo_x3) snprintf(name, name_bytes, "convt_halo_x3_kernel<%d>", Q.halo_x2 ? 2 : 3);
     else snprintf(name, name_bytes, "convt_halo_kernel");
   } else if (Q.halo) {
     if (Q.halo_s2 && Q.halo_x3) snprintf(name, name_bytes, "conv_halo_s2_x3_kernel<%d, %d>", Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);

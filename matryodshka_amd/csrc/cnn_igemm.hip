@@ -583,6 +583,7 @@ int launch_fixup(int bm, int bn, int mode, unsigned gx, unsigned gy, const ConvP
   if (bm == 64 && mode == MODE_CONVT) hipLaunchKernelGGL((conv_fixup_kernel<64, 64, MODE_CONVT>), dim3(gx, gy), dim3(256), 0, stream, p);
   else if (bm == 64 && mode == MODE_CONV) hipLaunchKernelGGL((conv_fixup_kernel<64, 64, MODE_CONV>), dim3(gx, gy), dim3(256), 0, stream, p);
   else if (bm == 128 && mode == MODE_CONV) hipLaunchKernelGGL((conv_fixup_kernel<128, 64, MODE_CONV>), dim3(gx, gy), dim3(256), 0, stream, p);
+  else if (bm == 128 && mode == MODE_CONVT) hipLaunchKernelGGL((conv_fixup_kernel<128, 64, MODE_CONVT>), dim3(gx, gy), dim3(256), 0, stream, p);
   else return msi::fail(MSI_E_UNSUPPORTED, "conv_fixup: tile %d x %d, mode %d", bm, bn, mode);
   return msi::check_launch("conv_fixup");
 }

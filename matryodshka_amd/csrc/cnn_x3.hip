@@ -825,10 +825,10 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
 // need no ln_apply launch.
 // (r05) FIVE patch rows: a class row of parity ph reads the input row itself and ONE neighbour -- the row above (ph = 0, and both parities of msi_train_net's VALID form) or the
 // row below (ph = 1) -- so the sixth row of the stride-1 geometry was staged and never read: 90 instead of 108 patch pixels (three instead of four loads per lane).
-template <int NS, int NPL>
-struct HaloGeomCT3 : HaloGeomX3<1, NS, NPL> {
-  typedef HaloGeomX3<1, NS, NPL> B_;
-  static constexpr int PH = 5, NPX = B_::PW * PH;
+template <int NS, int NPL, int TH = 4>
+struct HaloGeomCT3 : HaloGeomX3<1, NS, NPL, TH> {
+  typedef HaloGeomX3<1, NS, NPL, TH> B_;
+  static constexpr int PH = TH + 1, NPX = B_::PW * PH;
   static constexpr int A_BYTES = PH * B_::ROW_PITCH;
   static constexpr int LDS_BYTES = A_BYTES + B_::NSTG * B_::B_STAGE;
   static constexpr int NLOAD = (NPX * 8 + 255) / 256;
@@ -842,14 +842,16 @@ struct HaloGeomCT3 : HaloGeomX3<1, NS, NPL> {
 #ifndef MSI_CT3_NSTG   // weight ring of the six-product conv-transpose kernel: 2 (r05: 48.4 KB of LDS, three workgroups per CU; eight k-steps per chunk, so the
 #define MSI_CT3_NSTG 2 // stage of k-step J is the literal J & 1 and the DMA of k-step J + 1 goes out at the head of k-step J) or 3 (r04: 60.7 KB, two per CU)
 #endif
-template <int NP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, MSI_CT_MAXW)))
-convt_halo_x3_kernel(const ConvParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef HaloGeomCT3<(NP == 3 ? MSI_CT3_NSTG : 3), NP> G;
+// TH = 8 (r05, convt_halo8_x3_kernel, six-product form): 8 x 16 input pixels per workgroup and row parity -- a wave owns four input rows = TWO 32-pixel blocks per class that
+// share the weight fragments (as conv_halo8_x3_kernel: 18 instead of 24 fragment reads per 24 MFMAs, half the weight bytes / prologues / patch swaps per output); four
+// accumulators per wave, 9 x 18-pixel patch, 60.3 KB of LDS: two workgroups per CU.  Whole-grid rule as for the stride-1 tile (plan: >= 3 tiles per CU).
+template <int NP, int TH>
+__device__ __forceinline__ void convt_halo_x3_body(const ConvParams &p, char *smem) {
+  typedef HaloGeomCT3<(NP == 3 ? MSI_CT3_NSTG : 3), NP, TH> G;
   constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, NSTG = G::NSTG, PD = NSTG - 1;
+  constexpr int MT = TH / 4, BM = 16 * TH;
   static_assert(NSTG == 3 || NSTG == 2, "prefetch distance two or one");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(TH == 4 || (TH == 8 && NP == 3 && NSTG == 2), "the 8-row tile: six-product form, two-stage ring");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -885,7 +887,7 @@ convt_halo_x3_kernel(const ConvParams p) {
     b = q2;
   }
   const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
-  const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;
+  const int oh0 = tyi * TH, ow0 = (tile_m - tyi * p.halo_tx) * 16;
   const int H = p.Hin, W = p.Win;
   const int rowup = (ph && !p.wrap) ? 0 : 1;              // patch rows oh0 - rowup .. oh0 - rowup + 4: the neighbour row is above (1) or below (0) -- HaloGeomCT3
 
@@ -992,7 +994,7 @@ convt_halo_x3_kernel(const ConvParams p) {
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
   const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
   // fragment base of tap row th = 0 (patch row rowup + local row) and of th = 1 (one row up for ph = 0, one down for ph = 1)
-  const unsigned a_base0 = lds_base + (unsigned)((rowup + 2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
+  const unsigned a_base0 = lds_base + (unsigned)((rowup + 2 * MT * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
   // (msi_train_net's VALID form: tap 1 is the row ABOVE / the column to the LEFT in both parities -- tap_delta)
   const unsigned a_base1 = rowup ? a_base0 - G::ROW_PITCH : a_base0 + G::ROW_PITCH;
   const unsigned wadj = p.wrap ? 2u * G::PIX_BYTES : 0u;
@@ -1002,11 +1004,15 @@ convt_halo_x3_kernel(const ConvParams p) {
   for (int s_ = 0; s_ < 2; ++s_)
     b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-  f32x16 acc[2][1][1], acc_lo[2];
+  f32x16 acc[2][MT][1], acc_lo[2];   // [class][32-pixel block]
 #pragma unroll
   for (int cl = 0; cl < 2; ++cl)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[cl][0][0][r] = acc_lo[cl][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      acc_lo[cl][r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[cl][i][0][r] = 0.f;
+    }
 
   // k-step J of the chunk = class pw = J / 4, tap (th, tw) = ((J / 2) & 1, J & 1), weights in ring stage st (run-time).
   // The DMA of the k-step PD = 2 ahead and (J == 0) the next chunk's patch loads are issued after the first MFMA quarter;
@@ -1027,6 +1033,30 @@ convt_halo_x3_kernel(const ConvParams p) {
       if (J + 1 < 8) { issued_ = true; b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c, st ^ 1); }
       else if (c + 1 < c1) { issued_ = true; b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, st ^ 1); }
     }
+    if constexpr (MT == 2) {
+      /* two pixel blocks i = 0, 1 (the wave's rows 0-1 and 2-3) against ONE set of weight fragments per K16 step s: 18 reads, 24 MFMAs (conv_halo_x3_body's MT = 2 sequence) */
+      constexpr int C1_ = COFF_ + 2 * G::ROW_PITCH;
+      v4f xh_[2][2], xm_[2][2], xl_[2][2];   /* [s][i] */
+      bh_[0] = lds_read128<0>(b_s[0] + bst_); bm_[0] = lds_read128<G::B_PLANE>(b_s[0] + bst_); bl_[0] = lds_read128<2 * G::B_PLANE>(b_s[0] + bst_);
+      xh_[0][0] = lds_read128<COFF_>(ab_); xm_[0][0] = lds_read128<COFF_ + 64>(ab_); xl_[0][0] = lds_read128<COFF_ + 128>(ab_);
+      xh_[0][1] = lds_read128<C1_>(ab_); xm_[0][1] = lds_read128<C1_ + 64>(ab_); xl_[0][1] = lds_read128<C1_ + 128>(ab_);
+      bh_[1] = lds_read128<0>(b_s[1] + bst_); bm_[1] = lds_read128<G::B_PLANE>(b_s[1] + bst_); bl_[1] = lds_read128<2 * G::B_PLANE>(b_s[1] + bst_);
+      wait_lgkm6<6>(bh_[0], bm_[0], bl_[0], xh_[0][0], xm_[0][0], xl_[0][0]);
+      split_mfma<3>(acc[PWC_][0][0], acc_lo[PWC_], xh_[0][0], xm_[0][0], xl_[0][0], bh_[0], bm_[0], bl_[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      xh_[1][0] = lds_read128<COFF_ + 32>(ab_); xm_[1][0] = lds_read128<COFF_ + 96>(ab_); xl_[1][0] = lds_read128<COFF_ + 160>(ab_);
+      xh_[1][1] = lds_read128<C1_ + 32>(ab_); xm_[1][1] = lds_read128<C1_ + 96>(ab_); xl_[1][1] = lds_read128<C1_ + 160>(ab_);
+      if (J == 0 && c + 1 < c1) patch_load(c + 1);
+      wait_lgkm6<9>(xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);
+      split_mfma<3>(acc[PWC_][1][0], acc_lo[PWC_], xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm6<3>(bh_[1], bm_[1], bl_[1], xh_[1][0], xm_[1][0], xl_[1][0]);
+      split_mfma<3>(acc[PWC_][0][0], acc_lo[PWC_], xh_[1][0], xm_[1][0], xl_[1][0], bh_[1], bm_[1], bl_[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm6<0>(xh_[1][1], xm_[1][1], xl_[1][1], bh_[1], bm_[1], bl_[1]);
+      split_mfma<3>(acc[PWC_][1][0], acc_lo[PWC_], xh_[1][1], xm_[1][1], xl_[1][1], bh_[1], bm_[1], bl_[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     if (!(MSI_CT3_ABLATE & 8))
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
@@ -1059,6 +1089,7 @@ convt_halo_x3_kernel(const ConvParams p) {
         else if (c + 1 < c1) { issued_ = true; b_issue(2 * ph + (JN_ >> 2), JN_ & 3, c + 1, sn_); }
         }
       }
+    }
     }
     if (NSTG == 2) {   /* (the DMA went out before this k-step's patch loads: in-order return) */
       if (J == 0 && c + 1 < c1) wait_vmcnt<NPLD>();
@@ -1104,19 +1135,19 @@ convt_halo_x3_kernel(const ConvParams p) {
 
   // ---- epilogue: two class tiles ----
   if (!full) {
-    constexpr int SLAB = 64 * 64 * 4;
+    constexpr int SLAB = BM * 64 * 4;
     if (p.tile_cnt == nullptr) {                          // separate fix-up launch (conv_fixup_kernel, class = blockIdx.y)
 #pragma unroll
       for (int cl = 0; cl < 2; ++cl) {
-        const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 2 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
-        dump_acc<1, 1, 0>(acc[cl], rsrc_p, tid);
+        const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 2 + cl) * (BM * 64)), 0, SLAB, 0x00020000);
+        dump_acc<MT, 1, 0>(acc[cl], rsrc_p, tid);
       }
       return;
     }
 #pragma unroll
     for (int cl = 0; cl < 2; ++cl) {
-      const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 2 + cl) * (64 * 64)), 0, SLAB, 0x00020000);
-      dump_acc<1, 1, MSI_HANDOFF_AUX>(acc[cl], rsrc_p, tid);
+      const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)slot * 2 + cl) * (BM * 64)), 0, SLAB, 0x00020000);
+      dump_acc<MT, 1, MSI_HANDOFF_AUX>(acc[cl], rsrc_p, tid);
     }
     const int nsp = t < p.n_main ? p.split0 : p.split;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1130,12 +1161,28 @@ convt_halo_x3_kernel(const ConvParams p) {
     handoff_acquire();
 #pragma unroll
     for (int cl = 0; cl < 2; ++cl) {
-      const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)(slot - ks) * 2 + cl) * (64 * 64)), 0, nsp * 2 * SLAB, 0x00020000);
-      sum_slabs<1, 1, MSI_HANDOFF_AUX>(acc[cl], rsrc_t, nsp, 2 * SLAB, tid);
+      const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + ((size_t)(slot - ks) * 2 + cl) * (BM * 64)), 0, nsp * 2 * SLAB, 0x00020000);
+      sum_slabs<MT, 1, MSI_HANDOFF_AUX>(acc[cl], rsrc_t, nsp, 2 * SLAB, tid);
     }
   }
 #pragma unroll
-  for (int cl = 0; cl < 2; ++cl) emit_tile<64, 64, MODE_CONVT>(p, acc[cl], tile_m, tile_n, 2 * ph + cl, b, tid);
+  for (int cl = 0; cl < 2; ++cl) emit_tile<BM, 64, MODE_CONVT>(p, acc[cl], tile_m, tile_n, 2 * ph + cl, b, tid);
+}
+
+template <int NP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, MSI_CT_MAXW)))
+convt_halo_x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  convt_halo_x3_body<NP, 4>(p, smem);
+#endif
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+convt_halo8_x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  convt_halo_x3_body<3, 8>(p, smem);
 #endif
 }
 
@@ -1146,10 +1193,13 @@ int launch_x3(const LayerLaunch &Q, const ConvParams &p, int rate, hipStream_t s
   const dim3 grid(Q.nblocks), block(256);
   if (Q.halo_t) {
     constexpr int lds_ct3 = HaloGeomCT3<MSI_CT3_NSTG, 3>::LDS_BYTES, lds_ct2 = HaloGeomCT3<3, 2>::LDS_BYTES;
-    if (Q.halo_x2) hipLaunchKernelGGL(convt_halo_x3_kernel<2>, grid, block, lds_ct2, stream, p);
+    constexpr int lds_ct8 = HaloGeomCT3<MSI_CT3_NSTG, 3, 8>::LDS_BYTES;
+    static_assert(lds_ct8 <= 65536, "convt_halo8_x3_kernel: LDS without the launch attribute");
+    if (Q.x3_th8) hipLaunchKernelGGL(convt_halo8_x3_kernel, grid, block, lds_ct8, stream, p);
+    else if (Q.halo_x2) hipLaunchKernelGGL(convt_halo_x3_kernel<2>, grid, block, lds_ct2, stream, p);
     else hipLaunchKernelGGL(convt_halo_x3_kernel<3>, grid, block, lds_ct3, stream, p);
     int rc = msi::check_launch("convt_halo_x3");
-    if (!rc && Q.nfix > 0 && p.tile_cnt == nullptr) rc = launch_fixup(64, 64, MODE_CONVT, Q.nfix, 2, p, stream);
+    if (!rc && Q.nfix > 0 && p.tile_cnt == nullptr) rc = launch_fixup(Q.x3_th8 ? 128 : 64, 64, MODE_CONVT, Q.nfix, 2, p, stream);
     return rc;
   }
   if (Q.halo_s2) {
