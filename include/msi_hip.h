@@ -353,7 +353,8 @@ typedef struct msi_net_plan msi_net_plan;
                                 /* the weight bytes L2 -> LDS, half the prologues / patch swaps per output, 0.75 fragment reads per MFMA, two workgroups per CU.  Same        */
                                 /* arithmetic and per-accumulator summation order as the 4-row tile.  Applied only where the layer's grid stays >= 3 such tiles per CU       */
                                 /* (smaller grids are cut into K-ranges either way and lose); bit 30 forces it on every eligible layer (tests).  Default 0x3ffff.            */
-                                /* The SAME conv-transposes take the 8 x 16-pixel tile under the same bit and rule (convt_halo8_x3_kernel: four accumulators per wave)        */
+                                /* The conv-transposes and the stride-2 layers take the 8 x 16-pixel tile under the same bit and rule (convt_halo8_x3_kernel: four            */
+                                /* accumulators per wave; conv_halo8_s2_x3_kernel: 9 x 17-pixel unit patches)                                                               */
 #define MSI_NET_OPT_X3_ROWPAR 17 /* fp32 plans, bit i = layer i: a stride-1, RATE-2 layer on the split (F32_SPLIT3) whose input height is a multiple of 8 runs on ROW-PARITY  */
                                  /* tiles: a tile's four rows are every other image row (tile row t = 2 t' + parity -> rows 8 t' + parity + 2 r), so along H a dilation-2 tap */
                                  /* is the NEXT tile row -- a 6 x 20-pixel patch instead of 8 x 20, the two-stage weight ring and three workgroups per CU instead of two.      */

@@ -426,6 +426,10 @@ int plan_layers(msi_net_plan *pl) {
     // the 400-tile layers conv3_x / conv6_x, cut into K-ranges either way, LOSE 12 %); bit 30 of the option forces it on every eligible layer (tests)
     Q.x3_th8 = Q.halo_x3 && !Q.halo_x2 && !Q.halo_s2 && L.rate == 1 && L.in_h % 8 == 0 && ((pl->opt[MSI_NET_OPT_X3_TILE8] >> li) & 1) &&
                ((long)(L.in_h / 8) * (L.in_w / 16) * ((L.cout + 63) / 64) * desc->batch >= 3L * pl->num_cus || ((pl->opt[MSI_NET_OPT_X3_TILE8] >> 30) & 1));
+    // ... and the stride-2 layers of the six-product form (conv_halo8_s2_x3_kernel, r05): whole 8 x 16 tiles of the OUTPUT grid, same bit and grid rule
+    if (Q.halo_x3 && !Q.halo_x2 && Q.halo_s2 && L.out_h % 8 == 0 && ((pl->opt[MSI_NET_OPT_X3_TILE8] >> li) & 1) &&
+        ((long)(L.out_h / 8) * (L.out_w / 16) * ((L.cout + 63) / 64) * desc->batch >= 3L * pl->num_cus || ((pl->opt[MSI_NET_OPT_X3_TILE8] >> 30) & 1)))
+      Q.x3_th8 = 1;
     if (Q.x3_th8) BM = 128;
     // rate-2 layers of the split kernels on row-parity tiles (conv_halo_x3_kernel<3, ...>, halo_row): the dilation along H becomes the tile's row stride --
     // a 6 x 20-pixel patch, the two-stage weight ring, three workgroups per CU (the plain rate-2 tile: 8 x 20, three stages, two)
@@ -914,7 +918,8 @@ int32_t msi_net_plan_layer_kernel(const msi_net_plan *plan, int32_t layer, char 
     else if (Q.halo_x3) snprintf(name, name_bytes, "convt_halo_x3_kernel<%d>", Q.halo_x2 ? 2 : 3);
     else snprintf(name, name_bytes, "convt_halo_kernel");
   } else if (Q.halo) {
-    if (Q.halo_s2 && Q.halo_x3) snprintf(name, name_bytes, "conv_halo_s2_x3_kernel<%d, %d>", Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);
+    if (Q.halo_s2 && Q.halo_x3 && Q.x3_th8) snprintf(name, name_bytes, "conv_halo8_s2_x3_kernel<%d>", Q.halo_apply ? 1 : 0);
+    else if (Q.halo_s2 && Q.halo_x3) snprintf(name, name_bytes, "conv_halo_s2_x3_kernel<%d, %d>", Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);
     else if (Q.halo_s2) snprintf(name, name_bytes, "conv_halo_s2_kernel<%d>", Q.halo_apply ? 1 : 0);
     else if (Q.x3_th8) snprintf(name, name_bytes, "conv_halo8_x3_kernel<%d, 3>", Q.halo_apply ? 1 : 0);
     else if (Q.halo_x3) snprintf(name, name_bytes, "conv_halo_x3_kernel<%d, %d, %d>", Q.p.row_par ? 3 : L.rate, Q.halo_apply ? 1 : 0, Q.halo_x2 ? 2 : 3);

@@ -530,9 +530,9 @@ __device__ __forceinline__ void split_finish(f32x16 &acc, const f32x16 &lo, unsi
 #ifndef MSI_S2X3_NSTG   // weight ring of the six-product stride-2 kernel: 2 (r05: 43.1 KB of LDS, three workgroups per CU; the DMA of a k-step is issued at the head of
 #define MSI_S2X3_NSTG 2 // the one before it, as in conv_halo_x3_kernel at rate 1) or 3 (r04: 55.4 KB, two workgroups per CU)
 #endif
-template <int NP>
+template <int NP, int TH = 4>
 struct HaloGeomS2X3 {
-  static constexpr int PW = 17, PH = 5, NPX = PW * PH;
+  static constexpr int PW = 17, PH = TH + 1, NPX = PW * PH;
   static constexpr int PIX_BYTES = NP * 64 + 16;
   static constexpr int ROW_PITCH = ((PW * PIX_BYTES + 127) / 256) * 256 + 128;
   static constexpr int A_BYTES = PH * ROW_PITCH;
@@ -548,14 +548,14 @@ struct HaloGeomS2X3 {
 #define MSI_S2X3_ABLATE 0
 #endif
 #endif
-template <int APPLY, int NP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? MSI_S2X_WAVES : (MSI_S2X3_NSTG == 2 ? 3 : 2))))
-conv_halo_s2_x3_kernel(const ConvParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef HaloGeomS2X3<NP> G;
+// TH = 8 (r05, conv_halo8_s2_x3_kernel, six-product form): 8 x 16 output pixels per workgroup -- a wave owns four output rows = TWO 32-pixel blocks that share the weight fragments;
+// the four unit patches are 9 x 17 pixels and serve twice the outputs per swap; 58.0 KB of LDS: two workgroups per CU.  Grid rule as for the other 8-row tiles.
+template <int APPLY, int NP, int TH>
+__device__ __forceinline__ void conv_halo_s2_x3_body(const ConvParams &p, char *smem) {
+  typedef HaloGeomS2X3<NP, TH> G;
   constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD;
-  constexpr int MT = 1, NT = 1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MT = TH / 4, NT = 1, BM = 16 * TH;
+  static_assert(TH == 4 || (TH == 8 && NP == 3 && G::NSTG == 2), "the 8-row tile: six-product form, two-stage ring");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -591,7 +591,7 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
     b = q2;
   }
   const int tyi = (int)udiv_magic((unsigned)tile_m, (unsigned)p.halo_tx, p.mg_htx);
-  const int oh0 = tyi * 4, ow0 = (tile_m - tyi * p.halo_tx) * 16;   // the tile of the OUTPUT grid
+  const int oh0 = tyi * TH, ow0 = (tile_m - tyi * p.halo_tx) * 16;   // the tile of the OUTPUT grid
   const int H = p.Hin, W = p.Win, C = p.C0;
   // the first two weight k-steps (taps (0,0) and (0,2) of group c0) before anything else
   const int S = p.ksteps;
@@ -689,16 +689,20 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
   // ---- MFMA side (as conv_halo_kernel: a wave owns two tile rows x 16 columns x 32 channels) ----
   const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
   const unsigned lds_base = (unsigned)(size_t)(lds_void *)smem;
-  const unsigned a_base = lds_base + (unsigned)((2 * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
+  const unsigned a_base = lds_base + (unsigned)((2 * MT * wm + (frow >> 4)) * G::ROW_PITCH + ((frow & 15) ^ ((frow >> 4) << 3)) * G::PIX_BYTES + fh * 16);
   unsigned b_s[2];
   (void)fswz;
 #pragma unroll
   for (int s_ = 0; s_ < 2; ++s_)
     b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-  f32x16 acc[1][1], acc_lo;
+  f32x16 acc[MT][1], acc_lo;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][0][r] = acc_lo[r] = 0.f;
+  for (int r = 0; r < 16; ++r) {
+    acc_lo[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i][0][r] = 0.f;
+  }
 
   // k-step J = 0..8 of the current group: unit, tap and patch offsets are literals
   int c = c0, cpar = 0;   // (the group being multiplied -- unit 0's patch of group c0 is on its way -- and its ring parity)
@@ -717,6 +721,33 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
       else if (c + 1 < c1) b_issue(c + 1, s2_tap(0), stn_);
     }
     v4f ah_[2], am_[2], al_[2], bh_[2], bm_[2], bl_[2];
+    if constexpr (MT == 2) {
+      /* two pixel blocks i = 0, 1 (the wave's output rows 0-1 and 2-3) against ONE set of weight fragments per K16 step s: 18 reads, 24 MFMAs (conv_halo_x3_body's MT = 2 sequence) */
+      constexpr int A1_ = AOFF_ + 2 * G::ROW_PITCH;
+      v4f xh_[2][2], xm_[2][2], xl_[2][2];   /* [s][i] */
+      bh_[0] = lds_read128<0>(b_s[0] + bst_); bm_[0] = lds_read128<G::B_PLANE>(b_s[0] + bst_); bl_[0] = lds_read128<2 * G::B_PLANE>(b_s[0] + bst_);
+      xh_[0][0] = lds_read128<AOFF_>(a_base); xm_[0][0] = lds_read128<AOFF_ + 64>(a_base); xl_[0][0] = lds_read128<AOFF_ + 128>(a_base);
+      xh_[0][1] = lds_read128<A1_>(a_base); xm_[0][1] = lds_read128<A1_ + 64>(a_base); xl_[0][1] = lds_read128<A1_ + 128>(a_base);
+      bh_[1] = lds_read128<0>(b_s[1] + bst_); bm_[1] = lds_read128<G::B_PLANE>(b_s[1] + bst_); bl_[1] = lds_read128<2 * G::B_PLANE>(b_s[1] + bst_);
+      wait_lgkm6<6>(bh_[0], bm_[0], bl_[0], xh_[0][0], xm_[0][0], xl_[0][0]);
+      split_mfma<3>(acc[0][0], acc_lo, xh_[0][0], xm_[0][0], xl_[0][0], bh_[0], bm_[0], bl_[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      xh_[1][0] = lds_read128<AOFF_ + 32>(a_base); xm_[1][0] = lds_read128<AOFF_ + 96>(a_base); xl_[1][0] = lds_read128<AOFF_ + 160>(a_base);
+      xh_[1][1] = lds_read128<A1_ + 32>(a_base); xm_[1][1] = lds_read128<A1_ + 96>(a_base); xl_[1][1] = lds_read128<A1_ + 160>(a_base);
+      if (FIRST_ && more_) {
+        if (U_ < 3) patch_load(c, IC<(U_ + 1) & 3>{});
+        else patch_load(c + 1, IC<0>{});
+      }
+      wait_lgkm6<9>(xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);
+      split_mfma<3>(acc[1][0], acc_lo, xh_[0][1], xm_[0][1], xl_[0][1], bh_[0], bm_[0], bl_[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm6<3>(bh_[1], bm_[1], bl_[1], xh_[1][0], xm_[1][0], xl_[1][0]);
+      split_mfma<3>(acc[0][0], acc_lo, xh_[1][0], xm_[1][0], xl_[1][0], bh_[1], bm_[1], bl_[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm6<0>(xh_[1][1], xm_[1][1], xl_[1][1], bh_[1], bm_[1], bl_[1]);
+      split_mfma<3>(acc[1][0], acc_lo, xh_[1][1], xm_[1][1], xl_[1][1], bh_[1], bm_[1], bl_[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     if (!(MSI_S2X3_ABLATE & 8))
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
@@ -751,6 +782,7 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
         else if (c + 1 < c1) b_issue(c + 1, s2_tap((J + 2) % 9), (J + 2) % 3);
         }
       }
+    }
     }
     {
       const bool issued_ = (J + 2 < 9) || (c + 1 < c1);
@@ -793,8 +825,8 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
 
   // ---- epilogue: as conv_halo_kernel ----
   if (!full) {
-    constexpr int SLAB = 64 * 64 * 4;
-    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)slot * (64 * 64)), 0, SLAB, 0x00020000);
+    constexpr int SLAB = BM * 64 * 4;
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)slot * (BM * 64)), 0, SLAB, 0x00020000);
     if (p.tile_cnt == nullptr) {
       dump_acc<MT, NT, 0>(acc, rsrc_p, tid);
       return;
@@ -810,11 +842,28 @@ conv_halo_s2_x3_kernel(const ConvParams p) {
     __syncthreads();
     if (*s_old != nsp - 1) return;
     handoff_acquire();
-    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (64 * 64)), 0, nsp * SLAB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)(p.partial + (size_t)(slot - ks) * (BM * 64)), 0, nsp * SLAB, 0x00020000);
     sum_slabs<MT, NT, MSI_HANDOFF_AUX>(acc, rsrc_t, nsp, SLAB, tid);
     __syncthreads();   // (s_old has been read by every thread before the strip below reuses LDS)
   }
-  emit_tile<64, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, smem);
+  emit_tile<BM, 64, MODE_CONV>(p, acc, tile_m, tile_n, 0, b, tid, smem);
+}
+
+template <int APPLY, int NP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? MSI_S2X_WAVES : (MSI_S2X3_NSTG == 2 ? 3 : 2))))
+conv_halo_s2_x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv_halo_s2_x3_body<APPLY, NP, 4>(p, smem);
+#endif
+}
+
+template <int APPLY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+conv_halo8_s2_x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv_halo_s2_x3_body<APPLY, 3, 8>(p, smem);
 #endif
 }
 
@@ -1202,7 +1251,12 @@ int launch_x3(const LayerLaunch &Q, const ConvParams &p, int rate, hipStream_t s
     if (!rc && Q.nfix > 0 && p.tile_cnt == nullptr) rc = launch_fixup(Q.x3_th8 ? 128 : 64, 64, MODE_CONVT, Q.nfix, 2, p, stream);
     return rc;
   }
-  if (Q.halo_s2) {
+  if (Q.halo_s2 && Q.x3_th8) {
+    typedef HaloGeomS2X3<3, 8> G8s_;
+    static_assert(G8s_::LDS_BYTES <= 65536, "conv_halo8_s2_x3_kernel: LDS without the launch attribute");
+    if (Q.halo_apply) hipLaunchKernelGGL((conv_halo8_s2_x3_kernel<1>), grid, block, G8s_::LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((conv_halo8_s2_x3_kernel<0>), grid, block, G8s_::LDS_BYTES, stream, p);
+  } else if (Q.halo_s2) {
     if (Q.halo_x2) {
       if (Q.halo_apply) hipLaunchKernelGGL((conv_halo_s2_x3_kernel<1, 2>), grid, block, HaloGeomS2X3<2>::LDS_BYTES, stream, p);
       else hipLaunchKernelGGL((conv_halo_s2_x3_kernel<0, 2>), grid, block, HaloGeomS2X3<2>::LDS_BYTES, stream, p);

@@ -24,21 +24,23 @@ TOL = 1e-3
 # (r05: the stride-1, rate-1 layers of the six-product form whose grid is >= 3 tiles of 8 x 16 pixels per CU run conv_halo8_x3_kernel -- plan option X3_TILE8:
 #  every such layer at the batches of configs[3] / [4]; conv1_1, conv2_1, conv7_2, conv8_2 at configs[1])
 # (r05: the rate-2 layers conv4_x run on row-parity tiles -- plan option X3_ROWPAR, first template argument 3: dilation 2 along W, row stride 2 along H)
-def f32_big_grid(np_, wide=(0, 2, 4, 5, 11, 12, 14, 16), wide_ct=(10, 13, 15)):
+def f32_big_grid(np_, wide=(0, 2, 4, 5, 11, 12, 14, 16), wide_ct=(10, 13, 15), wide_s2=(1, 3, 6)):
     c = lambda r, a: "conv_halo_x3_kernel<%d, %d, %d>" % (r, a, np_)      # noqa: E731
     s2, ct = "conv_halo_s2_x3_kernel<1, %d>" % np_, "convt_halo_x3_kernel<%d>" % np_
     k = [c(1, 0), s2, c(1, 1), s2, c(1, 1), c(1, 1), s2, c(3, 1), c(3, 1), c(3, 1), ct, c(1, 1), c(1, 1), ct, c(1, 1), ct, c(1, 1)]
     if np_ == 3:
         for i in wide:
             k[i] = "conv_halo8_x3_kernel<%d, 3>" % (0 if i == 0 else 1)
-        for i in wide_ct:          # (r05: the conv-transposes on the 8 x 16-pixel tile under the same grid rule)
+        for i in wide_ct:          # (r05: the conv-transposes and the stride-2 layers on the 8 x 16-pixel tile under the same grid rule)
             k[i] = "convt_halo8_x3_kernel"
+        for i in wide_s2:
+            k[i] = "conv_halo8_s2_x3_kernel<1>"
     return k
 
 
 DEFAULT_PLANES = 3          # (plan option F32_SPLIT_F16 -- the three-product fp16 form, 2 planes -- is opt-in)
 F32_BIG_GRID = f32_big_grid(DEFAULT_PLANES)
-F32_CONFIG1 = f32_big_grid(DEFAULT_PLANES, wide=(0, 2, 14, 16), wide_ct=(15,))
+F32_CONFIG1 = f32_big_grid(DEFAULT_PLANES, wide=(0, 2, 14, 16), wide_ct=(15,), wide_s2=(1,))
 BF16_CONFIG2 = ["conv_halo_bf16_kernel<256, 64, 1, 0, 4>", "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 1, 0, 8>", "conv_halo_bf16_kernel<128, 128, 1, 1, 8>",
                 "conv_halo_bf16_s2_kernel<1, 4>", "conv_halo_bf16_kernel<128, 128, 2, 0, 8>", "conv_halo_bf16_kernel<128, 128, 2, 1, 8>",
@@ -127,7 +129,7 @@ def test_config3_bench_batches_every_frame(batch):
     m, got, (bfix, h, w, d) = _ods_batch(cfg, batch)
     kern = _plan_kernels(m, batch, h, w, d)
     assert [k[0] for k in kern] == F32_BIG_GRID, kern
-    assert all(k[2] == 0 for k in kern if k[0] != "convt_halo8_x3_kernel")   # (whole tiles; the 8-row conv-transpose tiles of a rank's 4-frame shard end in a K-range tail)
+    assert all(k[2] == 0 for k in kern if not k[0].startswith(("convt_halo8_x3_kernel", "conv_halo8_s2_x3_kernel")))   # (whole tiles; the 8-row conv-transpose / stride-2 tiles of a rank's 4-frame shard end in a K-range tail)
     rep = {k: _check_every_frame(z, k, got[k], bfix, TOL) for k in ("psv", "rgba_layers", "rgb", "depth")}
     print("config3 b=%d (max, mean, samples per group, frames):" % batch, rep)
     del got
@@ -158,7 +160,7 @@ def test_config4_bench_batches_every_face(batch):
     assert m.network_status() == 0
     kern = _plan_kernels(m, batch, n, n, d)
     # (the conv-transposes take the 8-row tile where their grid is >= 3 tiles per CU: conv7_1 / conv8_1 at 8 faces, not conv6_1)
-    assert [k[0] for k in kern] == f32_big_grid(DEFAULT_PLANES, wide_ct=(10, 13, 15) if batch >= 64 else (13, 15)), kern
+    assert [k[0] for k in kern] == (F32_BIG_GRID if batch >= 64 else f32_big_grid(DEFAULT_PLANES, wide_ct=(13, 15), wide_s2=(1, 3))), kern
     native = MSI(weights=weights, coord_net=True, input_type="PP")      # (the native-arithmetic plan still switches kernels with the batch)
     native.net_options[__import__("matryodshka_amd")._native.NET_OPT_F32_SPLIT3] = 0
     assert [k[0] for k in _plan_kernels(native, 2, n, n, d)][6] == "conv_igemm_kernel<64, 64, 0, 0>"
@@ -177,7 +179,7 @@ def test_config1_plan_is_the_profiled_one():
     plan = N.NetPlan(nets.make_desc(1, 320, 640, 192, 64, 64, True, "f32"))
     k = [plan.layer_kernel(i) for i in range(18)]
     assert [x[0] for x in k[:17]] == F32_CONFIG1 and k[17][0] == "conv_igemm_kernel<64, 64, 2, 0>", k
-    assert [x[2] for x in k[:17]] == [64, 64, 32, 32, 32, 32, 400, 400, 400, 400, 400, 32, 32, 32, 32, 32, 64], k   # (conv8_1 on the 8-row tile: 800 tiles, 32 of them cut)
+    assert [x[2] for x in k[:17]] == [64, 32, 32, 32, 32, 32, 400, 400, 400, 400, 400, 32, 32, 32, 32, 32, 64], k   # (conv1_2 / conv8_1 on the 8-row tile: 800 tiles, 32 of them cut)
     plan.set_option(N.NET_OPT_F32_SPLIT3, 0)
     k = [plan.layer_kernel(i)[0] for i in range(17)]
     assert k[6] == "conv_igemm_kernel<64, 64, 0, 0>" and k[0] == "conv_halo_kernel<1, 0>" and k[1] == "conv_halo_s2_kernel<1>" and k[10] == "conv_igemm_kernel<64, 64, 1, 0>", k
