@@ -84,7 +84,7 @@ def main():
         nl = 17 if fused_tail else 18
         ha = c.execute("select start, end from kernels where name like '%head_assemble%' order by start").fetchall()
         for nm, r, fl in zip(NAMES[:nl], conv[-nl:], flops[:nl]):
-            tmpl = r[0].split("<")[1].split(">")[0] if "<" in r[0] else "?"
+            tmpl = "<" + r[0].split("<")[1].split(">")[0] + ">" if "<" in r[0] else ""
             us = (r[2] - r[1]) / 1e3
             nxt = [q[1] for q in conv if q[1] > r[1]]
             fx = [(e - s0) / 1e3 for s0, e in fix if r[2] <= s0 < r[2] + 200000 and (not nxt or s0 < nxt[0])]
@@ -95,7 +95,7 @@ def main():
             # three-product fp16 split 833.3 fp32-equivalent TFLOP/s -- bench.split_peak)
             lpk = peak if bf16 else bench.split_peak(short(r[0]).split("(")[0])
             peak_time += fl / lpk / 1e6
-            print("%-10s %s<%s> blocks=%d lds=%d vgpr=%d agpr=%d  %8.1f us + fixup %5.1f us  %7.1f TFLOP/s (%4.1f%% of %.1f)" % (
+            print("%-10s %s%s blocks=%d lds=%d vgpr=%d agpr=%d  %8.1f us + fixup %5.1f us  %7.1f TFLOP/s (%4.1f%% of %.1f)" % (
                 nm, kind, tmpl, (r[3] // r[6]) * r[4] * r[5], r[7], r[8], r[9], us, fus, fl / (us + fus) / 1e6,
                 100 * fl / (us + fus) / 1e6 / lpk, lpk))
         if fused_tail and ha:
