@@ -62,17 +62,29 @@ def build(force=False, verbose=True):
     if failed:
         raise RuntimeError("hipcc failed for " + ", ".join(failed))
     if rebuilt or force or _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        # Link to a temporary name and move it onto LIB only when the lint has passed: a library that was never linted (objdump missing, lint crashed)
+        # or that the lint refused must not be found by the next build() as "up to date" (the gate used to fail open).
+        tmp = LIB + ".unlinted"
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         if not os.environ.get("MSI_SKIP_ISA_LINT"):
             from matryodshka_amd import isa_lint
-            bad = isa_lint.lint(LIB, verbose=verbose)
+            try:
+                bad = isa_lint.lint(tmp, verbose=verbose)
+            except Exception:
+                os.replace(tmp, LIB + ".rejected")
+                if os.path.exists(LIB):
+                    os.remove(LIB)
+                raise
             if bad:
-                os.replace(LIB, LIB + ".rejected")
-                raise RuntimeError("isa_lint: %d packed-fp32 instructions route a HIGH register half to the LOW lane (first: %s in %s); see matryodshka_amd/isa_lint.py"
-                                   % (len(bad), bad[0][1], bad[0][0]))
+                os.replace(tmp, LIB + ".rejected")
+                if os.path.exists(LIB):
+                    os.remove(LIB)
+                raise RuntimeError("isa_lint: %d finding(s) (a packed-fp32 instruction routing a HIGH register half to the LOW lane, or a VALU write of a wide store's data "
+                                   "less than two wait states behind it; first: %s in %s); see matryodshka_amd/isa_lint.py" % (len(bad), bad[0][1], bad[0][0]))
+        os.replace(tmp, LIB)
     return LIB
 
 

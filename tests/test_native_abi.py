@@ -57,6 +57,40 @@ def test_lint_recognises_a_valu_write_of_a_wide_stores_data_in_the_next_instruct
     assert isa_lint._valu_dest("\ts_mov_b64 s[28:29], exec") is None
 
 
+def test_lint_tracks_every_pending_store_and_every_vgpr_a_valu_instruction_writes():
+    """Round 6 (ADVICE r05 / VERDICT r05 item 5d): back-to-back stores each keep their own wait-state count; v_swap_b32 writes both operands; MFMA / 64-bit
+    destinations are ranges; load destinations on a just-stored register are counted, not refused (the module docstring says why)."""
+    from matryodshka_amd import isa_lint
+    scan = isa_lint.scan_kernel_text
+    a = "\tbuffer_store_dwordx4 v[46:49], v86, s[8:11], 0 offen"
+    b = "\tbuffer_store_dwordx4 v[50:53], v86, s[8:11], 0 offen offset:16"
+    # store A; store B; VALU write of A's data: one wait state behind A (the r05 lint forgot A when it saw B)
+    bad, nstore, nload = scan([a, b, "\tv_mul_lo_u32 v46, v98, s28"])
+    assert nstore == 2 and len(bad) == 1 and "v[46:49]" in bad[0] and "(1 wait state(s))" in bad[0]
+    # ... and of B's data, zero wait states behind B
+    bad, _, _ = scan([a, b, "\tv_add_u32 v53, v1, v2"])
+    assert len(bad) == 1 and "v[50:53]" in bad[0] and "(0 wait state(s))" in bad[0]
+    # two wait states behind A (an s_nop 0 counts one; s_nop 1 two): clean
+    assert scan([a, "\ts_nop 0", "\tv_mov_b32 v5, v6", "\tv_mul_lo_u32 v46, v98, s28"])[0] == []
+    assert scan([a, "\ts_nop 1", "\tv_mul_lo_u32 v46, v98, s28"])[0] == []
+    assert len(scan([a, "\ts_nop 0", "\tv_mul_lo_u32 v46, v98, s28"])[0]) == 1
+    # v_swap_b32 writes BOTH operands
+    assert len(scan([a, "\tv_swap_b32 v3, v47"])[0]) == 1
+    assert isa_lint.vgpr_writes("\tv_swap_b32 v3, v47") == [((3, 3), "valu"), ((47, 47), "valu")]
+    # MFMA / accvgpr reads: the whole destination range
+    assert isa_lint.vgpr_writes("\tv_mfma_f32_32x32x16_bf16 v[40:55], v[2:5], v[6:9], v[40:55]") == [((40, 55), "valu")]
+    assert len(scan([a, "\tv_mfma_f32_32x32x16_bf16 v[40:55], v[2:5], v[6:9], v[40:55]"])[0]) == 1
+    assert isa_lint.vgpr_writes("\tv_accvgpr_read_b32 v48, a3") == [((48, 48), "valu")]
+    assert isa_lint.vgpr_writes("\tv_accvgpr_write_b32 a3, v48") == []
+    # loads: recognised, counted, not refused; LDS-DMA loads have no VGPR destination
+    assert isa_lint.vgpr_writes("\tglobal_load_dwordx4 v[14:17], v[2:3], off offset:32") == [((14, 17), "load")]
+    assert isa_lint.vgpr_writes("\tds_read_b128 v[116:119], v26") == [((116, 119), "load")]
+    assert isa_lint.vgpr_writes("\tbuffer_load_dwordx4 v1, s[8:11], s14 offen lds") == []
+    bad, _, nload = scan(["\tglobal_store_dwordx4 v[10:11], v[14:17], off", "\tglobal_load_dwordx4 v[14:17], v[2:3], off offset:32"])
+    assert bad == [] and nload == 1
+    assert isa_lint._find_objdump().endswith("llvm-objdump")
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under matryodshka_amd/ or include/ may mention it."""
     for base in ("matryodshka_amd", "include"):
