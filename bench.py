@@ -246,26 +246,29 @@ def dist_check(args, rank, local_rank, world):
     cfg = CONFIGS[args.config]
     use_gpu = torch.cuda.is_available()
     dev = torch.device("cuda", local_rank % torch.cuda.device_count()) if use_gpu else torch.device("cpu")
-    if world > 1:
+    use_pg = world > 1 or args.force_process_group
+    if use_pg:
+        if use_gpu:
+            torch.cuda.set_device(dev)
         mdist.init_process_group()
     cin, nout, ngf = 24, 8, 8
     weights = nets.init_weights(cin, nout, ngf, True, seed=8964) if rank == 0 else None
-    if world > 1:
+    if use_pg:
         weights = mdist.broadcast_weights(weights, cin, nout, ngf, True, dev, src=0)
     blob_sum = float(nets.flatten_params(weights, cin, nout, ngf, True).astype(np.float64).sum())
     lo, hi, total = mdist.step_frames(cfg["total"], cfg["per_rank"], rank, world)
-    if world > 1:
+    if use_pg:
         mdist.barrier()
-    t = mdist.max_over_ranks(1.0 + rank, dev) if world > 1 else 1.0
-    sums = mdist.gather_floats(blob_sum, dev) if world > 1 else [blob_sum]
-    ranges = mdist.gather_ranges(lo, hi, dev) if world > 1 else [(lo, hi)]
+    t = mdist.max_over_ranks(1.0 + rank, dev) if use_pg else 1.0
+    sums = mdist.gather_floats(blob_sum, dev) if use_pg else [blob_sum]
+    ranges = mdist.gather_ranges(lo, hi, dev) if use_pg else [(lo, hi)]
     if rank == 0:
         print(json.dumps({"dist_check": True, "n_gpus": world, "config": args.config,
-                          "world_size_process_group": torch.distributed.get_world_size() if world > 1 else 1,
-                          "backend": torch.distributed.get_backend() if world > 1 else None,
+                          "world_size_process_group": torch.distributed.get_world_size() if use_pg else 1,
+                          "backend": torch.distributed.get_backend() if use_pg else None,
                           "frames_per_step": total, "frame_ranges_per_rank": ranges, "max_over_ranks": t,
                           "weights_equal_on_all_ranks": len(set(sums)) == 1}), flush=True)
-    if world > 1:
+    if use_pg:
         torch.distributed.destroy_process_group()
 
 
@@ -308,6 +311,10 @@ def main():
                     help="HIP streams consecutive frames are issued on (1 = strictly one frame at a time, the "
                          "default and the configuration BASELINE quotes; 2 = software-pipeline independent frames, "
                          "each still batch 1, to fill the tile-quantisation tails of the small layers; config 1 only)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="initialise torch.distributed even at --gpus 1 (world_size 1; backend nccl = RCCL on a GPU box) and run the weight broadcast, "
+                         "barriers, MAX-over-ranks and gathers through it exactly as an N-rank run does: first contact with RCCL on a one-GPU box "
+                         "(`distributed.backend` and a measured `weight_broadcast_ms` on the line; VERDICT r05 item 4)")
     ap.add_argument("--dist-check", action="store_true",
                     help="only the N-rank plumbing of this file: launch, rendezvous, weight broadcast, frame ranges, barrier and "
                          "max-over-ranks -- no frame loop, no kernels; runs without a GPU on gloo (tests/test_dist_cpu.py) and "
@@ -324,6 +331,13 @@ def main():
         raise SystemExit(self_launch(args.gpus))                # `python bench.py --gpus N` typed directly: become N ranks
     if args.gpus != world:
         raise SystemExit("--gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
+    use_pg = world > 1 or args.force_process_group
+    if use_pg and "WORLD_SIZE" not in os.environ:               # --force-process-group typed without a launcher: a one-rank rendezvous on a free local port
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(s_.getsockname()[1])})
+        s_.close()
     if args.dist_check:
         return dist_check(args, rank, local_rank, world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
@@ -339,7 +353,7 @@ def main():
     from matryodshka_amd import MSI, nets
     from matryodshka_amd import dist as mdist
 
-    if world > 1:
+    if use_pg:
         mdist.init_process_group()
         # the data path of an N-GPU run is RCCL over xGMI; anything else must be asked for explicitly (functional tests)
         if not os.environ.get("MSI_DIST_BACKEND"):
@@ -355,7 +369,7 @@ def main():
     # weights: rank 0 initialises, everyone receives them over RCCL (xGMI); timed, outside the frame loop
     weights = nets.init_weights(cin, nout, NGF, coord, seed=8964) if rank == 0 else None
     broadcast_ms = None
-    if world > 1:
+    if use_pg:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         weights = mdist.broadcast_weights(weights, cin, nout, NGF, coord, dev, src=0)
@@ -474,7 +488,7 @@ def main():
     def timed_region(nsteps):
         """EXACTLY nsteps steps between barrier + synchronize on both sides; max over ranks."""
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             mdist.barrier()
         torch.cuda.synchronize()
         ev = []
@@ -483,12 +497,12 @@ def main():
             result = step(k, ev if args.streams == 1 else None)
         torch.cuda.synchronize()
         t_own = time.perf_counter()                              # this rank's own finish time (before the closing barrier)
-        if world > 1:
+        if use_pg:
             mdist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         own.append(t_own - t0)
-        elapsed = mdist.max_over_ranks(elapsed, dev) if world > 1 else elapsed
+        elapsed = mdist.max_over_ranks(elapsed, dev) if use_pg else elapsed
         # one (start, end) event pair per network forward; --substreams S: S forwards per step, each timed on its own stream --
         # their SUM is the step's network time (sub-batches overlap with other stages, not with each other's convolutions)
         per_fwd = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(len(ev) // 2)]
@@ -520,7 +534,7 @@ def main():
         own.clear()
     elapsed, cnn_ms, result = timed_region(args.steps)             # the contract region: `value` comes from here
     repeats = [timed_region(args.steps)[0] for _ in range(max(0, args.repeats))]
-    per_rank_ms = mdist.gather_floats(own[0] / args.steps * 1e3, dev) if world > 1 else [own[0] / args.steps * 1e3]
+    per_rank_ms = mdist.gather_floats(own[0] / args.steps * 1e3, dev) if use_pg else [own[0] / args.steps * 1e3]
 
     # strong-scaling reading of the same path (config 1): a FIXED batch of --strong-frames frames sharded over the ranks,
     # each rank running its shard as consecutive batch-1 frames; barrier + synchronize on both sides, max over ranks
@@ -530,18 +544,18 @@ def main():
         times = []
         for _ in range(5):
             torch.cuda.synchronize()
-            if world > 1:
+            if use_pg:
                 mdist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for k in range(shi - slo):
                 step(k)
             torch.cuda.synchronize()
-            if world > 1:
+            if use_pg:
                 mdist.barrier()
             torch.cuda.synchronize()
             t = time.perf_counter() - t0
-            times.append(mdist.max_over_ranks(t, dev) if world > 1 else t)
+            times.append(mdist.max_over_ranks(t, dev) if use_pg else t)
         t = float(np.median(times))
         strong = {"frames": args.strong_frames, "frames_of_rank0": shi - slo, "ms": round(t * 1e3, 4),
                   "frames_per_s": round(args.strong_frames / t, 3), "regions_ms": [round(x * 1e3, 4) for x in times],
@@ -571,9 +585,12 @@ def main():
                "note": "plan option F32_SPLIT_F16 (bench.py --arithmetic split_f16): 2-way fp16 split of both operands (22 significand bits), THREE products on the fp16 MFMA, "
                        "fp32 accumulation -- measured against fp64 it has the error of a plain fp32 convolution (profiles/r04_split_numerics.txt), operands limited to the "
                        "fp16 range (status word); opt-in, reported beside the default, never as `value`"}
-    ranges = mdist.gather_ranges(lo, hi, dev) if world > 1 else [(lo, hi)]
-    nccl_world = torch.distributed.get_world_size() if world > 1 else 1
-    backend = torch.distributed.get_backend() if world > 1 else None
+    ranges = mdist.gather_ranges(lo, hi, dev) if use_pg else [(lo, hi)]
+    nccl_world = torch.distributed.get_world_size() if use_pg else 1
+    backend = torch.distributed.get_backend() if use_pg else None
+    if use_pg:                       # the last collective is behind us: every rank leaves the group together (rank 0 goes on alone with the per-stage pass)
+        mdist.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
 

@@ -392,7 +392,9 @@ int32_t msi_net_plan_status(const msi_net_plan *plan, const void *workspace, msi
  * MSI_E_RANGE.  msi_net_plan_calibrate measures instead: layer by layer it runs the network on `net_input` (a representative frame, device memory, the
  * forward's layout), moves / centres each layer's window on the measured raw rms and rewrites the four scale doubles at ln_scale_offset of `packed`
  * (DEVICE memory, modified in place; every plan that shares the blob sees the new windows).  Blocking (it synchronises `stream` several times per layer),
- * a one-off of a few dozen forwards; *layers_changed (may be NULL) = layers whose exponent moved.  MSI_E_RANGE if a layer has no finite, non-constant output. */
+ * a one-off of a few dozen forwards; *layers_changed (may be NULL) = layers whose exponent moved.  MSI_E_RANGE if a layer has no finite, non-constant output.
+ * ALL OR NOTHING (round 6): on ANY error return every window is written back as it was on entry.  Within a batch the window is centred on the samples it
+ * resolves; a constant sample among others is left out (a forward flags it itself). */
 int32_t msi_net_plan_calibrate(const msi_net_plan *plan, float *packed, const void *net_input, void *workspace, size_t workspace_bytes,
                                msi_stream_t stream, int32_t *layers_changed);
 /* net_input [B,H,W,in_channels] (fp32, or bf16 when desc.dtype = MSI_DTYPE_BF16) -> pred [B,H,W,num_outputs] fp32. */

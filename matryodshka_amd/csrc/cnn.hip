@@ -971,53 +971,70 @@ int32_t msi_net_plan_calibrate(const msi_net_plan *plan, float *packed, const vo
   const size_t nwords = (size_t)desc->batch * LN_SHARDS * LN_WORDS;
   std::vector<long long> sums(nwords);
   char *ws = static_cast<char *>(workspace);
-  for (int li = 0; li < MSI_NET_NUM_LAYERS - 1; ++li) {
+  // ALL OR NOTHING: the windows of every layer as they were on entry; any error return writes back those of the layers touched so far, so a frame that
+  // cannot be calibrated on (constant, non-finite) leaves the packed blob exactly as it found it.
+  constexpr int NL = MSI_NET_NUM_LAYERS - 1;
+  double orig[NL][LN_SCL_DOUBLES];
+  hipError_t he = hipSuccess;
+  for (int li = 0; li < NL && he == hipSuccess; ++li)
+    he = hipMemcpyAsync(orig[li], packed + net.layers[li].lnscl_off, sizeof(orig[li]), hipMemcpyDeviceToHost, stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(stream);
+  if (he != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_plan_calibrate: %s", hipGetErrorString(he));
+  int touched = 0;                         // layers 0 .. touched - 1 may hold new windows
+  auto restore = [&]() {
+    for (int l = 0; l < touched; ++l)
+      (void)hipMemcpyAsync(packed + net.layers[l].lnscl_off, orig[l], sizeof(orig[l]), hipMemcpyHostToDevice, stream);
+    (void)hipStreamSynchronize(stream);    // (orig is on this stack frame)
+  };
+  for (int li = 0; li < NL; ++li) {
     const Layer &L = net.layers[li];
-    double scl[LN_SCL_DOUBLES];
-    hipError_t he = hipMemcpyAsync(scl, packed + L.lnscl_off, sizeof(scl), hipMemcpyDeviceToHost, stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(stream);
-    if (he != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_plan_calibrate: %s", hipGetErrorString(he));
+    const double *scl = orig[li];
     int e0 = LN_S1_BITS - (int)lrint(log2(scl[0])), e = e0;
     bool settled = false;
+    touched = li + 1;
     for (int it = 0; it < 24 && !settled; ++it) {
       const double ns[LN_SCL_DOUBLES] = {ldexp(1.0, LN_S1_BITS - e), ldexp(1.0, LN_S2_BITS - 2 * e), ldexp(1.0, -(LN_S1_BITS - e)), ldexp(1.0, -(LN_S2_BITS - 2 * e))};
       he = hipMemcpyAsync(packed + L.lnscl_off, ns, sizeof(ns), hipMemcpyHostToDevice, stream);
       if (he == hipSuccess) he = hipStreamSynchronize(stream);   // (ns is on this stack frame)
-      if (he != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_plan_calibrate: %s", hipGetErrorString(he));
+      if (he != hipSuccess) { restore(); return msi::fail(MSI_E_LAUNCH, "net_plan_calibrate: %s", hipGetErrorString(he)); }
       int rc = run_layers(plan, packed, net_input, nullptr, workspace, workspace_bytes, stream_, li + 1);
-      if (rc) return rc;
+      if (rc) { restore(); return rc; }
       int word = 0;
       he = hipMemcpyAsync(sums.data(), ws + L.sums_off, nwords * sizeof(long long), hipMemcpyDeviceToHost, stream);
       if (he == hipSuccess) he = hipMemcpyAsync(&word, ws + net.err_off, sizeof(int), hipMemcpyDeviceToHost, stream);
       if (he == hipSuccess) he = hipStreamSynchronize(stream);
-      if (he != hipSuccess) return msi::fail(MSI_E_LAUNCH, "net_plan_calibrate: %s", hipGetErrorString(he));
+      if (he != hipSuccess) { restore(); return msi::fail(MSI_E_LAUNCH, "net_plan_calibrate: %s", hipGetErrorString(he)); }
       if (word & STATUS_LN_OVERFLOW) { e += 12; if (e > 120) break; continue; }   // a share left the window (or the data is not finite: the loop gives up at 2^120)
-      // per sample: sum x^2 in units of 1 / S2; below ~1e6 sqrt(waves) units the variance is resolved to < 6 digits (ln_mean_inv's rule, restated on the host)
-      double rmin = 1e300, rmax = 0.0;
-      bool under = false;
+      // per sample: sum x^2 in units of 1 / S2; below ~1e6 sqrt(waves) units the variance is resolved to < 6 digits (ln_mean_inv's rule, restated on the host).
+      // The window is centred on the samples it RESOLVES; a constant sample (a black frame in a batch) or one far below the others is left out instead of
+      // dragging the window down 12 bits at a time until nothing fits -- a forward flags such a sample itself.
+      double rmin = 1e300, rmax = 0.0, amin = 1e300, amax = 0.0;   // (resolved samples | every sample with a non-zero sum of squares)
       for (int b = 0; b < desc->batch; ++b) {
-        double h1 = 0.0, h2 = 0.0;
-        for (int sh = 0; sh < LN_SHARDS; ++sh) {
-          h1 += (double)sums[((size_t)b * LN_SHARDS + sh) * LN_WORDS];
+        double h2 = 0.0;
+        for (int sh = 0; sh < LN_SHARDS; ++sh)
           h2 += (double)sums[((size_t)b * LN_SHARDS + sh) * LN_WORDS + 1];
-        }
-        if (h2 * h2 < LN_UNDERFLOW_UNITS_SQ * (L.ln_count / 1024.0 + 1.0)) under = true;
-        const double mu = h1 * ns[2] / L.ln_count;
-        double ms = h2 * ns[3] / L.ln_count;               // E[x^2]: the window has to hold the raw values themselves
-        (void)mu;
+        const bool under = h2 * h2 < LN_UNDERFLOW_UNITS_SQ * (L.ln_count / 1024.0 + 1.0);
+        const double ms = h2 * ns[3] / L.ln_count;           // E[x^2]: the window has to hold the raw values themselves
         const double r = sqrt(ms > 0.0 ? ms : 0.0);
-        rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax;
+        if (r > 0.0) { amin = r < amin ? r : amin; amax = r > amax ? r : amax; }
+        if (r > 0.0 && !under) { rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
       }
-      if (under && rmax == 0.0) { e -= 12; if (e < -120) break; continue; }        // nothing resolved at all: look lower
-      if (rmax > 0.0) {
-        const int ec = (int)lrint(0.5 * (log2(rmax) + log2(rmin > 0.0 ? rmin : rmax)));
-        if (ec > e + 1 || ec < e - 1) { e = ec; continue; }                         // centre the window (to within an octave) and measure once more in the new unit
-      }
-      if (under) { e -= 12; if (e < -120) break; continue; }
-      settled = true;
+      if (rmax > 0.0) {                                                              // something is resolved: centre on it (to within an octave), measure once more in the new unit
+        const int ec = (int)lrint(0.5 * (log2(rmax) + log2(rmin)));
+        if (ec > e + 1 || ec < e - 1) { e = ec; continue; }
+        settled = true;
+      } else if (amax > 0.0) {                                                       // seen but not resolved: go to where the coarse reading points, else lower
+        const int ec = (int)lrint(0.5 * (log2(amax) + log2(amin)));
+        if (ec > e + 1 || ec < e - 1) e = ec; else e -= 12;
+        if (e < -120) break;
+      } else { e -= 12; if (e < -120) break; }                                       // nothing at all in this window: look lower
     }
-    if (!settled)
-      return msi::fail(MSI_E_RANGE, "net_plan_calibrate: layer %s has no finite, non-constant raw output to centre a LayerNorm window on (non-finite input or weights?)", L.name);
+    if (!settled) {
+      restore();
+      if (layers_changed) *layers_changed = 0;
+      return msi::fail(MSI_E_RANGE, "net_plan_calibrate: layer %s has no finite, non-constant raw output to centre a LayerNorm window on (non-finite input or weights, "
+                       "or a constant frame?); the windows are unchanged", L.name);
+    }
     if (e != e0 && layers_changed) ++*layers_changed;
   }
   return MSI_OK;

@@ -119,18 +119,26 @@ def run_sample(model, images, baseline, tgt_pos, planes, num_planes, ngf, test_o
         except MsiError as e:
             deferred.append(e)
     check_status()
-    if deferred and "LayerNorm" in str(deferred[0]) and not getattr(model, "_harness_calibrated", False):
-        # the windows are an estimate from the weights (msi_hip.h, msi_net_plan_calibrate): measure them on this sample once and repeat the forward
-        model._harness_calibrated = True
+    # Calibration state is per packed blob (one per resolution / channel count: a blob for another size has its own windows) and is recorded only when
+    # msi_net_plan_calibrate SUCCEEDED -- it is all-or-nothing, so a degenerate first sample (a black frame) leaves the windows as they were and the next flagged
+    # sample tries again (at most three failed attempts per blob).
+    nout = {"blend_psv": 2 * num_planes, "blend_bg": 2 * num_planes + 3, "blend_bg_psv": 3 * num_planes + 3, "alpha_only": num_planes}[which_color_pred]
+    ckey = tuple(net_input.shape[1:]) + (nout, ngf)
+    cstate = model.__dict__.setdefault("_harness_calibration", {})     # ckey -> "ok" | number of failed attempts
+    if deferred and "LayerNorm" in str(deferred[0]) and cstate.get(ckey, 0) != "ok" and cstate.get(ckey, 0) < 3:
+        # the windows are an estimate from the weights (msi_hip.h, msi_net_plan_calibrate): measure them on this sample and repeat the forward
         try:
-            nout = {"blend_psv": 2 * num_planes, "blend_bg": 2 * num_planes + 3, "blend_bg_psv": 3 * num_planes + 3, "alpha_only": num_planes}[which_color_pred]
             moved = model.calibrate(net_input, nout, ngf)
+            cstate[ckey] = "ok"
             print("LayerNorm windows calibrated on %s: %d layers moved" % (dirname, moved))
             del deferred[:]
             outs, net_input = model.infer_msi(src, ref, None, None, eye, eye, intr, which_color_pred, num_planes, planes,
                                               extra_outputs="blend_weights alphas psv", ngf=ngf)
             check_status()
         except MsiError as e:
+            if cstate.get(ckey, 0) != "ok":
+                cstate[ckey] = cstate.get(ckey, 0) + 1
+                print("LayerNorm windows NOT calibrated on %s (windows unchanged; attempt %d of 3): %s" % (dirname, cstate[ckey], e))
             deferred.append(e)
     jouts = None
     if jitter_pose is not None:      # test.py:141-147: second inference with the sweep rotated by jitter_pose^-1

@@ -172,7 +172,8 @@ class MSI(object):
         ([B,H,W,Cin], the forward's layout; a representative frame).  The packer derives the windows from the weights alone; a checkpoint whose trained
         gamma / beta / weights break that estimate makes network_status() raise MSI_E_RANGE on every frame -- call this once (the harness does, on the
         first flagged sample) and the windows follow the measurement.  The packed blob is modified in place on the device: every plan of this model
-        (any batch size) uses the new windows.  Blocking; returns the number of layers whose window moved."""
+        (any batch size) uses the new windows.  Blocking; returns the number of layers whose window moved.  All or nothing: when it raises (MSI_E_RANGE: a layer
+        without finite, non-constant output on this frame) the windows are exactly what they were before the call."""
         b, h, w, cin = net_input.shape
         if num_outputs is None:
             num_outputs = cin // 3          # blend_psv: 6 D -> 2 D

@@ -119,7 +119,13 @@ def layer_norm_relu(x, gamma, beta, affine_out=None, raw16=False):
     shift = (be - mean * inv * g).float()
     if affine_out is not None:      # tests: the per-sample, per-channel affine [B, 2, C]
         affine_out.append(torch.stack([scale.flatten(1), shift.flatten(1)], dim=1).numpy())
-    if raw16:
+    if raw16 == "scaled":
+        # the kernels' power-of-two pre-scale made explicit (needed only where raw values leave fp16's RANGE, e.g. tests/test_gpu_calibrate.py's mis-scaled
+        # networks; in-range values round identically with and without it): bring each sample's rms to ~1 before the fp16 rounding
+        rms = torch.sqrt((xd ** 2).mean(dim=(1, 2, 3), keepdim=True)).clamp_min(1e-300)
+        p2 = torch.exp2(-torch.round(torch.log2(rms))).float()
+        x = (x * p2).half().float() / p2
+    elif raw16:
         x = x.half().float()
     return torch.relu(x * scale + shift)
 
@@ -180,7 +186,8 @@ def conv_split_f16(fn, x, w):
 
 
 def forward(weights, net_input, coord_net=True, return_activations=False, bf16=False, split3_products=False):
-    """split3_products: False | True (six bf16 products, conv_split3) | "f16" (three fp16 products, conv_split_f16)."""
+    """split3_products: False | True (six bf16 products, conv_split3) | "f16" (three fp16 products, conv_split_f16).
+    bf16: False | True | "scaled" (True with the fp16 raw storage's power-of-two pre-scale explicit: layer_norm_relu)."""
     return _forward(weights, net_input, coord_net, return_activations, bf16, split3_products)
 
 
