@@ -43,3 +43,31 @@ def test_thousands_of_back_to_back_forwards_are_bit_identical(env, coord, f16, f
         bad += sum(0 if torch.equal(o, first) else 1 for o in outs)
     assert m.network_status() == 0
     assert bad == 0, "%d of %d forwards differ from the first" % (bad, runs)
+
+
+@pytest.mark.parametrize("shape,runs,expect", [
+    pytest.param((1, 320, 640, 192, 64, 64), 1500, "config1", id="headline-coordnet-bf16x6-1x320x640"),
+    pytest.param((4, 640, 1280, 192, 64, 64), 1500, "big", id="config3-grid-coordnet-bf16x6-4x640x1280"),
+])
+def test_the_headline_plan_and_a_configs3_grid_are_bit_identical_over_thousands_of_forwards(env, shape, runs, expect):
+    """the detector above stressed msi_train_net and CoordNet on the fp16 form, not the DEFAULT plan of BASELINE configs[1] (CoordNet, six-product
+    form, 1 x 320 x 640: conv_halo8_x3 / convt_halo8_x3 / conv_halo8_s2_x3 and the row-parity conv_halo_x3<3, ...> kernels, all new in r05) nor a configs[3] / [4] grid
+    (every layer on whole 8-row tiles).  The kernel list is asserted, so the test cannot silently stress something else after a plan change."""
+    torch, MSI, nets, N, onets = env
+    from tests.test_gpu_bench_plans import F32_CONFIG1, F32_BIG_GRID
+    b, h, w, cin, nout, ngf = shape
+    m = MSI(weights=onets.init_weights(cin, nout, ngf=ngf, coord_net=True, seed=31, randomize_affine=True), coord_net=True)
+    x = torch.rand((b, h, w, cin), device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)) * 2 - 1
+    plan = m._plan(b, h, w, cin, nout, ngf)
+    kern = [plan.layer_kernel(i)[0] for i in range(17)]
+    assert kern == (F32_CONFIG1 if expect == "config1" else F32_BIG_GRID), kern
+    if expect == "config1":
+        assert {"conv_halo8_x3_kernel<0, 3>", "conv_halo8_x3_kernel<1, 3>", "convt_halo8_x3_kernel", "conv_halo8_s2_x3_kernel<1>", "conv_halo_x3_kernel<3, 1, 3>"} <= set(kern)
+    first = m.run_net(x, nout, ngf).clone()
+    assert bool(torch.isfinite(first).all())
+    bad = 0
+    for i in range(runs // 3):
+        outs = [m.run_net(x, nout, ngf).clone() for _ in range(3)]
+        bad += sum(0 if torch.equal(o, first) else 1 for o in outs)
+    assert m.network_status() == 0
+    assert bad == 0, "%d of %d forwards differ from the first" % (bad, runs)
