@@ -40,7 +40,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int ABL = MSI_HALO_ABLATE;
 #ifdef MSI_CONV_TIMING
-  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime(), ts0r = __builtin_amdgcn_s_memrealtime();   // (ts0r: the constant 100 MHz counter, tools/clock_probe.sh)
 #endif
   typedef HaloGeomB<BM, BN, RATE> G;
   constexpr int NTHR = 64 * NW, WR = NW / 2;                   // NW = 4 or 8 waves in WR x 2: a wave owns 32 MT x 32 NT of the tile
@@ -307,7 +307,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
 #ifdef MSI_CONV_TIMING
   if (p.dbg && tid == 0) {
     unsigned long long *o = p.dbg + (size_t)blockIdx.x * 24;
-    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime(); o[22] = ts0r; o[23] = __builtin_amdgcn_s_memrealtime();
     o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
     o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
   }
@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 convt_halo_bf16_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifdef MSI_CONV_TIMING
-  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime(), ts0r = __builtin_amdgcn_s_memrealtime();   // (ts0r: the constant 100 MHz counter, tools/clock_probe.sh)
 #endif
   typedef HaloGeomB<BM, BN, 1> G;
   constexpr int PW = G::PW, NPX = G::NPX, NLOAD = G::NLOAD, MT = BM / 64, NT = BN / 64;
@@ -861,7 +861,7 @@ convt_halo_bf16_kernel(const ConvParams p) {
 #ifdef MSI_CONV_TIMING
   if (p.dbg && tid == 0) {
     unsigned long long *o = p.dbg + (size_t)blockIdx.x * 24;
-    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime(); o[22] = ts0r; o[23] = __builtin_amdgcn_s_memrealtime();
     o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
     o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
   }

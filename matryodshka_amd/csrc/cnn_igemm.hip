@@ -20,7 +20,7 @@ conv_igemm_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
 #ifdef MSI_CONV_TIMING
-  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime(), ts0r = __builtin_amdgcn_s_memrealtime();   // (ts0r: the constant 100 MHz counter, tools/clock_probe.sh)
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -413,7 +413,7 @@ _Pragma("unroll")                                                               
   auto stamp = [&]() __attribute__((always_inline)) {
     if (p.dbg && tid == 0) {
       unsigned long long *o = p.dbg + (size_t)blockIdx.x * 24;
-      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime(); o[22] = ts0r; o[23] = __builtin_amdgcn_s_memrealtime();
       o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: wave, simd, cu, sh, se ...
       o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // XCC_ID
     }

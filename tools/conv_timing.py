@@ -56,6 +56,10 @@ for li in layers:
     dur = t[:, 3] - t[:, 0]
     print("%-10s blocks %5d  span %8d ticks | per block: prologue %6.0f  loop %8.0f  epilogue %6.0f  total %8.0f (min %d max %d) | sum(block time)/span = %.2f resident blocks" % (
         names[li], len(t), span, pro.mean(), loop.mean(), epi.mean(), dur.mean(), dur.min(), dur.max(), dur.sum() / span))
+    if t[:, 22].any() and t[:, 23].any():   # (r06) s_memrealtime at entry / exit: the constant 100 MHz counter -> the clock s_memtime advanced at under THIS kernel
+        real = (t[:, 23].max() - t[:, 22].min()) / 100e6
+        print("           launch span %.1f us by s_memrealtime (100 MHz) -> s_memtime advanced at %.3f GHz; k-loop share of a block's ticks %.0f %%" % (
+            real * 1e6, span / real / 1e9, 100.0 * loop.sum() / dur.sum()))
     if t[:, 6].any() and t[:, 10].any():   # stamps inside the prologue of conv_halo_bf16_kernel
         e = t[t[:, 6] != 0]
         ln = (e[:, 8] - e[:, 7]).mean() if e[:, 8].any() else 0.0
