@@ -181,6 +181,35 @@ def geometry_bytes(h, w, d, psv_bytes=4):
 _ORIG_AFFINITY = None
 
 
+def sustained_matrix_rate(dev, seconds=0.25):
+    """What THIS part's matrix pipes sustain on CHANGING bf16 operands with nothing else running (msi_probe_matrix_rate; tools/ubench/clock_probe.hip,
+    profiles/r06_clock.txt): dense bf16 PFLOP/s, and the shader clock (s_memtime cycles per s_memrealtime second) it ran at.  The 2.5 PFLOP/s dense peak is a
+    constant-operand figure at 2.4 GHz; under changing operands the clock itself falls (power), so `roofline.frac_of_sustained` prices the convolutions
+    against what the silicon delivers before a single byte is fed to it.  ~0.6 s, after the timed regions."""
+    from matryodshka_amd import _native as N
+    nwg = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+    ticks = torch.zeros((nwg, 2), dtype=torch.int64, device=dev)
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    for changing in (1, 0):
+        iters = 20000
+        for attempt in range(3):                   # calibrate the iteration count to ~`seconds`, then measure
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            N.check(N.lib.msi_probe_matrix_rate(changing, iters, nwg, ticks.data_ptr(), sink.data_ptr(), stream), "msi_probe_matrix_rate")
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            if attempt < 2:
+                iters = max(1000, int(iters * seconds * 1e3 / max(ms, 1e-3)))
+        t = ticks.cpu().numpy().astype(np.float64)
+        ghz = float(np.median(t[:, 0] / (t[:, 1] / 100e6))) / 1e9
+        out["changing" if changing else "constant"] = {"pflops": round(nwg * 4 * iters * 12 * 2 * 32 * 32 * 16 / (ms * 1e-3) / 1e15, 4), "shader_clock_ghz": round(ghz, 3),
+                                                        "ms": round(ms, 1)}
+    return out
+
+
 def pin_to_gpu_numa_node(device_index):
     """Pin this rank's launch thread (and the threads it starts) to the CPUs local to its GPU: the PCI device's
     `local_cpulist` under /sys (eight GPUs hang off two sockets; a rank launching from the far socket pays a cross-socket
@@ -636,8 +665,10 @@ def main():
     if args.substreams > 1:   # the per-stage pass runs the whole batch on one stream: not the configuration that was timed
         stages["note"] = "per-stage pass = whole batch on ONE stream (substreams only changes the timed region)"
 
+    sustained = sustained_matrix_rate(dev)
     unit = "faces/s" if cfg["kind"] == "pp" else "frames/s"
     arithmetic = None
+    nx2 = nx3 = 0
     if B > 0:
         plan = model._plan(B, H, W, cin, nout, NGF)
         kern = [plan.layer_kernel(i)[0] for i in range(17)]
@@ -679,7 +710,12 @@ def main():
                                   "(s_memtime ticks against wall time, tools/conv_timing.py / profiles/r04_e_conv_phase_timing.txt): the conv kernels are power-bound (DESIGN.md section 4); a matrix-only loop with CHANGING fp16 operands sustains 1.61-1.79 PFLOP/s on this part (tools/ubench/lds_mfma_rate.hip, "
                                   "profiles/r04_f_lds_mfma_rate.txt), i.e. 537-595 fp32-equivalent TFLOP/s for the three-product form",
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4),
-                     "frac_of_fp32_mfma_peak": None if bf16 else round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                     "frac_of_fp32_mfma_peak": None if bf16 else round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "frac_of_sustained": round(cnn_tflops / (peak * sustained["changing"]["pflops"] * 1e3 / PEAK_BF16_MFMA_TFLOPS), 4) if (bf16 or nx2 + nx3 == 17) else None,
+                     "sustained_matrix_rate": dict(sustained, note="msi_probe_matrix_rate on THIS box after the timed regions: matrix-only loop (no memory / LDS traffic), bf16 MFMA back to back, on operands that "
+                                                   "change between consecutive instructions vs constant ones; dense PFLOP/s and the shader clock (s_memtime cycles per s_memrealtime second). "
+                                                   "frac_of_sustained = achieved / (peak x changing.pflops / 2.5): an EXTRA key, `frac` stays on the nominal peak (profiles/r06_clock.txt)"),
+                     "traffic": traffic,
                      "traffic_stale": traffic_stale,
                      "algorithmic_bytes": conv_bytes,
                      "traffic_ratio": None if traffic is None else round(traffic / conv_bytes, 3),

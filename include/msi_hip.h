@@ -61,13 +61,21 @@ const char *msi_version(void);
  *   4: msi_net_plan_layer_kernel; render status word (msi_render_status_*); sweep volume takes shared poses (round 4)
  *   5: packed blob carries the fp16-split (x2) block; MSI_NET_OPT_F32_SPLIT_F16, MSI_NET_STATUS_F16_SPLIT_RANGE (round 4)
  *   6: msi_net_plan_calibrate; MSI_NET_OPT_X3_TILE8 (round 5)
- *   7: MSI_NET_OPT_X3_ROWPAR (round 5) */
-#define MSI_ABI_VERSION 7
+ *   7: MSI_NET_OPT_X3_ROWPAR (round 5)
+ *   8: msi_probe_matrix_rate (round 6) */
+#define MSI_ABI_VERSION 8
 int32_t msi_abi_version(void);
 const char *msi_last_error_string(void);
 /* CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 for a new message): the per-tensor checksum of
  * the TensorFlow checkpoints test.py:191-202 restores (matryodshka_amd/tf_checkpoint.py verifies it on load). */
 uint32_t msi_crc32c_host(const void *data_host, size_t n, uint32_t crc);
+
+/* Measurement aid (round 6; bench.py's `roofline.frac_of_sustained`; no reference counterpart): `num_workgroups` workgroups of four waves issue
+ * `iterations` x 12 v_mfma_f32_32x32x16_bf16 back to back per wave -- no memory or LDS traffic -- on operands that change between consecutive instructions
+ * (changing_operands = 1) or stay constant (0).  Dense bf16 flops = num_workgroups x 4 x iterations x 12 x 2 x 32 x 32 x 16; time it with events on `stream`.
+ * ticks_device (may be NULL): [num_workgroups][2] = per-workgroup deltas of s_memtime (shader-clock cycles) and s_memrealtime (100 MHz).  sink_device: one float. */
+int32_t msi_probe_matrix_rate(int32_t changing_operands, int64_t iterations, int32_t num_workgroups, uint64_t *ticks_device, float *sink_device,
+                              msi_stream_t stream);
 
 /* ---- geometry tables (host) -------------------------------------------------
  * spherical.lat_long_grid (spherical.py:42-44) is separable; the kernels take

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmsi_hip.so")
 MSI_OK = 0
 MSI_NET_NUM_LAYERS = 18
 RENDER_STATUS_ORIGIN_OUTSIDE = 1
-MSI_ABI_VERSION = 7          # include/msi_hip.h: the version this binding's struct layouts and signatures are written for
+MSI_ABI_VERSION = 8          # include/msi_hip.h: the version this binding's struct layouts and signatures are written for
 
 
 class MsiError(RuntimeError):
@@ -55,6 +55,7 @@ SIGNATURES = {
     "msi_abi_version": (c_int32, []),
     "msi_last_error_string": (c_char_p, []),
     "msi_crc32c_host": (ctypes.c_uint32, [_P, c_size_t, ctypes.c_uint32]),
+    "msi_probe_matrix_rate": (_I, [_I, ctypes.c_int64, _I, _P, _P, _P]),
     "msi_trig_table_floats": (c_size_t, [_I, _I]),
     "msi_build_trig_tables_host": (_I, [_I, _I, _P]),
     "msi_preprocess_u8_f32": (_I, [_P, _P, c_size_t, _P]),

@@ -21,6 +21,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE
 NO_SLP = ["-fno-slp-vectorize"]
 SOURCES = [
     ("common.cpp", ["-x", "hip"]),
+    ("probe.hip", []),                                                     # msi_probe_matrix_rate (measurement aid of bench.py)
     ("geometry.hip", ["-ffp-contract=off"] + NO_SLP + os.environ.get("MSI_GEO_DEFINES", "").split()),   # e.g. MSI_GEO_DEFINES="-DMSI_SWEEP_WAVES=5" (tuning)
 ]
 # the K2 convolution path: one translation unit per kernel family (r05; cnn_device.h holds what they share), compiled in parallel

@@ -414,7 +414,8 @@ __device__ __forceinline__ void conv_halo_x3_body(const ConvParams &p, char *sme
       o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime(); o[22] = ts0r; o[23] = __builtin_amdgcn_s_memrealtime();
       o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
       o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
-    };
+    }
+  };
 #endif
   if (!full) {
     constexpr int SLAB = BM * 64 * 4;

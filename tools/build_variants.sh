@@ -22,7 +22,7 @@ for spec in "$@"; do
       /opt/rocm/bin/hipcc $COMMON $BASE_CNN $flags -c matryodshka_amd/csrc/$u.hip -o /tmp/vbuild/${u}_$name.o 2>>/tmp/vbuild/$name.log || ok=0
       objs="$objs /tmp/vbuild/${u}_$name.o"
     done
-    [ $ok == 1 ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_variants/libmsi_$name.so matryodshka_amd/csrc/_obj/common.o $geo $objs &&
+    [ $ok == 1 ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_variants/libmsi_$name.so matryodshka_amd/csrc/_obj/common.o matryodshka_amd/csrc/_obj/probe.o $geo $objs &&
     echo "built $name (cnn: $BASE_CNN $flags; geometry: $BASE_GEO $gflags)" || { echo "FAILED $name"; tail -5 /tmp/vbuild/$name.log; } ) &
   pids+=($!)
 done

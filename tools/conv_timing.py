@@ -57,9 +57,19 @@ for li in layers:
     print("%-10s blocks %5d  span %8d ticks | per block: prologue %6.0f  loop %8.0f  epilogue %6.0f  total %8.0f (min %d max %d) | sum(block time)/span = %.2f resident blocks" % (
         names[li], len(t), span, pro.mean(), loop.mean(), epi.mean(), dur.mean(), dur.min(), dur.max(), dur.sum() / span))
     if t[:, 22].any() and t[:, 23].any():   # (r06) s_memrealtime at entry / exit: the constant 100 MHz counter -> the clock s_memtime advanced at under THIS kernel
-        real = (t[:, 23].max() - t[:, 22].min()) / 100e6
-        print("           launch span %.1f us by s_memrealtime (100 MHz) -> s_memtime advanced at %.3f GHz; k-loop share of a block's ticks %.0f %%" % (
-            real * 1e6, span / real / 1e9, 100.0 * loop.sum() / dur.sum()))
+        # per CU (s_memtime is a per-XCD counter: spans are only meaningful within one CU): ticks between the CU's first entry and last exit over the same interval in real time
+        hw_, xcc_ = t[:, 4], t[:, 5] & 0xf
+        key_ = (xcc_ << 16) | (((hw_ >> 13) & 0x7) << 12) | (((hw_ >> 12) & 0x1) << 8) | ((hw_ >> 8) & 0xf)
+        ghz, real_us = [], []
+        for k_ in np.unique(key_):
+            b_ = t[key_ == k_]
+            rt = (b_[:, 23].max() - b_[:, 22].min()) / 100e6
+            if rt > 2e-6:
+                ghz.append((b_[:, 3].max() - b_[:, 0].min()) / rt / 1e9)
+                real_us.append(rt * 1e6)
+        if ghz:
+            print("           launch span %.1f us by s_memrealtime (100 MHz) -> s_memtime advanced at %.3f GHz (median of %d CUs; min %.3f max %.3f); k-loop share of a block's ticks %.0f %%" % (
+                (t[:, 23].max() - t[:, 22].min()) / 100.0, float(np.median(ghz)), len(ghz), min(ghz), max(ghz), 100.0 * loop.sum() / dur.sum()))
     if t[:, 6].any() and t[:, 10].any():   # stamps inside the prologue of conv_halo_bf16_kernel
         e = t[t[:, 6] != 0]
         ln = (e[:, 8] - e[:, 7]).mean() if e[:, 8].any() else 0.0
