@@ -426,6 +426,21 @@ __device__ __forceinline__ void gather3(__amdgpu_buffer_rsrc_t img, const TapsB 
   out[2] = blend4(t, a.z, b.z, c.z, d.z);
 }
 
+// The 16-byte pieces of a wave's whole-pixel strip.  nt != 0 (block-uniform; the host sets it when the volume is larger than the 256-MB Infinity Cache): non-temporal
+// stores -- a volume that cannot stay cached until conv1_1 reads it should not evict what can (r06, same-box A/B at configs[2]: sweep 1.07 -> 0.98 ms per 16 frames;
+// configs[3] -1 %; at batch 1 the 157-MB volume stays cached and keeps plain stores).  -DMSI_SWEEP_ABLATE_STORE: timing experiment only (no stores at all).
+__device__ __forceinline__ void sweep_store16(uint4 *dst, const uint4 &v, int nt) {
+#ifdef MSI_SWEEP_ABLATE_STORE
+  if (nt < 0) *dst = v;
+#else
+  if (nt) {
+    __builtin_nontemporal_store(v.x, &dst->x); __builtin_nontemporal_store(v.y, &dst->y); __builtin_nontemporal_store(v.z, &dst->z); __builtin_nontemporal_store(v.w, &dst->w);
+  } else {
+    *dst = v;
+  }
+#endif
+}
+
 // One work item = (pixel, NS consecutive depths) for up to `bchunk` frames of the batch; depth is the fastest index so a
 // wavefront's 64 lanes write 64 x NS consecutive 12-byte texels of the NHWC volume.  The source images (2.4 MB) stay L2-resident.
 // OutT = float, or unsigned short = bf16 bits (the bf16 network input of BASELINE configs[2]).
@@ -574,7 +589,7 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
       uint4 *dst = reinterpret_cast<uint4 *>(psv + first);
       constexpr int NV = WAVE_ELEMS * (int)sizeof(OutT) / 16;
 #pragma unroll
-      for (int k = lane; k < NV; k += 64) dst[k] = src[k];
+      for (int k = lane; k < NV; k += 64) sweep_store16(dst + k, src[k], coalesce >> 1);
       continue;
     }
 #pragma unroll
@@ -587,6 +602,248 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
         store_elem(psv, o + q * 3 + 2, out[sidx][q][2]);
       }
     }
+  }
+}
+
+// ---- K1 with an LDS-staged source patch (round 6) --------------------------------
+// What bounds ods_sweep_kernel once the corners are reused across frames is neither bytes (1.07 x the algorithmic traffic) nor VALU but the
+// SIXTEEN dependent 12-byte gathers per thread and frame through the vector L1's address path (~21 cycles per instruction and CU).  The
+// footprint of those gathers is tiny: a block's 256 / ng pixels of one row sample, over all depths and both sources, a patch of a few rows
+// x (pixels + 2 disparities) columns of each image.  This kernel stages that patch once per frame and block in LDS -- coalesced row segments,
+// texels padded to 16 bytes -- and gathers with ds_read_b128 (two address registers per sample: the corners are base, base + 16, base + pitch,
+// base + pitch + 16) instead of buffer_load_dwordx3.  The patch is found, not assumed: when a thread computes its corners it also takes the
+// UNWRAPPED corner (x0, y0) relative to the block's own position (W - 1 - j0, i), wrapped into [-n/2, n/2) so that the seam is nothing special;
+// a block-wide min / max gives the box, and a block whose box does not fit (polar rows, where the disparity grows like 1 / cos(lat); rows whose
+// near planes are invalid and sample pixel (1, 1); rotated poses) keeps gathering from memory exactly as ods_sweep_kernel does -- a block-uniform
+// choice made once per (pose, baseline), not per frame.  Same corners, same weights, same blend: the volume is bit-identical.
+// Frames: patch buffers alternate (frame b in buffer b & 1), so ONE block barrier per frame orders both "patch b is visible" and "everybody is
+// done with patch b - 1"; the next frame's texels are requested into registers before this frame's gathers.
+constexpr int SW_PMAX = 384;                 // texels per source and buffer (16 B each): 2 buffers x 2 sources x 6 KB
+constexpr int SW_NST = (SW_PMAX + 255) / 256;   // texels a thread stages per source
+
+struct TapsL {
+  TapsB t;
+  int x0, y0;                                // unwrapped, clamped corner (make_taps_ranged's x0 / y0)
+};
+__device__ __forceinline__ TapsL make_taps_lds(float u, float v, int width, int height) {
+  TapsL r;
+  r.t = make_taps_bytes(u, v, width, height);
+  r.x0 = max(-1, min((int)floorf(u), width - 1));
+  r.y0 = max(-1, min((int)floorf(v), height - 1));
+  return r;
+}
+__device__ __forceinline__ int centred(int d, int n) {          // d in (-2n, 2n) -> the representative of d mod n in [-n/2, n/2)
+  const int half = n >> 1;
+  d = d < -half ? d + n : d;
+  d = d >= n - half ? d - n : d;
+  d = d < -half ? d + n : d;
+  d = d >= n - half ? d - n : d;
+  return d;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <typename OutT, int NS>
+__global__ void __launch_bounds__(256)
+ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__ image1, const float *__restrict__ pose0,
+                     const float *__restrict__ pose1, const float *__restrict__ intrinsics, const float *__restrict__ depths,
+                     const float *__restrict__ trig, int batch, int height, int width, int nd,
+                     OutT *__restrict__ psv, int channels, PixConsts K, unsigned ng_magic, int bchunk, int nt) {
+  // grid as ods_sweep_kernel<OutT, NS, 2, 1> with the whole-pixel store path; the host guarantees 256 % ng == 0 and (W * ng) % 256 == 0,
+  // so every block is full and owns 256 / ng complete pixels of row blockIdx.y
+  const int ng = nd / NS;
+  const int tid = threadIdx.x;
+  const int idx = blockIdx.x * 256 + tid;
+  unsigned jq = __umulhi((unsigned)idx, ng_magic);
+  if ((unsigned)idx - jq * (unsigned)ng >= (unsigned)ng) ++jq;
+  const int j = (int)jq, d0 = (idx - j * ng) * NS;
+  const int i = blockIdx.y;
+  const int b_lo = blockIdx.z * bchunk, b_hi = min(batch, b_lo + bchunk);
+  unsigned j0q = __umulhi((unsigned)(blockIdx.x * 256), ng_magic);
+  if ((unsigned)(blockIdx.x * 256) - j0q * (unsigned)ng >= (unsigned)ng) ++j0q;
+  const int xc = width - 1 - (int)j0q;        // where the block's first pixel samples at infinite depth (identity pose): the centre the box is measured from
+
+  const float cs = trig[j], ss = trig[width + j];
+  const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
+  const int img_bytes = height * width * 12;
+  const float csct = cs * ct, ssct = ss * ct;
+  float depth[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) depth[q] = depths[d0 + q];
+
+  const int lane = tid & 63, wave = tid >> 6;
+  unsigned plq = __umulhi((unsigned)lane, ng_magic);
+  if ((unsigned)lane - plq * (unsigned)ng >= (unsigned)ng) ++plq;
+  const int pl = (int)plq, dg = lane - pl * ng;
+  constexpr int WAVE_ELEMS = 384 * NS;
+  __shared__ __attribute__((aligned(16))) OutT s_out[4][WAVE_ELEMS];
+  __shared__ __attribute__((aligned(16))) float4 s_patch[2][2][SW_PMAX];     // [buffer][source][texel]
+  __shared__ int s_box[4];
+
+  unsigned eqmask = 0;
+  {
+    const unsigned *U0 = reinterpret_cast<const unsigned *>(pose0), *U1 = reinterpret_cast<const unsigned *>(pose1);
+    const unsigned *UI = reinterpret_cast<const unsigned *>(intrinsics);
+    for (int b = b_lo + 1; b < b_hi; ++b) {
+      bool eq = UI[(size_t)b * 9] == UI[(size_t)(b - 1) * 9];
+#pragma unroll
+      for (int k = 0; k < 12; ++k)
+        eq = eq && (U0[(size_t)b * 16 + k] == U0[(size_t)(b - 1) * 16 + k]) && (U1[(size_t)b * 16 + k] == U1[(size_t)(b - 1) * 16 + k]);
+      eqmask |= (eq ? 1u : 0u) << (b - b_lo);
+    }
+    eqmask = __builtin_amdgcn_readfirstlane(eqmask);
+  }
+  TapsB taps[2][NS];
+  int lbase[2][NS];                            // float4 index of a sample's corner (y0, x0) in its source's patch
+  unsigned goff[SW_NST];                       // byte offset in the image of the texels this thread stages (same for both sources), ~0u = none
+  f32x3_g stg[2][SW_NST];
+  int pitch = 0;
+  bool lds_mode = false, pending = false;
+  auto stage_load = [&](int b) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t im0 = __builtin_amdgcn_make_buffer_rsrc((void *)(image0 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t im1 = __builtin_amdgcn_make_buffer_rsrc((void *)(image1 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < SW_NST; ++k) {           // (offsets beyond the descriptor -- ~0u -- return zeros: texels nobody reads)
+      stg[0][k] = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(im0, goff[k], 0, 0));
+      stg[1][k] = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(im1, goff[k], 0, 0));
+    }
+  };
+  for (int b = b_lo; b < b_hi; ++b) {
+    const float *P0 = pose0 + (size_t)b * 16;
+    const float *P1 = pose1 + (size_t)b * 16;
+    const bool reuse = (eqmask >> (b - b_lo)) & 1u;
+    float out[2][NS][3];
+    if (!reuse) {
+      const float r = intrinsics[(size_t)b * 9];
+      bool same = true;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) same = same && (P0[k] == P1[k]);
+      int xr[2][NS], yr[2][NS];
+      int xmin = 0x7fffffff, xmax = -0x7fffffff, ymin = 0x7fffffff, ymax = -0x7fffffff;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        float u, v;
+        const OdsQuad q0 = ods_quad(P0, r, depth[q], csct, st, ssct);
+        ods_tail(q0, 1.0f, K, u, v);
+        TapsL t0 = make_taps_lds(u, v, width, height);
+        if (same) {
+          ods_tail(q0, -1.0f, K, u, v);
+        } else {
+          const OdsQuad q1 = ods_quad(P1, r, depth[q], csct, st, ssct);
+          ods_tail(q1, -1.0f, K, u, v);
+        }
+        TapsL t1 = make_taps_lds(u, v, width, height);
+        taps[0][q] = t0.t; taps[1][q] = t1.t;
+        xr[0][q] = centred(t0.x0 - xc, width); yr[0][q] = centred(t0.y0 - i, height);
+        xr[1][q] = centred(t1.x0 - xc, width); yr[1][q] = centred(t1.y0 - i, height);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          xmin = min(xmin, xr[s_][q]); xmax = max(xmax, xr[s_][q]);
+          ymin = min(ymin, yr[s_][q]); ymax = max(ymax, yr[s_][q]);
+        }
+      }
+      // the block's box (both sources share it: the two disparities mirror each other around the same centre)
+      if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = -0x7fffffff; s_box[2] = 0x7fffffff; s_box[3] = -0x7fffffff; }
+      __syncthreads();
+      xmin = wave_min_i(xmin); xmax = wave_max_i(xmax); ymin = wave_min_i(ymin); ymax = wave_max_i(ymax);
+      if (lane == 0) { atomicMin(&s_box[0], xmin); atomicMax(&s_box[1], xmax); atomicMin(&s_box[2], ymin); atomicMax(&s_box[3], ymax); }
+      __syncthreads();
+      xmin = s_box[0]; xmax = s_box[1]; ymin = s_box[2]; ymax = s_box[3];
+      const int pw = xmax - xmin + 2, ph = ymax - ymin + 2;          // (+ the x1 / y1 corners)
+      pitch = ((pw + 7) & ~15) + 8;                                   // >= pw, = 8 mod 16: consecutive patch rows start half the banks apart
+      lds_mode = ph * pitch <= SW_PMAX;
+      pending = false;
+      if (lds_mode) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          lbase[0][q] = (yr[0][q] - ymin) * pitch + (xr[0][q] - xmin);
+          lbase[1][q] = (yr[1][q] - ymin) * pitch + (xr[1][q] - xmin);
+        }
+        const float rp = 1.0f / (float)pitch;
+#pragma unroll
+        for (int k = 0; k < SW_NST; ++k) {
+          const int t = tid + k * 256;
+          int yy = (int)(((float)t + 0.5f) * rp);                     // t / pitch (t < 512, pitch <= 384: exact up to the correction below)
+          yy += (t - yy * pitch >= pitch) ? 1 : 0;
+          yy -= (t - yy * pitch < 0) ? 1 : 0;
+          const int xx = t - yy * pitch;
+          const int row = floor_mod(i + ymin + yy + height, height), col = floor_mod(xc + xmin + xx + width, width);
+          goff[k] = (t < SW_PMAX && yy < ph && xx < pw) ? __umul24((unsigned)(row * width + col), 12u) : 0xffffffffu;
+        }
+      }
+    }
+    if (lds_mode) {
+      if (!pending) stage_load(b);
+      float4 *pb0 = s_patch[b & 1][0], *pb1 = s_patch[b & 1][1];
+#pragma unroll
+      for (int k = 0; k < SW_NST; ++k) {
+        const int t = tid + k * 256;
+        if (t < SW_PMAX) {
+          pb0[t] = float4{stg[0][k].x, stg[0][k].y, stg[0][k].z, 0.f};
+          pb1[t] = float4{stg[1][k].x, stg[1][k].y, stg[1][k].z, 0.f};
+        }
+      }
+      __syncthreads();                                                 // patch b visible; everybody is done with patch b - 1 (its buffer is free for b + 1)
+      pending = (b + 1 < b_hi) && ((eqmask >> (b + 1 - b_lo)) & 1u);
+      if (pending) stage_load(b + 1);
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          const float4 *pp = (s_ ? pb1 : pb0) + lbase[s_][q];
+          const float4 a = pp[0], bb = pp[1], c = pp[pitch], d = pp[pitch + 1];
+          const TapsB &t = taps[s_][q];
+          out[s_][q][0] = blend4(t, a.x, bb.x, c.x, d.x);
+          out[s_][q][1] = blend4(t, a.y, bb.y, c.y, d.y);
+          out[s_][q][2] = blend4(t, a.z, bb.z, c.z, d.z);
+        }
+    } else {
+      const __amdgpu_buffer_rsrc_t img0 = __builtin_amdgcn_make_buffer_rsrc((void *)(image0 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t img1 = __builtin_amdgcn_make_buffer_rsrc((void *)(image1 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        gather3(img0, taps[0][q], out[0][q]);
+        gather3(img1, taps[1][q], out[1][q]);
+      }
+    }
+    // whole-pixel stores through the wave's strip: exactly ods_sweep_kernel's
+    const long p = ((long)b * height + i) * width + j;
+    OutT *w = s_out[wave];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const int e0 = pl * 6 * nd + sidx * 3 * nd + dg * NS * 3;
+      if constexpr (sizeof(OutT) == 2 && NS % 2 == 0) {
+        unsigned *wd = reinterpret_cast<unsigned *>(w + e0);
+        const float *v = &out[sidx][0][0];
+#pragma unroll
+        for (int k = 0; k < 3 * NS / 2; ++k) {
+          unsigned pk;
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(v[2 * k]), "v"(v[2 * k + 1]));
+          wd[k] = pk;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) store_elem(w, (size_t)(e0 + q * 3 + c), out[sidx][q][c]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const size_t first = (size_t)(p - pl) * channels;
+    const uint4 *src = reinterpret_cast<const uint4 *>(w);
+    uint4 *dst = reinterpret_cast<uint4 *>(psv + first);
+    constexpr int NV = WAVE_ELEMS * (int)sizeof(OutT) / 16;
+#pragma unroll
+    for (int k = lane; k < NV; k += 64) sweep_store16(dst + k, src[k], nt);
   }
 }
 
@@ -1257,6 +1514,12 @@ int msi_compose_poses_f32(const float *lhs, const float *rhs, float *out, int32_
 #ifndef MSI_SWEEP_BCHUNK
 #define MSI_SWEEP_BCHUNK 16
 #endif
+#ifndef MSI_SWEEP_NT   // -1 never / 0 by volume size / 1 always (A/B builds)
+#define MSI_SWEEP_NT 0
+#endif
+#ifndef MSI_SWEEP_LDS_MIN_BATCH   // smallest batch that takes ods_sweep_lds_kernel (tuning: -DMSI_SWEEP_LDS_MIN_BATCH=1 / a huge value)
+#define MSI_SWEEP_LDS_MIN_BATCH 2
+#endif
 static int sweep_common(const float *image, const float *image1, const float *pose, const float *pose1,
                         const float *intrinsics,
                         const float *depths, const float *trig, int32_t batch,
@@ -1280,16 +1543,30 @@ static int sweep_common(const float *image, const float *image1, const float *po
   // corners when their poses / baselines agree; chunks keep grid.z >= 1 and every chunk but the last full
   const int bchunk = batch < MSI_SWEEP_BCHUNK ? batch : MSI_SWEEP_BCHUNK;
   const dim3 grid((unsigned)(((long)width * (num_depths / ns) + 255) / 256), height, (batch + bchunk - 1) / bchunk);
+  // non-temporal whole-pixel stores when the volume cannot stay in the 256-MB Infinity Cache anyway (sweep_store16)
+  const int nt = MSI_SWEEP_NT < 0 ? 0 : (MSI_SWEEP_NT > 0 || (size_t)batch * height * width * psv_channels * (psv_bf16 ? 2 : 4) > ((size_t)256 << 20)) ? 1 : 0;
 #define MSI_LAUNCH_SWEEP(T, NS_, NSRC_, LOOP_)                                                                          \
   hipLaunchKernelGGL((ods_sweep_kernel<T, NS_, NSRC_, LOOP_>), grid, dim3(256), 0, msi::as_stream(stream), image, image1, \
                      pose, pose1, intrinsics, depths, trig, batch, height, width, num_depths, (float)order,      \
                      static_cast<T *>(psv), psv_channels, channel_offset, make_consts(height, width),           \
                      (num_depths / NS_) == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)(num_depths / NS_)),  \
-                     (pair && 64 % (num_depths / NS_) == 0 && ((long)width * (num_depths / NS_)) % 64 == 0) ? 1 : 0, bchunk)
+                     (pair && 64 % (num_depths / NS_) == 0 && ((long)width * (num_depths / NS_)) % 64 == 0) ? 1 + 2 * nt : 0, bchunk)
 #define MSI_LAUNCH_SWEEP_N(T, NSRC_, LOOP_)                                                              \
   { if (ns == 4) MSI_LAUNCH_SWEEP(T, 4, NSRC_, LOOP_); else if (ns == 2) MSI_LAUNCH_SWEEP(T, 2, NSRC_, LOOP_); else MSI_LAUNCH_SWEEP(T, 1, NSRC_, LOOP_); }
 #define MSI_LAUNCH_SWEEP_L(T, NSRC_) { if (bchunk > 1) MSI_LAUNCH_SWEEP_N(T, NSRC_, 1) else MSI_LAUNCH_SWEEP_N(T, NSRC_, 0) }
 #define MSI_LAUNCH_SWEEP_T(T) { if (pair) MSI_LAUNCH_SWEEP_L(T, 2) else MSI_LAUNCH_SWEEP_L(T, 1) }
+  // the LDS-staged form (ods_sweep_lds_kernel): the double volume with whole-pixel stores, full blocks of complete pixels, NS = 2, and a batch worth a frame loop
+  const int ng2 = num_depths / 2;
+  if (pair && ns == 2 && batch >= MSI_SWEEP_LDS_MIN_BATCH && ng2 > 0 && 64 % ng2 == 0 && ((long)width * ng2) % 256 == 0) {
+    const unsigned magic = ng2 == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)ng2);
+    if (psv_bf16)
+      hipLaunchKernelGGL((ods_sweep_lds_kernel<unsigned short, 2>), grid, dim3(256), 0, msi::as_stream(stream), image, image1, pose, pose1, intrinsics, depths, trig, batch,
+                         height, width, num_depths, static_cast<unsigned short *>(psv), psv_channels, make_consts(height, width), magic, bchunk, nt);
+    else
+      hipLaunchKernelGGL((ods_sweep_lds_kernel<float, 2>), grid, dim3(256), 0, msi::as_stream(stream), image, image1, pose, pose1, intrinsics, depths, trig, batch,
+                         height, width, num_depths, static_cast<float *>(psv), psv_channels, make_consts(height, width), magic, bchunk, nt);
+    return msi::check_launch("ods_sphere_sweep (lds)");
+  }
   if (psv_bf16) MSI_LAUNCH_SWEEP_T(unsigned short) else MSI_LAUNCH_SWEEP_T(float)
 #undef MSI_LAUNCH_SWEEP_T
 #undef MSI_LAUNCH_SWEEP_L

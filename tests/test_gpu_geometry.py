@@ -386,6 +386,66 @@ def test_sweep_batch_loop_reuses_corners_only_between_equal_frames(gpu, b, d, bf
         assert np.abs(_np(whole) - want).max() <= TOL
 
 
+def _rot(ax, ay, az):
+    cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]); rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    m = np.eye(4); m[:3, :3] = rz @ ry @ rx
+    return m.astype(np.float32)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("h,w,d,b", [(24, 64, 16, 5), (40, 64, 32, 3), (16, 32, 64, 2), (24, 128, 8, 19)])
+def test_lds_staged_sweep_is_bit_identical_to_the_gather_kernel(gpu, h, w, d, b, bf16):
+    """Round 6: ods_sweep_lds_kernel stages the source patch a block's samples fall into in LDS and gathers from there; blocks whose box
+    does not fit keep gathering from memory.  Taken for the double volume at batch >= 2 when blocks are full ((W * D / 2) % 256 == 0).  It must reproduce, bit for
+    bit, (a) the two single-source sweeps (ods_sweep_kernel, the gather form) and (b) every frame swept alone (batch 1: gather form) -- on a batch that mixes identical
+    frames (corner reuse + patch prefetch), a translated source, a ROTATED source (samples anywhere: fallback blocks), a rotated reference, a large baseline
+    (wide polar boxes, invalid near planes sampling pixel (1, 1)), and, at b = 19, a second 16-frame chunk."""
+    torch, m, o = gpu
+    from matryodshka_amd import _native as N
+    assert (w * (d // 2)) % 256 == 0 and 64 % (d // 2) == 0
+    inp = make_inputs(77, b, h, w)
+    ref = m.preprocess_image(torch.from_numpy(inp["ref_image"]))
+    src = m.preprocess_image(torch.from_numpy(inp["src_image"]))
+    p0 = np.tile(np.eye(4, dtype=np.float32)[None], (b, 1, 1))
+    p1 = p0.copy()
+    intr = inp["intrinsics"].copy()
+    p1[1, 0, 3] = 0.01                                   # frame 1: translated source
+    if b > 2:
+        p1[2] = _rot(0.3, -0.5, 0.2); p1[2, :3, 3] = (0.01, -0.02, 0.005)      # frame 2: rotated source
+    if b > 3:
+        p0[3] = _rot(-0.1, 0.05, 0.0)                    # frame 3: rotated reference (frame 4 returns to the identity setting of frame 0)
+    if b > 6:
+        intr[5:7, 0, 0] = 0.4                            # frames 5, 6: a baseline 12 x the usual one, equal to each other (reuse with wide boxes)
+    if b > 17:
+        p1[17, 2, 3] = 0.015
+    t0, t1, ti = torch.from_numpy(p0).cuda(), torch.from_numpy(p1).cuda(), torch.from_numpy(intr).cuda()
+    depths = torch.tensor(m.inv_depths(1.0, 100.0, d), dtype=torch.float32).cuda()
+    trig = m._trig(h, w)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    whole = torch.full((b, h, w, 6 * d), 7.0, dtype=dt, device="cuda")
+    two = torch.zeros_like(whole)
+    alone = torch.zeros_like(whole)
+    N.check(N.lib.msi_ods_sweep_volume(ref.data_ptr(), src.data_ptr(), t0.data_ptr(), t1.data_ptr(), ti.data_ptr(),
+                                       depths.data_ptr(), trig.data_ptr(), b, h, w, d, whole.data_ptr(), int(bf16), None), "volume")
+    single = N.lib.msi_ods_sphere_sweep_bf16 if bf16 else N.lib.msi_ods_sphere_sweep_f32
+    for k, (img, pose, order) in enumerate(((ref, t0, 1), (src, t1, -1))):
+        N.check(single(img.data_ptr(), pose.data_ptr(), ti.data_ptr(), depths.data_ptr(), trig.data_ptr(), b, h, w, d,
+                       order, two.data_ptr(), 6 * d, k * 3 * d, None), "single")
+    for k in range(b):
+        N.check(N.lib.msi_ods_sweep_volume(ref[k:k + 1].data_ptr(), src[k:k + 1].data_ptr(), t0[k:k + 1].data_ptr(), t1[k:k + 1].data_ptr(),
+                                           ti[k:k + 1].data_ptr(), depths.data_ptr(), trig.data_ptr(), 1, h, w, d,
+                                           alone[k:k + 1].data_ptr(), int(bf16), None), "volume of one frame")
+    torch.cuda.synchronize()
+    assert torch.equal(whole, two), int((whole != two).sum())
+    assert torch.equal(whole, alone)
+    if not bf16:
+        G = __import__("oracle.geometry", fromlist=["x"])
+        want = np.concatenate([G.ods_sphere_sweep(o.preprocess_image(img), order, m.inv_depths(1.0, 100.0, d), pose, intr)
+                               for img, pose, order in ((inp["ref_image"], p0, 1), (inp["src_image"], p1, -1))], axis=3)
+        assert np.abs(_np(whole) - want).max() <= TOL
+
+
 def test_pair_launches_equal_single_ones(gpu):
     """preprocess / deprocess of the two images of a frame in one launch: same bits as the single-image entry points."""
     torch, m, o = gpu
