@@ -142,7 +142,10 @@ struct LayerLaunch {
 
 
 constexpr int HA_TP = 32;   // pixels per workgroup
-constexpr int HA_LG = 32;   // at most this many layers per workgroup: D = 64 runs as two layer groups (grid.y)
+#ifndef MSI_HA_LG
+#define MSI_HA_LG 32
+#endif
+constexpr int HA_LG = MSI_HA_LG;   // at most this many layers per workgroup: D = 64 runs as two layer groups (grid.y)
 
 struct HeadAsmParams {
   const float *x;            // conv8_2 raw [B,H,W,C0]
@@ -470,6 +473,9 @@ __device__ __forceinline__ void sum_slabs(f32x16 (&acc)[MT][NT], __amdgpu_buffer
 // the bf16 operand it becomes after the affine (measured on the oracle: mean |bf16 path - fp32 oracle| + 0.3 %; a bf16
 // raw output would be + 19 %).  The statistics are taken from the fp32 accumulators as before.
 constexpr int EPI_STAGE_BYTES = 48 * 1024;   // emit_whole_tile's staging strips (four waves x MT x 32 pixels x (row + 16 bytes)): what a caller that stages must own
+#ifndef MSI_EPI_NT   // experiment (r06): 1 = non-temporal stores of the staged epilogue's raw outputs
+#define MSI_EPI_NT 0
+#endif
 #ifndef MSI_EPI_ABLATE   // timing experiments only: 1 no stores, 2 no statistics atomics, 4 no statistics arithmetic
 #define MSI_EPI_ABLATE 0
 #endif
@@ -622,7 +628,7 @@ __device__ __forceinline__ void emit_whole_tile(const ConvParams &p, f32x16 (&ac
         // VALU write of vdata lost a few stores per launch on gfx950 (the next instruction was the address arithmetic of the following store, allocated onto the freed data
         // register).  The compiler's hazard recognizer inserts the wait state for wide stores only when soffset is NOT a register; with an SGPR there it emits none.  Proven by
         // inserting `s_nop 0` after the stores of ONE kernel in the assembly (profiles/r05_store_hazard.txt); matryodshka_amd/isa_lint.py now refuses a library with that sequence.
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pc[i][k]), rsrc_y, v0 + (unsigned)((ro * rowstep + co * colstep) * rowb), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pc[i][k]), rsrc_y, v0 + (unsigned)((ro * rowstep + co * colstep) * rowb), 0, MSI_EPI_NT ? 2 : 0);
       }
   }
   MSI_STAMP(17)

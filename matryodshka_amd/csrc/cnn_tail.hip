@@ -296,7 +296,11 @@ head_assemble_kernel(const HeadAsmParams p) {
       o.y = w * fg[1] + omw * bg[1];
       o.z = w * fg[2] + omw * bg[2];
       o.w = rq[lg + d];
+#if defined(MSI_HA_NT) && MSI_HA_NT
+      __builtin_nontemporal_store(o.x, &dst->x); __builtin_nontemporal_store(o.y, &dst->y); __builtin_nontemporal_store(o.z, &dst->z); __builtin_nontemporal_store(o.w, &dst->w);
+#else
       *dst = o;
+#endif
     }
   }
 #endif

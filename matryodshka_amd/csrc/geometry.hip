@@ -1249,16 +1249,29 @@ __global__ void resize_bilinear_kernel(const float4 *__restrict__ in, float4 *__
 // once by apply_pose (projector.py:155) and once inside project_perspective through
 // intrinsics @ pose (spherical.py:258-259); the 3x3 intrinsics are zero-padded to 4x4
 // (projector.py:145-148), so only rows 0..2 of the product are used.
+// FAST (round 6): the form for full waves of complete pixels (64 % D == 0, (W * D) % 256 == 0, 16-byte-aligned runs; the host decides).  Same arithmetic, same bits;
+// what changes is the plumbing the ODS sweep went through in rounds 1-2: (a) M = K4 @ pose -- 60 multiply-adds that depend on the FACE only -- is computed by twelve
+// threads and broadcast through LDS instead of by every thread; (b) a corner is ONE 12-byte buffer load, not three dword loads behind 64-bit address arithmetic;
+// (c) a wave's 64 / D complete pixels leave through a wave-private LDS strip as 16-byte-per-lane stores of whole 3 D-float runs instead of 3 dword stores at a
+// 12-byte stride per lane; non-temporal when the volume exceeds the Infinity Cache (sweep_store16).  Measured at configs[4] (64 faces, two sweeps each): DESIGN.md section 4.
+template <int FAST>
 __global__ void __launch_bounds__(256)
 pp_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose,
                 const float *__restrict__ intrinsics, const float *__restrict__ depths, int batch,
                 int height, int width, int nd, float s0, float sstep, float t0, float tstep,
-                float *__restrict__ psv, int channels, int coff) {
+                float *__restrict__ psv, int channels, int coff, unsigned nd_magic, int nt) {
   // grid = (ceil(W*D / 256), H, B): 32-bit index math only (64-bit div/mod are emulated in ~100
   // VALU instructions each and used to dominate this kernel)
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= width * nd) return;
-  const int j = idx / nd, d = idx - j * nd;
+  if (!FAST && idx >= width * nd) return;
+  int j, d;
+  if (FAST) {
+    unsigned jq = __umulhi((unsigned)idx, nd_magic);   // idx / nd by multiply-high (+ one correction)
+    if ((unsigned)idx - jq * (unsigned)nd >= (unsigned)nd) ++jq;
+    j = (int)jq; d = idx - j * nd;
+  } else {
+    j = idx / nd; d = idx - j * nd;
+  }
   const int i = blockIdx.y, b = blockIdx.z;
   const long p = ((long)b * height + i) * width + j;
   const float S = s0 + sstep * (float)j, T = t0 + tstep * (float)i;
@@ -1278,6 +1291,16 @@ pp_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose,
   }
   // project_perspective: M = K4 @ pose, rows 0..2; the padded column contributes 0 * pose[3][c]
   float pr[3];
+  __shared__ float s_m[12];
+  if (FAST) {
+    if (threadIdx.x < 12) {
+      const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+      s_m[threadIdx.x] = ((Kb[r * 3 + 0] * P[c] + Kb[r * 3 + 1] * P[4 + c]) + Kb[r * 3 + 2] * P[8 + c]) + 0.0f * P[12 + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pr[r] = ((s_m[r * 4 + 0] * x + s_m[r * 4 + 1] * y) + s_m[r * 4 + 2] * z) + s_m[r * 4 + 3] * 1.0f;
+  } else {
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     float m[4];
@@ -1286,8 +1309,34 @@ pp_sweep_kernel(const float *__restrict__ image, const float *__restrict__ pose,
       m[c] = ((Kb[r * 3 + 0] * P[c] + Kb[r * 3 + 1] * P[4 + c]) + Kb[r * 3 + 2] * P[8 + c]) + 0.0f * P[12 + c];
     pr[r] = ((m[0] * x + m[1] * y) + m[2] * z) + m[3] * 1.0f;
   }
+  }
   const float u = pr[0] / pr[2], v = pr[1] / pr[2];
   const Taps t = make_taps(u, v, width, height);
+  if (FAST) {
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc((void *)(image + (size_t)b * height * width * 3), 0, height * width * 12, 0x00020000);
+    const f32x3_g a = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, (unsigned)(t.y0 * width + t.x0) * 12u, 0, 0));
+    const f32x3_g bq = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, (unsigned)(t.y0 * width + t.x1) * 12u, 0, 0));
+    const f32x3_g c = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, (unsigned)(t.y1 * width + t.x0) * 12u, 0, 0));
+    const f32x3_g dq = __builtin_bit_cast(f32x3_g, (u32x3_g)__builtin_amdgcn_raw_buffer_load_b96(img, (unsigned)(t.y1 * width + t.x1) * 12u, 0, 0));
+    const float o0 = blend4(t, a.x, bq.x, c.x, dq.x), o1 = blend4(t, a.y, bq.y, c.y, dq.y), o2 = blend4(t, a.z, bq.z, c.z, dq.z);
+    // whole-pixel runs through the wave's strip: lane = (pixel of the wave, depth); the wave's 64 / D pixels are consecutive, each owns 3 D contiguous floats at + coff
+    __shared__ __attribute__((aligned(16))) float s_out[4][192];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *w = s_out[wave];
+    __builtin_amdgcn_wave_barrier();
+    w[lane * 3 + 0] = o0; w[lane * 3 + 1] = o1; w[lane * 3 + 2] = o2;      // (lane = pl * D + d: the strip IS the pixels' runs back to back)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 48) {
+      const int vpp = (3 * nd) >> 2;                                         // 16-byte vectors per pixel run
+      unsigned plq = __umulhi((unsigned)lane, 0xffffffffu / (unsigned)vpp + 1u);
+      if ((unsigned)lane - plq * (unsigned)vpp >= (unsigned)vpp) --plq;      // (lane < 48, vpp >= 3: the estimate is exact or one too large)
+      const int pl = (int)plq, k = lane - pl * vpp;
+      const long pw0 = ((long)b * height + i) * width + (long)((blockIdx.x * 256 + wave * 64) / nd);
+      uint4 *dst = reinterpret_cast<uint4 *>(psv + (size_t)(pw0 + pl) * channels + coff) + k;
+      sweep_store16(dst, reinterpret_cast<const uint4 *>(w)[lane], nt);
+    }
+    return;
+  }
   const float *img = image + (size_t)b * height * width * 3;
   const float *pa = img + ((size_t)t.y0 * width + t.x0) * 3;
   const float *pb = img + ((size_t)t.y0 * width + t.x1) * 3;
@@ -1759,9 +1808,19 @@ int msi_perspective_plane_sweep_f32(const float *image, const float *pose, const
   // spherical.uv_grid (spherical.py:46-48), tf.linspace fp32 semantics
   const float s0 = (float)(-1.0 + 1.0 / width), s1 = (float)(1.0 - 1.0 / width);
   const float t0 = (float)(-1.0 + 1.0 / height), t1 = (float)(1.0 - 1.0 / height);
-  hipLaunchKernelGGL(pp_sweep_kernel, grid, dim3(256), 0, msi::as_stream(stream), image, pose,
-                     intrinsics, depths, batch, height, width, num_depths, s0, (s1 - s0) / (float)(width - 1), t0,
-                     (t1 - t0) / (float)(height - 1), psv, psv_channels, channel_offset);
+  const unsigned magic = num_depths == 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)num_depths);
+  const int nt = (size_t)batch * height * width * psv_channels * 4 > ((size_t)256 << 20) ? 1 : 0;
+  // full waves of complete pixels whose 3 D-float runs are 16-byte aligned, 32-bit byte offsets into one face
+  const bool fast = 64 % num_depths == 0 && ((long)width * num_depths) % 256 == 0 && (3 * num_depths) % 4 == 0 && psv_channels % 4 == 0 && channel_offset % 4 == 0 &&
+                    (long)height * width * 12 < 2147483647L && num_depths >= 4;
+  if (fast)
+    hipLaunchKernelGGL(pp_sweep_kernel<1>, grid, dim3(256), 0, msi::as_stream(stream), image, pose,
+                       intrinsics, depths, batch, height, width, num_depths, s0, (s1 - s0) / (float)(width - 1), t0,
+                       (t1 - t0) / (float)(height - 1), psv, psv_channels, channel_offset, magic, nt);
+  else
+    hipLaunchKernelGGL(pp_sweep_kernel<0>, grid, dim3(256), 0, msi::as_stream(stream), image, pose,
+                       intrinsics, depths, batch, height, width, num_depths, s0, (s1 - s0) / (float)(width - 1), t0,
+                       (t1 - t0) / (float)(height - 1), psv, psv_channels, channel_offset, magic, nt);
   return msi::check_launch("perspective_plane_sweep");
 }
 

@@ -446,6 +446,32 @@ def test_lds_staged_sweep_is_bit_identical_to_the_gather_kernel(gpu, h, w, d, b,
         assert np.abs(_np(whole) - want).max() <= TOL
 
 
+@pytest.mark.parametrize("h,w,d,b", [(16, 32, 32, 3), (24, 64, 16, 2), (8, 64, 4, 2), (8, 8, 64, 1)])
+def test_pp_sweep_fast_form_is_bit_identical_to_the_generic_one(gpu, h, w, d, b):
+    """Round 6: pp_sweep_kernel<1> (face matrix through LDS, 12-byte buffer loads, whole-pixel 16-byte stores through a wave strip) is taken when waves hold complete
+    pixels and the runs are 16-byte aligned; a channel offset of 1 into a wider volume forces the generic form on the SAME problem: every value must agree bit for bit."""
+    torch, m, o = gpu
+    from matryodshka_amd import _native as N
+    assert 64 % d == 0 and (w * d) % 256 == 0
+    rng = np.random.RandomState(5 + d)
+    img = torch.from_numpy(rng.uniform(-1, 1, size=(b, h, w, 3)).astype(np.float32)).cuda()
+    pose = np.tile(np.eye(4, dtype=np.float32)[None], (b, 1, 1))
+    pose[:, 0, 3] = -0.032
+    if b > 1:
+        pose[1] = _rot(0.05, -0.1, 0.02); pose[1, :3, 3] = (0.02, 0.01, -0.03)
+    intr = np.tile(np.array([[w / 2.0, 0, w / 2.0], [0, h / 2.0, h / 2.0], [0, 0, 1]], dtype=np.float32)[None], (b, 1, 1))
+    depths = torch.tensor(m.inv_depths(1.0, 100.0, d), dtype=torch.float32).cuda()
+    tp, ti = torch.from_numpy(pose).cuda(), torch.from_numpy(intr).cuda()
+    fast = torch.full((b, h, w, 6 * d), 7.0, device="cuda")
+    slow = torch.full((b, h, w, 6 * d + 4), 7.0, device="cuda")
+    for coff in (0, 3 * d):
+        N.check(N.lib.msi_perspective_plane_sweep_f32(img.data_ptr(), tp.data_ptr(), ti.data_ptr(), depths.data_ptr(), b, h, w, d, fast.data_ptr(), 6 * d, coff, None), "pp fast")
+        N.check(N.lib.msi_perspective_plane_sweep_f32(img.data_ptr(), tp.data_ptr(), ti.data_ptr(), depths.data_ptr(), b, h, w, d, slow.data_ptr(), 6 * d + 4, coff + 1, None), "pp generic")
+    torch.cuda.synchronize()
+    assert torch.equal(fast, slow[..., 1:6 * d + 1])
+    assert bool((slow[..., 0] == 7.0).all()) and bool((slow[..., 6 * d + 1:] == 7.0).all()) and not bool((fast == 7.0).any())
+
+
 def test_pair_launches_equal_single_ones(gpu):
     """preprocess / deprocess of the two images of a frame in one launch: same bits as the single-image entry points."""
     torch, m, o = gpu
