@@ -95,6 +95,25 @@ for li in layers:
         nblk.append(len(b))
     print("           %d CUs seen; blocks per CU %d..%d; per-CU span %.0f..%.0f ticks; resident workgroups %.2f (avg), in k-loop %.2f (avg)" % (
         len(res), min(nblk), max(nblk), min(spans), max(spans), np.mean(res), np.mean(inl)))
+    # (r06) lockstep check: share of each CU's span during which exactly n of its workgroups are inside their k-loop (n = 0: the matrix pipes have nothing to issue),
+    # and how spread the entry times of the workgroups that share a CU's first "round" are
+    hist = np.zeros(8)
+    first_spread = []
+    for k in np.unique(cu_key):
+        b = t[cu_key == k]
+        ev = sorted([(tt_, 1) for tt_ in b[:, 1]] + [(tt_, -1) for tt_ in b[:, 2]])
+        lo, hi = b[:, 0].min(), b[:, 3].max()
+        cur, last = 0, lo
+        for tt_, dlt in ev:
+            hist[min(cur, 7)] += tt_ - last
+            last = tt_; cur += dlt
+        hist[min(cur, 7)] += hi - last
+        st = np.sort(b[:, 0])
+        nres = max(1, int(round((b[:, 3] - b[:, 0]).sum() / (hi - lo))))
+        first_spread.append(st[min(nres, len(st)) - 1] - st[0])
+    hist /= hist.sum()
+    print("           share of CU time with n workgroups in their k-loop: " + "  ".join("n=%d %.1f%%" % (n, 100 * hist[n]) for n in range(5)) +
+          " | entry spread of a CU's first round: median %.0f ticks" % np.median(first_spread))
 lib.msi_debug_conv_occupancy.argtypes = [ctypes.c_int]
 lib.msi_debug_conv_occupancy.restype = ctypes.c_int
 for lds in (32768, 32784, 40960, 49152):
