@@ -106,7 +106,7 @@ def main():
         # the HBM-bound stages of the same step: algorithmic bytes (bench.geometry_bytes: SURVEY.md 8d) / average launch duration against the 8 TB/s HBM3E peak,
         # so that bench.py's stages.*.frac can be re-derived from this file alone.  head_assemble = the fused tail (head + K3's bytes)
         gb = bench.geometry_bytes(H, W, D, 2 if bf16 else 4)
-        stage_of = (("ods_sweep_kernel", "sweep"), ("pp_sweep_kernel", "sweep"), ("head_assemble_kernel", "assemble"), ("assemble_kernel", "assemble"),
+        stage_of = (("ods_sweep_kernel", "sweep"), ("ods_sweep_lds_kernel", "sweep"), ("pp_sweep_kernel", "sweep"), ("head_assemble_kernel", "assemble"), ("assemble_kernel", "assemble"),
                     ("mpi_render_kernel", "render"), ("render_kernel", "render"))
         print("\n# HBM-bound kernels (per launch of %d frame(s); algorithmic bytes / average duration; peak %.0f GB/s):" % (batch, bench.PEAK_HBM_GBS))
         seen = set()
