@@ -706,9 +706,10 @@ def main():
                     "note": "region 0 is the contract region `value` / `ms_per_step` are computed from"},
         "roofline": {"kernel": "conv_halo*_kernel + conv_igemm_kernel (the 3x3 / 4x4 conv launches of one forward, %s implicit GEMM)" % ("bf16 MFMA" if bf16 else str(arithmetic)),
                      "bound": "mfma", "achieved": round(cnn_tflops, 3), "peak": round(peak, 2),
-                     "peak_note": "dense MFMA peak of the instruction each layer runs on, blended by the layers' flops (fp32 MFMA 157.3; six-product bf16 split 2500 / 6 = 416.7, three-product fp16 split 2500 / 3 = 833.3 fp32-equivalent; bf16 2500 TFLOP/s) -- all quoted at the 2.4 GHz peak clock; under the split kernels the part clocks ~1.4-1.6 GHz "
-                                  "(s_memtime ticks against wall time, tools/conv_timing.py / profiles/r04_e_conv_phase_timing.txt): the conv kernels are power-bound (DESIGN.md section 4); a matrix-only loop with CHANGING fp16 operands sustains 1.61-1.79 PFLOP/s on this part (tools/ubench/lds_mfma_rate.hip, "
-                                  "profiles/r04_f_lds_mfma_rate.txt), i.e. 537-595 fp32-equivalent TFLOP/s for the three-product form",
+                     "peak_note": "dense MFMA peak of the instruction each layer runs on, blended by the layers' flops (fp32 MFMA 157.3; six-product bf16 split 2500 / 6 = 416.7, three-product fp16 split 2500 / 3 = 833.3 fp32-equivalent; bf16 2500 TFLOP/s) -- all quoted at the 2.4 GHz peak clock "
+                                  "on constant operands.  On operands that change between consecutive MFMAs the part itself clocks 1.76-1.89 GHz and a matrix-only loop sustains 1.72-1.91 PFLOP/s (sustained_matrix_rate below is THIS box's figure; "
+                                  "s_memtime counts real shader cycles, the driver's sclk reading is stale on this pool: profiles/r06_clock.txt); the six-product kernels run at that same clock, so what separates `frac_of_sustained` from 1 is skeleton "
+                                  "(launch ramp, tile quantisation, prologue / epilogue: profiles/r06_residency.txt), not power",
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4),
                      "frac_of_fp32_mfma_peak": None if bf16 else round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                      "frac_of_sustained": round(cnn_tflops / (peak * sustained["changing"]["pflops"] * 1e3 / PEAK_BF16_MFMA_TFLOPS), 4) if (bf16 or nx2 + nx3 == 17) else None,
