@@ -344,6 +344,9 @@ def main():
                     help="initialise torch.distributed even at --gpus 1 (world_size 1; backend nccl = RCCL on a GPU box) and run the weight broadcast, "
                          "barriers, MAX-over-ranks and gathers through it exactly as an N-rank run does: first contact with RCCL on a one-GPU box "
                          "(`distributed.backend` and a measured `weight_broadcast_ms` on the line; VERDICT r05 item 4)")
+    ap.add_argument("--no-sustained-probe", action="store_true",
+                    help="skip msi_probe_matrix_rate (roofline.frac_of_sustained / sustained_matrix_rate become null): profiling runs, where the probe's 0.5 s of "
+                         "matrix-only kernels would sit in the kernel table")
     ap.add_argument("--dist-check", action="store_true",
                     help="only the N-rank plumbing of this file: launch, rendezvous, weight broadcast, frame ranges, barrier and "
                          "max-over-ranks -- no frame loop, no kernels; runs without a GPU on gloo (tests/test_dist_cpu.py) and "
@@ -665,7 +668,7 @@ def main():
     if args.substreams > 1:   # the per-stage pass runs the whole batch on one stream: not the configuration that was timed
         stages["note"] = "per-stage pass = whole batch on ONE stream (substreams only changes the timed region)"
 
-    sustained = sustained_matrix_rate(dev)
+    sustained = None if args.no_sustained_probe else sustained_matrix_rate(dev)
     unit = "faces/s" if cfg["kind"] == "pp" else "frames/s"
     arithmetic = None
     nx2 = nx3 = 0
@@ -712,8 +715,8 @@ def main():
                                   "(launch ramp, tile quantisation, prologue / epilogue: profiles/r06_residency.txt), not power",
                      "unit": "TFLOP/s", "frac": round(cnn_tflops / peak, 4),
                      "frac_of_fp32_mfma_peak": None if bf16 else round(cnn_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-                     "frac_of_sustained": round(cnn_tflops / (peak * sustained["changing"]["pflops"] * 1e3 / PEAK_BF16_MFMA_TFLOPS), 4) if (bf16 or nx2 + nx3 == 17) else None,
-                     "sustained_matrix_rate": dict(sustained, note="msi_probe_matrix_rate on THIS box after the timed regions: matrix-only loop (no memory / LDS traffic), bf16 MFMA back to back, on operands that "
+                     "frac_of_sustained": round(cnn_tflops / (peak * sustained["changing"]["pflops"] * 1e3 / PEAK_BF16_MFMA_TFLOPS), 4) if (sustained and (bf16 or nx2 + nx3 == 17)) else None,
+                     "sustained_matrix_rate": None if sustained is None else dict(sustained, note="msi_probe_matrix_rate on THIS box after the timed regions: matrix-only loop (no memory / LDS traffic), bf16 MFMA back to back, on operands that "
                                                    "change between consecutive instructions vs constant ones; dense PFLOP/s and the shader clock (s_memtime cycles per s_memrealtime second). "
                                                    "frac_of_sustained = achieved / (peak x changing.pflops / 2.5): an EXTRA key, `frac` stays on the nominal peak (profiles/r06_clock.txt)"),
                      "traffic": traffic,

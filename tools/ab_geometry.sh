@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/ab
 for rep in 1 2; do for v in old new; do
   cp tools/_variants/libmsi_$v.so matryodshka_amd/libmsi_hip.so
-  rocprofv3 --kernel-trace -d gpurun_out/ab -o ${v}$rep -- python bench.py --steps 20 --warmup 3 --repeats 0 --no-cpu-baseline --prewarm 0.3 --strong-frames 0 > /dev/null 2>&1
+  rocprofv3 --kernel-trace -d gpurun_out/ab -o ${v}$rep -- python bench.py --steps 20 --warmup 3 --repeats 0 --no-cpu-baseline --no-sustained-probe --prewarm 0.3 --strong-frames 0 > /dev/null 2>&1
   python - <<PY
 import sqlite3
 c=sqlite3.connect("gpurun_out/ab/${v}${rep}_results.db")

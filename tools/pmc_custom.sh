@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/pmcc
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmcc/s$i -o p -- python bench.py --config $CFG ${BENCH_EXTRA:-} --steps 3 --warmup 1 --repeats 0 --no-cpu-baseline --prewarm 0 --strong-frames 0 --no-settle > gpurun_out/pmcc/s$i.log 2>&1 || tail -3 gpurun_out/pmcc/s$i.log
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmcc/s$i -o p -- python bench.py --config $CFG ${BENCH_EXTRA:-} --steps 3 --warmup 1 --repeats 0 --no-cpu-baseline --no-sustained-probe --prewarm 0 --strong-frames 0 --no-settle > gpurun_out/pmcc/s$i.log 2>&1 || tail -3 gpurun_out/pmcc/s$i.log
   python - "s$i" "$PAT" <<'PY'
 import sqlite3, sys, glob
 n, pat = sys.argv[1], sys.argv[2]

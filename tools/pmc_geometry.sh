@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/pmc
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*\|TA_[A-Z_0-9]*\|TCP_[A-Z_0-9]*\|GRBM_[A-Z_0-9]*" | sort -u | tr '\n' ' ' | head -c 6000 > gpurun_out/pmc/counters.txt
 for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_INSTS_LDS" "TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE SQ_WAVES"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmc/$n -o p -- python bench.py --steps 3 --warmup 1 --repeats 0 --no-cpu-baseline --prewarm 0 --strong-frames 0 > gpurun_out/pmc/$n.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmc/$n -o p -- python bench.py --steps 3 --warmup 1 --repeats 0 --no-cpu-baseline --no-sustained-probe --prewarm 0 --strong-frames 0 > gpurun_out/pmc/$n.log 2>&1
   python - "$n" <<'PY'
 import sqlite3, sys, glob
 n=sys.argv[1]

@@ -5,7 +5,7 @@ PAT=$1; CFG=${2:-1}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/pmck
 for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_INSTS_LDS" "SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS" "SQ_BUSY_CYCLES SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_LDS_MEM_VIOLATIONS"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmck/$n -o p -- python bench.py --config $CFG ${BENCH_EXTRA:-} --steps 3 --warmup 1 --repeats 0 --no-cpu-baseline --prewarm 0 --strong-frames 0 > gpurun_out/pmck/$n.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmck/$n -o p -- python bench.py --config $CFG ${BENCH_EXTRA:-} --steps 3 --warmup 1 --repeats 0 --no-cpu-baseline --no-sustained-probe --prewarm 0 --strong-frames 0 > gpurun_out/pmck/$n.log 2>&1
   python - "$n" "$PAT" <<'PY'
 import sqlite3, sys, glob
 n, pat = sys.argv[1], sys.argv[2]

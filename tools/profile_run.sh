@@ -28,13 +28,13 @@ except Exception as e:
 PY
 STEPS=20; [ "$CONFIG" != "1" ] && STEPS=6
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace -- python bench.py --config "$CONFIG" $EXTRA --steps $STEPS --warmup 3 --repeats 0 \
-  --no-cpu-baseline --prewarm 0 --strong-frames 0 --no-settle > "$OUT/prof.log" 2>&1
+  --no-cpu-baseline --no-sustained-probe --prewarm 0 --strong-frames 0 --no-settle > "$OUT/prof.log" 2>&1
 python tools/rocprof_summary.py "$OUT/prof/trace_results.db" $SUMARGS > "$OUT/kernel_stats.txt" 2> "$OUT/summary.err" || tail -3 "$OUT/summary.err"
 tail -24 "$OUT/kernel_stats.txt" | cut -c1-170
 if [ "${SKIP_PMC:-0}" != "1" ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$C" -o pmc -- python bench.py --config "$CONFIG" $EXTRA --steps 3 --warmup 1 --repeats 0 \
-      --no-cpu-baseline --prewarm 0 --strong-frames 0 --no-settle > "$OUT/pmc_$C.log" 2>&1
+      --no-cpu-baseline --no-sustained-probe --prewarm 0 --strong-frames 0 --no-settle > "$OUT/pmc_$C.log" 2>&1
   done
   python tools/hbm_traffic.py "$OUT/pmc_FETCH_SIZE/pmc_results.db" "$OUT/pmc_WRITE_SIZE/pmc_results.db" $SUMARGS --commit "$COMMIT" \
     > "$OUT/hbm_traffic.json" 2> "$OUT/traffic.err" || tail -3 "$OUT/traffic.err"

@@ -8,7 +8,7 @@ cp matryodshka_amd/libmsi_hip.so /tmp/libmsi_saved.so
 for r in $(seq $ROUNDS); do
   for v in tools/_variants/libmsi_*.so; do
     cp "$v" matryodshka_amd/libmsi_hip.so
-    rm -rf /tmp/vkt; rocprofv3 --kernel-trace -d /tmp/vkt -o t -- python bench.py --config $CFG $EXTRA --steps 10 --warmup 3 --repeats 0 --no-cpu-baseline --prewarm 0.5 --strong-frames 0 --no-settle > /tmp/vkt.json 2>/dev/null
+    rm -rf /tmp/vkt; rocprofv3 --kernel-trace -d /tmp/vkt -o t -- python bench.py --config $CFG $EXTRA --steps 10 --warmup 3 --repeats 0 --no-cpu-baseline --no-sustained-probe --prewarm 0.5 --strong-frames 0 --no-settle > /tmp/vkt.json 2>/dev/null
     python - "$v" "$PATS" "$r" <<'PY'
 import sqlite3, glob, sys, json
 v, pats, r = sys.argv[1], sys.argv[2].split("|"), sys.argv[3]
