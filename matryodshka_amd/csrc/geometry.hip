@@ -688,6 +688,8 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
   __shared__ __attribute__((aligned(16))) float4 s_patch[2][2][SW_PMAX];     // [buffer][source][texel]
   __shared__ int s_box[4];
 
+  // (r06, measured and dropped: the frame-equality mask worked out by wave 0 alone and handed over through LDS -- 3 % slower; wave-PRIVATE patches without any block
+  //  barrier in the frame loop -- 8 % slower at configs[2], 4 % at configs[3]: 2.3 x the staging loads, more fallback waves; gpurun_out/r06_eq.log, r06_wp.log)
   unsigned eqmask = 0;
   {
     const unsigned *U0 = reinterpret_cast<const unsigned *>(pose0), *U1 = reinterpret_cast<const unsigned *>(pose1);
@@ -757,6 +759,7 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
       if (lane == 0) { atomicMin(&s_box[0], xmin); atomicMax(&s_box[1], xmax); atomicMin(&s_box[2], ymin); atomicMax(&s_box[3], ymax); }
       __syncthreads();
       xmin = s_box[0]; xmax = s_box[1]; ymin = s_box[2]; ymax = s_box[3];
+      __syncthreads();                                              // (every wave has read the box before a later recompute -- possibly with no frame barrier in between: fallback blocks -- re-initialises it)
       const int pw = xmax - xmin + 2, ph = ymax - ymin + 2;          // (+ the x1 / y1 corners)
       pitch = ((pw + 7) & ~15) + 8;                                   // >= pw, = 8 mod 16: consecutive patch rows start half the banks apart
       lds_mode = ph * pitch <= SW_PMAX;
