@@ -618,7 +618,16 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
 // choice made once per (pose, baseline), not per frame.  Same corners, same weights, same blend: the volume is bit-identical.
 // Frames: patch buffers alternate (frame b in buffer b & 1), so ONE block barrier per frame orders both "patch b is visible" and "everybody is
 // done with patch b - 1"; the next frame's texels are requested into registers before this frame's gathers.
-constexpr int SW_PMAX = 384;                 // texels per source and buffer (16 B each): 2 buffers x 2 sources x 6 KB
+// Occupancy is what this kernel is most sensitive to (r06, same-box A/B at configs[2] / [3], gpurun_out/r06_occ*.log): 384 texels and four waves per SIMD 0.98 / 5.97 ms;
+// 256 texels -- ONE staged texel per thread and source instead of two -- 0.90 / 5.27; and five waves per SIMD (91 VGPRs, no scratch; 28.7 KB of LDS with fp32 strips: five
+// blocks per CU) 0.81 / 5.05 ms.  128 / 192 texels: the same; six waves (80 VGPRs) spill 56 bytes and lose (0.93 / 6.4).
+#ifndef MSI_SWEEP_PMAX
+#define MSI_SWEEP_PMAX 256
+#endif
+#ifndef MSI_SWEEP_LDS_WAVES   // amdgpu_waves_per_eu of ods_sweep_lds_kernel (tuning)
+#define MSI_SWEEP_LDS_WAVES 5
+#endif
+constexpr int SW_PMAX = MSI_SWEEP_PMAX;                 // texels per source and buffer (16 B each): 2 buffers x 2 sources x 4 KB
 constexpr int SW_NST = (SW_PMAX + 255) / 256;   // texels a thread stages per source
 
 struct TapsL {
@@ -652,7 +661,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 template <typename OutT, int NS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSI_SWEEP_LDS_WAVES, 8)))
 ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__ image1, const float *__restrict__ pose0,
                      const float *__restrict__ pose1, const float *__restrict__ intrinsics, const float *__restrict__ depths,
                      const float *__restrict__ trig, int batch, int height, int width, int nd,
@@ -703,6 +712,9 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
     }
     eqmask = __builtin_amdgcn_readfirstlane(eqmask);
   }
+  // (the wave's strip goes to its first pixel's row of the volume: one 64-bit product here, an add per frame)
+  const size_t frame_elems = (size_t)height * width * channels;
+  OutT *wdst = psv + (size_t)((((long)b_lo * height + i) * width + j) - pl) * channels;
   TapsB taps[2][NS];
   int lbase[2][NS];                            // float4 index of a sample's corner (y0, x0) in its source's patch
   unsigned goff[SW_NST];                       // byte offset in the image of the texels this thread stages (same for both sources), ~0u = none
@@ -818,7 +830,6 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
       }
     }
     // whole-pixel stores through the wave's strip: exactly ods_sweep_kernel's
-    const long p = ((long)b * height + i) * width + j;
     OutT *w = s_out[wave];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -841,9 +852,9 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
       }
     }
     __builtin_amdgcn_wave_barrier();
-    const size_t first = (size_t)(p - pl) * channels;
     const uint4 *src = reinterpret_cast<const uint4 *>(w);
-    uint4 *dst = reinterpret_cast<uint4 *>(psv + first);
+    uint4 *dst = reinterpret_cast<uint4 *>(wdst);          // the wave's first pixel of frame b
+    wdst += frame_elems;
     constexpr int NV = WAVE_ELEMS * (int)sizeof(OutT) / 16;
 #pragma unroll
     for (int k = lane; k < NV; k += 64) sweep_store16(dst + k, src[k], nt);
