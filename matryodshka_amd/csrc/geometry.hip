@@ -618,22 +618,52 @@ ods_sweep_kernel(const float *__restrict__ image0, const float *__restrict__ ima
 // choice made once per (pose, baseline), not per frame.  Same corners, same weights, same blend: the volume is bit-identical.
 // Frames: patch buffers alternate (frame b in buffer b & 1), so ONE block barrier per frame orders both "patch b is visible" and "everybody is
 // done with patch b - 1"; the next frame's texels are requested into registers before this frame's gathers.
-// Occupancy is what this kernel is most sensitive to (r06, same-box A/B at configs[2] / [3], gpurun_out/r06_occ*.log): 384 texels and four waves per SIMD 0.98 / 5.97 ms;
-// 256 texels -- ONE staged texel per thread and source instead of two -- 0.90 / 5.27; and five waves per SIMD (91 VGPRs, no scratch; 28.7 KB of LDS with fp32 strips: five
-// blocks per CU) 0.81 / 5.05 ms.  128 / 192 texels: the same; six waves (80 VGPRs) spill 56 bytes and lose (0.93 / 6.4).
+// Occupancy is what this kernel is most sensitive to (r06, same-box A/Bs at configs[2] / [3], gpurun_out/r06_occ*.log, r06_w6.log): 384 texels and four waves per SIMD
+// 0.98 / 5.97 ms; 256 texels -- ONE staged texel per thread and source instead of two -- 0.90 / 5.27; five waves per SIMD (91 VGPRs) 0.81 / 5.05-5.3; and, once the
+// per-sample state was cut to a weight quadruple + one packed corner word (TapsC) and the depths are re-read where the corners are computed, SIX waves without a spill
+// (80 VGPRs; 192 texels so that six blocks' LDS fit with fp32 strips: 24.6 KB) 0.74 / 4.85 ms.  Six waves WITH spills (56 bytes) had lost (0.93 / 6.4); 128 texels: more
+// fallback blocks at configs[3] (5.2 ms).
+#ifndef MSI_SWEEP_PREFETCH   // 1: the next frame's patch texels are requested into registers before this frame's gathers (tuning: 0 frees six registers)
+#define MSI_SWEEP_PREFETCH 1
+#endif
 #ifndef MSI_SWEEP_PMAX
-#define MSI_SWEEP_PMAX 256
+#define MSI_SWEEP_PMAX 192
 #endif
 #ifndef MSI_SWEEP_LDS_WAVES   // amdgpu_waves_per_eu of ods_sweep_lds_kernel (tuning)
-#define MSI_SWEEP_LDS_WAVES 5
+#define MSI_SWEEP_LDS_WAVES 6
 #endif
-constexpr int SW_PMAX = MSI_SWEEP_PMAX;                 // texels per source and buffer (16 B each): 2 buffers x 2 sources x 4 KB
+constexpr int SW_PMAX = MSI_SWEEP_PMAX;                 // texels per source and buffer (16 B each): 2 buffers x 2 sources x 3 KB
 constexpr int SW_NST = (SW_PMAX + 255) / 256;   // texels a thread stages per source
 
 struct TapsL {
   TapsB t;
   int x0, y0;                                // unwrapped, clamped corner (make_taps_ranged's x0 / y0)
 };
+// What ods_sweep_lds_kernel keeps per sample across frames: the weights and ONE word for the corners.  Blocks that read their patch from LDS need no memory offsets at
+// all; fallback blocks rebuild the four byte offsets from corner a's (bits 0-27: H * W * 12 < 2^28) and two flags -- x1 wrapped to column 0 (bit 30), y1 wrapped to row 0
+// (bit 31) -- with three adds per frame and sample.  Twelve registers less than four offsets per sample: the kernel fits five waves per SIMD with room to spare.
+struct TapsC {
+  unsigned oaf;
+  float wa, wb, wc, wd;
+};
+__device__ __forceinline__ TapsC compact_taps(const TapsB &t) {
+  TapsC c;
+  c.oaf = t.oa | (t.ob < t.oa ? 0x40000000u : 0u) | (t.oc < t.oa ? 0x80000000u : 0u);   // (x1 = x0 + 1 unless it wrapped to 0: then ob < oa; likewise y1)
+  c.wa = t.wa; c.wb = t.wb; c.wc = t.wc; c.wd = t.wd;
+  return c;
+}
+__device__ __forceinline__ TapsB expand_taps(const TapsC &c, int width, int height) {
+  TapsB t;
+  t.oa = c.oaf & 0x0fffffffu;
+  const unsigned dx = (c.oaf & 0x40000000u) ? (unsigned)(-(width - 1) * 12) : 12u;
+  const unsigned dy = (c.oaf & 0x80000000u) ? (unsigned)(-(height - 1) * width * 12) : (unsigned)(width * 12);
+  t.ob = t.oa + dx; t.oc = t.oa + dy; t.od = t.oa + dy + dx;
+  t.wa = c.wa; t.wb = c.wb; t.wc = c.wc; t.wd = c.wd;
+  return t;
+}
+__device__ __forceinline__ float blend4(const TapsC &t, float a, float b, float c, float d) {
+  return ((t.wa * a + t.wb * b) + t.wc * c) + t.wd * d;
+}
 __device__ __forceinline__ TapsL make_taps_lds(float u, float v, int width, int height) {
   TapsL r;
   r.t = make_taps_bytes(u, v, width, height);
@@ -684,9 +714,6 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
   const float ct = trig[2 * width + i], st = trig[2 * width + height + i];
   const int img_bytes = height * width * 12;
   const float csct = cs * ct, ssct = ss * ct;
-  float depth[NS];
-#pragma unroll
-  for (int q = 0; q < NS; ++q) depth[q] = depths[d0 + q];
 
   const int lane = tid & 63, wave = tid >> 6;
   unsigned plq = __umulhi((unsigned)lane, ng_magic);
@@ -715,7 +742,7 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
   // (the wave's strip goes to its first pixel's row of the volume: one 64-bit product here, an add per frame)
   const size_t frame_elems = (size_t)height * width * channels;
   OutT *wdst = psv + (size_t)((((long)b_lo * height + i) * width + j) - pl) * channels;
-  TapsB taps[2][NS];
+  TapsC taps[2][NS];
   int lbase[2][NS];                            // float4 index of a sample's corner (y0, x0) in its source's patch
   unsigned goff[SW_NST];                       // byte offset in the image of the texels this thread stages (same for both sources), ~0u = none
   f32x3_g stg[2][SW_NST];
@@ -741,6 +768,9 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
 #pragma unroll
       for (int k = 0; k < 12; ++k) same = same && (P0[k] == P1[k]);
       int xr[2][NS], yr[2][NS];
+      float depth[NS];                          // (read where the corners are computed, not held across the frame loop)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) depth[q] = depths[d0 + q];
       int xmin = 0x7fffffff, xmax = -0x7fffffff, ymin = 0x7fffffff, ymax = -0x7fffffff;
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
@@ -755,7 +785,7 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
           ods_tail(q1, -1.0f, K, u, v);
         }
         TapsL t1 = make_taps_lds(u, v, width, height);
-        taps[0][q] = t0.t; taps[1][q] = t1.t;
+        taps[0][q] = compact_taps(t0.t); taps[1][q] = compact_taps(t1.t);
         xr[0][q] = centred(t0.x0 - xc, width); yr[0][q] = centred(t0.y0 - i, height);
         xr[1][q] = centred(t1.x0 - xc, width); yr[1][q] = centred(t1.y0 - i, height);
 #pragma unroll
@@ -807,7 +837,7 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
         }
       }
       __syncthreads();                                                 // patch b visible; everybody is done with patch b - 1 (its buffer is free for b + 1)
-      pending = (b + 1 < b_hi) && ((eqmask >> (b + 1 - b_lo)) & 1u);
+      pending = MSI_SWEEP_PREFETCH && (b + 1 < b_hi) && ((eqmask >> (b + 1 - b_lo)) & 1u);
       if (pending) stage_load(b + 1);
 #pragma unroll
       for (int q = 0; q < NS; ++q)
@@ -815,7 +845,7 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
         for (int s_ = 0; s_ < 2; ++s_) {
           const float4 *pp = (s_ ? pb1 : pb0) + lbase[s_][q];
           const float4 a = pp[0], bb = pp[1], c = pp[pitch], d = pp[pitch + 1];
-          const TapsB &t = taps[s_][q];
+          const TapsC &t = taps[s_][q];
           out[s_][q][0] = blend4(t, a.x, bb.x, c.x, d.x);
           out[s_][q][1] = blend4(t, a.y, bb.y, c.y, d.y);
           out[s_][q][2] = blend4(t, a.z, bb.z, c.z, d.z);
@@ -825,8 +855,8 @@ ods_sweep_lds_kernel(const float *__restrict__ image0, const float *__restrict__
       const __amdgpu_buffer_rsrc_t img1 = __builtin_amdgcn_make_buffer_rsrc((void *)(image1 + (size_t)b * height * width * 3), 0, img_bytes, 0x00020000);
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
-        gather3(img0, taps[0][q], out[0][q]);
-        gather3(img1, taps[1][q], out[1][q]);
+        gather3(img0, expand_taps(taps[0][q], width, height), out[0][q]);
+        gather3(img1, expand_taps(taps[1][q], width, height), out[1][q]);
       }
     }
     // whole-pixel stores through the wave's strip: exactly ods_sweep_kernel's
