@@ -324,7 +324,7 @@ conv_halo_bf16_kernel(const ConvParams p) {
 // (1.5 GB of HBM round trips per 16 frames).
 struct HaloGeomBS2 {
   static constexpr int TH = 8;
-  static constexpr int PW = 17, PH = TH + 1, NPX = PW * PH;
+  [[maybe_unused]] static constexpr int PW = 17, PH = TH + 1, NPX = PW * PH;
   static constexpr int PIX_BYTES = 144;
   static constexpr int ROW_PITCH = (PW * PIX_BYTES + 255) / 256 * 256;   // (a multiple of 256: see HaloGeomB)
   static constexpr int A_BYTES = PH * ROW_PITCH;

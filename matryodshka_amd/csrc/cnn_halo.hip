@@ -29,7 +29,7 @@ struct HaloGeom {
   static constexpr int B_STAGE = 64 * ROW_BYTES;          // one k-step of weights: 64 output rows x 128 B
   static constexpr int NSTG = 3;                          // 9 taps per chunk = 3 x 3 stages: the stage of a tap is a literal
   static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
-  static constexpr int NLOAD = (NPX * 8 + 255) / 256;     // float4 patch elements per thread and chunk
+  [[maybe_unused]] static constexpr int NLOAD = (NPX * 8 + 255) / 256;     // float4 patch elements per thread and chunk
 };
 
 template <int RATE, int APPLY>
@@ -309,7 +309,7 @@ struct HaloGeomS2 {
   static constexpr int B_STAGE = 64 * ROW_BYTES;
   static constexpr int NSTG = 3;
   static constexpr int LDS_BYTES = A_BYTES + NSTG * B_STAGE;
-  static constexpr int NLOAD = (NPX * 8 + 255) / 256;
+  [[maybe_unused]] static constexpr int NLOAD = (NPX * 8 + 255) / 256;
   static_assert(LDS_BYTES >= EPI_STAGE_BYTES / 2, "the epilogue's staging strips of a 64 x 64 fp32 tile (18 KB)");
 };
 

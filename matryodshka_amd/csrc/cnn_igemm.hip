@@ -589,7 +589,7 @@ int launch_fixup(int bm, int bn, int mode, unsigned gx, unsigned gy, const ConvP
 }
 int debug_conv_occupancy(int lds_bytes) {
   int n = -1;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<64, 64, MODE_CONV, 0>, 256, (size_t)lds_bytes);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<64, 64, MODE_CONV, 0>, 256, (size_t)lds_bytes);
   return n;
 }
 }  // namespace msi_cnn

@@ -696,7 +696,7 @@ __device__ __forceinline__ void conv_halo_s2_x3_body(const ConvParams &p, char *
 #pragma unroll
   for (int s_ = 0; s_ < 2; ++s_)
     b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
-  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8), unused));
   f32x16 acc[MT][1], acc_lo;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void convt_halo_x3_body(const ConvParams &p, char *sm
 #pragma unroll
   for (int s_ = 0; s_ < 2; ++s_)
     b_s[s_] = lds_base + G::A_BYTES + (wn * 32 + frow) * G::B_ROW + (((2 * s_ + fh) ^ ((frow >> 2) & 3)) << 4);
-  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8), unused));
   f32x16 acc[2][MT][1], acc_lo[2];   // [class][32-pixel block]
 #pragma unroll
   for (int cl = 0; cl < 2; ++cl)
