@@ -71,3 +71,14 @@ def test_the_headline_plan_and_a_configs3_grid_are_bit_identical_over_thousands_
         bad += sum(0 if torch.equal(o, first) else 1 for o in outs)
     assert m.network_status() == 0
     assert bad == 0, "%d of %d forwards differ from the first" % (bad, runs)
+
+
+def test_lds_staged_sweep_soak_against_the_gather_kernel():
+    """Round 6: tools/sweep_soak.py, bounded for the suite (90 launches per case instead of 600: profiles/r06_sweep_soak.txt) -- the LDS-staged sweep (patch double buffer, one
+    block barrier per frame, box reduction, register prefetch) at configs[2] / configs[3]-shard shapes and on mixed poses, every volume bit-identical to the gather kernel's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "sweep_soak.py"), "--runs", "90"], cwd=root, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0 and p.stdout.count(": 0 of 90 volumes differ") == 4, p.stdout[-3000:]
